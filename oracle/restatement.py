@@ -1,0 +1,522 @@
+"""Plain-PyTorch CPU restatement of the reference hot path (test oracle).
+
+Every class keeps the reference's attribute names so that ``state_dict`` keys
+are interchangeable with the reference modules and with the HIP-backed modules
+in ``openvivqa_amd``.  Citations are ``file:line`` under ``/root/reference``.
+
+This file is the *checker*: it is imported only by tests, by
+``__graft_entry__.smoke()`` and by the ``cpu_baseline`` leg of ``bench.py``.
+"""
+from __future__ import annotations
+
+import math
+from contextlib import contextmanager
+from typing import Optional
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+MASK_VALUE = -10e4  # models/utils.py:56,64,71  (== -100000.0)
+
+__all__ = [
+    "MASK_VALUE", "padding_mask", "sequential_mask", "self_attention_masks",
+    "sinusoid_positions", "sinusoid_table", "sdpa_core",
+    "OracleSDPA", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
+    "OracleGuidedEncoderLayer", "OracleCrossModalityEncoderLayer",
+    "OracleEncoder", "OracleGuidedAttentionEncoder", "OracleCoAttentionEncoder",
+    "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
+    "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
+    "OracleFeatureEmbedding", "noam_lambda", "oracle_train_step", "build_oracle_encoder",
+]
+
+
+# --------------------------------------------------------------------------
+# masks / positions                                  models/utils.py:32-73
+# --------------------------------------------------------------------------
+def padding_mask(seq: torch.Tensor, padding_idx: int) -> torch.Tensor:
+    """Additive key-padding mask, (B,1,1,N), values in {-0.0, -1e5}.
+
+    models/utils.py:44-57: a row is padding iff its feature sum equals
+    ``padding_idx * D`` (token tensors are treated as D == 1)."""
+    s = seq.unsqueeze(-1) if seq.dim() == 2 else seq
+    hit = s.sum(dim=-1) == (padding_idx * s.shape[-1])
+    return (hit.long() * MASK_VALUE)[:, None, None, :]
+
+
+def sequential_mask(t: int) -> torch.Tensor:
+    """Causal additive mask (1,1,T,T).  models/utils.py:59-66."""
+    return (torch.ones(t, t).triu(1) * MASK_VALUE)[None, None]
+
+
+def self_attention_masks(pad: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
+    """OR of padding and causal masks -> (B,1,T,T).  models/utils.py:68-73."""
+    return ((pad != 0) | (seq != 0)).long() * MASK_VALUE
+
+
+def sinusoid_positions(n: int, d: int, temperature: float = 10000.0) -> torch.Tensor:
+    """(n, d) fp32 table of the encoder positional embedding.
+
+    models/modules/pos_embeddings.py:58-72 called with mask=None: positions are
+    cumsum(ones) = 1..n, channel c uses temperature**(2*(c//2)/d), even
+    channels take sin and odd channels cos (interleaved)."""
+    pos = torch.arange(1, n + 1, dtype=torch.float32)[:, None]
+    c = torch.arange(d, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(c, 2, rounding_mode="floor") / d)
+    ang = pos / dim_t
+    out = torch.empty(n, d, dtype=torch.float32)
+    out[:, 0::2] = ang[:, 0::2].sin()
+    out[:, 1::2] = ang[:, 1::2].cos()
+    return out
+
+
+def sinusoid_table(max_len: int, d: int, padding_idx: Optional[int] = None) -> torch.Tensor:
+    """Decoder position table (max_len, d).  models/utils.py:21-38: positions
+    0..max_len-1, channel pair j uses 10000**(2j/d); row padding_idx zeroed."""
+    pos = torch.arange(max_len, dtype=torch.float32)[:, None]
+    j = torch.arange(d // 2, dtype=torch.float32)[None, :]
+    ang = pos / 10000 ** (2 * j / d)
+    out = torch.zeros(max_len, d)
+    out[:, 0::2] = ang.sin()
+    out[:, 1::2] = ang.cos()
+    if padding_idx is not None:
+        out[padding_idx] = 0
+    return out
+
+
+# --------------------------------------------------------------------------
+# attention                                  models/modules/attentions.py
+# --------------------------------------------------------------------------
+def sdpa_core(q, k, v, mask, d_k):
+    """softmax(q k^T / sqrt(d_k) + mask) v on (B,H,n,d) tensors.
+    models/modules/attentions.py:53-57.  Returns (out, att)."""
+    att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d_k)
+    if mask is not None:
+        att = att + mask
+    att = torch.softmax(att, dim=-1)
+    return torch.matmul(att, v), att
+
+
+class OracleSDPA(nn.Module):
+    """ScaledDotProductAttention.  models/modules/attentions.py:10-60."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.d_model, self.h = cfg.D_MODEL, cfg.HEAD
+        self.d_k, self.d_v = cfg.D_KEY, cfg.D_VALUE
+        self.fc_q = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_k = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_v = nn.Linear(self.d_model, self.h * self.d_v)
+        self.fc_o = nn.Linear(self.h * self.d_v, self.d_model)
+        for lin in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):  # :36-44
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+
+    def forward(self, queries, keys, values, attention_mask=None, **kw):
+        b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
+        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).transpose(1, 2)
+        k = self.fc_k(keys).view(b, nk, self.h, self.d_k).transpose(1, 2)
+        v = self.fc_v(values).view(b, nk, self.h, self.d_v).transpose(1, 2)
+        o, att = sdpa_core(q, k, v, attention_mask, self.d_k)
+        o = o.transpose(1, 2).reshape(b, nq, self.h * self.d_v)
+        return self.fc_o(o), att
+
+
+class _Stateful(nn.Module):
+    """State-buffer machinery.  models/modules/containers.py:4-70."""
+
+    def __init__(self):
+        super().__init__()
+        self._is_stateful = False
+        self._state_names = []
+        self._state_defaults = {}
+
+    def register_state(self, name, default):
+        self._state_names.append(name)
+        self._state_defaults[name] = None if default is None else default.clone().detach()
+        self.register_buffer(name, default)
+
+    def _walk(self):
+        yield self
+        for m in self.children():
+            if isinstance(m, _Stateful):
+                yield from m._walk()
+            elif isinstance(m, nn.ModuleList):
+                for mm in m:
+                    if isinstance(mm, _Stateful):
+                        yield from mm._walk()
+
+    def apply_to_states(self, fn):
+        for m in self._walk():
+            for name in m._state_names:
+                m._buffers[name] = fn(m._buffers[name])
+
+    def enable_statefulness(self, batch_size):
+        for m in self._walk():
+            for name in m._state_names:
+                d = m._state_defaults[name]
+                if d is None:
+                    m._buffers[name] = None
+                else:
+                    t = d.clone().to(m._buffers[name].device).unsqueeze(0)
+                    m._buffers[name] = t.expand([batch_size] + list(t.shape[1:])).contiguous()
+            m._is_stateful = True
+
+    def disable_statefulness(self):
+        for m in self._walk():
+            for name in m._state_names:
+                d = m._state_defaults[name]
+                m._buffers[name] = None if d is None else d.clone().to(m._buffers[name].device)
+            m._is_stateful = False
+
+    @contextmanager
+    def statefulness(self, batch_size):
+        self.enable_statefulness(batch_size)
+        try:
+            yield
+        finally:
+            self.disable_statefulness()
+
+
+class OracleMHA(_Stateful):
+    """MultiHeadAttention: post-LN residual wrapper, optional AoA gate and
+    running K/V state.  models/modules/attentions.py:293-339."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        d = cfg.D_MODEL
+        self.use_aoa = cfg.USE_AOA
+        if self.use_aoa:
+            self.informative_attention = nn.Linear(2 * d, d)
+            self.gated_attention = nn.Linear(2 * d, d)
+        self.attention = OracleSDPA(cfg)
+        self.dropout = nn.Dropout(p=cfg.DROPOUT)
+        self.layer_norm = nn.LayerNorm(d)
+        self.can_be_stateful = cfg.CAN_BE_STATEFUL
+        if self.can_be_stateful:
+            self.register_state("running_keys", torch.zeros((0, d)))
+            self.register_state("running_values", torch.zeros((0, d)))
+
+    def forward(self, queries, keys, values, attention_mask, **kw):
+        if self.can_be_stateful and self._is_stateful:  # :320-325
+            self.running_keys = torch.cat([self.running_keys, keys], 1)
+            self.running_values = torch.cat([self.running_values, values], 1)
+            keys, values = self.running_keys, self.running_values
+        out, _ = self.attention(queries, keys, values, attention_mask, **kw)
+        out = self.layer_norm(queries + self.dropout(out))  # :330-331
+        if self.use_aoa:  # :333-337
+            z = torch.cat([queries, out], dim=-1)
+            out = self.informative_attention(z) * torch.sigmoid(self.gated_attention(z))
+        return out
+
+
+class OraclePWFF(nn.Module):
+    """LN(x + drop(fc2(drop(gelu(fc1 x))))).  positionwise_feed_forward.py:5-28."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.fc1 = nn.Linear(cfg.D_MODEL, cfg.D_FF)
+        self.fc2 = nn.Linear(cfg.D_FF, cfg.D_MODEL)
+        self.dropout_1 = nn.Dropout(p=cfg.DROPOUT)
+        self.dropout_2 = nn.Dropout(p=cfg.DROPOUT)
+        self.layer_norm = nn.LayerNorm(cfg.D_MODEL)
+
+    def forward(self, x):
+        h = self.dropout_1(F.gelu(self.fc1(x)))
+        return self.layer_norm(x + self.dropout_2(self.fc2(h)))
+
+
+# --------------------------------------------------------------------------
+# encoder layers / encoders                    models/modules/encoders.py
+# --------------------------------------------------------------------------
+class OracleEncoderLayer(nn.Module):
+    """encoders.py:9-19."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.mhatt = OracleMHA(cfg)
+        self.pwff = OraclePWFF(cfg)
+
+    def forward(self, queries, keys, values, attention_mask, **kw):
+        return self.pwff(self.mhatt(queries, keys, values, attention_mask, **kw))
+
+
+class OracleGuidedEncoderLayer(nn.Module):
+    """MCAN SGA unit.  encoders.py:74-99."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_mhatt = OracleMHA(cfg)
+        self.guided_mhatt = OracleMHA(cfg)
+        self.pwff = OraclePWFF(cfg)
+
+    def forward(self, queries, keys, values, self_attention_mask, guided_attention_mask, **kw):
+        x = self.self_mhatt(queries, queries, queries, self_attention_mask, **kw)
+        x = self.guided_mhatt(x, keys, values, guided_attention_mask, **kw)
+        return self.pwff(x)
+
+
+class OracleCrossModalityEncoderLayer(nn.Module):
+    """encoders.py:21-72.  The two cross-attention results are computed and
+    then overwritten by the self-attention results (lines 39-66), so the
+    cross-attention parameters never influence the output."""
+
+    def __init__(self, cfg, compute_dead_cross_attention: bool = True):
+        super().__init__()
+        self.vision_language_mhattn = OracleMHA(cfg.VISION_LANGUAGE_ATTENTION)
+        self.language_vision_mhattn = OracleMHA(cfg.LANGUAGE_VISION_ATTENTION)
+        self.vision_mhattn = OracleMHA(cfg.VISION_SELF_ATTENTION)
+        self.language_mhattn = OracleMHA(cfg.LANGUAGE_SELF_ATTENTION)
+        self.vision_pff = OraclePWFF(cfg.VISION_SELF_ATTENTION)
+        self.language_pff = OraclePWFF(cfg.LANGUAGE_SELF_ATTENTION)
+        self.compute_dead = compute_dead_cross_attention
+
+    def forward(self, vision_features, vision_padding_mask, language_features, language_padding_mask, **kw):
+        if self.compute_dead:
+            self.vision_language_mhattn(vision_features, language_features, language_features, language_padding_mask)
+            self.language_vision_mhattn(language_features, vision_features, vision_features, vision_padding_mask)
+        v = self.vision_mhattn(vision_features, vision_features, vision_features, vision_padding_mask)
+        l = self.language_mhattn(language_features, language_features, language_features, language_padding_mask)
+        return self.vision_pff(v), self.language_pff(l)
+
+
+class _PosLN(nn.Module):
+    def _prologue(self, ln, x):
+        # encoders.py:113,154,192-193,243-244: LN(x) + fp32 sinusoid table
+        return ln(x) + sinusoid_positions(x.shape[1], x.shape[2]).to(x.device)[None]
+
+
+class OracleEncoder(_PosLN):
+    """Self-attention stack.  encoders.py:101-117."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.d_model = cfg.D_MODEL
+        self.layers = nn.ModuleList([OracleEncoderLayer(cfg.SELF_ATTENTION) for _ in range(cfg.LAYERS)])
+
+    def forward(self, features, padding_mask):
+        out = self._prologue(self.layer_norm, features)
+        for layer in self.layers:
+            out = layer(out, out, out, padding_mask)
+        return out
+
+
+class OracleGuidedAttentionEncoder(_PosLN):
+    """MCAN guided stack; both MHAs come from GUIDED_ATTENTION.  encoders.py:137-164."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.d_model = cfg.D_MODEL
+        self.guided_attn_layers = nn.ModuleList(
+            [OracleGuidedEncoderLayer(cfg.GUIDED_ATTENTION) for _ in range(cfg.LAYERS)])
+
+    def forward(self, vision_features, vision_padding_mask, language_features, language_padding_mask):
+        out = self._prologue(self.layer_norm, vision_features)
+        for layer in self.guided_attn_layers:
+            out = layer(out, language_features, language_features, vision_padding_mask, language_padding_mask)
+        return out
+
+
+class OracleCoAttentionEncoder(_PosLN):
+    """ViLBERT-style chained co-attention.  encoders.py:166-224."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.vision_layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.language_layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.d_model = cfg.D_MODEL
+        mk = lambda c: nn.ModuleList([OracleEncoderLayer(c) for _ in range(cfg.LAYERS)])
+        self.vision_language_attn_layers = mk(cfg.VISION_LANGUAGE_ATTENTION)
+        self.language_vision_attn_layers = mk(cfg.LANGUAGE_VISION_ATTENTION)
+        self.vision_self_attn_layers = mk(cfg.VISION_SELF_ATTENTION)
+        self.language_self_attn_layers = mk(cfg.LANGUAGE_SELF_ATTENTION)
+
+    def forward(self, vision_features, vision_padding_mask, language_features, language_padding_mask):
+        v = self._prologue(self.vision_layer_norm, vision_features)
+        l = self._prologue(self.language_layer_norm, language_features)
+        for vl, lv, vs, ls in zip(self.vision_language_attn_layers, self.language_vision_attn_layers,
+                                  self.vision_self_attn_layers, self.language_self_attn_layers):
+            v = vl(v, l, l, language_padding_mask)
+            l = lv(l, v, v, vision_padding_mask)
+            v = vs(v, v, v, vision_padding_mask)
+            l = ls(l, l, l, language_padding_mask)
+        return v, l
+
+
+class OracleCrossModalityEncoder(_PosLN):
+    """LXMERT-style.  encoders.py:226-253."""
+
+    def __init__(self, cfg, compute_dead_cross_attention: bool = True):
+        super().__init__()
+        self.vision_layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.language_layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.d_model = cfg.D_MODEL
+        self.layers = nn.ModuleList(
+            [OracleCrossModalityEncoderLayer(cfg, compute_dead_cross_attention) for _ in range(cfg.LAYERS)])
+
+    def forward(self, vision_features, vision_padding_mask, language_features, language_padding_mask):
+        v = self._prologue(self.vision_layer_norm, vision_features)
+        l = self._prologue(self.language_layer_norm, language_features)
+        for layer in self.layers:
+            v, l = layer(v, vision_padding_mask, l, language_padding_mask)
+        return v, l
+
+
+_ENCODERS = {
+    "Encoder": OracleEncoder,
+    "GuidedAttentionEncoder": OracleGuidedAttentionEncoder,
+    "CoAttentionEncoder": OracleCoAttentionEncoder,
+    "CrossModalityEncoder": OracleCrossModalityEncoder,
+}
+
+
+def build_oracle_encoder(cfg):
+    return _ENCODERS[cfg.ARCHITECTURE](cfg)
+
+
+# --------------------------------------------------------------------------
+# decoder                                      models/modules/decoders.py
+# --------------------------------------------------------------------------
+class OracleUsualEmbedding(nn.Module):
+    """Token embedding without pretrained vectors.  text_embeddings.py:56-80."""
+
+    def __init__(self, cfg, vocab):
+        super().__init__()
+        self.padding_idx = vocab.padding_idx
+        self.components = nn.Embedding(len(vocab), cfg.D_MODEL, vocab.padding_idx)
+
+    def forward(self, tokens):
+        pm = padding_mask(tokens, self.padding_idx)
+        sm = sequential_mask(tokens.shape[-1])
+        return self.components(tokens), (pm, sm)
+
+
+class OracleDecoderLayer(_Stateful):
+    """self-MHA -> enc-MHA -> FFN(ENC_ATTENTION cfg).  decoders.py:13-27."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = OracleMHA(cfg.SELF_ATTENTION)
+        self.enc_attn = OracleMHA(cfg.ENC_ATTENTION)
+        self.pwff = OraclePWFF(cfg.ENC_ATTENTION)
+
+    def forward(self, queries, keys, values, self_attention_mask, enc_attention_mask, **kw):
+        x = self.self_attn(queries, queries, queries, self_attention_mask)
+        x = self.enc_attn(x, keys, values, enc_attention_mask)
+        return self.pwff(x)
+
+
+class OracleDecoder(_Stateful):
+    """decoders.py:29-76 (teacher-forced and stateful single-step)."""
+
+    def __init__(self, cfg, vocab):
+        super().__init__()
+        self.d_model = cfg.D_MODEL
+        self.max_len = vocab.max_answer_length
+        self.padding_idx = vocab.padding_idx
+        self.N = cfg.LAYERS
+        self.word_emb = OracleUsualEmbedding(cfg.TEXT_EMBEDDING, vocab)
+        self.pos_emb = nn.Embedding.from_pretrained(
+            sinusoid_table(self.max_len + 1, cfg.D_MODEL, padding_idx=0), freeze=True)
+        self.layers = nn.ModuleList([OracleDecoderLayer(cfg.ATTENTION) for _ in range(cfg.LAYERS)])
+        self.fc = nn.Linear(cfg.D_MODEL, len(vocab), bias=False)
+        self.register_state("running_mask_self_attention", torch.zeros((1, 1, 0)).bool())
+        self.register_state("running_seq", torch.zeros((1,)).long())
+
+    def forward(self, answer_tokens, encoder_features, encoder_attention_mask):
+        b, t = answer_tokens.shape
+        pm = padding_mask(answer_tokens, self.padding_idx)
+        sam = self_attention_masks(pm, sequential_mask(t))
+        if self._is_stateful:  # :55-57
+            self.running_mask_self_attention = torch.cat([self.running_mask_self_attention, sam], -1)
+            sam = self.running_mask_self_attention
+        seq = torch.arange(1, t + 1).view(1, -1).expand(b, -1)
+        seq = seq.masked_fill(pm[:, 0, 0, :] != 0, 0)
+        if self._is_stateful:  # :61-63
+            self.running_seq.add_(1)
+            seq = self.running_seq
+        emb, _ = self.word_emb(answer_tokens)
+        out = emb + self.pos_emb(seq)
+        for layer in self.layers:
+            out = layer(out, encoder_features, encoder_features, sam, encoder_attention_mask)
+        return F.log_softmax(self.fc(out), dim=-1)
+
+
+# --------------------------------------------------------------------------
+# pointer scorers / feature embedding
+# --------------------------------------------------------------------------
+class OracleOcrPtrNet(nn.Module):
+    """q W_q (k W_k)^T / sqrt(qk) + additive mask.  models/mmf_m4c.py:367-396."""
+
+    def __init__(self, hidden_size, query_key_size=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.query_key_size = query_key_size or hidden_size
+        self.query = nn.Linear(hidden_size, self.query_key_size)
+        self.key = nn.Linear(hidden_size, self.query_key_size)
+
+    def forward(self, query_inputs, key_inputs, attention_mask):
+        m = attention_mask.squeeze(1)
+        q = self.query(query_inputs)
+        two_d = q.dim() == 2
+        if two_d:
+            q = q.unsqueeze(1)
+        s = torch.matmul(q, self.key(key_inputs).transpose(-1, -2)) / math.sqrt(self.query_key_size) + m
+        return s.squeeze(1) if two_d else s
+
+
+class OracleDynamicPointerNetwork(nn.Module):
+    """Bilinear scorer with a boolean -inf fill.  ``axis='key'`` follows
+    models/m4c.py:19-33, ``axis='query'`` follows models/iterative_m4c.py:18-32."""
+
+    def __init__(self, cfg, axis="key"):
+        super().__init__()
+        self.query = nn.Linear(cfg.D_MODEL, cfg.D_MODEL)
+        self.key = nn.Linear(cfg.D_MODEL, cfg.D_MODEL)
+        self.d_model = cfg.D_MODEL
+        self.axis = axis
+
+    def forward(self, query_inputs, key_inputs, attention_mask):
+        s = torch.matmul(self.query(query_inputs), self.key(key_inputs).transpose(-1, -2)) / math.sqrt(self.d_model)
+        if self.axis == "key":
+            return s.masked_fill(attention_mask.squeeze(1), float("-inf"))
+        return s.masked_fill(attention_mask.squeeze(1).squeeze(1).unsqueeze(-1), float("-inf"))
+
+
+class OracleFeatureEmbedding(nn.Module):
+    """Linear + GELU + dropout and zero-row padding mask.
+    models/modules/vision_embeddings.py:10-25 (restated from text: the module
+    does not import under transformers 5)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.proj = nn.Linear(cfg.D_FEATURE, cfg.D_MODEL)
+        self.gelu = nn.GELU()
+        self.dropout = nn.Dropout(cfg.DROPOUT)
+
+    def forward(self, features):
+        return self.dropout(self.gelu(self.proj(features))), padding_mask(features, 0)
+
+
+# --------------------------------------------------------------------------
+# training step (row T)      tasks/classification_task.py:120-139, base_task.py:46-76
+# --------------------------------------------------------------------------
+def noam_lambda(step: int, d_model: int, warmup: int) -> float:
+    """tasks/base_task.py:73-76: d^-.5 * min(s^-.5, s * warmup^-1.5), s = step+1."""
+    s = step + 1
+    return (d_model ** -0.5) * min(s ** -0.5, s * warmup ** -1.5)
+
+
+def oracle_train_step(params, loss_fn, optim, scheduler=None):
+    """One reference-ordered step: forward -> zero_grad -> backward -> Adam step
+    -> loss.item() -> scheduler.step()."""
+    loss = loss_fn()
+    optim.zero_grad()
+    loss.backward()
+    optim.step()
+    val = loss.item()
+    if scheduler is not None:
+        scheduler.step()
+    return val
