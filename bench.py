@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VQA samples/s, forward+backward+optimizer step of the MCAN encoder stack
+(d=512, L=6, B=64 per GPU, 100 regions x 20 tokens, bf16) -- BASELINE.json `metric`, configs[1].
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL = torch.distributed "nccl"), weak scaling (64 samples per GPU).
+A "step" is: forward -> loss -> backward -> gradient all-reduce -> Adam, on synthetic inputs
+already resident in HBM.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP
+events, live) and `cpu_baseline` (the oracle restatement timed on the host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_SAMPLE_FWD_BWD = 16.31e9  # MCAN encoders L=6, matmul FLOPs, fwd+bwd = 3x fwd
+PEAK_BF16 = 2.5e15                   # dense MFMA peak, MI355X_MICROARCH.md chip table
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "mcan_bench.yaml"))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def gemm_launch_list(B, NV, NT, D, DFF, L):
+    """(M, N, K, epilogue) of every forward GEMM launch of one step, grouped by kernel family."""
+    mv, mt = B * NV, B * NT
+    bias, gelu, resid = [], [], []
+    for _ in range(L):  # text EncoderLayer
+        bias.append((mt, 3 * D, D))
+        resid.append((mt, D, D))
+        gelu.append((mt, DFF, D))
+        resid.append((mt, D, DFF))
+    for _ in range(L):  # GuidedEncoderLayer
+        bias.append((mv, 3 * D, D))
+        resid.append((mv, D, D))
+        bias.append((mv, D, D))
+        bias.append((mt, 2 * D, D))
+        resid.append((mv, D, D))
+        gelu.append((mv, DFF, D))
+        resid.append((mv, D, DFF))
+    return {"bias": bias, "gelu": gelu, "residual": resid}
+
+
+def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
+    """Time the dominant kernel family (forward MFMA GEMM with fused epilogue) over exactly the
+    launch list of one step, with HIP events on the launch stream."""
+    from openvivqa_amd import ops
+    fam = gemm_launch_list(B, NV, NT, D, DFF, L)
+    results = {}
+    for name, shapes in fam.items():
+        epi = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "residual": ops.EPI_BIAS_RESIDUAL}[name]
+        bufs = {}
+        for (M, N, K) in set(shapes):
+            x = torch.randn(M, K, device=device).bfloat16()
+            w = (torch.randn(N, K, device=device) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=device)
+            r = torch.randn(M, N, device=device).bfloat16()
+            y = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+            u = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+            bufs[(M, N, K)] = (x, w, b, r, y, u)
+
+        def run_all():
+            for s in shapes:
+                x, w, b, r, y, u = bufs[s]
+                ops.linear_fwd(x, w, b, epi, residual=r if name == "residual" else None, out=y,
+                               preact_out=u if name == "gelu" else None)
+        # replay the launch list from a hipGraph so that host launch latency is not what is timed
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run_all()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run_all()
+        g.replay()
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            g.replay()
+        e1.record(st)
+        torch.cuda.synchronize()
+        total_s = e0.elapsed_time(e1) * 1e-3 / reps
+        flops = sum(2.0 * M * N * K for (M, N, K) in shapes)
+        results[name] = dict(launches=len(shapes), time_s=total_s, flops=flops,
+                             avg_launch_us=total_s / len(shapes) * 1e6)
+    dom = max(results, key=lambda k: results[k]["time_s"])
+    r = results[dom]
+    achieved = r["flops"] / r["time_s"] / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
+        "kernel": f"gemm_nt_bf16_kernel<{dom}>", "launches_per_step": r["launches"],
+        "avg_launch_us": round(r["avg_launch_us"], 2),
+        "families": {k: {"avg_launch_us": round(v["avg_launch_us"], 2),
+                         "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in results.items()},
+    }
+
+
+def cpu_baseline(cfg, steps):
+    """The oracle (plain-PyTorch CPU restatement, fp32, train mode) on the same workload."""
+    import oracle as O
+    from openvivqa_amd.mcan_stack import synthetic_batch
+    b = cfg.BENCH
+    torch.manual_seed(0)
+    te = O.build_oracle_encoder(cfg.MODEL.SELF_ENCODER).train()
+    ve = O.build_oracle_encoder(cfg.MODEL.GUIDED_ENCODER).train()
+    params = list(te.parameters()) + list(ve.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98))
+    v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, cfg.MODEL.D_MODEL, b.MIN_REGIONS,
+                                   b.MIN_TOKENS, b.SEED, "cpu", torch.float32)
+
+    def one():
+        lo = te(t, tm)
+        vo = ve(v, vm, lo, tm)
+        loss = vo.pow(2).mean() + lo.pow(2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.item()
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(b.BATCH_PER_GPU / dt, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{steps} timed steps (+1 warm-up) of the full B={b.BATCH_PER_GPU} L=6 "
+            f"fwd+bwd+Adam step, fp32, train mode; {dt:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    else:
+        dist = None
+
+    import openvivqa_amd as A
+    from openvivqa_amd import ops
+    from openvivqa_amd.mcan_stack import MCANEncoderStack, synthetic_batch
+    from openvivqa_amd.train import TrainStep, noam_lr_scale
+
+    cfg = A.get_config(args.config)
+    b = cfg.BENCH
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    A.set_compute_dtype(dtype)
+    A.manual_seed(b.SEED + rank)
+    torch.manual_seed(b.SEED)  # identical initial weights on every rank
+    model = MCANEncoderStack(cfg.MODEL).to(device).train()
+    D = cfg.MODEL.D_MODEL
+    v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,
+                                   b.SEED + rank, device, dtype)
+    loss_buf = torch.zeros(1, device=device)
+
+    def forward_loss(v_, vm_, t_, tm_):
+        vo, lo = model(v_, vm_, t_, tm_)
+        dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss_buf, accumulate=False)
+        dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True)
+        return (vo, lo), (dvo, dlo)
+
+    comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
+    ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
+                   lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,
+                   comm_dtype=comm, compute_dtype=dtype)
+    ts.loss = loss_buf
+
+    for _ in range(args.warmup):
+        ts.step(v, vm, t, tm)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step(v, vm, t, tm)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = float(loss_buf.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * b.BATCH_PER_GPU * args.steps / dt
+        out = {
+            "metric": "VQA samples/sec fwd+bwd, MCAN d=512 L=6, B=64, 100 regions x 20 tokens",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: MCAN encoder stack (Encoder + GuidedAttentionEncoder) d=512 L=6 H=8 "
+                       "dff=2048, 64 samples/GPU x (100 regions + 20 tokens), padded lengths, dropout 0.1, "
+                       "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
+                       "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
+                       "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if world > 1 else None},
+            "final_loss": round(final_loss, 6),
+            "step_tflops": round(value * FLOPS_PER_SAMPLE_FWD_BWD / 1e12, 1),
+            "step_frac_of_bf16_peak": round(value * FLOPS_PER_SAMPLE_FWD_BWD / world / PEAK_BF16, 4),
+        }
+        if not args.no_roofline and args.dtype == "bf16":
+            sa = cfg.MODEL.SELF_ENCODER.SELF_ATTENTION
+            out["roofline"] = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
+                                             cfg.MODEL.SELF_ENCODER.LAYERS)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * ovqa_hip.h -- C ABI of the MI355X (gfx950) cross-modal attention hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its
+ * hot path is a chain of stock PyTorch ops inside Python modules.  Each entry
+ * point below replaces one such chain and cites it (paths are relative to the
+ * reference tree).  Signatures carry only plain pointers (device memory),
+ * sizes, strides and a HIP stream handle -- no torch types -- so any host
+ * (ctypes, pybind, cgo, JNI) can bind them; INTEGRATION.md shows the ctypes
+ * stub the Python host side uses.
+ *
+ * Conventions
+ *   - all tensors are row-major; `ld*` are row strides in ELEMENTS.
+ *   - dtype: OVQA_F32 (exact fp32 kernels) or OVQA_BF16 (bf16 storage, fp32
+ *     accumulation, MFMA contractions).  Weight/bias GRADIENTS, LayerNorm
+ *     statistics, log-sum-exp and masks are always fp32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Nothing here allocates, frees or synchronises: every entry point is
+ *     capturable into a hipGraph.  Scratch comes from the caller (`ws`).
+ *   - return value: OVQA_OK or a negative ovqa_status; ovqa_last_error() gives
+ *     a human-readable message for the calling thread.
+ *   - dropout: keep(element) is a pure function of (seed, site, *step_ptr,
+ *     element index) -- see ovqa_dropout_keep_mask -- so backward regenerates
+ *     the mask instead of storing it.  p == 0 disables it.
+ */
+#ifndef OVQA_HIP_H
+#define OVQA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVQA_ABI_VERSION 1
+
+typedef enum {
+  OVQA_OK = 0,
+  OVQA_ERR_BAD_ARG = -1,      /* null pointer, negative size, bad enum            */
+  OVQA_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover (documented) */
+  OVQA_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after a launch    */
+  OVQA_ERR_WORKSPACE = -4     /* caller-provided scratch too small                 */
+} ovqa_status;
+
+typedef enum { OVQA_F32 = 0, OVQA_BF16 = 1 } ovqa_dtype;
+
+/* Epilogues of ovqa_linear_fwd. */
+typedef enum {
+  OVQA_EPI_BIAS = 0,           /* y = xW^T + b                                   */
+  OVQA_EPI_BIAS_GELU = 1,      /* u = xW^T + b ; preact = u ; y = drop(gelu(u))  */
+  OVQA_EPI_BIAS_RESIDUAL = 2   /* y = residual + drop(xW^T + b)                  */
+} ovqa_epilogue;
+
+typedef struct {
+  float p;                 /* drop probability, 0 = off                        */
+  uint32_t seed;           /* per-process seed                                 */
+  uint32_t site;           /* unique id of the dropout call site               */
+  const uint32_t* step;    /* device pointer to the step counter (may be NULL) */
+} ovqa_dropout;
+
+int ovqa_abi_version(void);
+const char* ovqa_last_error(void);
+/* Scratch bytes the caller must provide to the entry points that take `ws`. */
+int64_t ovqa_workspace_bytes(void);
+
+/* ---------------------------------------------------------------------------
+ * nn.Linear forward (+ fused epilogue).
+ *   replaces: fc_q/fc_k/fc_v/fc_o  models/modules/attentions.py:49-51,58
+ *             fc1 + F.gelu + dropout_1, fc2 + dropout_2 + residual add
+ *                                   models/modules/positionwise_feed_forward.py:24-26
+ *             dropout + residual add of MultiHeadAttention  attentions.py:330-331
+ *             OcrPtrNet.query/key   models/mmf_m4c.py:376-389
+ *   x [M,K] (ldx), w [N,K] row-major ([out,in], the nn.Linear layout) of
+ *   `dtype`, bias fp32 [N] (may be NULL), y [M,N] (ldy).  `preact` [M,N]
+ *   (ld = N) receives u for BIAS_GELU (may be NULL when no backward is
+ *   needed).  `residual` [M,N] (ldres) for BIAS_RESIDUAL.
+ * ------------------------------------------------------------------------- */
+int ovqa_linear_fwd(int dtype, int epilogue,
+                    const void* x, int64_t ldx, const void* w, const float* bias,
+                    const void* residual, int64_t ldres,
+                    void* y, int64_t ldy, void* preact,
+                    int64_t M, int64_t N, int64_t K,
+                    const ovqa_dropout* drop, void* stream);
+
+/* dX = dY W  (autograd of nn.Linear w.r.t. its input).
+ *   dy [M,N] (lddy), w [N,K], dx [M,K] (lddx).
+ *   If `gelu_preact` != NULL the FFN backward is fused:
+ *       dx = (dY W) * dropmask/(1-p) * gelu'(gelu_preact)      (fc2 -> fc1 seam,
+ *       positionwise_feed_forward.py:24-25), with `drop` describing dropout_1.
+ *   If `accumulate` != 0, dx += result (dtype of dx). */
+int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
+                         void* dx, int64_t lddx, const void* gelu_preact,
+                         int64_t M, int64_t N, int64_t K, int accumulate,
+                         const ovqa_dropout* drop, void* stream);
+
+/* dW = dY^T X (fp32 [N,K]), db = column sums of dY (fp32 [N], may be NULL).
+ *   accumulate != 0 adds into dw/db, otherwise overwrites.
+ *   ws: scratch of ovqa_workspace_bytes(). */
+int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy,
+                           const void* x, int64_t ldx, float* dw, float* db,
+                           int64_t M, int64_t N, int64_t K, int accumulate,
+                           void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * LayerNorm over the last dim (+ optional positional table add).
+ *   replaces: nn.LayerNorm in MultiHeadAttention / PositionWiseFeedForward
+ *             (attentions.py:312,331; positionwise_feed_forward.py:21,26) and
+ *             the encoder prologue LN(x) + SinusoidPositionalEmbedding(x)
+ *             (encoders.py:113,154,192-193,243-244; pos_embeddings.py:58-72).
+ *   x [M,D] of `in_dtype`, y [M,D] of `dtype`; gamma/beta fp32 [D];
+ *   mean/rstd fp32 [M] (saved for backward, may be NULL);
+ *   pos fp32 [pos_rows, D] or NULL: y[m] += pos[m % pos_rows].
+ * ------------------------------------------------------------------------- */
+int ovqa_layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma,
+                       const float* beta, const float* pos, int64_t pos_rows,
+                       void* y, float* mean, float* rstd,
+                       int64_t M, int64_t D, float eps, void* stream);
+
+/* dx = LN backward; dgamma/dbeta fp32 [D] (accumulate flag as above).
+ *   If drop != NULL and drop->p > 0, `dx_dropped` [M,D] additionally receives
+ *   dx * keep/(1-p): the gradient flowing into the branch that went through
+ *   dropout before the residual add (attentions.py:330, pwff.py:25).
+ *   dx_dtype is the dtype of dx (fp32 for the prologue whose input was fp32). */
+int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype,
+                       const float* gamma, const float* mean, const float* rstd,
+                       void* dx, void* dx_dropped, float* dgamma, float* dbeta,
+                       int64_t M, int64_t D, int accumulate,
+                       const ovqa_dropout* drop, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Attention core: softmax(q k^T * scale + mask) v, all heads of all samples.
+ *   replaces: ScaledDotProductAttention.forward  attentions.py:49-57 (the
+ *             permutes are folded into addressing: q/k/v/o are indexed as
+ *             [b, n, h*d + c] with row strides ld*, so the kernels read the
+ *             projection outputs in place -- also from a packed QKV buffer).
+ *   mask: fp32 additive, element (b,h,i,j) at mask[b*msb + h*msh + i*msq + j]
+ *         (strides 0 broadcast; NULL = no mask).  Mask value semantics follow
+ *         models/utils.py:44-73 (-1e5, not -inf: fully masked rows give a
+ *         uniform distribution).
+ *   lse fp32 [B,H,nq] (may be NULL); att [B,H,nq,nk] probabilities of `dtype`
+ *   (NULL unless the caller wants the second return value of the reference).
+ * ------------------------------------------------------------------------- */
+int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                       const void* v, int64_t ldv, const float* mask,
+                       int64_t msb, int64_t msh, int64_t msq,
+                       void* o, int64_t ldo, float* lse, void* att,
+                       int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
+                       float scale, void* stream);
+
+/* Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
+ * the caller (rowsum(dO*O)); dq/dk/dv use the same [b,n,h*d+c] addressing. */
+int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo,
+                       const void* q, int64_t ldq, const void* k, int64_t ldk,
+                       const void* v, int64_t ldv, const void* o, int64_t ldo,
+                       const float* lse, const float* mask,
+                       int64_t msb, int64_t msh, int64_t msq,
+                       void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv,
+                       float* delta,
+                       int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
+                       float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Pointer scorer: scores[b,t,n] = q[b,t,:].k[b,n,:] * scale (+ mask | -inf fill).
+ *   replaces: OcrPtrNet.forward  models/mmf_m4c.py:391-394 (additive mask) and
+ *             DynamicPointerNetwork.forward  models/m4c.py:30-31 (key-axis
+ *             -inf fill), models/iterative_m4c.py:29-30 (query-axis fill).
+ *   add_mask fp32 [B,n] or NULL; key_fill / query_fill uint8 [B,n] / [B,t] or
+ *   NULL (non-zero => -inf).  scores fp32 [B,t,n].  Backward = two calls of
+ *   ovqa_batched_gemm.
+ * ------------------------------------------------------------------------- */
+int ovqa_pointer_score(int dtype, const void* q, const void* k, const float* add_mask,
+                       const uint8_t* key_fill, const uint8_t* query_fill, float* scores,
+                       int64_t B, int64_t T, int64_t Nk, int64_t D, float scale, void* stream);
+
+/* C[b] = alpha * op(A[b]) op(B[b])  (batched, strided; C of c_dtype). */
+int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b,
+                      const void* A, int64_t lda, int64_t stride_a,
+                      const void* Bm, int64_t ldb, int64_t stride_b,
+                      void* C, int64_t ldc, int64_t stride_c,
+                      int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimiser step on a flat parameter arena (row T of SURVEY 8a):
+ *   Adam(betas) exactly as torch.optim.Adam (tasks/base_task.py:46) on fp32
+ *   master weights; also refreshes the bf16 shadow copy used by the kernels.
+ *   lr_scale_ptr / step_ptr are device scalars so a captured graph can replay
+ *   with a schedule (tasks/base_task.py:73-76).  grad_scale multiplies g first
+ *   (1/world_size after a sum all-reduce).
+ * ------------------------------------------------------------------------- */
+int ovqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   void* shadow_bf16, int64_t n, float lr, const float* lr_scale_ptr,
+                   float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, const uint32_t* step_ptr, void* stream);
+
+/* step counter++ (device side, inside the graph) */
+int ovqa_increment_step(uint32_t* step_ptr, void* stream);
+
+/* fp32 -> bf16 / bf16 -> fp32 flat casts (shadow refresh after load_state_dict). */
+int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+
+/* Materialise the dropout keep-mask the fused kernels use (tests, debugging):
+ * out[i] = 1 if element i of a [rows, cols] site is kept. */
+int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream);
+
+/* mean-of-squares loss used by the stack-level bench harness:
+ * loss += sum(x^2)/n (fp32 scalar, device), dx = 2*x/n * loss_scale. */
+int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n,
+                         int accumulate_loss, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVQA_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libovqa_hip.so (the C ABI in include/ovqa_hip.h).
+
+There is deliberately no fallback: if the library is missing or a kernel
+reports an error, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
+
+OVQA_F32, OVQA_BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+ABI_VERSION = 1
+
+c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("step", C.c_void_p)]
+
+
+_DP = C.POINTER(Dropout)
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "ovqa_abi_version": [],
+    "ovqa_last_error": [],
+    "ovqa_workspace_bytes": [],
+    "ovqa_linear_fwd": [c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                        c_i64, c_i64, c_i64, _DP, c_vp],
+    "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, _DP, c_vp],
+    "ovqa_linear_bwd_weight": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],
+    "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_layernorm_bwd": [c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                           c_i64, c_i64, c_int, _DP, c_vp, c_vp],
+    "ovqa_attention_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
+                           c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                           c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
+                           c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_pointer_score": [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_batched_gemm": [c_int, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
+                          c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
+    "ovqa_increment_step": [c_vp, c_vp],
+    "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],
+    "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
+    "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+}
+_RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_workspace_bytes": C.c_int64}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load the shared library and declare every prototype.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"HIP kernel library not found at {p}; build it with "
+                "`python -m openvivqa_amd.build` (needs hipcc, targets gfx950). There is no CPU fallback.")
+        lib = C.CDLL(p)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        got = lib.ovqa_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libovqa_hip.so ABI version {got} != expected {ABI_VERSION}; rebuild")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ovqa_last_error()
+        raise RuntimeError(f"ovqa kernel error {rc} in {what}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,188 @@
+// extern "C" entry points of libovqa_hip.so (declared in include/ovqa_hip.h).
+// Validates arguments, then routes OVQA_F32 to the exact-fp32 kernels and
+// OVQA_BF16 to the MFMA kernels (falling back to the bf16 instantiation of the
+// reference-grade kernels only for shapes the MFMA kernels do not tile, or when
+// OVQA_FORCE_SIMPLE=1 is set for A/B debugging -- both are HIP kernels, there
+// is no CPU path in this library).
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void ovqa_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static bool force_simple() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_FORCE_SIMPLE");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+static inline bool dtype_ok(int d) { return d == OVQA_F32 || d == OVQA_BF16; }
+
+extern "C" {
+
+int ovqa_abi_version(void) { return OVQA_ABI_VERSION; }
+const char* ovqa_last_error(void) { return g_err; }
+int64_t ovqa_workspace_bytes(void) { return ovqa::kWorkspaceBytes; }
+
+int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
+                    const void* residual, int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N,
+                    int64_t K, const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_fwd: bad dtype %d", dtype);
+  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_fwd: bad sizes M=%lld N=%lld K=%lld", (long long)M,
+               (long long)N, (long long)K);
+  if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && w && y, OVQA_ERR_BAD_ARG, "linear_fwd: null pointer");
+  OVQA_REQUIRE(ldx >= K && ldy >= N, OVQA_ERR_BAD_ARG, "linear_fwd: ldx/ldy smaller than the row length");
+  OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_fwd: more than 2^32 elements");
+  const DropArgs da = make_drop_args(drop);
+  hipStream_t st = as_stream(stream);
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_fwd_supported(epilogue, M, N, K, ldx, ldy, ldres))
+    return ovqa::mfma_linear_fwd(epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
+  return ovqa::simple_linear_fwd(dtype, epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
+}
+
+int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
+                         const void* gelu_preact, int64_t M, int64_t N, int64_t K, int accumulate,
+                         const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_bwd_data: bad dtype %d", dtype);
+  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_bwd_data: bad sizes");
+  if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(dy && w && dx, OVQA_ERR_BAD_ARG, "linear_bwd_data: null pointer");
+  OVQA_REQUIRE(lddy >= N && lddx >= K, OVQA_ERR_BAD_ARG, "linear_bwd_data: ld smaller than the row length");
+  return ovqa::simple_linear_bwd_data(dtype, dy, lddy, w, dx, lddx, gelu_preact, M, N, K, accumulate,
+                                      make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db,
+                           int64_t M, int64_t N, int64_t K, int accumulate, void* ws, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_bwd_weight: bad dtype %d", dtype);
+  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_bwd_weight: bad sizes");
+  OVQA_REQUIRE(dw != nullptr, OVQA_ERR_BAD_ARG, "linear_bwd_weight: dw is NULL");
+  OVQA_REQUIRE(M == 0 || (dy && x), OVQA_ERR_BAD_ARG, "linear_bwd_weight: null pointer");
+  (void)ws;
+  return ovqa::simple_linear_bwd_weight(dtype, dy, lddy, x, ldx, dw, db, M, N, K, accumulate, as_stream(stream));
+}
+
+int ovqa_layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta,
+                       const float* pos, int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D,
+                       float eps, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(in_dtype), OVQA_ERR_BAD_ARG, "layernorm_fwd: bad dtype");
+  OVQA_REQUIRE(M >= 0 && D > 0, OVQA_ERR_BAD_ARG, "layernorm_fwd: bad sizes");
+  OVQA_REQUIRE(M == 0 || (x && gamma && beta && y), OVQA_ERR_BAD_ARG, "layernorm_fwd: null pointer");
+  OVQA_REQUIRE(pos == nullptr || pos_rows > 0, OVQA_ERR_BAD_ARG, "layernorm_fwd: pos_rows must be > 0");
+  return ovqa::layernorm_fwd(dtype, in_dtype, x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps,
+                             as_stream(stream));
+}
+
+int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,
+                       const float* mean, const float* rstd, void* dx, void* dx_dropped, float* dgamma, float* dbeta,
+                       int64_t M, int64_t D, int accumulate, const ovqa_dropout* drop, void* ws, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(dx_dtype) && dtype_ok(x_dtype), OVQA_ERR_BAD_ARG, "layernorm_bwd: bad dtype");
+  OVQA_REQUIRE(M >= 0 && D > 0, OVQA_ERR_BAD_ARG, "layernorm_bwd: bad sizes");
+  OVQA_REQUIRE(M == 0 || (dy && x && gamma && mean && rstd && dx), OVQA_ERR_BAD_ARG, "layernorm_bwd: null pointer");
+  OVQA_REQUIRE(M * D < (1ll << 32), OVQA_ERR_UNSUPPORTED, "layernorm_bwd: more than 2^32 elements");
+  DropArgs da = make_drop_args(drop);
+  if (da.p <= 0.f) dx_dropped = nullptr;
+  return ovqa::layernorm_bwd(dtype, dx_dtype, dy, x, x_dtype, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D,
+                             accumulate, da, ws, as_stream(stream));
+}
+
+int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       const float* mask, int64_t msb, int64_t msh, int64_t msq, void* o, int64_t ldo, float* lse,
+                       void* att, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv, float scale,
+                       void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_fwd: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_fwd: bad sizes");
+  if (B == 0 || nq == 0) return OVQA_OK;
+  OVQA_REQUIRE(q && k && v && o, OVQA_ERR_BAD_ARG, "attention_fwd: null pointer");
+  OVQA_REQUIRE(ldq >= H * dk && ldk >= H * dk && ldv >= H * dv && ldo >= H * dv, OVQA_ERR_BAD_ARG,
+               "attention_fwd: row stride smaller than H*d");
+  OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_fwd: B*H too large");
+  ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, msq, o, ldo, lse, att,
+                   (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+  return ovqa::simple_attention_fwd(dtype, a, as_stream(stream));
+}
+
+int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                       const void* v, int64_t ldv, const void* o, int64_t ldo, const float* lse, const float* mask,
+                       int64_t msb, int64_t msh, int64_t msq, void* dq, int64_t lddq, void* dk_, int64_t lddk,
+                       void* dv_, int64_t lddv, float* delta, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk,
+                       int64_t dv, float scale, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_bwd: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_bwd: bad sizes");
+  if (B == 0 || nq == 0) return OVQA_OK;
+  OVQA_REQUIRE(d_o && q && k && v && o && dq && dk_ && dv_, OVQA_ERR_BAD_ARG, "attention_bwd: null pointer");
+  ovqa::AttnBwdArgs a{d_o, q, k, v, o, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
+                      lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+  return ovqa::simple_attention_bwd(dtype, a, as_stream(stream));
+}
+
+int ovqa_pointer_score(int dtype, const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,
+                       const uint8_t* query_fill, float* scores, int64_t B, int64_t T, int64_t Nk, int64_t D,
+                       float scale, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "pointer_score: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && T >= 0 && Nk >= 0 && D > 0, OVQA_ERR_BAD_ARG, "pointer_score: bad sizes");
+  if (B == 0 || T == 0 || Nk == 0) return OVQA_OK;
+  OVQA_REQUIRE(q && k && scores, OVQA_ERR_BAD_ARG, "pointer_score: null pointer");
+  return ovqa::simple_pointer_score(dtype, q, k, add_mask, key_fill, query_fill, scores, B, T, Nk, D, scale,
+                                    as_stream(stream));
+}
+
+int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b, const void* A, int64_t lda, int64_t stride_a,
+                      const void* Bm, int64_t ldb, int64_t stride_b, void* C, int64_t ldc, int64_t stride_c,
+                      int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(c_dtype), OVQA_ERR_BAD_ARG, "batched_gemm: bad dtype");
+  OVQA_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, OVQA_ERR_BAD_ARG, "batched_gemm: bad sizes");
+  if (batch == 0 || M == 0 || N == 0) return OVQA_OK;
+  OVQA_REQUIRE(A && Bm && C, OVQA_ERR_BAD_ARG, "batched_gemm: null pointer");
+  return ovqa::simple_batched_gemm(dtype, c_dtype, trans_a, trans_b, A, lda, stride_a, Bm, ldb, stride_b, C, ldc,
+                                   stride_c, batch, M, N, K, alpha, as_stream(stream));
+}
+
+int ovqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                   float lr, const float* lr_scale_ptr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, const uint32_t* step_ptr, void* stream) {
+  OVQA_REQUIRE(n >= 0, OVQA_ERR_BAD_ARG, "adam_step: bad n");
+  OVQA_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), OVQA_ERR_BAD_ARG, "adam_step: null pointer");
+  return ovqa::adam_step(param, grad, exp_avg, exp_avg_sq, shadow_bf16, n, lr, lr_scale_ptr, beta1, beta2, eps,
+                         weight_decay, grad_scale, step_ptr, as_stream(stream));
+}
+
+int ovqa_increment_step(uint32_t* step_ptr, void* stream) {
+  OVQA_REQUIRE(step_ptr, OVQA_ERR_BAD_ARG, "increment_step: null pointer");
+  return ovqa::increment_step(step_ptr, as_stream(stream));
+}
+
+int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+  OVQA_REQUIRE(n >= 0, OVQA_ERR_BAD_ARG, "cast: bad n");
+  OVQA_REQUIRE(n == 0 || (src && dst), OVQA_ERR_BAD_ARG, "cast: null pointer");
+  return ovqa::cast(src_dtype, dst_dtype, src, dst, n, as_stream(stream));
+}
+
+int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream) {
+  OVQA_REQUIRE(drop && out && n >= 0, OVQA_ERR_BAD_ARG, "dropout_keep_mask: bad argument");
+  OVQA_REQUIRE(n < (1ll << 32), OVQA_ERR_UNSUPPORTED, "dropout_keep_mask: more than 2^32 elements");
+  return ovqa::dropout_keep_mask(make_drop_args(drop), out, n, as_stream(stream));
+}
+
+int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss,
+                         void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "sq_loss: bad dtype");
+  OVQA_REQUIRE(x && loss, OVQA_ERR_BAD_ARG, "sq_loss: null pointer");
+  return ovqa::sq_loss_fwd_bwd(dtype, x, dx, loss, n, accumulate_loss, as_stream(stream));
+}
+
+}  // extern "C"

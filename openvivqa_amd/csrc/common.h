@@ -1,0 +1,111 @@
+// Shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ovqa_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+
+// ---- host-side error plumbing -------------------------------------------
+void ovqa_set_error(const char* fmt, ...);
+#define OVQA_REQUIRE(cond, code, ...)          \
+  do {                                         \
+    if (!(cond)) {                             \
+      ovqa_set_error(__VA_ARGS__);             \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+static inline int ovqa_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ovqa_set_error("%s: %s", what, hipGetErrorString(e));
+    return OVQA_ERR_LAUNCH;
+  }
+  return OVQA_OK;
+}
+
+// ---- scalar conversion -----------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---- wave reductions (64-wide) --------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- dropout: stateless counter hash ---------------------------------------
+// keep(idx) is a pure function of (seed, site, step, idx); forward and backward
+// regenerate it.  fmix32 of murmur3 over idx * golden ^ key.
+struct DropState {
+  uint32_t key;
+  uint32_t thresh;  // drop iff hash < thresh
+  float inv_keep;   // 1/(1-p)
+  bool on;
+};
+__host__ __device__ __forceinline__ uint32_t ovqa_fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+struct DropArgs {  // by-value kernel argument
+  float p;
+  uint32_t seed;
+  uint32_t site;
+  const uint32_t* step;
+};
+static inline DropArgs make_drop_args(const ovqa_dropout* d) {
+  DropArgs a{0.f, 0u, 0u, nullptr};
+  if (d) { a.p = d->p; a.seed = d->seed; a.site = d->site; a.step = d->step; }
+  return a;
+}
+__device__ __forceinline__ DropState drop_init(const DropArgs& a) {
+  DropState s;
+  s.on = a.p > 0.f;
+  uint32_t step = (a.step != nullptr) ? *a.step : 0u;
+  s.key = ovqa_fmix32(a.seed ^ ovqa_fmix32(a.site * 0x9E3779B1u + step * 0x7F4A7C15u + 0x1234567u));
+  double t = (double)a.p * 4294967296.0;
+  s.thresh = (a.p >= 1.f) ? 0xFFFFFFFFu : (uint32_t)t;
+  s.inv_keep = (a.p < 1.f) ? 1.f / (1.f - a.p) : 0.f;
+  return s;
+}
+__device__ __forceinline__ bool drop_keep(const DropState& s, uint32_t idx) {
+  return ovqa_fmix32(idx * 0x9E3779B1u ^ s.key) >= s.thresh;
+}
+// multiplier applied to a value that went through dropout (1 when off)
+__device__ __forceinline__ float drop_mul(const DropState& s, uint32_t idx) {
+  if (!s.on) return 1.f;
+  return drop_keep(s, idx) ? s.inv_keep : 0.f;
+}
+
+// ---- exact GELU (erf form, F.gelu default) ----------------------------------
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+  const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

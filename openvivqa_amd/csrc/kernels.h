@@ -1,0 +1,75 @@
+// Internal (C++) interface between api.hip and the kernel translation units.
+#pragma once
+#include "common.h"
+
+namespace ovqa {
+
+constexpr int64_t kWorkspaceBytes = 64ll << 20;  // scratch the caller provides (`ws`)
+
+// ---- gemm_simple.hip (exact fp32 path, also instantiated for bf16) ----------
+int simple_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
+                      const void* residual, int64_t ldres, void* y, int64_t ldy, void* preact,
+                      int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
+int simple_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
+                           const void* preact, int64_t M, int64_t N, int64_t K, int accumulate,
+                           const DropArgs& da, hipStream_t st);
+int simple_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
+                             float* db, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t st);
+int simple_batched_gemm(int dtype, int c_dtype, int ta, int tb, const void* A, int64_t lda, int64_t sa,
+                        const void* B, int64_t ldb, int64_t sb, void* C, int64_t ldc, int64_t sc, int64_t batch,
+                        int64_t M, int64_t N, int64_t K, float alpha, hipStream_t st);
+int simple_pointer_score(int dtype, const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,
+                         const uint8_t* query_fill, float* scores, int64_t B, int64_t T, int64_t Nk, int64_t D,
+                         float scale, hipStream_t st);
+
+// ---- attention_simple.hip ----------------------------------------------------
+struct AttnArgs {
+  const void *q, *k, *v;
+  int64_t ldq, ldk, ldv;
+  const float* mask;
+  int64_t msb, msh, msq;
+  void* o;
+  int64_t ldo;
+  float* lse;
+  void* att;
+  int B, H, nq, nk, dk, dv;
+  float scale;
+};
+struct AttnBwdArgs {
+  const void *d_o, *q, *k, *v, *o;
+  int64_t lddo, ldq, ldk, ldv, ldo;
+  const float *lse, *mask;
+  int64_t msb, msh, msq;
+  void *dq, *dk_, *dv_;
+  int64_t lddq, lddk, lddv;
+  float* delta;
+  int B, H, nq, nk, dk, dv;
+  float scale;
+};
+int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
+int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);
+
+// ---- layernorm.hip -----------------------------------------------------------
+int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta, const float* pos,
+                  int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                  hipStream_t st);
+int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,
+                  const float* mean, const float* rstd, void* dx, void* dx_dropped, float* dgamma, float* dbeta,
+                  int64_t M, int64_t D, int accumulate, const DropArgs& da, void* ws, hipStream_t st);
+
+// ---- misc.hip ------------------------------------------------------------------
+int adam_step(float* param, const float* grad, float* m, float* v, void* shadow, int64_t n, float lr,
+              const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
+              const uint32_t* step_ptr, hipStream_t st);
+int increment_step(uint32_t* step_ptr, hipStream_t st);
+int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st);
+int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st);
+int sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss, hipStream_t st);
+
+// ---- gemm_mfma.hip / attention_mfma.hip (bf16, MFMA) ---------------------------
+bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldres);
+int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
+                    int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
+                    const DropArgs& da, hipStream_t st);
+
+}  // namespace ovqa

@@ -1,0 +1,292 @@
+// LayerNorm forward/backward (one wavefront per row, rows cached in registers),
+// fused with the positional-table add of the encoder prologue and with the
+// dropout mask of the residual branch in backward.  HBM-bound: vectorised
+// 16-byte loads, wave-shuffle row reductions, no LDS in the forward.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int VEC = 8;        // elements per lane per chunk
+constexpr int MAX_CHUNKS = 4; // D <= 64*8*4 = 2048
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[VEC]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&o)[VEC]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[VEC]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < VEC; i++) o[i] = (float)a[i];
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[VEC]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[VEC]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[VEC]) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < VEC; i++) a[i] = (bf16)v[i];
+  *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+// ---------------------------------------------------------------- forward
+template <typename TIN, typename TOUT, int CHUNKS>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ pos,
+                                                     int pos_rows, TOUT* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TIN* xr = x + (int64_t)row * D;
+  float v[CHUNKS][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const int col = (c * 64 + lane) * VEC;
+    if (col < D) {
+      load8<TIN>(xr + col, v[c]);
+#pragma unroll
+      for (int i = 0; i < VEC; i++) s += v[c][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; i++) v[c][i] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const int col = (c * 64 + lane) * VEC;
+    if (col < D) {
+#pragma unroll
+      for (int i = 0; i < VEC; i++) {
+        const float d = v[c][i] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  TOUT* yr = y + (int64_t)row * D;
+  const float* pr = pos ? pos + (int64_t)(row % pos_rows) * D : nullptr;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const int col = (c * 64 + lane) * VEC;
+    if (col < D) {
+      float g[VEC], b[VEC], o[VEC];
+      load8<float>(gamma + col, g);
+      load8<float>(beta + col, b);
+#pragma unroll
+      for (int i = 0; i < VEC; i++) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+      if (pr) {
+        float p[VEC];
+        load8<float>(pr + col, p);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] += p[i];
+      }
+      store8<TOUT>(yr + col, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// Each wave walks rows (row = wave_global, += total_waves); per-lane column
+// partials of dgamma/dbeta stay in registers, are combined across the block's
+// 4 waves through LDS and written to ws[block][2][D]; ln_bwd_reduce sums them.
+template <typename TDY, typename TX, typename TDX, int CHUNKS>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, TDX* __restrict__ dx,
+                                                     TDY* __restrict__ dx_dropped, float* __restrict__ partial,
+                                                     int M, int D, DropArgs da) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int total_waves = gridDim.x * 4;
+  const DropState ds = drop_init(da);
+  float dg[CHUNKS][VEC], db[CHUNKS][VEC], g[CHUNKS][VEC];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const int col = (c * 64 + lane) * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
+    if (col < D) load8<float>(gamma + col, g[c]);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += total_waves) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[CHUNKS][VEC], d[CHUNKS][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        load8<TX>(x + (int64_t)row * D + col, xh[c]);
+        load8<TDY>(dy + (int64_t)row * D + col, d[c]);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          xh[c][i] = (xh[c][i] - mu) * rs;
+          dg[c][i] += d[c][i] * xh[c][i];
+          db[c][i] += d[c][i];
+          d[c][i] *= g[c][i];
+          s1 += d[c][i];
+          s2 += d[c][i] * xh[c][i];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        float o[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = rs * (d[c][i] - c1 - xh[c][i] * c2);
+        store8<TDX>(dx + (int64_t)row * D + col, o);
+        if (dx_dropped) {
+#pragma unroll
+          for (int i = 0; i < VEC; i++) o[i] *= drop_mul(ds, (uint32_t)row * (uint32_t)D + col + i);
+          store8<TDY>(dx_dropped + (int64_t)row * D + col, o);
+        }
+      }
+    }
+  }
+  // combine the 4 waves of the block
+  if (wave > 0) {
+    float* s = smem + (int64_t)(wave - 1) * 2 * D;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        store8<float>(s + col, dg[c]);
+        store8<float>(s + D + col, db[c]);
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + (int64_t)blockIdx.x * 2 * D;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        for (int w = 0; w < 3; w++) {
+          float a[VEC], b[VEC];
+          load8<float>(smem + (int64_t)w * 2 * D + col, a);
+          load8<float>(smem + (int64_t)w * 2 * D + D + col, b);
+#pragma unroll
+          for (int i = 0; i < VEC; i++) { dg[c][i] += a[i]; db[c][i] += b[i]; }
+        }
+        store8<float>(out + col, dg[c]);
+        store8<float>(out + D + col, db[c]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // over 2*D
+  if (i >= 2 * D) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * 2 * D + i];
+  float* base = (i < D) ? dgamma : dbeta;
+  if (base == nullptr) return;
+  float* dst = base + ((i < D) ? i : i - D);
+  *dst = accumulate ? (*dst + s) : s;
+}
+
+template <typename TIN, typename TOUT>
+int fwd_dispatch(const void* x, const float* gamma, const float* beta, const float* pos, int64_t pos_rows, void* y,
+                 float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
+  const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
+  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define LN_FWD(C)                                                                                              \
+  hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, C>), grid, block, 0, st, (const TIN*)x, gamma, beta, pos,      \
+                     (int)(pos ? pos_rows : 1), (TOUT*)y, mean, rstd, (int)M, (int)D, eps)
+  switch (chunks) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    default: LN_FWD(4); break;
+  }
+#undef LN_FWD
+  return ovqa_check_launch("layernorm_fwd");
+}
+
+template <typename TDY, typename TX, typename TDX>
+int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                 void* dx_dropped, float* dgamma, float* dbeta, int64_t M, int64_t D, int accumulate,
+                 const DropArgs& da, void* ws, hipStream_t st) {
+  const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
+  int nblocks = (int)((M + 3) / 4);
+  if (nblocks > 512) nblocks = 512;
+  OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
+  float* partial = (float*)ws;
+  const size_t smem = (size_t)3 * 2 * D * sizeof(float);
+#define LN_BWD(C)                                                                                            \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C>), dim3(nblocks), dim3(256), smem, st, (const TDY*)dy,   \
+                     (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
+  switch (chunks) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    default: LN_BWD(4); break;
+  }
+#undef LN_BWD
+  int rc = ovqa_check_launch("layernorm_bwd");
+  if (rc != OVQA_OK) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(256), 0, st, partial, nblocks,
+                     (int)D, dgamma, dbeta, accumulate);
+  return ovqa_check_launch("layernorm_bwd_reduce");
+}
+
+}  // namespace
+
+namespace ovqa {
+
+int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta, const float* pos,
+                  int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                  hipStream_t st) {
+  OVQA_REQUIRE(D % VEC == 0 && D <= 64 * VEC * MAX_CHUNKS, OVQA_ERR_UNSUPPORTED,
+               "layernorm: D=%lld must be a multiple of 8 and <= 2048", (long long)D);
+  if (M == 0) return OVQA_OK;
+  if (dtype == OVQA_F32 && in_dtype == OVQA_F32)
+    return fwd_dispatch<float, float>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+  if (dtype == OVQA_BF16 && in_dtype == OVQA_BF16)
+    return fwd_dispatch<bf16, bf16>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+  if (dtype == OVQA_BF16 && in_dtype == OVQA_F32)
+    return fwd_dispatch<float, bf16>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+  ovqa_set_error("layernorm_fwd: unsupported dtype combination in=%d out=%d", in_dtype, dtype);
+  return OVQA_ERR_UNSUPPORTED;
+}
+
+int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,
+                  const float* mean, const float* rstd, void* dx, void* dx_dropped, float* dgamma, float* dbeta,
+                  int64_t M, int64_t D, int accumulate, const DropArgs& da, void* ws, hipStream_t st) {
+  OVQA_REQUIRE(D % VEC == 0 && D <= 64 * VEC * MAX_CHUNKS, OVQA_ERR_UNSUPPORTED,
+               "layernorm: D=%lld must be a multiple of 8 and <= 2048", (long long)D);
+  OVQA_REQUIRE(ws != nullptr, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws is NULL");
+  if (M == 0) return OVQA_OK;
+  if (dtype == OVQA_F32 && x_dtype == OVQA_F32 && dx_dtype == OVQA_F32)
+    return bwd_dispatch<float, float, float>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
+  if (dtype == OVQA_BF16 && x_dtype == OVQA_BF16 && dx_dtype == OVQA_BF16)
+    return bwd_dispatch<bf16, bf16, bf16>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
+  if (dtype == OVQA_BF16 && x_dtype == OVQA_F32 && dx_dtype == OVQA_F32)
+    return bwd_dispatch<bf16, float, float>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
+  ovqa_set_error("layernorm_bwd: unsupported dtype combination dy=%d x=%d dx=%d", dtype, x_dtype, dx_dtype);
+  return OVQA_ERR_UNSUPPORTED;
+}
+
+}  // namespace ovqa

@@ -1,0 +1,170 @@
+// Flat-arena optimiser step, casts, dropout-mask materialisation and the
+// stack-level bench loss.  All HBM-bound streaming kernels: 16-byte accesses,
+// grid-stride, <= 2048 workgroups.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16* __restrict__ shadow, int64_t n, float lr,
+                                                   const float* __restrict__ lr_scale_ptr, float b1, float b2,
+                                                   float eps, float wd, float grad_scale,
+                                                   const uint32_t* __restrict__ step_ptr) {
+  const float t = (float)(step_ptr ? *step_ptr : 1u);
+  const float lr_eff = lr * (lr_scale_ptr ? *lr_scale_ptr : 1.f);
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2 = 1.f - powf(b2, t);
+  const float step_size = lr_eff / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x;
+    const float* ga = &gg.x;
+    float* ma = &mm.x;
+    float* va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float gk = ga[k] * grad_scale + wd * pa[k];
+      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
+      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
+      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
+      pa[k] -= step_size * ma[k] / denom;
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (shadow) {
+      bf16x4 s;
+#pragma unroll
+      for (int k = 0; k < 4; k++) s[k] = (bf16)pa[k];
+      reinterpret_cast<bf16x4*>(shadow)[i] = s;
+    }
+  }
+  // tail (n not a multiple of 4)
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gk = g[i] * grad_scale + wd * p[i];
+    const float mk = b1 * m[i] + (1.f - b1) * gk;
+    const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk;
+    v[i] = vk;
+    const float pk = p[i] - step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
+    p[i] = pk;
+    if (shadow) shadow[i] = (bf16)pk;
+  }
+}
+
+__global__ void increment_kernel(uint32_t* s) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *s = *s + 1u;
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+
+__global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __restrict__ out, int64_t n) {
+  const DropState ds = drop_init(da);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (!ds.on || drop_keep(ds, (uint32_t)i)) ? 1 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, T* __restrict__ dx,
+                                                      float* __restrict__ loss, int64_t n) {
+  __shared__ float red[4];
+  const float inv_n = 1.f / (float)n;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = to_f32<T>(x[i]);
+    s += v * v;
+    if (dx) dx[i] = from_f32<T>(2.f * v * inv_n);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+inline int blocks_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+namespace ovqa {
+
+int adam_step(float* param, const float* grad, float* m, float* v, void* shadow, int64_t n, float lr,
+              const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
+              const uint32_t* step_ptr, hipStream_t st) {
+  if (n == 0) return OVQA_OK;
+  OVQA_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                   ((uintptr_t)v % 16 == 0) && (shadow == nullptr || (uintptr_t)shadow % 8 == 0),
+               OVQA_ERR_BAD_ARG, "adam_step: arena pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, grad, m, v, (bf16*)shadow, n,
+                     lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
+  return ovqa_check_launch("adam_step");
+}
+
+int increment_step(uint32_t* step_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, st, step_ptr);
+  return ovqa_check_launch("increment_step");
+}
+
+int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st) {
+  if (n == 0) return OVQA_OK;
+  dim3 grid(blocks_for(n)), block(256);
+  if (src_dtype == OVQA_F32 && dst_dtype == OVQA_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, block, 0, st, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == OVQA_BF16 && dst_dtype == OVQA_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, block, 0, st, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == OVQA_F32 && dst_dtype == OVQA_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dtype == OVQA_BF16 && dst_dtype == OVQA_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)src, (bf16*)dst, n);
+  else {
+    ovqa_set_error("cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    return OVQA_ERR_BAD_ARG;
+  }
+  return ovqa_check_launch("cast");
+}
+
+int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st) {
+  if (n == 0) return OVQA_OK;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, st, da, out, n);
+  return ovqa_check_launch("dropout_keep_mask");
+}
+
+int sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss, hipStream_t st) {
+  OVQA_REQUIRE(n > 0, OVQA_ERR_BAD_ARG, "sq_loss: n must be > 0");
+  if (!accumulate_loss) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (e != hipSuccess) {
+      ovqa_set_error("sq_loss: hipMemsetAsync: %s", hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+  }
+  dim3 grid(blocks_for(n) > 512 ? 512 : blocks_for(n)), block(256);
+  if (dtype == OVQA_F32)
+    hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (float*)dx, loss, n);
+  else
+    hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (bf16*)dx, loss, n);
+  return ovqa_check_launch("sq_loss");
+}
+
+}  // namespace ovqa

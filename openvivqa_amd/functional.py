@@ -1,0 +1,319 @@
+"""Block-level autograd functions over the HIP kernels.
+
+One ``torch.autograd.Function`` per reference *block* (not per op), with a
+hand-written backward that calls the backward kernels in sequence and writes
+weight gradients straight into the parameter arena:
+
+  prologue      LN(x) + sinusoid table            encoders.py:113 / pos_embeddings.py:58-72
+  mha_block     fc_q/k/v -> attention core -> fc_o -> dropout -> +residual -> LN
+                                                  attentions.py:46-60, 319-331
+  ffn_block     fc1 -> GELU -> drop -> fc2 -> drop -> +residual -> LN
+                                                  positionwise_feed_forward.py:23-28
+  linear        nn.Linear (pointer heads, vocabulary projection, AoA gates)
+  attention_core  softmax(qk^T/sqrt(d)+mask)v on projected tensors
+
+Parameters are passed to ``apply`` only so that autograd schedules the node;
+their gradients are produced by the kernels into ``arena.grad`` (``p.grad`` is
+a view of it) and the functions return ``None`` for them.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL
+
+
+def _c(t: Optional[torch.Tensor]):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def _wgrad(arena, dy, x, w_params, b_params):
+    """dW/db of a (possibly packed) linear, written into the arena's grad buffer."""
+    gw, acc = arena.grad_views(w_params)
+    gb = None
+    if b_params:
+        gb, acc_b = arena.grad_views(b_params)
+        if acc_b != acc:  # mixed None / existing .grad: zero the fresh one, accumulate both
+            (gb if acc else gw).zero_()
+            acc = True
+    ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc)
+
+
+# ------------------------------------------------------------------ prologue
+class _Prologue(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, st):
+        arena, T = st["arena"], st["dtype"]
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, arena.master_of(gamma), arena.master_of(beta), st["eps"], out_dtype=T,
+                                          pos=st["pos"])
+        ctx.st = st
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena = st["arena"]
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = st["gamma"], st["beta"]
+        gg, acc = arena.grad_views([gamma])
+        gb, _ = arena.grad_views([beta])
+        dx, _ = ops.layernorm_bwd(_c(dy), x, arena.master_of(gamma), mean, rstd, gg, gb, dx_dtype=x.dtype,
+                                  accumulate=acc)
+        return dx if ctx.needs_input_grad[0] else None, None, None, None
+
+
+def prologue(x, layer_norm, pos, arena, dtype):
+    st = dict(arena=arena, dtype=dtype, eps=layer_norm.eps, pos=pos, gamma=layer_norm.weight, beta=layer_norm.bias)
+    return _Prologue.apply(x, layer_norm.weight, layer_norm.bias, st)
+
+
+# ------------------------------------------------------------------ MHA block
+def same_tensor(a, b) -> bool:
+    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+                      and a.dtype == b.dtype)
+
+
+def _canon(queries, keys, values, same):
+    """Make the aliasing declared in ``same`` ("all" | "kv" | "none") explicit by identity."""
+    queries = _c(queries)
+    if same == "all":
+        return queries, queries, queries
+    keys = _c(keys)
+    if same == "kv":
+        return queries, keys, keys
+    return queries, keys, _c(values)
+
+
+def _project_qkv(st, queries, keys, values):
+    """Returns q, k, v (strided views of packed projection buffers) and the mode."""
+    arena, a = st["arena"], st["att"]
+    wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
+    bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
+    nqk, nv = wq.shape[0], wv.shape[0]
+    if queries is keys and keys is values:
+        qkv = ops.linear_fwd(queries, arena.packed([wq, wk, wv]), arena.packed([bq, bk, bv], "master"))
+        return qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:], "self", (qkv,)
+    q = ops.linear_fwd(queries, arena.compute(wq), arena.master_of(bq))
+    if keys is values:
+        kv = ops.linear_fwd(keys, arena.packed([wk, wv]), arena.packed([bk, bv], "master"))
+        return q, kv[..., :nqk], kv[..., nqk:], "cross", (q, kv)
+    k = ops.linear_fwd(keys, arena.compute(wk), arena.master_of(bk))
+    v = ops.linear_fwd(values, arena.compute(wv), arena.master_of(bv))
+    return q, k, v, "general", (q, k, v)
+
+
+class _MHABlock(Function):
+    """LN(queries + dropout(fc_o(attention(fc_q(queries), fc_k(keys), fc_v(values)))))."""
+
+    @staticmethod
+    def forward(ctx, queries, keys, values, mask, st, *params):
+        arena, a, ln = st["arena"], st["att"], st["ln"]
+        queries, keys, values = _canon(queries, keys, values, st["same"])
+        q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
+        o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h)
+        drop = st["drop"]
+        pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
+                             residual=queries, drop=drop)
+        y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
+        ctx.st, ctx.mode = st, mode
+        ctx.mask = mask
+        ctx.save_for_backward(queries, keys, values, o, lse, pre, mean, rstd, *bufs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, mode = ctx.st, ctx.mode
+        arena, a, ln, drop = st["arena"], st["att"], st["ln"], st["drop"]
+        queries, keys, values, o, lse, pre, mean, rstd, *bufs = ctx.saved_tensors
+        gg, acc = arena.grad_views([ln.weight])
+        gb, _ = arena.grad_views([ln.bias])
+        dpre, dpre_d = ops.layernorm_bwd(_c(dy), pre, arena.master_of(ln.weight), mean, rstd, gg, gb, drop=drop,
+                                         accumulate=acc)
+        # fc_o
+        _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
+        d_o = ops.linear_bwd_data(dpre_d, arena.compute(a.fc_o.weight))
+        nqk = a.fc_q.weight.shape[0]
+        wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
+        bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
+        B, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
+        T, dev = queries.dtype, queries.device
+        if mode == "self":
+            (qkv,) = bufs
+            q, k, v = qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
+                              dv=dqkv[..., 2 * nqk:])
+            _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
+            ops.linear_bwd_data(dqkv, arena.packed([wq, wk, wv]), out=dpre, accumulate=True)
+            return dpre, None, None, None, None, *([None] * len(st["params"]))
+        if mode == "cross":
+            q, kv = bufs
+            k, v = kv[..., :nqk], kv[..., nqk:]
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(kv)
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
+            _wgrad(arena, dq, queries, [wq], [bq])
+            ops.linear_bwd_data(dq, arena.compute(wq), out=dpre, accumulate=True)
+            _wgrad(arena, dkv, keys, [wk, wv], [bk, bv])
+            dkeys = ops.linear_bwd_data(dkv, arena.packed([wk, wv])) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
+            return dpre, dkeys, None, None, None, *([None] * len(st["params"]))
+        q, k, v = bufs
+        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h)
+        _wgrad(arena, dq, queries, [wq], [bq])
+        ops.linear_bwd_data(dq, arena.compute(wq), out=dpre, accumulate=True)
+        _wgrad(arena, dk, keys, [wk], [bk])
+        _wgrad(arena, dv, values, [wv], [bv])
+        dkeys = ops.linear_bwd_data(dk, arena.compute(wk)) if ctx.needs_input_grad[1] else None
+        dvalues = ops.linear_bwd_data(dv, arena.compute(wv)) if ctx.needs_input_grad[2] else None
+        return dpre, dkeys, dvalues, None, None, *([None] * len(st["params"]))
+
+
+def mha_block(queries, keys, values, mask, st):
+    """Forward of the fused MHA block; uses autograd only when needed."""
+    st = dict(st)
+    st["same"] = ("all" if same_tensor(queries, keys) and same_tensor(keys, values)
+                  else "kv" if same_tensor(keys, values) else "none")
+    if torch.is_grad_enabled():
+        return _MHABlock.apply(queries, keys, values, mask, st, *st["params"])
+    arena, a, ln = st["arena"], st["att"], st["ln"]
+    queries, keys, values = _canon(queries, keys, values, st["same"])
+    q, k, v, _, _ = _project_qkv(st, queries, keys, values)
+    o, _, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=False)
+    pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
+                         residual=queries, drop=st["drop"])
+    y, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps, save_stats=False)
+    return y
+
+
+# ------------------------------------------------------------------ FFN block
+class _FFNBlock(Function):
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        arena, m = st["arena"], st["mod"]
+        x = _c(x)
+        h, u = ops.linear_fwd(x, arena.compute(m.fc1.weight), arena.master_of(m.fc1.bias), EPI_BIAS_GELU,
+                              want_preact=True, drop=st["drop1"])
+        pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL,
+                             residual=x, drop=st["drop2"])
+        ln = m.layer_norm
+        y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
+        ctx.st = st
+        ctx.save_for_backward(x, h, u, pre, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena, m = st["arena"], st["mod"]
+        ln = m.layer_norm
+        x, h, u, pre, mean, rstd = ctx.saved_tensors
+        gg, acc = arena.grad_views([ln.weight])
+        gb, _ = arena.grad_views([ln.bias])
+        dpre, dpre_d = ops.layernorm_bwd(_c(dy), pre, arena.master_of(ln.weight), mean, rstd, gg, gb, drop=st["drop2"],
+                                         accumulate=acc)
+        _wgrad(arena, dpre_d, h, [m.fc2.weight], [m.fc2.bias])
+        du = ops.linear_bwd_data(dpre_d, arena.compute(m.fc2.weight), preact=u, drop=st["drop1"])
+        _wgrad(arena, du, x, [m.fc1.weight], [m.fc1.bias])
+        ops.linear_bwd_data(du, arena.compute(m.fc1.weight), out=dpre, accumulate=True)
+        return dpre, None, *([None] * len(st["params"]))
+
+
+def ffn_block(x, st):
+    if torch.is_grad_enabled():
+        return _FFNBlock.apply(x, st, *st["params"])
+    arena, m = st["arena"], st["mod"]
+    x = _c(x)
+    h = ops.linear_fwd(x, arena.compute(m.fc1.weight), arena.master_of(m.fc1.bias), EPI_BIAS_GELU, drop=st["drop1"])
+    pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL, residual=x,
+                         drop=st["drop2"])
+    ln = m.layer_norm
+    y, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps, save_stats=False)
+    return y
+
+
+# ------------------------------------------------------------------ plain linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        arena, lin = st["arena"], st["lin"]
+        x = _c(x)
+        bias = arena.master_of(lin.bias) if lin.bias is not None else None
+        y = ops.linear_fwd(x, arena.compute(lin.weight), bias)
+        ctx.st = st
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena, lin = st["arena"], st["lin"]
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        _wgrad(arena, dy, x, [lin.weight], [lin.bias] if lin.bias is not None else [])
+        dx = ops.linear_bwd_data(dy, arena.compute(lin.weight)) if ctx.needs_input_grad[0] else None
+        return dx, None, *([None] * len(st["params"]))
+
+
+def linear(x, lin, arena):
+    """y = lin(x) through the HIP GEMM (x is cast to the arena's compute dtype by the caller)."""
+    params = [lin.weight] + ([lin.bias] if lin.bias is not None else [])
+    st = dict(arena=arena, lin=lin, params=params)
+    if torch.is_grad_enabled():
+        return _Linear.apply(x, st, *params)
+    bias = arena.master_of(lin.bias) if lin.bias is not None else None
+    return ops.linear_fwd(_c(x), arena.compute(lin.weight), bias)
+
+
+# ------------------------------------------------------------------ attention core on projected tensors
+class _AttentionCore(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, h, need_att):
+        o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att)
+        ctx.h, ctx.mask = h, mask
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.mark_non_differentiable(*([att] if att is not None else []))
+        return (o, att) if need_att else (o, None)
+
+    @staticmethod
+    def backward(ctx, d_o, _datt):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h)
+        return dq, dk, dv, None, None, None
+
+
+def attention_core(q, k, v, mask, h, need_att=False):
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _AttentionCore.apply(q, k, v, mask, h, need_att)
+    o, _, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att, save_lse=False)
+    return o, att
+
+
+# ------------------------------------------------------------------ pointer scores
+class _PointerScore(Function):
+    @staticmethod
+    def forward(ctx, q, k, scale, add_mask, key_fill, query_fill):
+        q, k = _c(q), _c(k)
+        s = ops.pointer_score(q, k, scale, add_mask, key_fill, query_fill)
+        ctx.scale = scale
+        ctx.save_for_backward(q, k)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        q, k = ctx.saved_tensors
+        ds = torch.where(torch.isfinite(ds), ds, torch.zeros_like(ds)).to(q.dtype).contiguous()
+        dq = ops.batched_gemm(ds, k, alpha=ctx.scale)                 # [B,T,N] x [B,N,D]
+        dk = ops.batched_gemm(ds, q, trans_a=True, alpha=ctx.scale)   # [B,N,T] x [B,T,D]
+        return dq, dk, None, None, None, None
+
+
+def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad):
+        return _PointerScore.apply(q, k, scale, add_mask, key_fill, query_fill)
+    return ops.pointer_score(_c(q), _c(k), scale, add_mask, key_fill, query_fill)

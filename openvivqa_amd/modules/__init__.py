@@ -1,0 +1,17 @@
+"""HIP-backed modules registered under the reference's names."""
+from .containers import Module, ModuleDict, ModuleList
+from .pos_embeddings import SinusoidPositionalEmbedding
+from .attentions import MultiHeadAttention, ScaledDotProductAttention
+from .positionwise_feed_forward import PositionWiseFeedForward
+from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEncoderLayer, Encoder, EncoderLayer,
+                       GuidedAttentionEncoder, GuidedEncoderLayer)
+from .embeddings import FeatureEmbedding, UsualEmbedding
+from .decoders import Decoder, DecoderLayer
+from .pointer import DynamicPointerNetwork, OcrPtrNet
+
+__all__ = [
+    "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
+    "ScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
+    "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
+    "FeatureEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet",
+]

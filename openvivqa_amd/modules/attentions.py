@@ -1,0 +1,119 @@
+"""Attention modules backed by the HIP kernels (drop-in for models/modules/attentions.py).
+
+``ScaledDotProductAttention`` keeps the reference's parameters (fc_q/fc_k/fc_v/
+fc_o, xavier weights, zero biases -- attentions.py:16-44) and returns
+``(out, att)``; ``MultiHeadAttention`` keeps dropout -> residual -> post-LN,
+the optional AoA gate and the running K/V state (attentions.py:293-339) but runs
+as ONE fused block: packed QKV projection -> attention core -> output
+projection with bias+dropout+residual epilogue -> LayerNorm.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from .. import runtime as rt
+from ..builders.attention_builder import META_ATTENTION, build_attention
+from .containers import Module
+
+
+def _as_mask(mask):
+    if mask is None:
+        return None
+    if mask.dtype != torch.float32:
+        mask = mask.float()
+    while mask.dim() < 4:
+        mask = mask.unsqueeze(0)
+    return mask
+
+
+@META_ATTENTION.register()
+class ScaledDotProductAttention(nn.Module):
+    """softmax(Q K^T / sqrt(d_k) + mask) V with learned projections."""
+
+    def __init__(self, config):
+        super().__init__()
+        d_model, h, d_k, d_v = config.D_MODEL, config.HEAD, config.D_KEY, config.D_VALUE
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
+        self.init_weights()
+
+    def init_weights(self):
+        for lin in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.constant_(lin.bias, 0)
+
+    def _ovqa_param_groups(self):
+        # adjacency in the arena => the fused QKV projection reads one [3*H*d, D] matrix
+        return [[self.fc_q.weight, self.fc_k.weight, self.fc_v.weight],
+                [self.fc_q.bias, self.fc_k.bias, self.fc_v.bias]]
+
+    def forward(self, queries, keys, values, attention_mask=None, **kwargs):
+        """Returns (out, att) like the reference; ``att`` (B,H,nq,nk) is produced by the
+        kernel on request and is not differentiable."""
+        arena = rt.ensure_arena(self)
+        T, in_dtype = arena.compute_dtype, queries.dtype
+        same_kv = Fn.same_tensor(keys, values)
+        same_all = same_kv and Fn.same_tensor(queries, keys)
+        queries = queries.to(T)
+        keys = queries if same_all else keys.to(T)
+        values = keys if same_kv else values.to(T)
+        q = Fn.linear(queries, self.fc_q, arena)
+        k = Fn.linear(keys, self.fc_k, arena)
+        v = Fn.linear(values, self.fc_v, arena)
+        o, att = Fn.attention_core(q, k, v, _as_mask(attention_mask), self.h, need_att=True)
+        out = Fn.linear(o, self.fc_o, arena)
+        return out.to(in_dtype), att.to(in_dtype)
+
+
+class MultiHeadAttention(Module):
+    """Multi-head attention block with dropout, residual connection and post-LayerNorm."""
+
+    def __init__(self, config):
+        super().__init__()
+        d_model = config.D_MODEL
+        self.use_aoa = config.USE_AOA
+        if self.use_aoa:
+            self.informative_attention = nn.Linear(2 * d_model, d_model)
+            self.gated_attention = nn.Linear(2 * d_model, d_model)
+        self.attention = build_attention(config)  # registry call, attentions.py:309
+        self.dropout = nn.Dropout(p=config.DROPOUT)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.can_be_stateful = config.CAN_BE_STATEFUL
+        if self.can_be_stateful:
+            self.register_state("running_keys", torch.zeros((0, d_model)))
+            self.register_state("running_values", torch.zeros((0, d_model)))
+        self._site = rt.new_dropout_site()
+
+    def forward(self, queries, keys, values, attention_mask, **kwargs):
+        arena = rt.ensure_arena(self)
+        T = arena.compute_dtype
+        same_kv = Fn.same_tensor(keys, values)
+        same_all = same_kv and Fn.same_tensor(queries, keys)
+        queries = queries.to(T)
+        keys = queries if same_all else keys.to(T)
+        values = keys if same_kv else values.to(T)
+        if self.can_be_stateful and self._is_stateful:  # attentions.py:320-325
+            self.running_keys = torch.cat([self.running_keys.to(T), keys], 1)
+            keys = self.running_keys
+            self.running_values = torch.cat([self.running_values.to(T), values], 1)
+            values = self.running_values
+        mask = _as_mask(attention_mask)
+        if type(self.attention) is ScaledDotProductAttention:
+            params = list(self.attention.parameters()) + list(self.layer_norm.parameters())
+            st = dict(arena=arena, att=self.attention, ln=self.layer_norm, params=params,
+                      drop=rt.dropout_spec(self.dropout.p, self._site, self.training, queries.device))
+            out = Fn.mha_block(queries, keys, values, mask, st)
+        else:  # other registered attention kernels: unfused composition
+            out, _ = self.attention(queries, keys, values, mask, **kwargs)
+            out = Fn.prologue(queries + self.dropout(out.to(T)), self.layer_norm, None, arena, T)
+        if self.use_aoa:  # attentions.py:333-337
+            z = torch.cat([queries, out], dim=-1)
+            i = Fn.linear(z, self.informative_attention, arena)
+            g = Fn.linear(z, self.gated_attention, arena)
+            out = i * torch.sigmoid(g)
+        return out

@@ -1,0 +1,83 @@
+"""Stateful-module machinery for autoregressive decoding.
+
+Behavioural mirror of models/modules/containers.py:4-77: named state buffers
+that are expanded to the batch when statefulness is enabled and restored to
+their defaults when it is disabled; ``apply_to_states`` lets beam search
+reorder every cache.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Callable, Iterator, Optional
+
+import torch
+from torch import nn
+
+
+class Module(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._is_stateful = False
+        self._state_names = []
+        self._state_defaults = {}
+
+    def register_state(self, name: str, default: Optional[torch.Tensor]) -> None:
+        self._state_names.append(name)
+        self._state_defaults[name] = None if default is None else default.clone().detach()
+        self.register_buffer(name, default)
+
+    def _stateful_children(self) -> Iterator["Module"]:
+        for child in self.children():
+            if isinstance(child, Module):
+                yield child
+
+    def states(self):
+        for name in self._state_names:
+            yield self._buffers[name]
+        for child in self._stateful_children():
+            yield from child.states()
+
+    def apply_to_states(self, fn: Callable) -> None:
+        for name in self._state_names:
+            self._buffers[name] = fn(self._buffers[name])
+        for child in self._stateful_children():
+            child.apply_to_states(fn)
+
+    def _fresh(self, name: str, batch_size: Optional[int]):
+        default = self._state_defaults[name]
+        if default is None:
+            return None
+        t = default.clone().detach().to(self._buffers[name].device)
+        if batch_size is not None:
+            t = t.unsqueeze(0).expand([batch_size] + list(t.shape)).contiguous()
+        return t
+
+    def enable_statefulness(self, batch_size: int) -> None:
+        for child in self._stateful_children():
+            child.enable_statefulness(batch_size)
+        for name in self._state_names:
+            self._buffers[name] = self._fresh(name, batch_size)
+        self._is_stateful = True
+
+    def disable_statefulness(self) -> None:
+        for child in self._stateful_children():
+            child.disable_statefulness()
+        for name in self._state_names:
+            self._buffers[name] = self._fresh(name, None)
+        self._is_stateful = False
+
+    @contextmanager
+    def statefulness(self, batch_size: int):
+        self.enable_statefulness(batch_size)
+        try:
+            yield
+        finally:
+            self.disable_statefulness()
+
+
+class ModuleList(nn.ModuleList, Module):
+    pass
+
+
+class ModuleDict(nn.ModuleDict, Module):
+    pass

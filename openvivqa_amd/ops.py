@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point).
+
+PyTorch is used here for device memory and the current HIP stream only; all
+arithmetic happens in libovqa_hip.so.  Every function requires CUDA(HIP)
+tensors and raises otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL, OVQA_BF16, OVQA_F32
+
+_DT = {torch.float32: OVQA_F32, torch.bfloat16: OVQA_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"openvivqa_amd: unsupported dtype {t.dtype} (float32 or bfloat16)") from None
+
+
+def _dev(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            "openvivqa_amd kernels run only on an AMD GPU (tensor is on '%s'); there is no CPU fallback" % t.device)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t: torch.Tensor):
+    """Return (row_stride, n_rows) of a tensor viewed as [rows, features]."""
+    if t.stride(-1) != 1:
+        raise RuntimeError("last dimension must be contiguous")
+    if t.dim() == 2:
+        return t.stride(0), t.shape[0]
+    if t.dim() == 3:
+        if t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError("batch rows must be uniformly strided")
+        return t.stride(1), t.shape[0] * t.shape[1]
+    raise RuntimeError("expected a 2-D or 3-D tensor")
+
+
+@dataclass
+class DropSpec:
+    """Dropout call-site description (see ovqa_dropout in include/ovqa_hip.h)."""
+    p: float
+    seed: int
+    site: int
+    step: Optional[torch.Tensor] = None  # uint32/int32 device scalar
+
+    def c(self):
+        if self.p <= 0.0:
+            return None
+        return C.byref(_lib.Dropout(float(self.p), self.seed & 0xFFFFFFFF, self.site & 0xFFFFFFFF, _p(self.step)))
+
+
+def _drop(d: Optional[DropSpec]):
+    return None if d is None else d.c()
+
+
+_workspaces = {}
+
+
+def workspace(device: torch.device) -> torch.Tensor:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = _lib.load().ovqa_workspace_bytes()
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ---------------------------------------------------------------------------
+def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=False, drop=None, out=None,
+               preact_out=None):
+    """y = epilogue(x w^T + bias).  x [..., K] (rows may be strided), w [N, K]."""
+    _dev(x)
+    lib = _lib.load()
+    ldx, M = _rows(x)
+    N, K = w.shape
+    assert x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype
+    y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
+    ldy, _ = _rows(y)
+    preact = preact_out if preact_out is not None else (
+        torch.empty(M, N, dtype=x.dtype, device=x.device) if want_preact else None)
+    ldres = 0
+    if residual is not None:
+        ldres, mr = _rows(residual)
+        assert mr == M and residual.dtype == x.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    _lib.check(lib.ovqa_linear_fwd(_dt(x), epilogue, _p(x), ldx, _p(w), _p(bias), _p(residual), ldres, _p(y), ldy,
+                                   _p(preact), M, N, K, _drop(drop), _stream()), "linear_fwd")
+    return (y, preact) if want_preact else y
+
+
+def linear_bwd_data(dy, w, preact=None, drop=None, out=None, accumulate=False):
+    """dx = dy w  [* dropmask * gelu'(preact)]."""
+    _dev(dy)
+    lib = _lib.load()
+    lddy, M = _rows(dy)
+    N, K = w.shape
+    assert dy.shape[-1] == N and w.dtype == dy.dtype
+    dx = out if out is not None else torch.empty(*dy.shape[:-1], K, dtype=dy.dtype, device=dy.device)
+    lddx, _ = _rows(dx)
+    _lib.check(lib.ovqa_linear_bwd_data(_dt(dy), _p(dy), lddy, _p(w), _p(dx), lddx, _p(preact), M, N, K,
+                                        int(accumulate), _drop(drop), _stream()), "linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+    """dw (fp32 [N,K]) (+)= dy^T x ; db (fp32 [N]) (+)= colsum(dy)."""
+    _dev(dy)
+    lib = _lib.load()
+    lddy, M = _rows(dy)
+    ldx, Mx = _rows(x)
+    N, K = dy.shape[-1], x.shape[-1]
+    assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == N * K
+    assert db is None or (db.dtype == torch.float32 and db.numel() == N)
+    _lib.check(lib.ovqa_linear_bwd_weight(_dt(dy), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), M, N, K,
+                                          int(accumulate), _p(workspace(dy.device)), _stream()), "linear_bwd_weight")
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True):
+    _dev(x)
+    lib = _lib.load()
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    M = x.numel() // D
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    pos_rows = 0
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == D
+        pos_rows = pos.shape[0]
+    _lib.check(lib.ovqa_layernorm_fwd(_DT[out_dtype], _dt(x), _p(x), _p(gamma), _p(beta), _p(pos), pos_rows, _p(y),
+                                      _p(mean), _p(rstd), M, D, float(eps), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False):
+    """Returns (dx, dx_dropped) -- dx_dropped is dx when dropout is off."""
+    _dev(dy)
+    lib = _lib.load()
+    assert dy.is_contiguous() and x.is_contiguous()
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx_dtype = dx_dtype or dy.dtype
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    has_drop = drop is not None and drop.p > 0.0
+    dxd = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if has_drop else None
+    _lib.check(lib.ovqa_layernorm_bwd(_dt(dy), _DT[dx_dtype], _p(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd),
+                                      _p(dx), _p(dxd), _p(dgamma), _p(dbeta), M, D, int(accumulate), _drop(drop),
+                                      _p(workspace(dy.device)), _stream()), "layernorm_bwd")
+    return dx, (dxd if has_drop else dx)
+
+
+def _mask_strides(mask, B, H, nq, nk):
+    """Broadcast strides (in elements) of an additive fp32 mask of shape (b|1, h|1, q|1, nk)."""
+    if mask is None:
+        return None, 0, 0, 0
+    assert mask.dtype == torch.float32 and mask.dim() == 4 and mask.shape[-1] == nk and mask.stride(-1) == 1, \
+        f"mask must be fp32 (B|1, H|1, nq|1, nk); got {tuple(mask.shape)} {mask.dtype}"
+    sb = mask.stride(0) if mask.shape[0] > 1 else 0
+    sh = mask.stride(1) if mask.shape[1] > 1 else 0
+    sq = mask.stride(2) if mask.shape[2] > 1 else 0
+    assert mask.shape[0] in (1, B) and mask.shape[1] in (1, H) and mask.shape[2] in (1, nq)
+    return mask, sb, sh, sq
+
+
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
+    """q [B,nq,H*dk], k [B,nk,H*dk], v [B,nk,H*dv] (row-strided views allowed) -> o [B,nq,H*dv], lse, att."""
+    _dev(q)
+    lib = _lib.load()
+    B, nq = q.shape[0], q.shape[1]
+    nk = k.shape[1]
+    dk, dv = q.shape[2] // H, v.shape[2] // H
+    ldq, _ = _rows(q)
+    ldk, _ = _rows(k)
+    ldv, _ = _rows(v)
+    scale = (1.0 / math.sqrt(dk)) if scale is None else scale
+    o = torch.empty(B, nq, H * dv, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, nq, dtype=torch.float32, device=q.device) if save_lse else None
+    att = torch.empty(B, H, nq, nk, dtype=q.dtype, device=q.device) if need_att else None
+    mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    _lib.check(lib.ovqa_attention_fwd(_dt(q), _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(mask), sb, sh, sq, _p(o), H * dv,
+                                      _p(lse), _p(att), B, H, nq, nk, dk, dv, float(scale), _stream()), "attention_fwd")
+    return o, lse, att
+
+
+def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None):
+    _dev(q)
+    lib = _lib.load()
+    B, nq = q.shape[0], q.shape[1]
+    nk = k.shape[1]
+    dkk, dvv = q.shape[2] // H, v.shape[2] // H
+    scale = (1.0 / math.sqrt(dkk)) if scale is None else scale
+    dq = dq if dq is not None else torch.empty(B, nq, H * dkk, dtype=q.dtype, device=q.device)
+    dk = dk if dk is not None else torch.empty(B, nk, H * dkk, dtype=q.dtype, device=q.device)
+    dv = dv if dv is not None else torch.empty(B, nk, H * dvv, dtype=q.dtype, device=q.device)
+    delta = torch.empty(B, H, nq, dtype=torch.float32, device=q.device)
+    mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    _lib.check(lib.ovqa_attention_bwd(
+        _dt(q), _p(d_o), _rows(d_o)[0], _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v), _rows(v)[0], _p(o), _rows(o)[0],
+        _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
+        B, H, nq, nk, dkk, dvv, float(scale), _stream()), "attention_bwd")
+    return dq, dk, dv
+
+
+def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
+    """scores[b,t,n] = q[b,t].k[b,n]*scale (+ add_mask[b,n]) (-inf where key_fill[b,n] / query_fill[b,t])."""
+    _dev(q)
+    lib = _lib.load()
+    assert q.is_contiguous() and k.is_contiguous()
+    B, T, D = q.shape
+    Nk = k.shape[1]
+    s = torch.empty(B, T, Nk, dtype=torch.float32, device=q.device)
+    _lib.check(lib.ovqa_pointer_score(_dt(q), _p(q), _p(k), _p(add_mask), _p(key_fill), _p(query_fill), _p(s),
+                                      B, T, Nk, D, float(scale), _stream()), "pointer_score")
+    return s
+
+
+def batched_gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, out_dtype=None):
+    """C[i] = alpha * op(A[i]) op(B[i]) for contiguous 3-D tensors."""
+    _dev(a)
+    lib = _lib.load()
+    assert a.is_contiguous() and b.is_contiguous() and a.dim() == 3 and b.dim() == 3
+    batch = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    N = b.shape[1] if trans_b else b.shape[2]
+    out_dtype = out_dtype or a.dtype
+    c = torch.empty(batch, M, N, dtype=out_dtype, device=a.device)
+    _lib.check(lib.ovqa_batched_gemm(_dt(a), _DT[out_dtype], int(trans_a), int(trans_b), _p(a), a.shape[2],
+                                     a.shape[1] * a.shape[2], _p(b), b.shape[2], b.shape[1] * b.shape[2], _p(c), N,
+                                     M * N, batch, M, N, K, float(alpha), _stream()), "batched_gemm")
+    return c
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None, betas=(0.9, 0.98), eps=1e-8,
+              weight_decay=0.0, grad_scale=1.0):
+    _dev(param)
+    lib = _lib.load()
+    _lib.check(lib.ovqa_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(),
+                                  float(lr), _p(lr_scale), float(betas[0]), float(betas[1]), float(eps),
+                                  float(weight_decay), float(grad_scale), _p(step), _stream()), "adam_step")
+
+
+def increment_step(step):
+    _dev(step)
+    _lib.check(_lib.load().ovqa_increment_step(_p(step), _stream()), "increment_step")
+
+
+def cast(src, dst):
+    _dev(src)
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _lib.check(_lib.load().ovqa_cast(_dt(src), _dt(dst), _p(src), _p(dst), src.numel(), _stream()), "cast")
+    return dst
+
+
+def dropout_keep_mask(drop: DropSpec, n: int, device) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    _dev(out)
+    d = _lib.Dropout(float(drop.p), drop.seed & 0xFFFFFFFF, drop.site & 0xFFFFFFFF, _p(drop.step))
+    _lib.check(_lib.load().ovqa_dropout_keep_mask(C.byref(d), _p(out), n, _stream()), "dropout_keep_mask")
+    return out
+
+
+def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False):
+    """loss (fp32 device scalar) (+)= mean(x^2); returns d loss / d x (same dtype as x)."""
+    _dev(x)
+    assert x.is_contiguous()
+    dx = torch.empty_like(x) if want_grad else None
+    _lib.check(_lib.load().ovqa_sq_loss_fwd_bwd(_dt(x), _p(x), _p(dx), _p(loss), x.numel(), int(accumulate), _stream()),
+               "sq_loss")
+    return dx

@@ -1,0 +1,237 @@
+"""Host-side runtime: compute dtype, flat parameter arenas, dropout bookkeeping.
+
+Data layout in HBM:
+  * every block's parameters live in one flat fp32 *master* buffer; the
+    ``nn.Parameter`` objects keep their reference names/shapes (checkpoint
+    contract) but their ``.data`` are views into it;
+  * fc_q/fc_k/fc_v weights (and biases) of an attention are adjacent, so the
+    fused QKV projection reads ONE [3*H*dk, D] matrix without any copy;
+  * a same-layout fp32 *grad* buffer receives weight gradients straight from the
+    kernels (one flat all-reduce for data parallelism);
+  * in bf16 mode a same-layout bf16 *shadow* is what the MFMA kernels read; the
+    fused Adam kernel rewrites master and shadow together.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+
+_state = {"compute_dtype": torch.bfloat16, "seed": 0x5EED1234, "call": 0}
+_site_counter = itertools.count(1)
+_step_tensors: Dict[int, torch.Tensor] = {}
+
+ALIGN = 64  # elements; keeps every group start 256-byte aligned in fp32 and 128-byte in bf16
+
+
+def set_compute_dtype(dtype: torch.dtype) -> None:
+    """torch.float32: exact-fp32 HIP kernels (parity <= 1e-3 vs the reference);
+    torch.bfloat16 (default): bf16 storage + MFMA kernels (parity <= 1e-2)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _state["compute_dtype"] = dtype
+
+
+def get_compute_dtype() -> torch.dtype:
+    return _state["compute_dtype"]
+
+
+def manual_seed(seed: int) -> None:
+    _state["seed"] = int(seed) & 0xFFFFFFFF
+    _state["call"] = 0
+
+
+def new_dropout_site() -> int:
+    return next(_site_counter)
+
+
+def step_tensor(device: torch.device) -> torch.Tensor:
+    """Device-resident uint32 step counter mixed into every dropout key (lets a
+    captured graph draw fresh masks on each replay)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _step_tensors.get(idx)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _step_tensors[idx] = t
+    return t
+
+
+def dropout_spec(p: float, site: int, training: bool, device) -> Optional[ops.DropSpec]:
+    if not training or p <= 0.0:
+        return None
+    _state["call"] += 1
+    seed = (_state["seed"] + 0x9E3779B9 * _state["call"]) & 0xFFFFFFFF
+    return ops.DropSpec(p=float(p), seed=seed, site=site, step=step_tensor(device))
+
+
+class ParamArena:
+    """Flat fp32 master / fp32 grad / (bf16 shadow) buffers for a set of parameters."""
+
+    def __init__(self, groups: Sequence[Sequence[nn.Parameter]], device: torch.device, compute_dtype: torch.dtype):
+        self.device = device
+        self.compute_dtype = compute_dtype
+        self.params: List[nn.Parameter] = []
+        self.offsets: Dict[int, int] = {}
+        off = 0
+        for g in groups:
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            for p in g:
+                if id(p) in self.offsets:
+                    raise RuntimeError("parameter appears twice in an arena")
+                self.offsets[id(p)] = off
+                self.params.append(p)
+                off += p.numel()
+        self.numel = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.master = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.shadow = (torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
+                       if compute_dtype == torch.bfloat16 else None)
+        self.overwrite_grads = False  # harness mode: backward always overwrites the grad buffer
+        with torch.no_grad():
+            for p in self.params:
+                o = self.offsets[id(p)]
+                view = self.master[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                p._ovqa_arena = self
+        self._versions = None
+        self.refresh_shadow()
+
+    # -- views -------------------------------------------------------------
+    def _slice(self, buf, p):
+        o = self.offsets[id(p)]
+        return buf[o:o + p.numel()].view(p.shape)
+
+    def compute(self, p) -> torch.Tensor:
+        """Weight in the compute dtype (bf16 shadow or the fp32 master itself)."""
+        return self._slice(self.shadow if self.shadow is not None else self.master, p)
+
+    def master_of(self, p) -> torch.Tensor:
+        return self._slice(self.master, p)
+
+    def grad_of(self, p) -> torch.Tensor:
+        return self._slice(self.grad, p)
+
+    def packed(self, ps: Sequence[nn.Parameter], buf: str = "compute") -> torch.Tensor:
+        """One [sum(rows), cols] (or [sum(n)]) view over adjacent parameters."""
+        o0 = self.offsets[id(ps[0])]
+        n, o = 0, o0
+        for p in ps:
+            if self.offsets[id(p)] != o:
+                raise RuntimeError("parameters are not adjacent in the arena")
+            o += p.numel()
+            n += p.numel()
+        base = {"compute": self.shadow if self.shadow is not None else self.master,
+                "master": self.master, "grad": self.grad}[buf]
+        flat = base[o0:o0 + n]
+        if ps[0].dim() == 2:
+            return flat.view(n // ps[0].shape[1], ps[0].shape[1])
+        return flat
+
+    # -- consistency -------------------------------------------------------
+    def owns(self, ps: Iterable[nn.Parameter]) -> bool:
+        for p in ps:
+            if getattr(p, "_ovqa_arena", None) is not self or id(p) not in self.offsets:
+                return False
+            o = self.offsets[id(p)]
+            if p.data.data_ptr() != self.master.data_ptr() + 4 * o or p.device != self.master.device:
+                return False
+        return True
+
+    def refresh_shadow(self) -> None:
+        if self.shadow is not None:
+            ops.cast(self.master, self.shadow)
+        self._versions = [p._version for p in self.params]
+
+    def sync_if_stale(self) -> None:
+        """Re-cast the bf16 shadow if torch mutated a parameter in place
+        (load_state_dict, a torch optimiser step...)."""
+        if self.shadow is None:
+            return
+        if self._versions != [p._version for p in self.params]:
+            self.refresh_shadow()
+
+    def attach_grads(self) -> None:
+        for p in self.params:
+            p.grad = self.grad_of(p)
+
+    def grad_views(self, ps: Sequence[nn.Parameter]):
+        """(packed fp32 grad view over ``ps``, accumulate flag) for a backward pass,
+        following autograd's convention: a parameter whose ``.grad`` is None gets its
+        gradient written, an existing ``.grad`` is accumulated into."""
+        ps = list(ps)
+        views = [self.grad_of(p) for p in ps]
+        if self.overwrite_grads:
+            for p, v in zip(ps, views):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+            return self.packed(ps, "grad"), False
+        if all(p.grad is None for p in ps):
+            for p, v in zip(ps, views):
+                p.grad = v
+            return self.packed(ps, "grad"), False
+        for p, v in zip(ps, views):
+            if p.grad is None:
+                v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        return self.packed(ps, "grad"), True
+
+
+def collect_groups(module: nn.Module) -> List[List[nn.Parameter]]:
+    """Adjacency groups first (declared by modules via ``_ovqa_param_groups``), then the rest."""
+    seen, groups = set(), []
+    for m in module.modules():
+        fn = getattr(m, "_ovqa_param_groups", None)
+        if fn is None:
+            continue
+        for g in fn():
+            g = [p for p in g if id(p) not in seen]
+            if g:
+                groups.append(g)
+                seen.update(id(p) for p in g)
+    for p in module.parameters():
+        if id(p) not in seen:
+            groups.append([p])
+            seen.add(id(p))
+    return groups
+
+
+def build_arena(module: nn.Module, device=None, compute_dtype=None) -> ParamArena:
+    params = list(module.parameters())
+    if not params:
+        raise RuntimeError("module has no parameters")
+    device = torch.device(device) if device is not None else params[0].device
+    if device.type != "cuda":
+        raise RuntimeError("openvivqa_amd: parameters must be on an AMD GPU ('cuda' device) before the forward pass; "
+                           "there is no CPU fallback")
+    return ParamArena(collect_groups(module), device, compute_dtype or get_compute_dtype())
+
+
+def ensure_arena(block: nn.Module) -> ParamArena:
+    """Arena holding ``block``'s parameters (lazily created per block; a call to
+    ``prepare(model)`` replaces the per-block arenas by one model-wide arena)."""
+    params = list(block.parameters())
+    arena = getattr(params[0], "_ovqa_arena", None)
+    if arena is None or arena.compute_dtype != get_compute_dtype() or not arena.owns(params):
+        arena = build_arena(block)
+    arena.sync_if_stale()
+    return arena
+
+
+def prepare(model: nn.Module, device=None, compute_dtype=None) -> ParamArena:
+    """Put ALL parameters of ``model`` in one arena (one flat gradient buffer for
+    the data-parallel all-reduce and one fused optimiser launch)."""
+    if device is not None:
+        model.to(device)
+    if compute_dtype is not None:
+        set_compute_dtype(compute_dtype)
+    arena = build_arena(model)
+    model._ovqa_arena = arena
+    return arena

@@ -1,0 +1,46 @@
+"""Mask / position helpers with the reference's semantics (models/utils.py:32-73).
+
+These are O(B*N) index manipulations executed with stock torch ops on whatever
+device the inputs live on; they define what the attention kernels receive:
+additive fp32 masks with value -1e5 (not -inf, not boolean).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+MASK_VALUE = -10e4  # == -100000.0, models/utils.py:56
+
+
+def generate_padding_mask(sequences: Optional[torch.Tensor], padding_idx: int) -> Optional[torch.Tensor]:
+    """(B,1,1,N) additive mask; a position is padding iff its feature sum equals
+    padding_idx * D (token ids count as D == 1).  models/utils.py:44-57."""
+    if sequences is None:
+        return None
+    s = sequences.unsqueeze(-1) if sequences.dim() == 2 else sequences
+    is_pad = s.sum(dim=-1) == padding_idx * s.shape[-1]
+    return (is_pad.long() * MASK_VALUE).unsqueeze(1).unsqueeze(1)
+
+
+def generate_sequential_mask(seq_len: int) -> torch.Tensor:
+    """(1,1,T,T) causal additive mask.  models/utils.py:59-66."""
+    return (torch.triu(torch.ones(seq_len, seq_len), diagonal=1) * MASK_VALUE).unsqueeze(0).unsqueeze(0)
+
+
+def generate_self_attention_masks(padding_masks: torch.Tensor, sequential_masks: torch.Tensor) -> torch.Tensor:
+    """OR of the two masks -> (B,1,T,T).  models/utils.py:68-73."""
+    return torch.logical_or(padding_masks != 0, sequential_masks != 0).long() * MASK_VALUE
+
+
+def sinusoid_encoding_table(max_len: int, d_model: int, padding_idx: Optional[int] = None) -> torch.Tensor:
+    """Decoder position table, rows 0..max_len-1.  models/utils.py:21-38."""
+    pos = torch.arange(max_len, dtype=torch.float32).view(-1, 1)
+    dim = torch.arange(d_model // 2, dtype=torch.float32).view(1, -1)
+    ang = pos / 10000 ** (2 * dim / d_model)
+    out = torch.zeros(max_len, d_model)
+    out[:, ::2] = torch.sin(ang)
+    out[:, 1::2] = torch.cos(ang)
+    if padding_idx is not None:
+        out[padding_idx] = 0
+    return out

@@ -1,0 +1,302 @@
+"""Kernel-level parity of every C-ABI entry point against plain fp64/fp32 torch math.
+
+Tolerances (written here, per the north star): OVQA_F32 paths <= 1e-3 (in fact
+~1e-5); OVQA_BF16 paths <= 1e-2 *normalised* max error, i.e.
+max|a-b| / max(1, max|b|), inputs/outputs being bf16-rounded.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def ops():
+    from openvivqa_amd import ops as o
+    return o
+
+
+def nerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
+
+
+def tol(dtype):
+    return 1e-4 if dtype == F32 else 1e-2
+
+
+def rnd(*shape, dtype=F32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+LIN_SHAPES = [(37, 50, 29), (64, 64, 16), (256, 128, 64), (300, 256, 128), (6400, 512, 512), (1280, 1536, 512),
+              (128, 512, 2048)]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", LIN_SHAPES)
+def test_linear_fwd_epilogues(dtype, M, N, K):
+    o = ops()
+    x, w = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=1)
+    b, res = rnd(N, seed=2), rnd(M, N, dtype=dtype, seed=3)
+    xd, wd, bd, rd = x.double(), w.double(), b.double(), res.double()
+    u = xd @ wd.t() + bd
+    assert nerr(o.linear_fwd(x, w, b), u) < tol(dtype)
+    assert nerr(o.linear_fwd(x, w, None), xd @ wd.t()) < tol(dtype)
+    y, pre = o.linear_fwd(x, w, b, o.EPI_BIAS_GELU, want_preact=True)
+    assert nerr(pre, u) < tol(dtype) and nerr(y, gelu(u)) < tol(dtype)
+    assert nerr(o.linear_fwd(x, w, b, o.EPI_BIAS_RESIDUAL, residual=res), u + rd) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_linear_fwd_strided_and_3d(dtype):
+    o = ops()
+    big = rnd(4, 10, 3 * 64, dtype=dtype)
+    x = big[..., 64:128]  # row-strided view
+    w, b = rnd(128, 64, dtype=dtype, scale=0.1, seed=5), rnd(128, seed=6)
+    y = o.linear_fwd(x, w, b)
+    assert y.shape == (4, 10, 128)
+    assert nerr(y, x.double() @ w.double().t() + b.double()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(37, 50, 29), (256, 128, 64), (640, 512, 2048), (1280, 2048, 512)])
+def test_linear_bwd_data(dtype, M, N, K):
+    o = ops()
+    dy, w = rnd(M, N, dtype=dtype), rnd(N, K, dtype=dtype, scale=N ** -0.5, seed=1)
+    ref = dy.double() @ w.double()
+    assert nerr(o.linear_bwd_data(dy, w), ref) < tol(dtype)
+    base = rnd(M, K, dtype=dtype, seed=4)
+    out = base.clone()
+    o.linear_bwd_data(dy, w, out=out, accumulate=True)
+    assert nerr(out, ref + base.double()) < tol(dtype)
+    u = rnd(M, K, dtype=dtype, seed=7)
+    assert nerr(o.linear_bwd_data(dy, w, preact=u), ref * gelu_grad(u.double())) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(37, 50, 29), (256, 128, 64), (6400, 512, 512), (1280, 2048, 512)])
+def test_linear_bwd_weight(dtype, M, N, K):
+    o = ops()
+    dy, x = rnd(M, N, dtype=dtype, scale=M ** -0.5), rnd(M, K, dtype=dtype, seed=1)
+    dw = torch.full((N, K), 7.0, device=DEV)
+    db = torch.full((N,), 7.0, device=DEV)
+    o.linear_bwd_weight(dy, x, dw, db)
+    rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert nerr(dw, rw) < tol(dtype) and nerr(db, rb) < tol(dtype)
+    o.linear_bwd_weight(dy, x, dw, db, accumulate=True)
+    assert nerr(dw, 2 * rw) < 2 * tol(dtype) and nerr(db, 2 * rb) < 2 * tol(dtype)
+    dw2 = torch.zeros(N, K, device=DEV)
+    o.linear_bwd_weight(dy, x, dw2, None)
+    assert nerr(dw2, rw) < tol(dtype)
+
+
+def ln_ref(x, g, b, eps=1e-5):
+    x = x.double()
+    mu = x.mean(-1, keepdim=True)
+    var = x.var(-1, unbiased=False, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g.double() + b.double(), mu.squeeze(-1), 1 / torch.sqrt(var + eps).squeeze(-1)
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(F32, F32), (BF16, BF16), (F32, BF16)])
+@pytest.mark.parametrize("D", [32, 512, 768])
+def test_layernorm_fwd_bwd(in_dtype, out_dtype, D):
+    o = ops()
+    B, N = 3, 11
+    x = rnd(B, N, D, dtype=in_dtype, scale=2.0) + 0.5
+    g, b = (rnd(D, seed=1) * 0.2 + 1.0), rnd(D, seed=2) * 0.1
+    pos = rnd(N, D, seed=3)
+    y, mean, rstd = o.layernorm_fwd(x, g, b, 1e-5, out_dtype=out_dtype)
+    ry, rmu, rrs = ln_ref(x, g, b)
+    assert nerr(y, ry) < tol(out_dtype) and nerr(mean, rmu.reshape(-1)) < 1e-4 and nerr(rstd, rrs.reshape(-1)) < 1e-4
+    yp, _, _ = o.layernorm_fwd(x, g, b, 1e-5, out_dtype=out_dtype, pos=pos)
+    assert nerr(yp, ry + pos.double()[None]) < tol(out_dtype)
+    # backward vs autograd (fp64)
+    dy = rnd(B, N, D, dtype=out_dtype, seed=9)
+    xd = x.double().detach().cpu().requires_grad_(True)
+    gd, bd = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5).backward(dy.double().cpu())
+    dg, dbt = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx, dxd = o.layernorm_bwd(dy, x, g, mean, rstd, dg, dbt, dx_dtype=in_dtype)
+    assert dxd is dx
+    t = max(tol(in_dtype), tol(out_dtype))
+    assert nerr(dx, xd.grad) < t and nerr(dg, gd.grad) < t and nerr(dbt, bd.grad) < t
+    o.layernorm_bwd(dy, x, g, mean, rstd, dg, dbt, dx_dtype=in_dtype, accumulate=True)
+    assert nerr(dg, 2 * gd.grad) < 2 * t
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_layernorm_bwd_dropout_branch(dtype):
+    o = ops()
+    M, D = 40, 512
+    x, dy = rnd(M, D, dtype=dtype), rnd(M, D, dtype=dtype, seed=1)
+    g, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    _, mean, rstd = o.layernorm_fwd(x, g, b)
+    drop = o.DropSpec(p=0.25, seed=123, site=7, step=torch.tensor([5], dtype=torch.int32, device=DEV))
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx, dxd = o.layernorm_bwd(dy, x, g, mean, rstd, dg, db, drop=drop)
+    keep = o.dropout_keep_mask(drop, M * D, DEV).view(M, D).double()
+    assert nerr(dxd, dx.double() * keep / 0.75) < tol(dtype)
+
+
+ATT_SHAPES = [(2, 4, 5, 7, 8), (3, 8, 100, 100, 64), (2, 8, 100, 20, 64), (2, 8, 20, 20, 64), (2, 8, 20, 100, 64),
+              (2, 2, 1, 7, 16), (1, 8, 237, 237, 64), (2, 8, 182, 182, 96)]
+
+
+def att_ref(q, k, v, mask, H):
+    B, nq, nk = q.shape[0], q.shape[1], k.shape[1]
+    dk, dv = q.shape[2] // H, v.shape[2] // H
+    qh = q.double().view(B, nq, H, dk).transpose(1, 2)
+    kh = k.double().view(B, nk, H, dk).transpose(1, 2)
+    vh = v.double().view(B, nk, H, dv).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dk)
+    if mask is not None:
+        s = s + mask.double()
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, nq, H * dv), p, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mask_kind", ["none", "pad", "full", "causal"])
+@pytest.mark.parametrize("B,H,nq,nk,d", ATT_SHAPES)
+def test_attention_fwd_bwd(dtype, mask_kind, B, H, nq, nk, d):
+    o = ops()
+    if mask_kind == "causal" and nq != nk:
+        pytest.skip("causal needs nq == nk")
+    qkv_q = rnd(B, nq, 3 * H * d, dtype=dtype, seed=1)  # packed buffer: q is a strided view
+    q = qkv_q[..., :H * d]
+    k, v = rnd(B, nk, H * d, dtype=dtype, seed=2), rnd(B, nk, H * d, dtype=dtype, seed=3)
+    mask = None
+    if mask_kind == "pad":
+        mask = torch.zeros(B, 1, 1, nk, device=DEV)
+        mask[0, ..., nk // 2:] = -1e5
+        mask[-1] = -1e5  # fully padded sample -> uniform attention, no NaN
+    elif mask_kind == "full":
+        mask = (torch.rand(B, 1, nq, nk, generator=torch.Generator().manual_seed(4)) < 0.3).float().to(DEV) * -1e5
+    elif mask_kind == "causal":
+        mask = (torch.ones(nq, nq).triu(1) * -1e5)[None, None].to(DEV)
+    out, lse, att = o.attention_fwd(q, k, v, mask, H, need_att=True)
+    ro, rp, rl = att_ref(q, k, v, mask, H)
+    assert torch.isfinite(out.float()).all()
+    assert nerr(out, ro) < tol(dtype) and nerr(att, rp) < tol(dtype) and nerr(lse, rl) < 1e-3
+    # backward vs autograd fp64
+    d_o = rnd(B, nq, H * d, dtype=dtype, seed=5)
+    qd, kd, vd = (t.double().cpu().detach().clone().requires_grad_(True) for t in (q, k, v))
+    att_ref(qd, kd, vd, None if mask is None else mask.cpu(), H)[0].backward(d_o.double().cpu())
+    dq, dk, dv = o.attention_bwd(d_o, q, k, v, out, lse, mask, H)
+    t = tol(dtype) * (3 if dtype == BF16 else 1)
+    assert nerr(dq, qd.grad) < t and nerr(dk, kd.grad) < t and nerr(dv, vd.grad) < t
+
+
+def test_dropout_mask_statistics_and_epilogue():
+    o = ops()
+    n = 1 << 20
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    d1 = o.DropSpec(p=0.1, seed=42, site=1, step=step)
+    m1 = o.dropout_keep_mask(d1, n, DEV)
+    assert abs(m1.float().mean().item() - 0.9) < 3e-3
+    assert torch.equal(m1, o.dropout_keep_mask(d1, n, DEV))  # pure function
+    for other in (o.DropSpec(0.1, 43, 1, step), o.DropSpec(0.1, 42, 2, step),
+                  o.DropSpec(0.1, 42, 1, torch.tensor([4], dtype=torch.int32, device=DEV))):
+        m2 = o.dropout_keep_mask(other, n, DEV)
+        agree = (m1 == m2).float().mean().item()
+        assert abs(agree - (0.81 + 0.01)) < 5e-3  # independent masks
+    # fused epilogues use exactly this mask (index = m*N + n)
+    for dtype, (M, N, K) in [(F32, (40, 48, 32)), (BF16, (256, 128, 64))]:
+        x, w, b = rnd(M, K, dtype=dtype), rnd(N, K, dtype=dtype, scale=0.2, seed=1), rnd(N, seed=2)
+        res = rnd(M, N, dtype=dtype, seed=3)
+        d = o.DropSpec(p=0.3, seed=9, site=11, step=step)
+        keep = o.dropout_keep_mask(d, M * N, DEV).view(M, N).double() / 0.7
+        u = x.double() @ w.double().t() + b.double()
+        assert nerr(o.linear_fwd(x, w, b, o.EPI_BIAS_RESIDUAL, residual=res, drop=d), res.double() + u * keep) < tol(dtype)
+        assert nerr(o.linear_fwd(x, w, b, o.EPI_BIAS_GELU, drop=d), gelu(u) * keep) < tol(dtype)
+        dy, pre = rnd(M, N, dtype=dtype, seed=4), rnd(M, K, dtype=dtype, seed=5)
+        keep_k = o.dropout_keep_mask(d, M * K, DEV).view(M, K).double() / 0.7
+        ref = (dy.double() @ w.double()) * keep_k * gelu_grad(pre.double())
+        assert nerr(o.linear_bwd_data(dy, w, preact=pre, drop=d), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_pointer_score_and_batched_gemm(dtype):
+    o = ops()
+    B, T, N, D = 3, 12, 50, 96
+    q, k = rnd(B, T, D, dtype=dtype), rnd(B, N, D, dtype=dtype, seed=1)
+    s0 = q.double() @ k.double().transpose(1, 2) / math.sqrt(D)
+    am = torch.zeros(B, N, device=DEV)
+    am[1, 40:] = -1e5
+    assert nerr(o.pointer_score(q, k, 1 / math.sqrt(D), add_mask=am), s0 + am.double()[:, None]) < tol(dtype)
+    kf = torch.zeros(B, N, dtype=torch.uint8, device=DEV)
+    kf[2, 10:] = 1
+    s = o.pointer_score(q, k, 1 / math.sqrt(D), key_fill=kf)
+    assert torch.isinf(s[2, :, 10:]).all() and nerr(s[:2], s0[:2]) < tol(dtype)
+    qf = torch.zeros(B, T, dtype=torch.uint8, device=DEV)
+    qf[0, 5:] = 1
+    s = o.pointer_score(q, k, 1 / math.sqrt(D), query_fill=qf)
+    assert torch.isinf(s[0, 5:]).all() and nerr(s[1:], s0[1:]) < tol(dtype)
+    a, b = rnd(B, T, N, dtype=dtype, seed=2), rnd(B, N, D, dtype=dtype, seed=3)
+    assert nerr(o.batched_gemm(a, b, alpha=0.5), 0.5 * a.double() @ b.double()) < tol(dtype) * 4
+    assert nerr(o.batched_gemm(a, q, trans_a=True), a.double().transpose(1, 2) @ q.double()) < tol(dtype) * 4
+    assert nerr(o.batched_gemm(q, k, trans_b=True), q.double() @ k.double().transpose(1, 2)) < tol(dtype) * 4
+
+
+def test_adam_matches_torch_and_shadow():
+    o = ops()
+    n = 4099
+    p0 = rnd(n)
+    ref = torch.nn.Parameter(p0.clone().cpu())
+    opt = torch.optim.Adam([ref], lr=0.01, betas=(0.9, 0.98))
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pad = (n + 3) // 4 * 4
+    shadow = torch.zeros(pad, dtype=BF16, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lr_scale = torch.tensor([0.5], device=DEV)
+    for it in range(3):
+        g = rnd(n, seed=10 + it)
+        ref.grad = g.cpu().clone() / 4.0
+        for grp in opt.param_groups:
+            grp["lr"] = 0.01 * 0.5
+        opt.step()
+        o.increment_step(step)
+        o.adam_step(p, g, m, v, shadow, lr=0.01, step=step, lr_scale=lr_scale, grad_scale=0.25)
+    assert int(step.item()) == 3
+    assert nerr(p, ref.detach()) < 1e-5
+    assert torch.equal(shadow[:n], p.to(BF16))
+
+
+def test_sq_loss_and_cast():
+    o = ops()
+    for dtype in (F32, BF16):
+        x = rnd(7, 300, dtype=dtype)
+        loss = torch.full((1,), 5.0, device=DEV)
+        dx = o.sq_loss_fwd_bwd(x, loss)
+        assert abs(loss.item() - x.double().pow(2).mean().item()) < 1e-4
+        assert nerr(dx, 2 * x.double() / x.numel()) < tol(dtype)
+        o.sq_loss_fwd_bwd(x, loss, accumulate=True)
+        assert abs(loss.item() - 2 * x.double().pow(2).mean().item()) < 2e-4
+    a = rnd(1000)
+    b = torch.empty(1000, dtype=BF16, device=DEV)
+    assert torch.equal(o.cast(a, b), a.to(BF16))
+
+
+def test_errors_are_loud():
+    o = ops()
+    with pytest.raises(RuntimeError):
+        o.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))  # CPU tensors
+    with pytest.raises(RuntimeError):
+        o.layernorm_fwd(rnd(4, 12), torch.ones(12, device=DEV), torch.zeros(12, device=DEV))  # D % 8 != 0
