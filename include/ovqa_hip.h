@@ -148,11 +148,14 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
                        float scale, void* stream);
 
 /* Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
- * the caller (rowsum(dO*O)); dq/dk/dv use the same [b,n,h*d+c] addressing. */
+ * the caller (rowsum(P*dP)); dq/dk/dv use the same [b,n,h*d+c] addressing.
+ * d_att [B,H,nq,nk] (dtype, may be NULL) is the gradient w.r.t. the returned
+ * attention weights -- the reference's second return value is differentiable
+ * (attentions.py:56,60). */
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo,
                        const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, const void* o, int64_t ldo,
-                       const float* lse, const float* mask,
+                       const void* d_att, const float* lse, const float* mask,
                        int64_t msb, int64_t msh, int64_t msq,
                        void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv,
                        float* delta,

@@ -117,15 +117,16 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
 }
 
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
-                       const void* v, int64_t ldv, const void* o, int64_t ldo, const float* lse, const float* mask,
-                       int64_t msb, int64_t msh, int64_t msq, void* dq, int64_t lddq, void* dk_, int64_t lddk,
+                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_att, const float* lse,
+                       const float* mask, int64_t msb, int64_t msh, int64_t msq, void* dq, int64_t lddq, void* dk_,
+                       int64_t lddk,
                        void* dv_, int64_t lddv, float* delta, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk,
                        int64_t dv, float scale, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_bwd: bad dtype %d", dtype);
   OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_bwd: bad sizes");
   if (B == 0 || nq == 0) return OVQA_OK;
   OVQA_REQUIRE(d_o && q && k && v && o && dq && dk_ && dv_, OVQA_ERR_BAD_ARG, "attention_bwd: null pointer");
-  ovqa::AttnBwdArgs a{d_o, q, k, v, o, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
+  ovqa::AttnBwdArgs a{d_o, q, k, v, o, d_att, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
                       lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
   return ovqa::simple_attention_bwd(dtype, a, as_stream(stream));
 }

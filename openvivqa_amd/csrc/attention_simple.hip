@@ -93,22 +93,25 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(ovqa::AttnArgs a) 
 }
 
 // ---------------------------------------------------------------- backward: dQ (+ delta)
+// dS = P * (dP - delta), dP = dO V^T (+ d_att when the caller differentiates the returned
+// attention weights), delta_i = sum_j P_ij dP_ij  (== dO_i . O_i when d_att is absent).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(ovqa::AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nk = a.nk, dk = a.dk, dv = a.dv, nq = a.nq;
   float* Ks = smem;
   float* Vs = Ks + (size_t)nk * (dk + 1);
-  float* sbuf = Vs + (size_t)nk * (dv + 1);  // [4][nk]
-  float* qbuf = sbuf + 4 * (size_t)nk;       // [4][dk]
+  float* sbuf = Vs + (size_t)nk * (dv + 1);  // [4][nk]  p, then dS
+  float* dpbuf = sbuf + 4 * (size_t)nk;      // [4][nk]  dP
+  float* qbuf = dpbuf + 4 * (size_t)nk;      // [4][dk]
   float* dobuf = qbuf + 4 * (size_t)dk;      // [4][dv]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const T* q = (const T*)a.q;
   const T* k = (const T*)a.k;
   const T* v = (const T*)a.v;
-  const T* o = (const T*)a.o;
   const T* d_o = (const T*)a.d_o;
+  const T* datt = (const T*)a.d_att;
   T* dq = (T*)a.dq;
 
   for (int e = tid; e < nk * dk; e += 256) {
@@ -122,36 +125,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(ovqa::AttnBwdAr
   __syncthreads();
 
   float* sw = sbuf + (size_t)wave * nk;
+  float* pw = dpbuf + (size_t)wave * nk;
   float* qw = qbuf + (size_t)wave * dk;
   float* dw = dobuf + (size_t)wave * dv;
   const int row0 = blockIdx.y * ROWS_PER_BLOCK;
   for (int r = wave; r < ROWS_PER_BLOCK; r += 4) {
     const int i = row0 + r;
     const bool live = i < nq;
-    float dsum = 0.f;
     if (live) {
       for (int c = lane; c < dk; c += 64) qw[c] = to_f32<T>(q[((int64_t)b * nq + i) * a.ldq + h * dk + c]);
-      for (int c = lane; c < dv; c += 64) {
-        const float g = to_f32<T>(d_o[((int64_t)b * nq + i) * a.lddo + h * dv + c]);
-        dw[c] = g;
-        dsum += g * to_f32<T>(o[((int64_t)b * nq + i) * a.ldo + h * dv + c]);
-      }
+      for (int c = lane; c < dv; c += 64) dw[c] = to_f32<T>(d_o[((int64_t)b * nq + i) * a.lddo + h * dv + c]);
     }
-    const float delta = wave_sum(dsum);
     __syncthreads();
+    float dsum = 0.f;
     if (live) {
       const float lse = a.lse[((int64_t)b * a.H + h) * nq + i];
-      if (lane == 0) a.delta[((int64_t)b * a.H + h) * nq + i] = delta;
       for (int j = lane; j < nk; j += 64) {
         const float* kr = Ks + (size_t)j * (dk + 1);
         const float* vr = Vs + (size_t)j * (dv + 1);
         float s = 0.f, dp = 0.f;
         for (int c = 0; c < dk; c++) s = fmaf(qw[c], kr[c], s);
         for (int c = 0; c < dv; c++) dp = fmaf(dw[c], vr[c], dp);
+        if (datt) dp += to_f32<T>(datt[(((int64_t)b * a.H + h) * nq + i) * nk + j]);
         s = s * a.scale + mask_at(a.mask, a.msb, a.msh, a.msq, b, h, i, j);
         const float p = __expf(s - lse);
-        sw[j] = p * (dp - delta);
+        sw[j] = p;
+        pw[j] = dp;
+        dsum += p * dp;
       }
+    }
+    const float delta = wave_sum(dsum);
+    if (live) {
+      if (lane == 0) a.delta[((int64_t)b * a.H + h) * nq + i] = delta;
+      for (int j = lane; j < nk; j += 64) sw[j] = sw[j] * (pw[j] - delta);
     }
     __syncthreads();
     if (live) {
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(ovqa::AttnBwdA
   const T* k = (const T*)a.k;
   const T* v = (const T*)a.v;
   const T* d_o = (const T*)a.d_o;
+  const T* datt = (const T*)a.d_att;
   T* dkp = (T*)a.dk_;
   T* dvp = (T*)a.dv_;
 
@@ -221,6 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(ovqa::AttnBwdA
         float s = 0.f, dp = 0.f;
         for (int c = 0; c < dk; c++) s = fmaf(qr[c], kw[c], s);
         for (int c = 0; c < dv; c++) dp = fmaf(gr[c], vw[c], dp);
+        if (datt) dp += to_f32<T>(datt[(((int64_t)b * a.H + h) * nq + i) * nk + j]);
         s = s * a.scale + mask_at(a.mask, a.msb, a.msh, a.msq, b, h, i, j);
         const float p = __expf(s - lse_s[i]);
         pw[i] = p;
@@ -275,7 +283,7 @@ int fwd_t(const ovqa::AttnArgs& a, hipStream_t st) {
 
 template <typename T>
 int bwd_t(const ovqa::AttnBwdArgs& a, hipStream_t st) {
-  const size_t lds1 = ((size_t)a.nk * (a.dk + 1) + (size_t)a.nk * (a.dv + 1) + 4 * (size_t)a.nk + 4 * (size_t)a.dk +
+  const size_t lds1 = ((size_t)a.nk * (a.dk + 1) + (size_t)a.nk * (a.dv + 1) + 8 * (size_t)a.nk + 4 * (size_t)a.dk +
                        4 * (size_t)a.dv) * 4;
   int rc = set_lds_limit(attn_bwd_dq_simple_kernel<T>, lds1, "attention_bwd(dq)");
   if (rc != OVQA_OK) return rc;

@@ -36,7 +36,7 @@ struct AttnArgs {
   float scale;
 };
 struct AttnBwdArgs {
-  const void *d_o, *q, *k, *v, *o;
+  const void *d_o, *q, *k, *v, *o, *d_att;
   int64_t lddo, ldq, ldk, ldv, ldo;
   const float *lse, *mask;
   int64_t msb, msh, msq;

@@ -272,18 +272,23 @@ def linear(x, lin, arena):
 
 # ------------------------------------------------------------------ attention core on projected tensors
 class _AttentionCore(Function):
+    """(o, att) = attention(q, k, v); both outputs are differentiable, like the reference's."""
+
     @staticmethod
     def forward(ctx, q, k, v, mask, h, need_att):
         o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att)
-        ctx.h, ctx.mask = h, mask
+        ctx.h, ctx.mask, ctx.need_att = h, mask, need_att
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.mark_non_differentiable(*([att] if att is not None else []))
         return (o, att) if need_att else (o, None)
 
     @staticmethod
-    def backward(ctx, d_o, _datt):
+    def backward(ctx, d_o, d_att):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h)
+        if d_o is None:
+            d_o = torch.zeros_like(o)
+        if d_att is not None:
+            d_att = d_att.to(q.dtype).contiguous()
+        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h, d_att=d_att)
         return dq, dk, dv, None, None, None
 
 

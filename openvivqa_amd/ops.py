@@ -204,7 +204,7 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
     return o, lse, att
 
 
-def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None):
+def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None):
     _dev(q)
     lib = _lib.load()
     B, nq = q.shape[0], q.shape[1]
@@ -216,9 +216,11 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
     dv = dv if dv is not None else torch.empty(B, nk, H * dvv, dtype=q.dtype, device=q.device)
     delta = torch.empty(B, H, nq, dtype=torch.float32, device=q.device)
     mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    if d_att is not None:
+        assert d_att.is_contiguous() and d_att.dtype == q.dtype and d_att.shape == (B, H, nq, nk)
     _lib.check(lib.ovqa_attention_bwd(
         _dt(q), _p(d_o), _rows(d_o)[0], _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v), _rows(v)[0], _p(o), _rows(o)[0],
-        _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
+        _p(d_att), _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
         B, H, nq, nk, dkk, dvv, float(scale), _stream()), "attention_bwd")
     return dq, dk, dv
 

@@ -91,6 +91,7 @@ class ParamArena:
         self.shadow = (torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
                        if compute_dtype == torch.bfloat16 else None)
         self.overwrite_grads = False  # harness mode: backward always overwrites the grad buffer
+        self.kernel_written = set()   # ids of parameters whose gradient the HIP kernels produce
         with torch.no_grad():
             for p in self.params:
                 o = self.offsets[id(p)]
@@ -155,6 +156,21 @@ class ParamArena:
         if self._versions != [p._version for p in self.params]:
             self.refresh_shadow()
 
+    def foreign_ranges(self):
+        """Merged [start, end) element ranges of the grad buffer NOT written by the kernels during the
+        last backward: parameters that live in plain torch modules (autograd accumulates into their
+        ``.grad``) or that receive no gradient at all (dead cross-attention).  The training
+        harness zeroes exactly these before each backward; everything else is overwritten."""
+        spans = sorted((self.offsets[id(p)], self.offsets[id(p)] + p.numel()) for p in self.params
+                       if id(p) not in self.kernel_written)
+        merged = []
+        for s, e in spans:
+            if merged and s <= merged[-1][1] + ALIGN:
+                merged[-1][1] = max(merged[-1][1], e)
+            else:
+                merged.append([s, e])
+        return [(s, e) for s, e in merged]
+
     def attach_grads(self) -> None:
         for p in self.params:
             p.grad = self.grad_of(p)
@@ -165,6 +181,7 @@ class ParamArena:
         gradient written, an existing ``.grad`` is accumulated into."""
         ps = list(ps)
         views = [self.grad_of(p) for p in ps]
+        self.kernel_written.update(id(p) for p in ps)
         if self.overwrite_grads:
             for p, v in zip(ps, views):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():

@@ -132,9 +132,12 @@ class TrainStep:
         self.static_inputs = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.drop_step = rt.step_tensor(self.arena.device)
+        self._foreign = [(0, self.arena.numel)]  # until the first backward tells which grads the kernels own
 
     # -- one fwd+bwd on the static inputs (this is what gets captured) ------
     def _fwd_bwd(self):
+        for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
+            self.arena.grad[s:e].zero_()
         res = self.forward_loss(*self.static_inputs)
         if isinstance(res, tuple):
             outs, grads = res
@@ -143,11 +146,16 @@ class TrainStep:
             res.backward()
             self.loss.copy_(res.detach().float().reshape(1))
 
+    def _discover_foreign(self):
+        self._fwd_bwd()
+        self._foreign = self.arena.foreign_ranges()
+
     def _capture(self, inputs: Sequence[torch.Tensor]):
         self.static_inputs = [t.clone() for t in inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            self._discover_foreign()
             for _ in range(2):  # warm-up: allocator pools, lazy arenas, workspace
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)

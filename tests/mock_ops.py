@@ -1,0 +1,198 @@
+"""TEST-ONLY stand-in for ``openvivqa_amd.ops`` implemented with plain torch math on CPU.
+
+Purpose: exercise the HOST logic of the product (autograd plumbing in functional.py, arena
+bookkeeping, module wiring) in the CPU-only container.  It is never imported by the product;
+tests monkeypatch it in.  Semantics follow include/ovqa_hip.h exactly (same arguments, same
+in-place/accumulate behaviour), dropout excluded (p must be 0).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
+
+
+@dataclass
+class DropSpec:
+    p: float
+    seed: int
+    site: int
+    step: Optional[torch.Tensor] = None
+
+
+def workspace(device):
+    return torch.empty(1)
+
+
+def _gelu_grad(u):
+    return 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+
+
+def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=False, drop=None, out=None,
+               preact_out=None):
+    assert drop is None or drop.p == 0
+    u = x.float() @ w.float().t()
+    if bias is not None:
+        u = u + bias
+    pre = None
+    if epilogue == EPI_BIAS_GELU:
+        pre = u.to(x.dtype).reshape(-1, w.shape[0])
+        y = torch.nn.functional.gelu(u)
+    elif epilogue == EPI_BIAS_RESIDUAL:
+        y = residual.float() + u
+    else:
+        y = u
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    return (y, pre) if want_preact else y
+
+
+def linear_bwd_data(dy, w, preact=None, drop=None, out=None, accumulate=False):
+    dx = dy.float() @ w.float()
+    if preact is not None:
+        dx = dx * _gelu_grad(preact.float()).reshape(dx.shape)
+    if out is not None:
+        if accumulate:
+            out.add_(dx.to(out.dtype))
+        else:
+            out.copy_(dx.to(out.dtype))
+        return out
+    return dx.to(dy.dtype)
+
+
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+    d2, x2 = dy.reshape(-1, dy.shape[-1]).float(), x.reshape(-1, x.shape[-1]).float()
+    g = d2.t() @ x2
+    if accumulate:
+        dw.add_(g.view_as(dw))
+    else:
+        dw.copy_(g.view_as(dw))
+    if db is not None:
+        s = d2.sum(0)
+        if accumulate:
+            db.add_(s.view_as(db))
+        else:
+            db.copy_(s.view_as(db))
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True):
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = xf.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    y = (xf - mean[..., None]) * rstd[..., None] * gamma + beta
+    if pos is not None:
+        y = y + pos[None]
+    return y.to(out_dtype or x.dtype), mean.reshape(-1), rstd.reshape(-1)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False):
+    assert drop is None or drop.p == 0
+    D = x.shape[-1]
+    xf, df = x.float().reshape(-1, D), dy.float().reshape(-1, D)
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    dg, db = (df * xh).sum(0), df.sum(0)
+    if accumulate:
+        dgamma.add_(dg)
+        dbeta.add_(db)
+    else:
+        dgamma.copy_(dg)
+        dbeta.copy_(db)
+    dyg = df * gamma
+    dx = rstd[:, None] * (dyg - dyg.mean(-1, keepdim=True) - xh * (dyg * xh).mean(-1, keepdim=True))
+    dx = dx.reshape(x.shape).to(dx_dtype or dy.dtype)
+    return dx, dx
+
+
+def _heads(t, H):
+    B, n, F = t.shape
+    return t.float().reshape(B, n, H, F // H).transpose(1, 2)
+
+
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
+    qh, kh, vh = _heads(q, H), _heads(k, H), _heads(v, H)
+    scale = scale or 1.0 / math.sqrt(qh.shape[-1])
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, -1)
+    o = (p @ vh).transpose(1, 2).reshape(q.shape[0], q.shape[1], -1).to(q.dtype)
+    return o, torch.logsumexp(s, -1), (p.to(q.dtype) if need_att else None)
+
+
+def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None):
+    qh, kh, vh, gh = _heads(q, H), _heads(k, H), _heads(v, H), _heads(d_o, H)
+    scale = scale or 1.0 / math.sqrt(qh.shape[-1])
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + mask
+    p = torch.exp(s - lse[..., None])
+    dp = gh @ vh.transpose(-1, -2)
+    if d_att is not None:
+        dp = dp + d_att.float()
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    rdq = (ds @ kh * scale).transpose(1, 2).reshape(q.shape)
+    rdk = (ds.transpose(-1, -2) @ qh * scale).transpose(1, 2).reshape(k.shape)
+    rdv = (p.transpose(-1, -2) @ gh).transpose(1, 2).reshape(v.shape)
+    outs = []
+    for dst, r, like in ((dq, rdq, q), (dk, rdk, k), (dv, rdv, v)):
+        if dst is None:
+            outs.append(r.to(like.dtype))
+        else:
+            dst.copy_(r.to(dst.dtype))
+            outs.append(dst)
+    return tuple(outs)
+
+
+def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
+    s = q.float() @ k.float().transpose(1, 2) * scale
+    if add_mask is not None:
+        s = s + add_mask[:, None, :]
+    if key_fill is not None:
+        s = s.masked_fill(key_fill.bool()[:, None, :], float("-inf"))
+    if query_fill is not None:
+        s = s.masked_fill(query_fill.bool()[:, :, None], float("-inf"))
+    return s
+
+
+def batched_gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, out_dtype=None):
+    a2 = a.float().transpose(1, 2) if trans_a else a.float()
+    b2 = b.float().transpose(1, 2) if trans_b else b.float()
+    return (alpha * (a2 @ b2)).to(out_dtype or a.dtype)
+
+
+def cast(src, dst):
+    dst.copy_(src)
+    return dst
+
+
+def increment_step(step):
+    step.add_(1)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None, betas=(0.9, 0.98), eps=1e-8,
+              weight_decay=0.0, grad_scale=1.0):
+    t = float(step.item())
+    lr_eff = lr * (float(lr_scale.item()) if lr_scale is not None else 1.0)
+    g = grad * grad_scale + weight_decay * param
+    exp_avg.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    exp_avg_sq.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    denom = exp_avg_sq.sqrt() / math.sqrt(1 - betas[1] ** t) + eps
+    param.addcdiv_(exp_avg, denom, value=-lr_eff / (1 - betas[0] ** t))
+    if shadow is not None:
+        shadow.copy_(param)
+
+
+def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False):
+    v = x.float().pow(2).mean()
+    if accumulate:
+        loss.add_(v)
+    else:
+        loss.fill_(float(v))
+    return (2 * x.float() / x.numel()).to(x.dtype) if want_grad else None

@@ -1,0 +1,141 @@
+"""Block-level parity (forward, input grads, weight grads) of each fused HIP block against the
+oracle at BASELINE layer sizes (D=512, H=8, dff=2048, 100 regions x 20 tokens, padded samples).
+fp32 mode: rel-L2 <= 2e-4 everywhere; bf16 mode: rel-L2 <= 2e-2 (stated per assert)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape
+    return ((a - b).norm() / max(b.norm().item(), 1e-30)).item()
+
+
+@pytest.fixture(params=[F32, BF16], ids=["fp32", "bf16"])
+def mode(request):
+    import openvivqa_amd as A
+    A.set_compute_dtype(request.param)
+    yield request.param
+    A.set_compute_dtype(BF16)
+
+
+def _inputs(B=4, nv=100, nl=20, D=512, seed=0):
+    import oracle as O
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(B, nv, D, generator=g)
+    l = torch.randn(B, nl, D, generator=g)
+    v[1, 90:] = 0
+    v[2, 64:] = 0
+    l[0, 12:] = 0
+    l[3, 8:] = 0
+    return v, l, O.padding_mask(v, 0), O.padding_mask(l, 0)
+
+
+def _compare(name, mode, oracle_mod, hip_mod, call, inputs, grad_names):
+    hip_mod.load_state_dict(oracle_mod.state_dict())
+    oracle_mod.eval()
+    hip_mod = hip_mod.to(DEV).eval()
+    ins_o = {k: (v.clone().requires_grad_(True) if k in grad_names else v) for k, v in inputs.items()}
+    ins_h = {k: (v.clone().to(DEV).requires_grad_(True) if k in grad_names else v.to(DEV)) for k, v in inputs.items()}
+    out_o, out_h = call(oracle_mod, ins_o), call(hip_mod, ins_h)
+    if not isinstance(out_o, tuple):
+        out_o, out_h = (out_o,), (out_h,)
+    gen = torch.Generator().manual_seed(99)
+    ws = [torch.randn(o.shape, generator=gen) for o in out_o]
+    sum((o * w).sum() for o, w in zip(out_o, ws)).backward()
+    sum((o.float() * w.to(DEV)).sum() for o, w in zip(out_h, ws)).backward()
+    tol_f, tol_g = (2e-5, 2e-4) if mode == F32 else (1e-2, 2e-2)
+    report = []
+    for i, (a, b) in enumerate(zip(out_h, out_o)):
+        report.append((f"out{i}", rel_l2(a, b), tol_f))
+    for k in grad_names:
+        report.append((f"d{k}", rel_l2(ins_h[k].grad, ins_o[k].grad), tol_g))
+    go = dict(oracle_mod.named_parameters())
+    for k, p in hip_mod.named_parameters():
+        if go[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0
+            continue
+        if k.endswith("fc_k.bias"):
+            continue
+        report.append((f"dW[{k}]", rel_l2(p.grad, go[k].grad), tol_g))
+    bad = [(n, e, t) for n, e, t in report if not e < t]
+    assert not bad, f"{name}: " + ", ".join(f"{n}={e:.2e}(>{t:.0e})" for n, e, t in bad)
+
+
+def _cfg(**kw):
+    from openvivqa_amd.config import attention_config
+    return attention_config(**kw)
+
+
+def test_block_prologue(mode):
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    cfg = ConfigNode(dict(D_MODEL=512, LAYERS=0, SELF_ATTENTION=_cfg()))
+    torch.manual_seed(1)
+    o, h = O.OracleEncoder(cfg), M.Encoder(cfg)
+    with torch.no_grad():
+        o.layer_norm.weight.uniform_(0.5, 1.5)
+        o.layer_norm.bias.normal_(0, 0.1)
+    v, l, vm, lm = _inputs()
+    _compare("prologue", mode, o, h, lambda m, i: m(i["x"], i["mask"]), {"x": v, "mask": vm}, ["x"])
+
+
+@pytest.mark.parametrize("kind", ["self", "cross", "general"])
+def test_block_mha(mode, kind):
+    import oracle as O
+    import openvivqa_amd.modules as M
+    torch.manual_seed(2)
+    o, h = O.OracleMHA(_cfg()), M.MultiHeadAttention(_cfg())
+    with torch.no_grad():
+        for lin in (o.attention.fc_q, o.attention.fc_k, o.attention.fc_v, o.attention.fc_o):
+            lin.bias.normal_(0, 0.1)
+        o.layer_norm.weight.uniform_(0.5, 1.5)
+        o.layer_norm.bias.normal_(0, 0.1)
+    v, l, vm, lm = _inputs()
+    if kind == "self":
+        _compare("mha-self", mode, o, h, lambda m, i: m(i["x"], i["x"], i["x"], i["mask"]), {"x": v, "mask": vm}, ["x"])
+    elif kind == "cross":
+        _compare("mha-cross", mode, o, h, lambda m, i: m(i["x"], i["kv"], i["kv"], i["mask"]),
+                 {"x": v, "kv": l, "mask": lm}, ["x", "kv"])
+    else:
+        l2 = torch.randn(l.shape, generator=torch.Generator().manual_seed(5))
+        _compare("mha-general", mode, o, h, lambda m, i: m(i["x"], i["k"], i["v"], i["mask"]),
+                 {"x": v, "k": l, "v": l2, "mask": lm}, ["x", "k", "v"])
+
+
+def test_block_ffn(mode):
+    import oracle as O
+    import openvivqa_amd.modules as M
+    torch.manual_seed(3)
+    o, h = O.OraclePWFF(_cfg()), M.PositionWiseFeedForward(_cfg())
+    with torch.no_grad():
+        o.layer_norm.weight.uniform_(0.5, 1.5)
+        o.layer_norm.bias.normal_(0, 0.1)
+    v, l, vm, lm = _inputs()
+    _compare("ffn", mode, o, h, lambda m, i: m(i["x"]), {"x": v}, ["x"])
+
+
+def test_block_guided_layer(mode):
+    import oracle as O
+    import openvivqa_amd.modules as M
+    torch.manual_seed(4)
+    o, h = O.OracleGuidedEncoderLayer(_cfg()), M.GuidedEncoderLayer(_cfg())
+    v, l, vm, lm = _inputs()
+    _compare("guided-layer", mode, o, h,
+             lambda m, i: m(i["v"], i["l"], i["l"], i["vm"], i["lm"]), {"v": v, "l": l, "vm": vm, "lm": lm}, ["v", "l"])
+
+
+def test_sdpa_direct_with_differentiable_att(mode):
+    """ScaledDotProductAttention used directly returns (out, att) and BOTH are differentiable."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    torch.manual_seed(6)
+    o, h = O.OracleSDPA(_cfg()), M.ScaledDotProductAttention(_cfg())
+    v, l, vm, lm = _inputs(B=2)
+    _compare("sdpa", mode, o, h, lambda m, i: m(i["x"], i["kv"], i["kv"], i["mask"]),
+             {"x": v, "kv": l, "mask": lm}, ["x", "kv"])
