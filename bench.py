@@ -136,10 +136,13 @@ def cpu_baseline(cfg, steps):
     v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, cfg.MODEL.D_MODEL, b.MIN_REGIONS,
                                    b.MIN_TOKENS, b.SEED, "cpu", torch.float32)
 
+    gt = torch.Generator().manual_seed(1)
+    tv, tt = torch.randn(v.shape, generator=gt), torch.randn(t.shape, generator=gt)
+
     def one():
         lo = te(t, tm)
         vo = ve(v, vm, lo, tm)
-        loss = vo.pow(2).mean() + lo.pow(2).mean()
+        loss = (vo - tv).pow(2).mean() + (lo - tt).pow(2).mean()
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -186,11 +189,16 @@ def main():
     v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,
                                    b.SEED + rank, device, dtype)
     loss_buf = torch.zeros(1, device=device)
+    # MSE against fixed random targets: mean(out^2) alone is constant for LayerNorm outputs
+    # (degenerate gradient), see DESIGN.md section 6.
+    gt = torch.Generator().manual_seed(b.SEED + 7919 * (rank + 1))
+    tgt_v = torch.randn(v.shape, generator=gt).to(device=device, dtype=dtype)
+    tgt_t = torch.randn(t.shape, generator=gt).to(device=device, dtype=dtype)
 
     def forward_loss(v_, vm_, t_, tm_):
         vo, lo = model(v_, vm_, t_, tm_)
-        dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss_buf, accumulate=False)
-        dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True)
+        dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss_buf, accumulate=False, target=tgt_v)
+        dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
         return (vo, lo), (dvo, dlo)
 
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32

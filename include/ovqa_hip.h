@@ -205,9 +205,10 @@ int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t 
  * out[i] = 1 if element i of a [rows, cols] site is kept. */
 int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream);
 
-/* mean-of-squares loss used by the stack-level bench harness:
- * loss += sum(x^2)/n (fp32 scalar, device), dx = 2*x/n * loss_scale. */
-int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n,
+/* Mean-squared-error loss of the stack-level bench harness (fused forward+backward):
+ * loss (+)= sum((x-target)^2)/n (fp32 device scalar), dx = 2*(x-target)/n.
+ * target (dtype, may be NULL = 0).  NB a NULL target on LayerNorm outputs is a constant. */
+int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                          int accumulate_loss, void* stream);
 
 #ifdef __cplusplus

@@ -49,7 +49,7 @@ SIGNATURES = {
     "ovqa_increment_step": [c_vp, c_vp],
     "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],
     "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
-    "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }
 _RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_workspace_bytes": C.c_int64}
 

@@ -179,11 +179,11 @@ int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, vo
   return ovqa::dropout_keep_mask(make_drop_args(drop), out, n, as_stream(stream));
 }
 
-int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss,
-                         void* stream) {
+int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
+                         int accumulate_loss, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "sq_loss: bad dtype");
   OVQA_REQUIRE(x && loss, OVQA_ERR_BAD_ARG, "sq_loss: null pointer");
-  return ovqa::sq_loss_fwd_bwd(dtype, x, dx, loss, n, accumulate_loss, as_stream(stream));
+  return ovqa::sq_loss_fwd_bwd(dtype, x, target, dx, loss, n, accumulate_loss, as_stream(stream));
 }
 
 }  // extern "C"

@@ -64,7 +64,8 @@ int adam_step(float* param, const float* grad, float* m, float* v, void* shadow,
 int increment_step(uint32_t* step_ptr, hipStream_t st);
 int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st);
 int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st);
-int sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss, hipStream_t st);
+int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
+                    int accumulate_loss, hipStream_t st);
 
 // ---- gemm_mfma.hip / attention_mfma.hip (bf16, MFMA) ---------------------------
 bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldres);

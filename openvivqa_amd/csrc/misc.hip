@@ -81,14 +81,14 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, T* __restrict__ dx,
-                                                      float* __restrict__ loss, int64_t n) {
+__global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, const T* __restrict__ tgt,
+                                                      T* __restrict__ dx, float* __restrict__ loss, int64_t n) {
   __shared__ float red[4];
   const float inv_n = 1.f / (float)n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float v = to_f32<T>(x[i]);
+    const float v = to_f32<T>(x[i]) - (tgt ? to_f32<T>(tgt[i]) : 0.f);
     s += v * v;
     if (dx) dx[i] = from_f32<T>(2.f * v * inv_n);
   }
@@ -150,7 +150,8 @@ int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t s
   return ovqa_check_launch("dropout_keep_mask");
 }
 
-int sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, int accumulate_loss, hipStream_t st) {
+int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
+                    int accumulate_loss, hipStream_t st) {
   OVQA_REQUIRE(n > 0, OVQA_ERR_BAD_ARG, "sq_loss: n must be > 0");
   if (!accumulate_loss) {
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
@@ -161,9 +162,11 @@ int sq_loss_fwd_bwd(int dtype, const void* x, void* dx, float* loss, int64_t n, 
   }
   dim3 grid(blocks_for(n) > 512 ? 512 : blocks_for(n)), block(256);
   if (dtype == OVQA_F32)
-    hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (float*)dx, loss, n);
+    hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)target, (float*)dx,
+                       loss, n);
   else
-    hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (bf16*)dx, loss, n);
+    hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (const bf16*)target, (bf16*)dx, loss,
+                       n);
   return ovqa_check_launch("sq_loss");
 }
 

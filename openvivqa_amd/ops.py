@@ -283,11 +283,13 @@ def dropout_keep_mask(drop: DropSpec, n: int, device) -> torch.Tensor:
     return out
 
 
-def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False):
-    """loss (fp32 device scalar) (+)= mean(x^2); returns d loss / d x (same dtype as x)."""
+def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False, target=None):
+    """loss (fp32 device scalar) (+)= mean((x-target)^2); returns d loss / d x (same dtype as x)."""
     _dev(x)
     assert x.is_contiguous()
+    if target is not None:
+        assert target.is_contiguous() and target.dtype == x.dtype and target.numel() == x.numel()
     dx = torch.empty_like(x) if want_grad else None
-    _lib.check(_lib.load().ovqa_sq_loss_fwd_bwd(_dt(x), _p(x), _p(dx), _p(loss), x.numel(), int(accumulate), _stream()),
-               "sq_loss")
+    _lib.check(_lib.load().ovqa_sq_loss_fwd_bwd(_dt(x), _p(x), _p(target), _p(dx), _p(loss), x.numel(),
+                                                int(accumulate), _stream()), "sq_loss")
     return dx

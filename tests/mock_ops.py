@@ -189,7 +189,9 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None,
         shadow.copy_(param)
 
 
-def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False):
+def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False, target=None):
+    if target is not None:
+        x = x.float() - target.float()
     v = x.float().pow(2).mean()
     if accumulate:
         loss.add_(v)

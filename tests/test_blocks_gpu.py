@@ -29,9 +29,10 @@ def _inputs(B=4, nv=100, nl=20, D=512, seed=0):
     v = torch.randn(B, nv, D, generator=g)
     l = torch.randn(B, nl, D, generator=g)
     v[1, 90:] = 0
-    v[2, 64:] = 0
     l[0, 12:] = 0
-    l[3, 8:] = 0
+    if B > 3:
+        v[2, 64:] = 0
+        l[3, 8:] = 0
     return v, l, O.padding_mask(v, 0), O.padding_mask(l, 0)
 
 

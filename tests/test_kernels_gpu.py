@@ -315,6 +315,10 @@ def test_sq_loss_and_cast():
         assert nerr(dx, 2 * x.double() / x.numel()) < tol(dtype)
         o.sq_loss_fwd_bwd(x, loss, accumulate=True)
         assert abs(loss.item() - 2 * x.double().pow(2).mean().item()) < 2e-4
+        t = rnd(7, 300, dtype=dtype, seed=3)
+        dx = o.sq_loss_fwd_bwd(x, loss, target=t)
+        d = x.double() - t.double()
+        assert abs(loss.item() - d.pow(2).mean().item()) < 1e-4 and nerr(dx, 2 * d / x.numel()) < tol(dtype)
     a = rnd(1000)
     b = torch.empty(1000, dtype=BF16, device=DEV)
     assert torch.equal(o.cast(a, b), a.to(BF16))
