@@ -62,6 +62,10 @@ int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
   if (M == 0) return OVQA_OK;
   OVQA_REQUIRE(dy && w && dx, OVQA_ERR_BAD_ARG, "linear_bwd_data: null pointer");
   OVQA_REQUIRE(lddy >= N && lddx >= K, OVQA_ERR_BAD_ARG, "linear_bwd_data: ld smaller than the row length");
+  OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_bwd_data: more than 2^32 elements");
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_data_supported(M, N, K, lddy, lddx))
+    return ovqa::mfma_linear_bwd_data(dy, lddy, w, dx, lddx, gelu_preact, M, N, K, accumulate, make_drop_args(drop),
+                                      as_stream(stream));
   return ovqa::simple_linear_bwd_data(dtype, dy, lddy, w, dx, lddx, gelu_preact, M, N, K, accumulate,
                                       make_drop_args(drop), as_stream(stream));
 }
@@ -73,6 +77,16 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* 
   OVQA_REQUIRE(dw != nullptr, OVQA_ERR_BAD_ARG, "linear_bwd_weight: dw is NULL");
   OVQA_REQUIRE(M == 0 || (dy && x), OVQA_ERR_BAD_ARG, "linear_bwd_weight: null pointer");
   (void)ws;
+  if (M == 0) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), as_stream(stream));
+      if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), as_stream(stream));
+      OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "linear_bwd_weight: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    return OVQA_OK;
+  }
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_weight_supported(M, N, K, lddy, ldx))
+    return ovqa::mfma_linear_bwd_weight(dy, lddy, x, ldx, dw, db, M, N, K, accumulate, as_stream(stream));
   return ovqa::simple_linear_bwd_weight(dtype, dy, lddy, x, ldx, dw, db, M, N, K, accumulate, as_stream(stream));
 }
 

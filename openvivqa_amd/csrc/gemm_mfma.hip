@@ -1,130 +1,184 @@
-// bf16 MFMA GEMM for gfx950: Y[M,N] = X[M,K] . W[N,K]^T (+ fused epilogue).
+// bf16 MFMA GEMM family for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
 //
-// * 128x128x64 tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave),
-//   v_mfma_f32_16x16x32_bf16, fp32 accumulators (64 VGPRs per lane).
-// * Orientation is swapped (D = W_tile . X_tile^T) so that a lane's 4
-//   accumulator registers are 4 CONSECUTIVE output columns of one row:
-//   the epilogue reads bias/residual and writes y/preact as 8-byte vectors.
-// * LDS tiles are [128 rows][64 k] bf16 (128 B per row) with the 16-byte chunk
-//   index XOR-ed by (row & 7): both the ds_write_b128 of the staging pass and
-//   the ds_read_b128 fragment reads are bank-conflict free.
-// * global -> registers -> LDS staging, double-buffered in LDS: the loads of
-//   tile t+1 are issued before the MFMAs of tile t and written after them,
-//   one barrier per K-tile.
-// * blockIdx is remapped so that the workgroups sharing an X row-panel run on
-//   the same XCD (its L2 then serves the panel to all N-tiles).
+// One kernel template computes  Out(c, r) = sum_k Q(c, k) * P(r, k)  for a 128(c) x 128(r) tile per
+// 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 64 accumulator VGPRs per lane).  `r` is the
+// CONTIGUOUS output dimension: P is the MFMA A operand, so a lane's 4 accumulator registers are 4
+// consecutive r of one c and every epilogue access is an 8/16-byte vector.
+//
+// Each operand is either k-contiguous in memory ([row][k], row stride ld) or k-major ([k][row]):
+//
+//   forward   Y[m,n]   = sum_k X[m,k] W[n,k]      c=m  r=n   P=W  k-contiguous   Q=X   k-contiguous
+//   dX        dX[m,i]  = sum_n dY[m,n] W[n,i]     c=m  r=i   P=W  k-major        Q=dY  k-contiguous
+//   dW        dW[n,i]  = sum_m dY[m,n] X[m,i]     c=n  r=i   P=X  k-major        Q=dY  k-major
+//
+// so nn.Linear's [out,in] weights serve all three products without a transposed copy.
+//   * k-contiguous tiles live in LDS as [128 rows][64 k] (128 B rows), 16-byte chunk index XOR (row&7):
+//     ds_write_b128 staging and ds_read_b128 fragment reads are bank-conflict free.
+//   * k-major tiles live as [64 k][128 rows] (256 B rows) and fragments are fetched with the gfx950
+//     hardware-transposing read ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group); the
+//     32-byte pair index is XOR-ed with (k&3)|((k>>3)&1)<<2, which makes the 8 k-rows a half-wave
+//     touches land on 8 distinct 32-byte slots of the 256-byte bank row (conflict free), and keeps the
+//     staging ds_write_b128 conflict free too.
+//   * global -> registers -> LDS staging, LDS double-buffered: loads of tile t+1 are issued before the
+//     MFMAs of tile t and written after them; one barrier per K-tile.  Loads are unconditional
+//     (clamped addresses + zero select), fully unrolled: everything stays in VGPRs.
+//   * blockIdx is remapped so that the workgroups sharing a Q row-panel run on the same XCD.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BT = 128, BK = 64;
+constexpr int TILE_BYTES = BT * BK * 2;  // 16 KiB per operand tile
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chunk ^ (row & 7))) * 16; }
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-struct StageRegs {
-  uint4 a[4];
-  uint4 b[4];
+struct GemmArgs {
+  const bf16* P; int64_t ldp;  // r operand
+  const bf16* Q; int64_t ldq;  // c operand
+  int R, C, K;
+  int tiles_r, tiles_c;
 };
 
-// thread t loads chunk (t & 7) of rows (t >> 3) + 32*i, i = 0..3, of both tiles
-__device__ __forceinline__ void stage_load(StageRegs& r, const bf16* __restrict__ X, int64_t ldx,
-                                           const bf16* __restrict__ W, int64_t ldw, int m0, int n0, int k0, int M,
-                                           int tid) {
-  const int chunk = tid & 7, rbase = tid >> 3;
+__device__ __forceinline__ int kc_off(int row, int chunk) { return (row * 8 + (chunk ^ (row & 7))) * 16; }
+__device__ __forceinline__ int km_off(int krow, int chunk16) {
+  const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+  return krow * 256 + (((((chunk16 >> 1) ^ f) << 1) | (chunk16 & 1)) << 4);
+}
+
+// ---- staging: 4 x 16 B per thread per operand ------------------------------------------------
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16* __restrict__ Op, int64_t ld, int row0, int rows,
+                                           int k0, int K, int tid) {
+  if (!KMAJOR) {
+    const int chunk = tid & 7, rb = tid >> 3;
+    const int k = k0 + chunk * 8;
+    const bool kok = k < K;
+    const int kk = kok ? k : 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = rbase + 32 * i;
-    int gm = m0 + row;
-    gm = gm < M ? gm : M - 1;  // clamp: rows past M are never stored
-    r.a[i] = *reinterpret_cast<const uint4*>(X + (int64_t)gm * ldx + k0 + chunk * 8);
-    r.b[i] = *reinterpret_cast<const uint4*>(W + (int64_t)(n0 + row) * ldw + k0 + chunk * 8);
+    for (int i = 0; i < 4; i++) {
+      int row = row0 + rb + 32 * i;
+      row = row < rows ? row : rows - 1;
+      uint4 v = *reinterpret_cast<const uint4*>(Op + (int64_t)row * ld + kk);
+      r[i] = kok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else {
+    const int chunk = tid & 15, kb = tid >> 4;
+    int col = row0 + chunk * 8;
+    col = col <= rows - 8 ? col : rows - 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = k0 + kb + 16 * i;
+      const bool kok = k < K;
+      uint4 v = *reinterpret_cast<const uint4*>(Op + (int64_t)(kok ? k : 0) * ld + col);
+      r[i] = kok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 
-__device__ __forceinline__ void stage_store(const StageRegs& r, char* As, char* Bs, int tid) {
-  const int chunk = tid & 7, rbase = tid >> 3;
+template <bool KMAJOR>
+__device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* tile, int tid) {
+  if (!KMAJOR) {
+    const int chunk = tid & 7, rb = tid >> 3;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = rbase + 32 * i;
-    *reinterpret_cast<uint4*>(As + swz(row, chunk)) = r.a[i];
-    *reinterpret_cast<uint4*>(Bs + swz(row, chunk)) = r.b[i];
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(tile + kc_off(rb + 32 * i, chunk)) = r[i];
+  } else {
+    const int chunk = tid & 15, kb = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(tile + km_off(kb + 16 * i, chunk)) = r[i];
   }
 }
 
-template <typename Epi>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const bf16* __restrict__ X, int64_t ldx,
-                                                           const bf16* __restrict__ W, int64_t ldw, int M, int N,
-                                                           int K, int tiles_m, int tiles_n, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A|B][16 KiB]
+// ---- fragment fetch: 16 rows (base .. base+15) x 32 k (k-step ks) -> 8 bf16 per lane --------------
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 frag(const char* tile, int base, int ks, int lane) {
+  if (!KMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(tile + kc_off(base + (lane & 15), ks * 4 + (lane >> 4)));
+  } else {
+    const int kr = ks * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+    const int ch = (base >> 3) + ((lane & 3) >> 1);
+    const int sub = (lane & 1) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + km_off(kr, ch) + sub));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + km_off(kr + 4, ch) + sub));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+}
+
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wc = wave >> 1, wr = wave & 1;
 
-  // XCD-aware remap: consecutive ids on one XCD walk the N-tiles of one M-panel.
-  const int nwg = tiles_m * tiles_n;
+  // XCD-aware remap (bijective form): consecutive tile ids on one XCD walk the r-tiles of one c-panel.
+  const int nwg = g.tiles_r * g.tiles_c;
   int bid = blockIdx.x;
   {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
+  const int c0 = tc * BT, r0 = tr * BT;
 
-  f32x4 acc[4][4];  // [j: n sub-tile][i: m sub-tile]
+  f32x4 acc[4][4];  // [j: r sub-tile][i: c sub-tile]
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  StageRegs regs;
-  const int nkt = K / BK;
-  stage_load(regs, X, ldx, W, ldw, m0, n0, 0, M, tid);
-  stage_store(regs, smem, smem + TILE_BYTES, tid);
+  const int nkt = (g.K + BK - 1) / BK;
+  uint4 rp[4], rq[4];
+  stage_load<P_KMAJOR>(rp, g.P, g.ldp, r0, g.R, 0, g.K, tid);
+  stage_load<Q_KMAJOR>(rq, g.Q, g.ldq, c0, g.C, 0, g.K, tid);
+  stage_store<P_KMAJOR>(rp, smem, tid);
+  stage_store<Q_KMAJOR>(rq, smem + TILE_BYTES, tid);
   __syncthreads();
 
-  const int frow = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nkt; kt++) {
-    const int cur = kt & 1;
-    char* As = smem + cur * 2 * TILE_BYTES;
-    char* Bs = As + TILE_BYTES;
-    if (kt + 1 < nkt) stage_load(regs, X, ldx, W, ldw, m0, n0, (kt + 1) * BK, M, tid);
+    char* Ps = smem + (kt & 1) * 2 * TILE_BYTES;
+    char* Qs = Ps + TILE_BYTES;
+    char* Pn = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+    // prefetch of the next tile (the last iteration re-loads a valid tile that is never consumed)
+    const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK;
+    stage_load<P_KMAJOR>(rp, g.P, g.ldp, r0, g.R, kn, g.K, tid);
+    stage_load<Q_KMAJOR>(rq, g.Q, g.ldq, c0, g.C, kn, g.K, tid);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      bf16x8 xa[4], wb[4];
+      bf16x8 pf[4], qf[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        xa[i] = *reinterpret_cast<const bf16x8*>(As + swz(wm * 64 + i * 16 + frow, ks * 4 + fq));
+      for (int j = 0; j < 4; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * 64 + j * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        wb[j] = *reinterpret_cast<const bf16x8*>(Bs + swz(wn * 64 + j * 16 + frow, ks * 4 + fq));
+      for (int i = 0; i < 4; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * 64 + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
     }
     if (kt + 1 < nkt) {
-      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_store(regs, An, An + TILE_BYTES, tid);
+      stage_store<P_KMAJOR>(rp, Pn, tid);
+      stage_store<Q_KMAJOR>(rq, Pn + TILE_BYTES, tid);
     }
     __syncthreads();
   }
 
-  // D[j][i][reg]: n = n0 + wn*64 + j*16 + fq*4 + reg ; m = m0 + wm*64 + i*16 + frow
+  // acc[j][i][reg]: r = r0 + wr*64 + j*16 + (lane>>4)*4 + reg ; c = c0 + wc*64 + i*16 + (lane&15)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
-    if (m >= M) continue;
+    const int c = c0 + wc * 64 + i * 16 + (lane & 15);
+    if (c >= g.C) continue;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      epi(m, n, acc[j][i]);
+      const int r = r0 + wr * 64 + j * 16 + (lane >> 4) * 4;
+      if (r < g.R) epi(c, r, acc[j][i]);
     }
   }
 }
 
-// ------------------------------------------------------------------ epilogues (4 consecutive n)
+// ------------------------------------------------------------------ epilogues (c, r..r+3)
 __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
   bf16x4 v;
   v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
@@ -165,46 +219,170 @@ struct MEpiBiasResidual {
            (float)r[3] + (a[3] + b.w) * drop_mul(ds, idx + 3));
   }
 };
+// dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
+struct MEpiBwdData {
+  bf16* dx; int64_t lddx; const bf16* preact; int Kcols; int accumulate; DropArgs da;
+  __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (preact) {
+      const DropState ds = drop_init(da);
+      const bf16x4 u = *reinterpret_cast<const bf16x4*>(preact + (int64_t)m * Kcols + n);
+      const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + (uint32_t)n;
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_f((float)u[t]);
+    }
+    bf16* p = dx + (int64_t)m * lddx + n;
+    if (accumulate) {
+      const bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+      for (int t = 0; t < 4; t++) v[t] += (float)o[t];
+    }
+    store4(p, v[0], v[1], v[2], v[3]);
+  }
+};
+// dW (fp32) (+)= acc
+struct MEpiWgrad {
+  float* dw; int64_t ld; int accumulate;
+  __device__ __forceinline__ void operator()(int n, int i, const f32x4& a) const {
+    float4* p = reinterpret_cast<float4*>(dw + (int64_t)n * ld + i);
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (accumulate) {
+      const float4 o = *p;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *p = v;
+  }
+};
 
-template <typename Epi>
-int launch_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int64_t N, int64_t K, Epi epi,
-              hipStream_t st, const char* what) {
-  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)(N / BN);
+template <bool PK, bool QK, typename Epi>
+int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, int64_t C, int64_t K, Epi epi,
+           hipStream_t st, const char* what) {
+  GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
+             (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
   const size_t lds = 4 * TILE_BYTES;  // 64 KiB
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<Epi>), dim3(tiles_m * tiles_n), dim3(256), lds, st, (const bf16*)x, ldx,
-                     (const bf16*)w, ldw, (int)M, (int)N, (int)K, tiles_m, tiles_n, epi);
+  hipLaunchKernelGGL((gemm_bf16_kernel<PK, QK, Epi>), dim3(g.tiles_r * g.tiles_c), dim3(256), lds, st, g, epi);
   return ovqa_check_launch(what);
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// column sums of a bf16 [M, N] matrix into fp32 db (bias gradient): 16-byte loads, 64 x 8 columns per
+// workgroup, rows split over blockIdx.y with fp32 atomics only when more than one row-slab exists.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ dy, int64_t lddy,
+                                                          float* __restrict__ db, int M, int N, int rows_per_slab,
+                                                          int use_atomic) {
+  __shared__ float red[4][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + lane) * 8;
+  const int m0 = blockIdx.y * rows_per_slab;
+  const int m1 = min(M, m0 + rows_per_slab);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int m = m0 + wave; m < m1; m += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (int64_t)m * lddy + col);
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] += (float)v[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; t++) red[wave][lane][t] = s[t];
+  __syncthreads();
+  if (wave == 0 && col < N) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const float v = red[0][lane][t] + red[1][lane][t] + red[2][lane][t] + red[3][lane][t];
+      if (use_atomic) atomicAdd(db + col + t, v);
+      else db[col + t] = v;
+    }
+  }
 }
 
 }  // namespace
 
 namespace ovqa {
 
+bool mfma_gemm_supported(int64_t R, int64_t C, int64_t K, int64_t ld_p, int64_t ld_q) {
+  return R >= 8 && C >= 1 && K >= 8 && R % 8 == 0 && K % 8 == 0 && ld_p % 8 == 0 && ld_q % 8 == 0 &&
+         R < (1 << 30) && C < (1 << 30) && K < (1 << 30);
+}
+
 bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy,
                                int64_t ldres) {
   (void)epilogue;
-  return M >= 1 && N % BN == 0 && K % BK == 0 && ldx % 8 == 0 && ldy % 4 == 0 && ldres % 4 == 0;
+  return mfma_gemm_supported(N, M, K, K, ldx) && ldy % 4 == 0 && ldres % 4 == 0;
 }
 
 int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                     int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
                     const DropArgs& da, hipStream_t st) {
-  OVQA_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 8 == 0), OVQA_ERR_BAD_ARG,
-               "linear_fwd(bf16): x/w must be 16-byte and y 8-byte aligned");
+  OVQA_REQUIRE(aligned16(x) && aligned16(w) && ((uintptr_t)y % 8 == 0) && (!bias || aligned16(bias)) &&
+                   (!residual || (uintptr_t)residual % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0),
+               OVQA_ERR_BAD_ARG, "linear_fwd(bf16): pointer alignment (x/w/bias 16 B, y/residual/preact 8 B)");
   switch (epilogue) {
     case OVQA_EPI_BIAS:
-      return launch_nt(x, ldx, w, K, M, N, K, MEpiBias{(bf16*)y, ldy, bias}, st, "linear_fwd(mfma,bias)");
+      return launch<false, false>(w, K, x, ldx, N, M, K, MEpiBias{(bf16*)y, ldy, bias}, st, "linear_fwd(mfma,bias)");
     case OVQA_EPI_BIAS_GELU:
-      return launch_nt(x, ldx, w, K, M, N, K, MEpiBiasGelu{(bf16*)y, ldy, bias, (bf16*)preact, (int)N, da}, st,
-                       "linear_fwd(mfma,gelu)");
+      return launch<false, false>(w, K, x, ldx, N, M, K,
+                                  MEpiBiasGelu{(bf16*)y, ldy, bias, (bf16*)preact, (int)N, da}, st,
+                                  "linear_fwd(mfma,gelu)");
     case OVQA_EPI_BIAS_RESIDUAL:
       OVQA_REQUIRE(residual != nullptr, OVQA_ERR_BAD_ARG, "linear_fwd: residual epilogue needs a residual");
-      return launch_nt(x, ldx, w, K, M, N, K,
-                       MEpiBiasResidual{(bf16*)y, ldy, bias, (const bf16*)residual, ldres, (int)N, da}, st,
-                       "linear_fwd(mfma,residual)");
+      return launch<false, false>(w, K, x, ldx, N, M, K,
+                                  MEpiBiasResidual{(bf16*)y, ldy, bias, (const bf16*)residual, ldres, (int)N, da}, st,
+                                  "linear_fwd(mfma,residual)");
   }
   ovqa_set_error("linear_fwd: unknown epilogue %d", epilogue);
   return OVQA_ERR_BAD_ARG;
+}
+
+bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx) {
+  // dx[m,i] = sum_n dy[m,n] w[n,i]: r = i (R = K), c = m, reduction over N
+  return mfma_gemm_supported(K, M, N, K, lddy) && lddx % 4 == 0;
+}
+
+int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx, const void* preact,
+                         int64_t M, int64_t N, int64_t K, int accumulate, const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(aligned16(dy) && aligned16(w) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0),
+               OVQA_ERR_BAD_ARG, "linear_bwd_data(bf16): pointer alignment");
+  return launch<true, false>(w, K, dy, lddy, K, M, N,
+                             MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, accumulate, da}, st,
+                             "linear_bwd_data(mfma)");
+}
+
+bool mfma_linear_bwd_weight_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx) {
+  // dw[n,i] = sum_m dy[m,n] x[m,i]: r = i (R = K), c = n (C = N), reduction over M (any length, zero filled)
+  return K >= 8 && K % 8 == 0 && N >= 8 && N % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0 && M >= 1;
+}
+
+int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db, int64_t M,
+                           int64_t N, int64_t K, int accumulate, hipStream_t st) {
+  OVQA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw), OVQA_ERR_BAD_ARG,
+               "linear_bwd_weight(bf16): pointer alignment");
+  // the reduction length is passed as "K" of the kernel; K % 8 is not required for k-major operands
+  GemmArgs g{(const bf16*)x, ldx, (const bf16*)dy, lddy, (int)K, (int)N, (int)M,
+             (int)((K + BT - 1) / BT), (int)((N + BT - 1) / BT)};
+  hipLaunchKernelGGL((gemm_bf16_kernel<true, true, MEpiWgrad>), dim3(g.tiles_r * g.tiles_c), dim3(256),
+                     4 * TILE_BYTES, st, g, MEpiWgrad{dw, K, accumulate});
+  int rc = ovqa_check_launch("linear_bwd_weight(mfma)");
+  if (rc != OVQA_OK || db == nullptr) return rc;
+  const int col_blocks = (int)((N / 8 + 63) / 64);
+  int slabs = 1;
+  if (!accumulate) {
+    slabs = (int)((M + 255) / 256);
+    if (slabs > 64) slabs = 64;
+  }
+  const int rows_per_slab = (int)((M + slabs - 1) / slabs);
+  int use_atomic = (slabs > 1 || accumulate) ? 1 : 0;
+  if (use_atomic && !accumulate) {
+    hipError_t e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st);
+    if (e != hipSuccess) {
+      ovqa_set_error("linear_bwd_weight: hipMemsetAsync: %s", hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(col_blocks, slabs), dim3(256), 0, st, (const bf16*)dy, lddy, db, (int)M,
+                     (int)N, rows_per_slab, use_atomic);
+  return ovqa_check_launch("linear_bwd_weight(colsum)");
 }
 
 }  // namespace ovqa

@@ -67,7 +67,13 @@ int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t s
 int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                     int accumulate_loss, hipStream_t st);
 
-// ---- gemm_mfma.hip / attention_mfma.hip (bf16, MFMA) ---------------------------
+// ---- gemm_mfma.hip (bf16, MFMA) ----------------------------------------------
+bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx);
+int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx, const void* preact,
+                         int64_t M, int64_t N, int64_t K, int accumulate, const DropArgs& da, hipStream_t st);
+bool mfma_linear_bwd_weight_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx);
+int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db, int64_t M,
+                           int64_t N, int64_t K, int accumulate, hipStream_t st);
 bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldres);
 int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                     int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
