@@ -127,6 +127,8 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
   OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_fwd: B*H too large");
   ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, msq, o, ldo, lse, att,
                    (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_supported(a))
+    return ovqa::mfma_attention_fwd(a, as_stream(stream));
   return ovqa::simple_attention_fwd(dtype, a, as_stream(stream));
 }
 
@@ -142,6 +144,8 @@ int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, 
   OVQA_REQUIRE(d_o && q && k && v && o && dq && dk_ && dv_, OVQA_ERR_BAD_ARG, "attention_bwd: null pointer");
   ovqa::AttnBwdArgs a{d_o, q, k, v, o, d_att, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
                       lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_bwd_supported(a))
+    return ovqa::mfma_attention_bwd(a, as_stream(stream));
   return ovqa::simple_attention_bwd(dtype, a, as_stream(stream));
 }
 

@@ -1,0 +1,491 @@
+// MFMA attention core for gfx950 (bf16 storage, fp32 softmax), d_k = d_v = 64, n_k <= 256.
+//
+// Whole K and V of one (batch, head) stay resident in LDS (sequences are <= 237, so a
+// single-tile kernel without online-softmax rescaling is the right shape).  Scores are computed
+// TRANSPOSED, S^T = K Q^T, with v_mfma_f32_32x32x16_bf16: a lane then owns ONE query (its column) and
+// the key axis lives in its accumulator registers, so
+//   * the softmax row reduction is in-register plus one cross-half shuffle (lane ^ 32),
+//   * log-sum-exp / delta are per-lane scalars,
+//   * P^T is already laid out as the B operand of the second product  O^T = V^T P^T  (the key index is
+//     the accumulator row index), so P never leaves registers: no LDS round trip, no (B,H,nq,nk) tensor.
+//     V^T fragments come from the row-major V image through the transposing read ds_read_b64_tr_b16.
+// One 16-byte-chunk XOR swizzle, x(row) = ((row>>2)&3) | (((row>>1)&1)<<2), makes the 32-row
+// ds_read_b128 operand reads AND the transposing reads of the same [rows][64] image bank-conflict free.
+// Small problems are packed: a workgroup's 4 waves cover ceil(nq/32) query tiles of 4/W different
+// (batch, head) pairs, so the 20-token question stack still fills its waves.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int xs(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
+// byte offset of 16-byte chunk `ch` (0..7) of row `row` in a [rows][64 bf16] image
+__device__ __forceinline__ int img_off(int row, int ch) { return row * 128 + ((ch ^ xs(row)) << 4); }
+
+// cooperative load of `rows` x 64 bf16 (row stride ld) into an image of `rows_pad` rows, zero padded
+__device__ __forceinline__ void load_image(char* img, const bf16* __restrict__ src, int64_t ld, int rows, int rows_pad,
+                                           int tid, int nthreads) {
+  for (int e = tid; e < rows_pad * 8; e += nthreads) {
+    const int row = e >> 3, ch = e & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
+    *reinterpret_cast<uint4*>(img + img_off(row, ch)) = v;
+  }
+}
+
+// k-contiguous 32-row operand fragment (A or B of 32x32x16): lane -> row base+(lane&31), k = 16*ks + 8*(lane>>5) + j
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int base, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(img + img_off(base + (lane & 31), 2 * ks + (lane >> 5)));
+}
+// transposed operand fragment from a [k rows][64] image: lane -> column cbase+(lane&31),
+// element j <-> k row  kbase + 8*(j>>2) + 4*(lane>>5) + (j&3)   (the order an accumulator tile has)
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int kbase, int cbase, int lane) {
+  const int row = kbase + 4 * (lane >> 5) + ((lane >> 2) & 3);
+  const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int ch = col >> 3, sub = (col & 7) * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off(row, ch) + sub));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off(row + 8, ch) + sub));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------ forward
+// grid.x = ceil(B*H / G), grid.y = ceil(nq / (32*W)) ; W = query tiles per problem in this workgroup
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, int W, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int q_rows = 32 * W;                         // query rows staged per problem
+  const int prob_bytes = (q_rows + 2 * NKT * 32) * 128;
+  const int slot = wave / W, tq = wave % W;
+  const int q_blk0 = blockIdx.y * q_rows;
+
+  // ---- stage Q / K / V of the G problems of this workgroup (all threads)
+  for (int g = 0; g < G; g++) {
+    const int64_t pid = (int64_t)blockIdx.x * G + g;
+    if (pid >= (int64_t)a.B * a.H) break;
+    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+    char* base = smem + g * prob_bytes;
+    const bf16* q = (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64;
+    const bf16* k = (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64;
+    const bf16* v = (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64;
+    const int qr = min(q_rows, nq - q_blk0);
+    load_image(base, q, a.ldq, qr, q_rows, tid, 256);
+    load_image(base + q_rows * 128, k, a.ldk, nk, NKT * 32, tid, 256);
+    load_image(base + (q_rows + NKT * 32) * 128, v, a.ldv, nk, NKT * 32, tid, 256);
+  }
+  __syncthreads();
+
+  const int64_t pid = (int64_t)blockIdx.x * G + slot;
+  if (slot >= G || pid >= (int64_t)a.B * a.H) return;
+  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  const int q0 = q_blk0 + tq * 32;
+  if (q0 >= nq) return;
+  const char* Qs = smem + slot * prob_bytes;
+  const char* Ks = Qs + q_rows * 128;
+  const char* Vs = Ks + NKT * 32 * 128;
+
+  // ---- S^T = K Q^T  (rows = keys, columns = this wave's 32 queries)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
+  f32x16 st[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; t++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) st[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, t * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
+  }
+
+  // ---- softmax over keys (in-lane registers + the partner half-wave)
+  const int q = q0 + (lane & 31);
+  const bool qok = q < nq;
+  const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)(qok ? q : 0) * a.msq : nullptr;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int key = t * 32 + acc_row(r, lane);
+      float s = -INFINITY;
+      if (key < nk) s = st[t][r] * a.scale + (mrow ? mrow[key] : 0.f);
+      st[t][r] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float p = exp2f((st[t][r] - mx) * LOG2E);
+      st[t][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  if (qok && a.lse && lane < 32) a.lse[((int64_t)b * a.H + h) * nq + q] = mx + __logf(sum);
+  if (a.att && qok) {
+    bf16* arow = (bf16*)a.att + (((int64_t)b * a.H + h) * nq + q) * nk;
+#pragma unroll
+    for (int t = 0; t < NKT; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = t * 32 + acc_row(r, lane);
+        if (key < nk) arow[key] = (bf16)(st[t][r] * inv);
+      }
+  }
+
+  // ---- O^T = V^T P^T : P^T accumulator registers are the B operand (k = key), V^T via transposing reads
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) ot[d][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; t++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; j++) pb[j] = (bf16)st[t][8 * s + j];
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vs, t * 32 + 16 * s, d * 32, lane), pb, ot[d], 0, 0, 0);
+    }
+  if (qok) {
+    bf16* orow = (bf16*)a.o + ((int64_t)b * nq + q) * a.ldo + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o4[e] = (bf16)(ot[d][4 * g4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(orow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// Kernel A: one wave = 32 queries (columns).  delta_q = dO_q . O_q ;  for every key tile:
+//   S^T = K Q^T, dP^T = V dO^T, P^T = exp(S^T*scale + mask - lse_q), dS^T = P^T (dP^T - delta_q),
+//   dQ^T += K^T dS^T   (K^T through transposing reads, dS^T straight from the accumulator registers).
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nkt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int q_rows = 32 * W, k_rows = nkt * 32;
+  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128;  // Q | dO | K | V
+  const int slot = wave / W, tq = wave % W;
+  const int q_blk0 = blockIdx.y * q_rows;
+
+  for (int g = 0; g < G; g++) {
+    const int64_t pid = (int64_t)blockIdx.x * G + g;
+    if (pid >= (int64_t)a.B * a.H) break;
+    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+    char* base = smem + g * prob_bytes;
+    const int qr = min(q_rows, nq - q_blk0);
+    load_image(base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows, tid, 256);
+    load_image(base + q_rows * 128, (const bf16*)a.d_o + ((int64_t)b * nq + q_blk0) * a.lddo + h * 64, a.lddo, qr,
+               q_rows, tid, 256);
+    load_image(base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows, tid, 256);
+    load_image(base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk,
+               k_rows, tid, 256);
+  }
+  __syncthreads();
+
+  const int64_t pid = (int64_t)blockIdx.x * G + slot;
+  if (slot >= G || pid >= (int64_t)a.B * a.H) return;
+  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  const int q0 = q_blk0 + tq * 32;
+  if (q0 >= nq) return;
+  const char* Qs = smem + slot * prob_bytes;
+  const char* Gs = Qs + q_rows * 128;
+  const char* Ks = Gs + q_rows * 128;
+  const char* Vs = Ks + k_rows * 128;
+
+  const int q = q0 + (lane & 31);
+  const bool qok = q < nq;
+  const int qc = qok ? q : nq - 1;
+  // delta = dO . O over this lane's half of the 64 features, combined with the partner half-wave
+  float delta = 0.f;
+  {
+    const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * 64 + 32 * (lane >> 5);
+    const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * 64 + 32 * (lane >> 5);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
+      const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
+      const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) delta += (float)g8[e] * (float)oa[e] + (float)g8[4 + e] * (float)ob[e];
+    }
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  const float lse = a.lse[((int64_t)b * a.H + h) * nq + qc];
+  if (qok && lane < 32) a.delta[((int64_t)b * a.H + h) * nq + q] = delta;
+  const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
+
+  bf16x8 qf[4], gf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
+    gf[ks] = frag_rows(Gs, tq * 32, ks, lane);
+  }
+  f32x16 dqt[2];
+#pragma unroll
+  for (int d = 0; d < 2; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dqt[d][r] = 0.f;
+
+  for (int t = 0; t < nkt; t++) {
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, t * 32, ks, lane), gf[ks], dp, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int key = t * 32 + acc_row(r, lane);
+      float p = 0.f;
+      if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+      ds[r] = p * (dp[r] - delta);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 db;
+#pragma unroll
+      for (int j = 0; j < 8; j++) db[j] = (bf16)ds[8 * s + j];
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+        dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, t * 32 + 16 * s, d * 32, lane), db, dqt[d], 0, 0, 0);
+    }
+  }
+  if (qok) {
+    bf16* drow = (bf16*)a.dq + ((int64_t)b * nq + q) * a.lddq + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o4[e] = (bf16)(dqt[d][4 * g4 + e] * a.scale);
+        *reinterpret_cast<bf16x4*>(drow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+      }
+  }
+}
+
+// Kernel B: one wave = 32 keys (columns).  For every query tile (rows):
+//   S = Q K^T, dP = dO V^T, P = exp(S*scale + mask - lse_row), dS = P (dP - delta_row),
+//   dV^T += dO^T P ,  dK^T += Q^T dS    (dO^T / Q^T through transposing reads).
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nqt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int k_rows = 32 * W, q_rows = nqt * 32;
+  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128 + 2 * q_rows * 4;  // Q | dO | K | V | lse | delta
+  const int slot = wave / W, tk = wave % W;
+  const int k_blk0 = blockIdx.y * k_rows;
+
+  for (int g = 0; g < G; g++) {
+    const int64_t pid = (int64_t)blockIdx.x * G + g;
+    if (pid >= (int64_t)a.B * a.H) break;
+    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+    char* base = smem + g * prob_bytes;
+    const int kr = min(k_rows, nk - k_blk0);
+    load_image(base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows, tid, 256);
+    load_image(base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows, tid, 256);
+    load_image(base + 2 * q_rows * 128, (const bf16*)a.k + ((int64_t)b * nk + k_blk0) * a.ldk + h * 64, a.ldk, kr,
+               k_rows, tid, 256);
+    load_image(base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + ((int64_t)b * nk + k_blk0) * a.ldv + h * 64, a.ldv,
+               kr, k_rows, tid, 256);
+    float* ls = reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * 128);
+    for (int i = tid; i < q_rows; i += 256) {
+      ls[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
+      ls[q_rows + i] = i < nq ? a.delta[((int64_t)b * a.H + h) * nq + i] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int64_t pid = (int64_t)blockIdx.x * G + slot;
+  if (slot >= G || pid >= (int64_t)a.B * a.H) return;
+  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  const int k0 = k_blk0 + tk * 32;
+  if (k0 >= nk) return;
+  const char* Qs = smem + slot * prob_bytes;
+  const char* Gs = Qs + q_rows * 128;
+  const char* Ks = Gs + q_rows * 128;
+  const char* Vs = Ks + k_rows * 128;
+  const float* ls = reinterpret_cast<const float*>(Vs + k_rows * 128);
+
+  const int key = k0 + (lane & 31);
+  const bool kok = key < nk;
+  const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    kf[ks] = frag_rows(Ks, tk * 32, ks, lane);
+    vf[ks] = frag_rows(Vs, tk * 32, ks, lane);
+  }
+  f32x16 dvt[2], dkt[2];
+#pragma unroll
+  for (int d = 0; d < 2; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
+
+  for (int t = 0; t < nqt; t++) {
+    f32x16 s_, dp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int qi = t * 32 + acc_row(r, lane);
+      float pv = 0.f;
+      if (qi < nq && kok)
+        pv = exp2f((s_[r] * a.scale + (mcol ? mcol[(int64_t)qi * a.msq] : 0.f) - ls[qi]) * LOG2E);
+      p[r] = pv;
+      ds[r] = pv * (dp[r] - ls[q_rows + qi]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf16x8 pb, db;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s + j]; db[j] = (bf16)ds[8 * s + j]; }
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, t * 32 + 16 * s, d * 32, lane), pb, dvt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, t * 32 + 16 * s, d * 32, lane), db, dkt[d], 0, 0, 0);
+      }
+    }
+  }
+  if (kok) {
+    bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
+    bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        bf16x4 k4, v4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          k4[e] = (bf16)(dkt[d][4 * g4 + e] * a.scale);
+          v4[e] = (bf16)dvt[d][4 * g4 + e];
+        }
+        *reinterpret_cast<bf16x4*>(dkrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = k4;
+        *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
+      }
+  }
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes, const char* what) {
+  if (bytes > 160 * 1024) {
+    ovqa_set_error("%s: needs %zu B of LDS", what, bytes);
+    return OVQA_ERR_UNSUPPORTED;
+  }
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      ovqa_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+  }
+  return OVQA_OK;
+}
+
+template <int NKT>
+int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
+  int W = (a.nq + 31) / 32;
+  if (W > 4) W = 4;
+  if (W == 3) W = 4;
+  const int G = 4 / W;
+  const size_t lds = (size_t)G * (32 * W + 2 * NKT * 32) * 128;
+  int rc = ensure_lds(attn_fwd_mfma_kernel<NKT>, lds, "attention_fwd(mfma)");
+  if (rc != OVQA_OK) return rc;
+  const int64_t nprob = (int64_t)a.B * a.H;
+  dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKT>, grid, dim3(256), lds, st, a, W, G);
+  return ovqa_check_launch("attention_fwd(mfma)");
+}
+
+int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
+  const int64_t nprob = (int64_t)a.B * a.H;
+  {  // dQ: waves over query tiles, all keys resident
+    int W = (a.nq + 31) / 32;
+    if (W > 4) W = 4;
+    if (W == 3) W = 4;
+    const int G = 4 / W, nkt = (a.nk + 31) / 32;
+    const size_t lds = (size_t)G * (2 * 32 * W + 2 * nkt * 32) * 128;
+    int rc = ensure_lds(attn_bwd_dq_mfma_kernel, lds, "attention_bwd(mfma,dq)");
+    if (rc != OVQA_OK) return rc;
+    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), lds, st, a, W, G, nkt);
+    rc = ovqa_check_launch("attention_bwd(mfma,dq)");
+    if (rc != OVQA_OK) return rc;
+  }
+  {  // dK/dV: waves over key tiles, all queries resident
+    int W = (a.nk + 31) / 32;
+    if (W > 4) W = 4;
+    if (W == 3) W = 4;
+    const int G = 4 / W, nqt = (a.nq + 31) / 32;
+    const size_t lds = (size_t)G * ((2 * nqt * 32 + 2 * 32 * W) * 128 + 2 * nqt * 32 * 4);
+    int rc = ensure_lds(attn_bwd_dkv_mfma_kernel, lds, "attention_bwd(mfma,dkv)");
+    if (rc != OVQA_OK) return rc;
+    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), lds, st, a, W, G, nqt);
+    return ovqa_check_launch("attention_bwd(mfma,dkv)");
+  }
+}
+
+}  // namespace
+
+namespace ovqa {
+
+bool mfma_attention_bwd_supported(const AttnBwdArgs& a) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  auto al8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
+  return a.d_att == nullptr && a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.nq <= 256 &&
+         a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.lddo % 8 == 0 && a.ldo % 4 == 0 && a.lddq % 4 == 0 &&
+         a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && al(a.d_o) && al8(a.o) && al8(a.dq) &&
+         al8(a.dk_) && al8(a.dv_) && a.lse && a.delta;
+}
+
+int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st) { return launch_bwd(a, st); }
+
+bool mfma_attention_supported(const AttnArgs& a) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.ldq % 8 == 0 && a.ldk % 8 == 0 &&
+         a.ldv % 8 == 0 && a.ldo % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && (((uintptr_t)a.o & 7) == 0);
+}
+
+int mfma_attention_fwd(const AttnArgs& a, hipStream_t st) {
+  if (a.nk <= 32) return launch_fwd<1>(a, st);
+  if (a.nk <= 64) return launch_fwd<2>(a, st);
+  if (a.nk <= 128) return launch_fwd<4>(a, st);
+  return launch_fwd<8>(a, st);
+}
+
+}  // namespace ovqa

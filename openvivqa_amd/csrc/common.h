@@ -108,4 +108,28 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
   return cdf + u * pdf;
 }
 
+// Branch-free erf for the bf16 epilogues (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, far below bf16
+// resolution): GELU stays the exact-erf FORM of the reference (F.gelu default), not the tanh approximation.
+// Returns erf(u / sqrt(2)) and e = exp(-u*u/2) (shared with the Gaussian pdf of the GELU derivative).
+__device__ __forceinline__ float erf_sqrt2_fast(float u, float& e) {
+  const float x = fabsf(u) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.f));
+  e = __expf(-x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.f - p * t * e;
+  return copysignf(r, u);
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+  float e;
+  return 0.5f * u * (1.f + erf_sqrt2_fast(u, e));
+}
+__device__ __forceinline__ float gelu_grad_fast(float u) {
+  float e;
+  const float cdf = 0.5f * (1.f + erf_sqrt2_fast(u, e));
+  return fmaf(u * 0.39894228040143267794f, e, cdf);
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

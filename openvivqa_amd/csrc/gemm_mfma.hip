@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
   }
 
   // acc[j][i][reg]: r = r0 + wr*64 + j*16 + (lane>>4)*4 + reg ; c = c0 + wc*64 + i*16 + (lane&15)
+  epi.init();
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c = c0 + wc * 64 + i * 16 + (lane & 15);
@@ -190,27 +191,28 @@ __device__ __forceinline__ float4 bias4(const float* bias, int n) {
 
 struct MEpiBias {
   bf16* y; int64_t ldy; const float* bias;
+  __device__ __forceinline__ void init() {}
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     const float4 b = bias4(bias, n);
     store4(y + (int64_t)m * ldy + n, a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
   }
 };
 struct MEpiBiasGelu {
-  bf16* y; int64_t ldy; const float* bias; bf16* preact; int N; DropArgs da;
+  bf16* y; int64_t ldy; const float* bias; bf16* preact; int N; DropArgs da; DropState ds;
+  __device__ __forceinline__ void init() { ds = drop_init(da); }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
-    const DropState ds = drop_init(da);
     const float4 b = bias4(bias, n);
     const float u0 = a[0] + b.x, u1 = a[1] + b.y, u2 = a[2] + b.z, u3 = a[3] + b.w;
     if (preact) store4(preact + (int64_t)m * N + n, u0, u1, u2, u3);
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
-    store4(y + (int64_t)m * ldy + n, gelu_f(u0) * drop_mul(ds, idx), gelu_f(u1) * drop_mul(ds, idx + 1),
-           gelu_f(u2) * drop_mul(ds, idx + 2), gelu_f(u3) * drop_mul(ds, idx + 3));
+    store4(y + (int64_t)m * ldy + n, gelu_fast(u0) * drop_mul(ds, idx), gelu_fast(u1) * drop_mul(ds, idx + 1),
+           gelu_fast(u2) * drop_mul(ds, idx + 2), gelu_fast(u3) * drop_mul(ds, idx + 3));
   }
 };
 struct MEpiBiasResidual {
-  bf16* y; int64_t ldy; const float* bias; const bf16* res; int64_t ldres; int N; DropArgs da;
+  bf16* y; int64_t ldy; const float* bias; const bf16* res; int64_t ldres; int N; DropArgs da; DropState ds;
+  __device__ __forceinline__ void init() { ds = drop_init(da); }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
-    const DropState ds = drop_init(da);
     const float4 b = bias4(bias, n);
     const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + (int64_t)m * ldres + n);
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
@@ -221,15 +223,15 @@ struct MEpiBiasResidual {
 };
 // dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
 struct MEpiBwdData {
-  bf16* dx; int64_t lddx; const bf16* preact; int Kcols; int accumulate; DropArgs da;
+  bf16* dx; int64_t lddx; const bf16* preact; int Kcols; int accumulate; DropArgs da; DropState ds;
+  __device__ __forceinline__ void init() { ds = drop_init(da); }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (preact) {
-      const DropState ds = drop_init(da);
       const bf16x4 u = *reinterpret_cast<const bf16x4*>(preact + (int64_t)m * Kcols + n);
       const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + (uint32_t)n;
 #pragma unroll
-      for (int t = 0; t < 4; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_f((float)u[t]);
+      for (int t = 0; t < 4; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_fast((float)u[t]);
     }
     bf16* p = dx + (int64_t)m * lddx + n;
     if (accumulate) {
@@ -243,6 +245,7 @@ struct MEpiBwdData {
 // dW (fp32) (+)= acc
 struct MEpiWgrad {
   float* dw; int64_t ld; int accumulate;
+  __device__ __forceinline__ void init() {}
   __device__ __forceinline__ void operator()(int n, int i, const f32x4& a) const {
     float4* p = reinterpret_cast<float4*>(dw + (int64_t)n * ld + i);
     float4 v = make_float4(a[0], a[1], a[2], a[3]);
@@ -323,12 +326,12 @@ int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, con
       return launch<false, false>(w, K, x, ldx, N, M, K, MEpiBias{(bf16*)y, ldy, bias}, st, "linear_fwd(mfma,bias)");
     case OVQA_EPI_BIAS_GELU:
       return launch<false, false>(w, K, x, ldx, N, M, K,
-                                  MEpiBiasGelu{(bf16*)y, ldy, bias, (bf16*)preact, (int)N, da}, st,
+                                  MEpiBiasGelu{(bf16*)y, ldy, bias, (bf16*)preact, (int)N, da, DropState{}}, st,
                                   "linear_fwd(mfma,gelu)");
     case OVQA_EPI_BIAS_RESIDUAL:
       OVQA_REQUIRE(residual != nullptr, OVQA_ERR_BAD_ARG, "linear_fwd: residual epilogue needs a residual");
       return launch<false, false>(w, K, x, ldx, N, M, K,
-                                  MEpiBiasResidual{(bf16*)y, ldy, bias, (const bf16*)residual, ldres, (int)N, da}, st,
+                                  MEpiBiasResidual{(bf16*)y, ldy, bias, (const bf16*)residual, ldres, (int)N, da, DropState{}}, st,
                                   "linear_fwd(mfma,residual)");
   }
   ovqa_set_error("linear_fwd: unknown epilogue %d", epilogue);
@@ -345,7 +348,7 @@ int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, 
   OVQA_REQUIRE(aligned16(dy) && aligned16(w) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0),
                OVQA_ERR_BAD_ARG, "linear_bwd_data(bf16): pointer alignment");
   return launch<true, false>(w, K, dy, lddy, K, M, N,
-                             MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, accumulate, da}, st,
+                             MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, accumulate, da, DropState{}}, st,
                              "linear_bwd_data(mfma)");
 }
 

@@ -49,6 +49,12 @@ struct AttnBwdArgs {
 int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
 int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);
 
+// ---- attention_mfma.hip (bf16, d=64, nk<=256) --------------------------------------
+bool mfma_attention_supported(const AttnArgs& a);
+int mfma_attention_fwd(const AttnArgs& a, hipStream_t st);
+bool mfma_attention_bwd_supported(const AttnBwdArgs& a);
+int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st);
+
 // ---- layernorm.hip -----------------------------------------------------------
 int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta, const float* pos,
                   int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D, float eps,

@@ -196,13 +196,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   }
 }
 
+// dgamma/dbeta = column sums of the per-workgroup partials [nblocks][2*D]: 64 columns per workgroup,
+// 4 row groups, combined through LDS.
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // over 2*D
-  if (i >= 2 * D) return;
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;  // over 2*D
   float s = 0.f;
-  for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * 2 * D + i];
+  if (i < 2 * D)
+    for (int b = r; b < nblocks; b += 4) s += partial[(int64_t)b * 2 * D + i];
+  red[r][c] = s;
+  __syncthreads();
+  if (r != 0 || i >= 2 * D) return;
+  s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
   float* base = (i < D) ? dgamma : dbeta;
   if (base == nullptr) return;
   float* dst = base + ((i < D) ? i : i - D);
@@ -232,7 +240,7 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
                  const DropArgs& da, void* ws, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
   int nblocks = (int)((M + 3) / 4);
-  if (nblocks > 512) nblocks = 512;
+  if (nblocks > 256) nblocks = 256;
   OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
   float* partial = (float*)ws;
   const size_t smem = (size_t)3 * 2 * D * sizeof(float);
@@ -247,7 +255,7 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
 #undef LN_BWD
   int rc = ovqa_check_launch("layernorm_bwd");
   if (rc != OVQA_OK) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(256), 0, st, partial, nblocks,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64)), dim3(256), 0, st, partial, nblocks,
                      (int)D, dgamma, dbeta, accumulate);
   return ovqa_check_launch("layernorm_bwd_reduce");
 }
