@@ -87,19 +87,40 @@ int ovqa_linear_fwd(int dtype, int epilogue,
  *   If `gelu_preact` != NULL the FFN backward is fused:
  *       dx = (dY W) * dropmask/(1-p) * gelu'(gelu_preact)      (fc2 -> fc1 seam,
  *       positionwise_feed_forward.py:24-25), with `drop` describing dropout_1.
- *   If `accumulate` != 0, dx += result (dtype of dx). */
+ *   If `addend` [M,K] (ldadd) != NULL it is added (the residual-branch gradient;
+ *   may alias dx). */
 int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
                          void* dx, int64_t lddx, const void* gelu_preact,
-                         int64_t M, int64_t N, int64_t K, int accumulate,
+                         const void* addend, int64_t ldadd,
+                         int64_t M, int64_t N, int64_t K,
                          const ovqa_dropout* drop, void* stream);
 
 /* dW = dY^T X (fp32 [N,K]), db = column sums of dY (fp32 [N], may be NULL).
- *   accumulate != 0 adds into dw/db, otherwise overwrites.
+ *   accumulate: bit 0 -> dw += (else overwrite), bit 1 -> db += (else overwrite).
  *   ws: scratch of ovqa_workspace_bytes(). */
 int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy,
                            const void* x, int64_t ldx, float* dw, float* db,
                            int64_t M, int64_t N, int64_t K, int accumulate,
                            void* ws, void* stream);
+
+/* Grouped form: every weight gradient of a backward pass in ONE launch (the
+ * individual products have 16..64 output tiles each -- far fewer than 256 CUs --
+ * so they are deferred and tiled together instead of being split along M).
+ * `problems`/`tiles` are DEVICE arrays written by the host side: tiles[i] =
+ * {problem index, tile over N (128 rows), tile over K (128 cols), 0}. bf16 only. */
+typedef struct {
+  const void* dy;   /* [M,N], row stride lddy */
+  const void* x;    /* [M,K], row stride ldx  */
+  float* dw;        /* [N,K] fp32             */
+  int64_t lddy, ldx;
+  int32_t M, N, K;
+  int32_t accumulate;
+} ovqa_wgrad_problem;
+int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev,
+                                   const int32_t* tiles_dev, int64_t n_tiles, void* stream);
+/* db (fp32 [N]) (+)= column sums of dy [M,N] (bias gradient on its own). */
+int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N,
+                   int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LayerNorm over the last dim (+ optional positional table add).

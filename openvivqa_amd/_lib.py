@@ -19,6 +19,12 @@ ABI_VERSION = 1
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
 
+class WgradProblem(C.Structure):
+    """ovqa_wgrad_problem (include/ovqa_hip.h)."""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("lddy", C.c_int64), ("ldx", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("step", C.c_void_p)]
 
@@ -32,7 +38,9 @@ SIGNATURES = {
     "ovqa_workspace_bytes": [],
     "ovqa_linear_fwd": [c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                         c_i64, c_i64, c_i64, _DP, c_vp],
-    "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, _DP, c_vp],
+    "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
+    "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_vp],
+    "ovqa_bias_grad": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
     "ovqa_linear_bwd_weight": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],
     "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
     "ovqa_layernorm_bwd": [c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

@@ -55,19 +55,36 @@ int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const v
 }
 
 int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
-                         const void* gelu_preact, int64_t M, int64_t N, int64_t K, int accumulate,
+                         const void* gelu_preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
                          const ovqa_dropout* drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_bwd_data: bad dtype %d", dtype);
   OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_bwd_data: bad sizes");
   if (M == 0) return OVQA_OK;
   OVQA_REQUIRE(dy && w && dx, OVQA_ERR_BAD_ARG, "linear_bwd_data: null pointer");
-  OVQA_REQUIRE(lddy >= N && lddx >= K, OVQA_ERR_BAD_ARG, "linear_bwd_data: ld smaller than the row length");
+  OVQA_REQUIRE(lddy >= N && lddx >= K && (!addend || ldadd >= K), OVQA_ERR_BAD_ARG,
+               "linear_bwd_data: ld smaller than the row length");
   OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_bwd_data: more than 2^32 elements");
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_data_supported(M, N, K, lddy, lddx))
-    return ovqa::mfma_linear_bwd_data(dy, lddy, w, dx, lddx, gelu_preact, M, N, K, accumulate, make_drop_args(drop),
+    return ovqa::mfma_linear_bwd_data(dy, lddy, w, dx, lddx, gelu_preact, addend, ldadd, M, N, K, make_drop_args(drop),
                                       as_stream(stream));
-  return ovqa::simple_linear_bwd_data(dtype, dy, lddy, w, dx, lddx, gelu_preact, M, N, K, accumulate,
+  return ovqa::simple_linear_bwd_data(dtype, dy, lddy, w, dx, lddx, gelu_preact, addend, ldadd, M, N, K,
                                       make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev, const int32_t* tiles_dev,
+                                   int64_t n_tiles, void* stream) {
+  OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: bf16 only");
+  OVQA_REQUIRE(n_tiles >= 0 && (n_tiles == 0 || (problems_dev && tiles_dev)), OVQA_ERR_BAD_ARG,
+               "grouped_linear_bwd_weight: bad argument");
+  OVQA_REQUIRE(n_tiles < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: too many tiles");
+  return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, as_stream(stream));
+}
+
+int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate,
+                   void* stream) {
+  OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "bias_grad: bf16 only (fp32 goes through linear_bwd_weight)");
+  OVQA_REQUIRE(dy && db && M >= 0 && N > 0 && N % 8 == 0 && lddy % 8 == 0, OVQA_ERR_BAD_ARG, "bias_grad: bad argument");
+  return ovqa::colsum_bf16(dy, lddy, db, M, N, accumulate, as_stream(stream));
 }
 
 int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db,
@@ -77,17 +94,19 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* 
   OVQA_REQUIRE(dw != nullptr, OVQA_ERR_BAD_ARG, "linear_bwd_weight: dw is NULL");
   OVQA_REQUIRE(M == 0 || (dy && x), OVQA_ERR_BAD_ARG, "linear_bwd_weight: null pointer");
   (void)ws;
+  const int acc_w = accumulate & 1, acc_b = (accumulate >> 1) & 1;
   if (M == 0) {
-    if (!accumulate) {
-      hipError_t e = hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), as_stream(stream));
-      if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), as_stream(stream));
+    hipError_t e = hipSuccess;
+    if (!acc_w) e = hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), as_stream(stream));
+    if (e == hipSuccess && db && !acc_b) e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), as_stream(stream));
+    {
       OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "linear_bwd_weight: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     return OVQA_OK;
   }
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_weight_supported(M, N, K, lddy, ldx))
-    return ovqa::mfma_linear_bwd_weight(dy, lddy, x, ldx, dw, db, M, N, K, accumulate, as_stream(stream));
-  return ovqa::simple_linear_bwd_weight(dtype, dy, lddy, x, ldx, dw, db, M, N, K, accumulate, as_stream(stream));
+    return ovqa::mfma_linear_bwd_weight(dy, lddy, x, ldx, dw, db, M, N, K, acc_w, acc_b, as_stream(stream));
+  return ovqa::simple_linear_bwd_weight(dtype, dy, lddy, x, ldx, dw, db, M, N, K, acc_w, acc_b, as_stream(stream));
 }
 
 int ovqa_layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta,

@@ -416,13 +416,22 @@ int ensure_lds(K kernel, size_t bytes, const char* what) {
   return OVQA_OK;
 }
 
+// problems packed per workgroup: at most 4/W (one wave per 32-row tile) and what fits in ~150 KiB of LDS
+inline int pack_factor(int W, size_t prob_bytes) {
+  int G = 4 / W;
+  const int fit = (int)((150 * 1024) / prob_bytes);
+  if (G > fit) G = fit;
+  return G < 1 ? 1 : G;
+}
+
 template <int NKT>
 int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
   int W = (a.nq + 31) / 32;
   if (W > 4) W = 4;
   if (W == 3) W = 4;
-  const int G = 4 / W;
-  const size_t lds = (size_t)G * (32 * W + 2 * NKT * 32) * 128;
+  const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * 128;
+  const int G = pack_factor(W, prob);
+  const size_t lds = (size_t)G * prob;
   int rc = ensure_lds(attn_fwd_mfma_kernel<NKT>, lds, "attention_fwd(mfma)");
   if (rc != OVQA_OK) return rc;
   const int64_t nprob = (int64_t)a.B * a.H;
@@ -437,8 +446,10 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     int W = (a.nq + 31) / 32;
     if (W > 4) W = 4;
     if (W == 3) W = 4;
-    const int G = 4 / W, nkt = (a.nk + 31) / 32;
-    const size_t lds = (size_t)G * (2 * 32 * W + 2 * nkt * 32) * 128;
+    const int nkt = (a.nk + 31) / 32;
+    const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * 128;
+    const int G = pack_factor(W, prob);
+    const size_t lds = (size_t)G * prob;
     int rc = ensure_lds(attn_bwd_dq_mfma_kernel, lds, "attention_bwd(mfma,dq)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
@@ -450,8 +461,10 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     int W = (a.nk + 31) / 32;
     if (W > 4) W = 4;
     if (W == 3) W = 4;
-    const int G = 4 / W, nqt = (a.nq + 31) / 32;
-    const size_t lds = (size_t)G * ((2 * nqt * 32 + 2 * 32 * W) * 128 + 2 * nqt * 32 * 4);
+    const int nqt = (a.nq + 31) / 32;
+    const size_t prob = (size_t)(2 * nqt * 32 + 2 * 32 * W) * 128 + 2 * nqt * 32 * 4;
+    const int G = pack_factor(W, prob);
+    const size_t lds = (size_t)G * prob;
     int rc = ensure_lds(attn_bwd_dkv_mfma_kernel, lds, "attention_bwd(mfma,dkv)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));

@@ -107,21 +107,11 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int base, int ks, int l
   }
 }
 
+// one 128x128 output tile at (c0, r0): the whole K loop + epilogue
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wr = wave & 1;
-
-  // XCD-aware remap (bijective form): consecutive tile ids on one XCD walk the r-tiles of one c-panel.
-  const int nwg = g.tiles_r * g.tiles_c;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
-  const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  const int c0 = tc * BT, r0 = tr * BT;
 
   f32x4 acc[4][4];  // [j: r sub-tile][i: c sub-tile]
 #pragma unroll
@@ -179,6 +169,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
   }
 }
 
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
+  // XCD-aware remap (bijective form): consecutive tile ids on one XCD walk the r-tiles of one c-panel.
+  const int nwg = g.tiles_r * g.tiles_c;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
+  gemm_tile<P_KMAJOR, Q_KMAJOR, Epi>(g, tc * BT, tr * BT, epi, smem);
+}
+
 // ------------------------------------------------------------------ epilogues (c, r..r+3)
 __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
   bf16x4 v;
@@ -223,7 +227,7 @@ struct MEpiBiasResidual {
 };
 // dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
 struct MEpiBwdData {
-  bf16* dx; int64_t lddx; const bf16* preact; int Kcols; int accumulate; DropArgs da; DropState ds;
+  bf16* dx; int64_t lddx; const bf16* preact; int Kcols; const bf16* addend; int64_t ldadd; DropArgs da; DropState ds;
   __device__ __forceinline__ void init() { ds = drop_init(da); }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     float v[4] = {a[0], a[1], a[2], a[3]};
@@ -233,13 +237,12 @@ struct MEpiBwdData {
 #pragma unroll
       for (int t = 0; t < 4; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_fast((float)u[t]);
     }
-    bf16* p = dx + (int64_t)m * lddx + n;
-    if (accumulate) {
-      const bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+    if (addend) {
+      const bf16x4 o = *reinterpret_cast<const bf16x4*>(addend + (int64_t)m * ldadd + n);
 #pragma unroll
       for (int t = 0; t < 4; t++) v[t] += (float)o[t];
     }
-    store4(p, v[0], v[1], v[2], v[3]);
+    store4(dx + (int64_t)m * lddx + n, v[0], v[1], v[2], v[3]);
   }
 };
 // dW (fp32) (+)= acc
@@ -257,6 +260,18 @@ struct MEpiWgrad {
   }
 };
 
+// Grouped weight gradients: tile table entry {problem, tile_c (n), tile_r (i), -} -> one 128x128 tile of
+// dW_problem = dY^T X.  One launch covers every linear layer of a backward pass (no split-K, no slabs).
+__global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa_wgrad_problem* __restrict__ probs,
+                                                                      const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int4 t = tiles[blockIdx.x];
+  const ovqa_wgrad_problem pr = probs[t.x];
+  GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
+  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate};
+  gemm_tile<true, true, MEpiWgrad>(g, t.y * BT, t.z * BT, epi, smem);
+}
+
 template <bool PK, bool QK, typename Epi>
 int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, int64_t C, int64_t K, Epi epi,
            hipStream_t st, const char* what) {
@@ -269,11 +284,11 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// column sums of a bf16 [M, N] matrix into fp32 db (bias gradient): 16-byte loads, 64 x 8 columns per
-// workgroup, rows split over blockIdx.y with fp32 atomics only when more than one row-slab exists.
+// column sums of a bf16 [M, N] matrix into fp32 db (bias gradient).  HBM-bound streaming reduction:
+// one workgroup = 64 rows x 512 columns (16-byte loads, 16 rows in flight per wave), partial sums
+// combined across the 4 waves through LDS and across row slabs with fp32 atomics (db pre-zeroed).
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ dy, int64_t lddy,
-                                                          float* __restrict__ db, int M, int N, int rows_per_slab,
-                                                          int use_atomic) {
+                                                          float* __restrict__ db, int M, int N, int rows_per_slab) {
   __shared__ float red[4][64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + lane) * 8;
@@ -281,8 +296,18 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
   const int m1 = min(M, m0 + rows_per_slab);
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < N) {
-    for (int m = m0 + wave; m < m1; m += 4) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (int64_t)m * lddy + col);
+    const bf16* p = dy + col;
+    int m = m0 + wave;
+    for (; m + 12 < m1; m += 16) {  // 4 independent 16-byte loads per iteration
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(p + (int64_t)m * lddy);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(m + 4) * lddy);
+      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(m + 8) * lddy);
+      const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(m + 12) * lddy);
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] += ((float)v0[t] + (float)v1[t]) + ((float)v2[t] + (float)v3[t]);
+    }
+    for (; m < m1; m += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + (int64_t)m * lddy);
 #pragma unroll
       for (int t = 0; t < 8; t++) s[t] += (float)v[t];
     }
@@ -292,11 +317,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
   __syncthreads();
   if (wave == 0 && col < N) {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      const float v = red[0][lane][t] + red[1][lane][t] + red[2][lane][t] + red[3][lane][t];
-      if (use_atomic) atomicAdd(db + col + t, v);
-      else db[col + t] = v;
-    }
+    for (int t = 0; t < 8; t++)
+      atomicAdd(db + col + t, red[0][lane][t] + red[1][lane][t] + red[2][lane][t] + red[3][lane][t]);
   }
 }
 
@@ -344,11 +366,13 @@ bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t ldd
 }
 
 int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx, const void* preact,
-                         int64_t M, int64_t N, int64_t K, int accumulate, const DropArgs& da, hipStream_t st) {
-  OVQA_REQUIRE(aligned16(dy) && aligned16(w) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0),
+                         const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K, const DropArgs& da,
+                         hipStream_t st) {
+  OVQA_REQUIRE(aligned16(dy) && aligned16(w) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0) &&
+                   (!addend || ((uintptr_t)addend % 8 == 0 && ldadd % 4 == 0)),
                OVQA_ERR_BAD_ARG, "linear_bwd_data(bf16): pointer alignment");
   return launch<true, false>(w, K, dy, lddy, K, M, N,
-                             MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, accumulate, da, DropState{}}, st,
+                             MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, (const bf16*)addend, ldadd, da, DropState{}}, st,
                              "linear_bwd_data(mfma)");
 }
 
@@ -358,7 +382,7 @@ bool mfma_linear_bwd_weight_supported(int64_t M, int64_t N, int64_t K, int64_t l
 }
 
 int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db, int64_t M,
-                           int64_t N, int64_t K, int accumulate, hipStream_t st) {
+                           int64_t N, int64_t K, int accumulate, int accumulate_db, hipStream_t st) {
   OVQA_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw), OVQA_ERR_BAD_ARG,
                "linear_bwd_weight(bf16): pointer alignment");
   // the reduction length is passed as "K" of the kernel; K % 8 is not required for k-major operands
@@ -368,24 +392,31 @@ int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t 
                      4 * TILE_BYTES, st, g, MEpiWgrad{dw, K, accumulate});
   int rc = ovqa_check_launch("linear_bwd_weight(mfma)");
   if (rc != OVQA_OK || db == nullptr) return rc;
-  const int col_blocks = (int)((N / 8 + 63) / 64);
-  int slabs = 1;
+  return colsum_bf16(dy, lddy, db, M, N, accumulate_db, st);
+}
+
+int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, hipStream_t st) {
+  if (n_tiles == 0) return OVQA_OK;
+  hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3((unsigned)n_tiles), dim3(256), 4 * TILE_BYTES, st, probs_dev,
+                     reinterpret_cast<const int4*>(tiles_dev));
+  return ovqa_check_launch("grouped_linear_bwd_weight(mfma)");
+}
+
+int colsum_bf16(const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate, hipStream_t st) {
   if (!accumulate) {
-    slabs = (int)((M + 255) / 256);
-    if (slabs > 64) slabs = 64;
-  }
-  const int rows_per_slab = (int)((M + slabs - 1) / slabs);
-  int use_atomic = (slabs > 1 || accumulate) ? 1 : 0;
-  if (use_atomic && !accumulate) {
     hipError_t e = hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st);
     if (e != hipSuccess) {
-      ovqa_set_error("linear_bwd_weight: hipMemsetAsync: %s", hipGetErrorString(e));
+      ovqa_set_error("colsum: hipMemsetAsync: %s", hipGetErrorString(e));
       return OVQA_ERR_LAUNCH;
     }
   }
+  const int col_blocks = (int)((N / 8 + 63) / 64);
+  int slabs = (int)((M + 63) / 64);
+  if (slabs > 512) slabs = 512;
+  const int rows_per_slab = (int)((M + slabs - 1) / slabs);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(col_blocks, slabs), dim3(256), 0, st, (const bf16*)dy, lddy, db, (int)M,
-                     (int)N, rows_per_slab, use_atomic);
-  return ovqa_check_launch("linear_bwd_weight(colsum)");
+                     (int)N, rows_per_slab);
+  return ovqa_check_launch("colsum_bf16");
 }
 
 }  // namespace ovqa

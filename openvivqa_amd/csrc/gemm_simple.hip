@@ -134,7 +134,7 @@ struct EpiBiasResidual {
 // dX = dY W [* dropmask * gelu'(u)]
 template <typename T>
 struct EpiBwdData {
-  T* dx; int64_t lddx; const T* preact; int Kcols; int accumulate; DropArgs da;
+  T* dx; int64_t lddx; const T* preact; int Kcols; const T* addend; int64_t ldadd; DropArgs da;
   __device__ void operator()(int, int m, int n, float acc) const {
     float v = acc;
     if (preact) {
@@ -142,9 +142,8 @@ struct EpiBwdData {
       const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + n;
       v *= drop_mul(ds, idx) * gelu_grad_f(to_f32<T>(preact[(int64_t)m * Kcols + n]));
     }
-    T* p = dx + (int64_t)m * lddx + n;
-    if (accumulate) v += to_f32<T>(*p);
-    *p = from_f32<T>(v);
+    if (addend) v += to_f32<T>(addend[(int64_t)m * ldadd + n]);
+    dx[(int64_t)m * lddx + n] = from_f32<T>(v);
   }
 };
 struct EpiF32Out {
@@ -234,20 +233,21 @@ int simple_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const
 }
 
 int simple_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
-                           const void* preact, int64_t M, int64_t N, int64_t K, int accumulate,
+                           const void* preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
                            const DropArgs& da, hipStream_t st) {
   // dx[M,K] = dy[M,N] . w[N,K]   (A = dy, B = w as [red=N, cols=K], not transposed)
   if (dtype == OVQA_F32)
     return launch<float, false, false>(dy, lddy, 0, w, K, 0, 1, M, K, N,
-                                       EpiBwdData<float>{(float*)dx, lddx, (const float*)preact, (int)K, accumulate, da},
+                                       EpiBwdData<float>{(float*)dx, lddx, (const float*)preact, (int)K, (const float*)addend, ldadd, da},
                                        st, "linear_bwd_data");
   return launch<bf16, false, false>(dy, lddy, 0, w, K, 0, 1, M, K, N,
-                                    EpiBwdData<bf16>{(bf16*)dx, lddx, (const bf16*)preact, (int)K, accumulate, da}, st,
+                                    EpiBwdData<bf16>{(bf16*)dx, lddx, (const bf16*)preact, (int)K, (const bf16*)addend, ldadd, da}, st,
                                     "linear_bwd_data");
 }
 
 int simple_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
-                             float* db, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t st) {
+                             float* db, int64_t M, int64_t N, int64_t K, int accumulate, int accumulate_db,
+                             hipStream_t st) {
   // dw[N,K] = dy^T[N,M] . x[M,K]  (A = dy transposed, B = x not transposed, reduction over M)
   int rc;
   if (dtype == OVQA_F32) {
@@ -255,7 +255,7 @@ int simple_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void
                                     "linear_bwd_weight");
     if (rc == OVQA_OK && db) {
       hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st,
-                         (const float*)dy, lddy, db, (int)M, (int)N, accumulate);
+                         (const float*)dy, lddy, db, (int)M, (int)N, accumulate_db);
       rc = ovqa_check_launch("colsum");
     }
   } else {
@@ -263,7 +263,7 @@ int simple_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void
                                    "linear_bwd_weight");
     if (rc == OVQA_OK && db) {
       hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st,
-                         (const bf16*)dy, lddy, db, (int)M, (int)N, accumulate);
+                         (const bf16*)dy, lddy, db, (int)M, (int)N, accumulate_db);
       rc = ovqa_check_launch("colsum");
     }
   }

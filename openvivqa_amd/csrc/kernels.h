@@ -11,10 +11,11 @@ int simple_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const
                       const void* residual, int64_t ldres, void* y, int64_t ldy, void* preact,
                       int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
 int simple_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
-                           const void* preact, int64_t M, int64_t N, int64_t K, int accumulate,
+                           const void* preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
                            const DropArgs& da, hipStream_t st);
 int simple_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
-                             float* db, int64_t M, int64_t N, int64_t K, int accumulate, hipStream_t st);
+                             float* db, int64_t M, int64_t N, int64_t K, int accumulate, int accumulate_db,
+                             hipStream_t st);
 int simple_batched_gemm(int dtype, int c_dtype, int ta, int tb, const void* A, int64_t lda, int64_t sa,
                         const void* B, int64_t ldb, int64_t sb, void* C, int64_t ldc, int64_t sc, int64_t batch,
                         int64_t M, int64_t N, int64_t K, float alpha, hipStream_t st);
@@ -76,10 +77,13 @@ int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, floa
 // ---- gemm_mfma.hip (bf16, MFMA) ----------------------------------------------
 bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx);
 int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx, const void* preact,
-                         int64_t M, int64_t N, int64_t K, int accumulate, const DropArgs& da, hipStream_t st);
+                         const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K, const DropArgs& da,
+                         hipStream_t st);
+int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, hipStream_t st);
 bool mfma_linear_bwd_weight_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx);
 int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db, int64_t M,
-                           int64_t N, int64_t K, int accumulate, hipStream_t st);
+                           int64_t N, int64_t K, int accumulate, int accumulate_db, hipStream_t st);
+int colsum_bf16(const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate, hipStream_t st);
 bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldy, int64_t ldres);
 int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                     int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,

@@ -196,25 +196,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   }
 }
 
-// dgamma/dbeta = column sums of the per-workgroup partials [nblocks][2*D]: 64 columns per workgroup,
-// 4 row groups, combined through LDS.
+// dgamma/dbeta += column sums of the per-workgroup partials [nblocks][2*D]: grid (2D/64, row groups),
+// 64 columns x 4 partial rows in flight per workgroup, fp32 atomics across row groups (outputs pre-zeroed
+// unless accumulating).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int accumulate) {
+                                                            int rows_per_group) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + c;  // over 2*D
+  const int b0 = blockIdx.y * rows_per_group, b1 = min(nblocks, b0 + rows_per_group);
   float s = 0.f;
   if (i < 2 * D)
-    for (int b = r; b < nblocks; b += 4) s += partial[(int64_t)b * 2 * D + i];
+    for (int b = b0 + r; b < b1; b += 4) s += partial[(int64_t)b * 2 * D + i];
   red[r][c] = s;
   __syncthreads();
   if (r != 0 || i >= 2 * D) return;
   s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
   float* base = (i < D) ? dgamma : dbeta;
   if (base == nullptr) return;
-  float* dst = base + ((i < D) ? i : i - D);
-  *dst = accumulate ? (*dst + s) : s;
+  atomicAdd(base + ((i < D) ? i : i - D), s);
 }
 
 template <typename TIN, typename TOUT>
@@ -255,8 +256,18 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
 #undef LN_BWD
   int rc = ovqa_check_launch("layernorm_bwd");
   if (rc != OVQA_OK) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64)), dim3(256), 0, st, partial, nblocks,
-                     (int)D, dgamma, dbeta, accumulate);
+  if (!accumulate) {
+    hipError_t e = hipSuccess;
+    if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st);
+    if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st);
+    if (e != hipSuccess) {
+      ovqa_set_error("layernorm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+  }
+  const int groups = (nblocks + 15) / 16;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64), groups), dim3(256), 0, st, partial,
+                     nblocks, (int)D, dgamma, dbeta, 16);
   return ovqa_check_launch("layernorm_bwd_reduce");
 }
 

@@ -31,16 +31,35 @@ def _c(t: Optional[torch.Tensor]):
     return t if t is None or t.is_contiguous() else t.contiguous()
 
 
+_wgrad_queue = None
+
+
+def _flush_wgrads():
+    if _wgrad_queue is not None:
+        _wgrad_queue.flush()
+
+
 def _wgrad(arena, dy, x, w_params, b_params):
-    """dW/db of a (possibly packed) linear, written into the arena's grad buffer."""
-    gw, acc = arena.grad_views(w_params)
-    gb = None
-    if b_params:
-        gb, acc_b = arena.grad_views(b_params)
-        if acc_b != acc:  # mixed None / existing .grad: zero the fresh one, accumulate both
-            (gb if acc else gw).zero_()
-            acc = True
-    ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc)
+    """dW/db of a (possibly packed) linear into the arena's grad buffer.
+
+    bf16: the bias gradient (an HBM-bound column sum) runs now; the weight gradient is queued and
+    computed at the END of the backward pass by one grouped launch over all linears (each product
+    alone has only 16-64 output tiles, far fewer than the chip's 256 CUs).  The queued ``dy``/``x``
+    are never written afterwards (backward never updates a gradient tensor in place)."""
+    global _wgrad_queue
+    gw, acc_w = arena.grad_views(w_params)
+    gb, acc_b = arena.grad_views(b_params) if b_params else (None, False)
+    defer = dy.dtype == torch.bfloat16 and dy.is_cuda and dy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+    if not defer:
+        ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc_w, accumulate_db=acc_b)
+        return
+    if gb is not None:
+        ops.bias_grad(dy, gb, accumulate=acc_b)
+    if _wgrad_queue is None:
+        _wgrad_queue = ops.WgradQueue()
+    if not _wgrad_queue.items:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    _wgrad_queue.add(dy, x, gw, acc_w)
 
 
 # ------------------------------------------------------------------ prologue
@@ -150,8 +169,8 @@ class _MHABlock(Function):
             ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
                               dv=dqkv[..., 2 * nqk:])
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
-            ops.linear_bwd_data(dqkv, arena.packed([wq, wk, wv]), out=dpre, accumulate=True)
-            return dpre, None, None, None, None, *([None] * len(st["params"]))
+            dx = ops.linear_bwd_data(dqkv, arena.packed([wq, wk, wv]), addend=dpre)
+            return dx, None, None, None, None, *([None] * len(st["params"]))
         if mode == "cross":
             q, kv = bufs
             k, v = kv[..., :nqk], kv[..., nqk:]
@@ -159,19 +178,19 @@ class _MHABlock(Function):
             dkv = torch.empty_like(kv)
             ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
             _wgrad(arena, dq, queries, [wq], [bq])
-            ops.linear_bwd_data(dq, arena.compute(wq), out=dpre, accumulate=True)
+            dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
             _wgrad(arena, dkv, keys, [wk, wv], [bk, bv])
             dkeys = ops.linear_bwd_data(dkv, arena.packed([wk, wv])) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
-            return dpre, dkeys, None, None, None, *([None] * len(st["params"]))
+            return dx, dkeys, None, None, None, *([None] * len(st["params"]))
         q, k, v = bufs
         dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h)
         _wgrad(arena, dq, queries, [wq], [bq])
-        ops.linear_bwd_data(dq, arena.compute(wq), out=dpre, accumulate=True)
+        dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
         _wgrad(arena, dk, keys, [wk], [bk])
         _wgrad(arena, dv, values, [wv], [bv])
         dkeys = ops.linear_bwd_data(dk, arena.compute(wk)) if ctx.needs_input_grad[1] else None
         dvalues = ops.linear_bwd_data(dv, arena.compute(wv)) if ctx.needs_input_grad[2] else None
-        return dpre, dkeys, dvalues, None, None, *([None] * len(st["params"]))
+        return dx, dkeys, dvalues, None, None, *([None] * len(st["params"]))
 
 
 def mha_block(queries, keys, values, mask, st):
@@ -220,8 +239,8 @@ class _FFNBlock(Function):
         _wgrad(arena, dpre_d, h, [m.fc2.weight], [m.fc2.bias])
         du = ops.linear_bwd_data(dpre_d, arena.compute(m.fc2.weight), preact=u, drop=st["drop1"])
         _wgrad(arena, du, x, [m.fc1.weight], [m.fc1.bias])
-        ops.linear_bwd_data(du, arena.compute(m.fc1.weight), out=dpre, accumulate=True)
-        return dpre, None, *([None] * len(st["params"]))
+        dx = ops.linear_bwd_data(du, arena.compute(m.fc1.weight), addend=dpre)
+        return dx, None, *([None] * len(st["params"]))
 
 
 def ffn_block(x, st):

@@ -108,8 +108,8 @@ def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=Fa
     return (y, preact) if want_preact else y
 
 
-def linear_bwd_data(dy, w, preact=None, drop=None, out=None, accumulate=False):
-    """dx = dy w  [* dropmask * gelu'(preact)]."""
+def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
+    """dx = dy w  [* dropmask * gelu'(preact)]  [+ addend]   (addend may alias out)."""
     _dev(dy)
     lib = _lib.load()
     lddy, M = _rows(dy)
@@ -117,13 +117,18 @@ def linear_bwd_data(dy, w, preact=None, drop=None, out=None, accumulate=False):
     assert dy.shape[-1] == N and w.dtype == dy.dtype
     dx = out if out is not None else torch.empty(*dy.shape[:-1], K, dtype=dy.dtype, device=dy.device)
     lddx, _ = _rows(dx)
-    _lib.check(lib.ovqa_linear_bwd_data(_dt(dy), _p(dy), lddy, _p(w), _p(dx), lddx, _p(preact), M, N, K,
-                                        int(accumulate), _drop(drop), _stream()), "linear_bwd_data")
+    ldadd = 0
+    if addend is not None:
+        ldadd, ma = _rows(addend)
+        assert ma == M and addend.dtype == dy.dtype and addend.shape[-1] == K
+    _lib.check(lib.ovqa_linear_bwd_data(_dt(dy), _p(dy), lddy, _p(w), _p(dx), lddx, _p(preact), _p(addend), ldadd,
+                                        M, N, K, _drop(drop), _stream()), "linear_bwd_data")
     return dx
 
 
-def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, accumulate_db=None):
     """dw (fp32 [N,K]) (+)= dy^T x ; db (fp32 [N]) (+)= colsum(dy)."""
+    flags = int(bool(accumulate)) | (int(bool(accumulate if accumulate_db is None else accumulate_db)) << 1)
     _dev(dy)
     lib = _lib.load()
     lddy, M = _rows(dy)
@@ -132,7 +137,79 @@ def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
     assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == N * K
     assert db is None or (db.dtype == torch.float32 and db.numel() == N)
     _lib.check(lib.ovqa_linear_bwd_weight(_dt(dy), _p(dy), lddy, _p(x), ldx, _p(dw), _p(db), M, N, K,
-                                          int(accumulate), _p(workspace(dy.device)), _stream()), "linear_bwd_weight")
+                                          flags, _p(workspace(dy.device)), _stream()), "linear_bwd_weight")
+
+
+def bias_grad(dy, db, accumulate=False):
+    """db (fp32 [N]) (+)= column sums of dy (bf16 only; fp32 uses linear_bwd_weight)."""
+    _dev(dy)
+    lddy, M = _rows(dy)
+    _lib.check(_lib.load().ovqa_bias_grad(_dt(dy), _p(dy), lddy, _p(db), M, dy.shape[-1], int(accumulate), _stream()),
+               "bias_grad")
+
+
+class WgradQueue:
+    """Deferred weight gradients: (dy, x, dw) triples collected during a backward pass and computed by ONE
+    grouped launch (ovqa_grouped_linear_bwd_weight).  The queued activations stay alive until flush()."""
+
+    TILE = 128
+
+    def __init__(self):
+        self.items = []
+        self.keepalive = []  # host/device tables of captured launches must outlive the graph
+        self._cache = None
+        self._event = None
+
+    def add(self, dy, x, dw, accumulate):
+        lddy, M = _rows(dy)
+        ldx, Mx = _rows(x)
+        assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous()
+        self.items.append((dy, x, dw, lddy, ldx, M, dy.shape[-1], x.shape[-1], int(bool(accumulate))))
+
+    def flush(self):
+        if not self.items:
+            return
+        import numpy as np
+        items, self.items = self.items, []
+        dev = items[0][0].device
+        probs = (_lib.WgradProblem * len(items))()
+        tiles = []
+        for i, (dy, x, dw, lddy, ldx, M, N, K, acc) in enumerate(items):
+            probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), lddy, ldx, M, N, K, acc)
+            tn, tk = (N + self.TILE - 1) // self.TILE, (K + self.TILE - 1) // self.TILE
+            tiles.extend((M, i, c, r) for c in range(tn) for r in range(tk))
+        tiles.sort(key=lambda t: -t[0])  # longest reductions first
+        tile_arr = np.array([(i, c, r, 0) for (_, i, c, r) in tiles], dtype=np.int32)
+        prob_bytes = np.frombuffer(bytes(probs), dtype=np.uint8)
+        nbytes = prob_bytes.size + tile_arr.nbytes
+        host, devbuf = self._buffers(nbytes, dev)
+        host[:prob_bytes.size] = torch.from_numpy(prob_bytes.copy())
+        host[prob_bytes.size:nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
+        devbuf[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
+            OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), _stream()),
+            "grouped_linear_bwd_weight")
+        if torch.cuda.is_current_stream_capturing():
+            # the captured launch re-reads the tables and the queued tensors on every replay
+            self.keepalive.append((host, devbuf, items))
+            self._cache = None  # never reuse buffers a graph owns
+        else:
+            self._event = torch.cuda.Event()
+            self._event.record()
+
+    def _buffers(self, nbytes, dev):
+        """Pinned host + device table buffers, allocated OUTSIDE graph capture (warm-up pass) and reused:
+        pinned allocations are not permitted while a stream is capturing."""
+        cache = getattr(self, "_cache", None)
+        if cache is not None and cache[0].numel() >= nbytes and cache[1].device == dev:
+            ev = getattr(self, "_event", None)
+            if ev is not None and not torch.cuda.is_current_stream_capturing():
+                ev.synchronize()  # previous eager launch has consumed the host table
+            return cache
+        size = max(nbytes * 2, 1 << 16)
+        cache = (torch.empty(size, dtype=torch.uint8).pin_memory(), torch.empty(size, dtype=torch.uint8, device=dev))
+        self._cache = cache
+        return cache
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True):

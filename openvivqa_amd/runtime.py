@@ -77,8 +77,14 @@ class ParamArena:
         self.params: List[nn.Parameter] = []
         self.offsets: Dict[int, int] = {}
         off = 0
+        # matrices first, then every 1-D parameter (biases, LayerNorm affine): the 1-D tail is what the
+        # training harness zeroes with ONE memset per step (their gradients are reduced with atomics)
+        groups = sorted(groups, key=lambda g: 0 if g[0].dim() >= 2 else 1)
+        self.small_lo = None
         for g in groups:
             off = (off + ALIGN - 1) // ALIGN * ALIGN
+            if g[0].dim() < 2 and self.small_lo is None:
+                self.small_lo = off
             for p in g:
                 if id(p) in self.offsets:
                     raise RuntimeError("parameter appears twice in an arena")
@@ -86,6 +92,8 @@ class ParamArena:
                 self.params.append(p)
                 off += p.numel()
         self.numel = (off + ALIGN - 1) // ALIGN * ALIGN
+        if self.small_lo is None:
+            self.small_lo = self.numel
         self.master = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.shadow = (torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
@@ -183,10 +191,12 @@ class ParamArena:
         views = [self.grad_of(p) for p in ps]
         self.kernel_written.update(id(p) for p in ps)
         if self.overwrite_grads:
+            # harness mode: matrices are overwritten; the 1-D tail was zeroed for this step and is
+            # accumulated into (atomic column sums)
             for p, v in zip(ps, views):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
-            return self.packed(ps, "grad"), False
+            return self.packed(ps, "grad"), ps[0].dim() < 2
         if all(p.grad is None for p in ps):
             for p, v in zip(ps, views):
                 p.grad = v

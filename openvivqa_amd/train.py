@@ -136,8 +136,12 @@ class TrainStep:
 
     # -- one fwd+bwd on the static inputs (this is what gets captured) ------
     def _fwd_bwd(self):
+        a = self.arena
+        if a.small_lo < a.numel:  # bias / LayerNorm gradients: atomically reduced, so zero them (one memset)
+            a.grad[a.small_lo:].zero_()
         for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
-            self.arena.grad[s:e].zero_()
+            if s < a.small_lo:
+                a.grad[s:min(e, a.small_lo)].zero_()
         res = self.forward_loss(*self.static_inputs)
         if isinstance(res, tuple):
             outs, grads = res

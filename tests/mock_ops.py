@@ -53,20 +53,40 @@ def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=Fa
     return (y, pre) if want_preact else y
 
 
-def linear_bwd_data(dy, w, preact=None, drop=None, out=None, accumulate=False):
+def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
     dx = dy.float() @ w.float()
     if preact is not None:
         dx = dx * _gelu_grad(preact.float()).reshape(dx.shape)
+    if addend is not None:
+        dx = dx + addend.float()
     if out is not None:
-        if accumulate:
-            out.add_(dx.to(out.dtype))
-        else:
-            out.copy_(dx.to(out.dtype))
+        out.copy_(dx.to(out.dtype))
         return out
     return dx.to(dy.dtype)
 
 
-def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+def bias_grad(dy, db, accumulate=False):
+    s = dy.reshape(-1, dy.shape[-1]).float().sum(0)
+    if accumulate:
+        db.add_(s)
+    else:
+        db.copy_(s)
+
+
+class WgradQueue:
+    def __init__(self):
+        self.items = []
+
+    def add(self, dy, x, dw, accumulate):
+        self.items.append((dy, x, dw, accumulate))
+
+    def flush(self):
+        items, self.items = self.items, []
+        for dy, x, dw, acc in items:
+            linear_bwd_weight(dy, x, dw, None, accumulate=acc)
+
+
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, accumulate_db=None):
     d2, x2 = dy.reshape(-1, dy.shape[-1]).float(), x.reshape(-1, x.shape[-1]).float()
     g = d2.t() @ x2
     if accumulate:
@@ -75,7 +95,7 @@ def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
         dw.copy_(g.view_as(dw))
     if db is not None:
         s = d2.sum(0)
-        if accumulate:
+        if (accumulate if accumulate_db is None else accumulate_db):
             db.add_(s.view_as(db))
         else:
             db.copy_(s.view_as(db))

@@ -204,10 +204,9 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, comm_bf16, q):
+def _dp_worker(rank, world, rdv, comm_bf16, q):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + rdv, rank=rank, world_size=world)
     try:
         from openvivqa_amd.train import GradAllReducer
         n = 1000
@@ -226,8 +225,9 @@ def test_grad_allreduce_gloo_world2(comm_bf16):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, comm_bf16, q)) for r in range(2)]
+    import tempfile
+    rdv = os.path.join(tempfile.mkdtemp(prefix="ovqa_rdv_"), "store")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, rdv, comm_bf16, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(2))

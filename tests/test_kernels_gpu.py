@@ -83,8 +83,9 @@ def test_linear_bwd_data(dtype, M, N, K):
     ref = dy.double() @ w.double()
     assert nerr(o.linear_bwd_data(dy, w), ref) < tol(dtype)
     base = rnd(M, K, dtype=dtype, seed=4)
+    assert nerr(o.linear_bwd_data(dy, w, addend=base), ref + base.double()) < tol(dtype)
     out = base.clone()
-    o.linear_bwd_data(dy, w, out=out, accumulate=True)
+    o.linear_bwd_data(dy, w, out=out, addend=out)  # aliasing addend == out is allowed
     assert nerr(out, ref + base.double()) < tol(dtype)
     u = rnd(M, K, dtype=dtype, seed=7)
     assert nerr(o.linear_bwd_data(dy, w, preact=u), ref * gelu_grad(u.double())) < tol(dtype)
@@ -105,6 +106,29 @@ def test_linear_bwd_weight(dtype, M, N, K):
     dw2 = torch.zeros(N, K, device=DEV)
     o.linear_bwd_weight(dy, x, dw2, None)
     assert nerr(dw2, rw) < tol(dtype)
+
+
+def test_grouped_wgrad_and_bias_grad():
+    o = ops()
+    specs = [(6400, 512, 512), (1280, 1024, 512), (400, 1536, 512), (1280, 2048, 512), (6400, 512, 2048), (37, 32, 64)]
+    q = o.WgradQueue()
+    refs, outs = [], []
+    for i, (M, N, K) in enumerate(specs):
+        dy, x = rnd(M, N, dtype=BF16, scale=M ** -0.5, seed=i), rnd(M, K, dtype=BF16, seed=10 + i)
+        dw = torch.full((N, K), 3.0, device=DEV)
+        acc = i % 2 == 1
+        q.add(dy, x, dw, acc)
+        refs.append(dy.double().t() @ x.double() + (3.0 if acc else 0.0))
+        outs.append(dw)
+        db = torch.full((N,), 2.0, device=DEV)
+        o.bias_grad(dy, db)
+        assert nerr(db, dy.double().sum(0)) < 1e-2
+        o.bias_grad(dy, db, accumulate=True)
+        assert nerr(db, 2 * dy.double().sum(0)) < 2e-2
+    q.flush()
+    for (M, N, K), dw, ref in zip(specs, outs, refs):
+        assert nerr(dw, ref) < 1e-2, (M, N, K, nerr(dw, ref))
+    assert not q.items
 
 
 def ln_ref(x, g, b, eps=1e-5):

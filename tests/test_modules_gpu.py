@@ -177,7 +177,7 @@ def test_fullsize_mcan_against_reference_checksum(mode):
     for n, ref in zip(names, c.out["grad_norms"].tolist()):
         if n.endswith("fc_k.bias"):
             continue
-        assert abs(got[n] - ref) <= gtol * max(ref, 1e-6) + 1e-7, (n, got[n], ref)
+        assert abs(got[n] - ref) <= 2 * gtol * max(ref, 1e-6) + 1e-7, (n, got[n], ref)  # norms: 2x the elementwise bar
 
 
 @pytest.mark.parametrize("B", [64])
