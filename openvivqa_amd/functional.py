@@ -18,6 +18,7 @@ a view of it) and the functions return ``None`` for them.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -49,7 +50,8 @@ def _wgrad(arena, dy, x, w_params, b_params):
     global _wgrad_queue
     gw, acc_w = arena.grad_views(w_params)
     gb, acc_b = arena.grad_views(b_params) if b_params else (None, False)
-    defer = dy.dtype == torch.bfloat16 and dy.is_cuda and dy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+    defer = (dy.dtype == torch.bfloat16 and dy.is_cuda and dy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
+             and os.environ.get("OVQA_DEFER_WGRAD", "1") != "0")
     if not defer:
         ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc_w, accumulate_db=acc_b)
         return

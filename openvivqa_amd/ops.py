@@ -164,6 +164,9 @@ class WgradQueue:
         lddy, M = _rows(dy)
         ldx, Mx = _rows(x)
         assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous()
+        if any(it[2].data_ptr() == dw.data_ptr() for it in self.items):
+            # the same weight used twice in one backward pass: its two contributions must be ordered
+            self.flush()
         self.items.append((dy, x, dw, lddy, ldx, M, dy.shape[-1], x.shape[-1], int(bool(accumulate))))
 
     def flush(self):
@@ -181,6 +184,9 @@ class WgradQueue:
         tiles.sort(key=lambda t: -t[0])  # longest reductions first
         tile_arr = np.array([(i, c, r, 0) for (_, i, c, r) in tiles], dtype=np.int32)
         prob_bytes = np.frombuffer(bytes(probs), dtype=np.uint8)
+        pad = (-prob_bytes.size) % 16  # keep the int4 tile table 16-byte aligned
+        if pad:
+            prob_bytes = np.concatenate([prob_bytes, np.zeros(pad, dtype=np.uint8)])
         nbytes = prob_bytes.size + tile_arr.nbytes
         host, devbuf = self._buffers(nbytes, dev)
         host[:prob_bytes.size] = torch.from_numpy(prob_bytes.copy())
