@@ -112,9 +112,10 @@ typedef struct {
   const void* dy;   /* [M,N], row stride lddy */
   const void* x;    /* [M,K], row stride ldx  */
   float* dw;        /* [N,K] fp32             */
+  float* db;        /* [N] fp32 bias gradient (column sums of dy) or NULL */
   int64_t lddy, ldx;
   int32_t M, N, K;
-  int32_t accumulate;
+  int32_t accumulate; /* bit 0: dw +=, bit 1: db += */
 } ovqa_wgrad_problem;
 int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev,
                                    const int32_t* tiles_dev, int64_t n_tiles, void* stream);

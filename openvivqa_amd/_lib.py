@@ -21,7 +21,8 @@ c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
 class WgradProblem(C.Structure):
     """ovqa_wgrad_problem (include/ovqa_hip.h)."""
-    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("lddy", C.c_int64), ("ldx", C.c_int64),
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("lddy", C.c_int64), ("ldx", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
 
 

@@ -107,8 +107,11 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int base, int ks, int l
   }
 }
 
-// one 128x128 output tile at (c0, r0): the whole K loop + epilogue
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
+// one 128x128 output tile at (c0, r0): the whole K loop + epilogue.
+// COLSUM: the tile at r0 == 0 also reduces the Q operand over k (bias gradient = column sums of dY) with
+// one extra MFMA per c sub-tile against an all-ones A fragment -- the sums come out of the matrix pipe,
+// no LDS traffic, no cross-lane reduction; epi.colsum(c, value) receives them.
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wr = wave & 1;
@@ -118,6 +121,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bool do_colsum = false;
+  if constexpr (COLSUM) do_colsum = r0 == 0 && wr == 0 && epi.wants_colsum();
+  f32x4 cs[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 4; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
 
   const int nkt = (g.K + BK - 1) / BK;
   uint4 rp[4], rq[4];
@@ -147,6 +159,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
 #pragma unroll
         for (int i = 0; i < 4; i++)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+      if constexpr (COLSUM) {
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, qf[i], cs[i], 0, 0, 0);
+        }
+      }
     }
     if (kt + 1 < nkt) {
       stage_store<P_KMAJOR>(rp, Pn, tid);
@@ -155,6 +173,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
     __syncthreads();
   }
 
+  if constexpr (COLSUM) {
+    if (do_colsum && lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int c = c0 + wc * 64 + i * 16 + lane;
+        if (c < g.C) epi.colsum(c, cs[i][0]);
+      }
+    }
+  }
   // acc[j][i][reg]: r = r0 + wr*64 + j*16 + (lane>>4)*4 + reg ; c = c0 + wc*64 + i*16 + (lane&15)
   epi.init();
 #pragma unroll
@@ -247,8 +274,10 @@ struct MEpiBwdData {
 };
 // dW (fp32) (+)= acc
 struct MEpiWgrad {
-  float* dw; int64_t ld; int accumulate;
+  float* dw; int64_t ld; int accumulate; float* db; int accumulate_db;
   __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ bool wants_colsum() const { return db != nullptr; }
+  __device__ __forceinline__ void colsum(int n, float v) const { db[n] = accumulate_db ? db[n] + v : v; }
   __device__ __forceinline__ void operator()(int n, int i, const f32x4& a) const {
     float4* p = reinterpret_cast<float4*>(dw + (int64_t)n * ld + i);
     float4 v = make_float4(a[0], a[1], a[2], a[3]);
@@ -268,8 +297,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
   const int4 t = tiles[blockIdx.x];
   const ovqa_wgrad_problem pr = probs[t.x];
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
-  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate};
-  gemm_tile<true, true, MEpiWgrad>(g, t.y * BT, t.z * BT, epi, smem);
+  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
+  gemm_tile<true, true, MEpiWgrad, true>(g, t.y * BT, t.z * BT, epi, smem);
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tc = blockIdx.x / g.tiles_r, tr = blockIdx.x % g.tiles_r;
+  gemm_tile<true, true, MEpiWgrad, true>(g, tc * BT, tr * BT, epi, smem);
 }
 
 template <bool PK, bool QK, typename Epi>
@@ -388,11 +423,9 @@ int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t 
   // the reduction length is passed as "K" of the kernel; K % 8 is not required for k-major operands
   GemmArgs g{(const bf16*)x, ldx, (const bf16*)dy, lddy, (int)K, (int)N, (int)M,
              (int)((K + BT - 1) / BT), (int)((N + BT - 1) / BT)};
-  hipLaunchKernelGGL((gemm_bf16_kernel<true, true, MEpiWgrad>), dim3(g.tiles_r * g.tiles_c), dim3(256),
-                     4 * TILE_BYTES, st, g, MEpiWgrad{dw, K, accumulate});
-  int rc = ovqa_check_launch("linear_bwd_weight(mfma)");
-  if (rc != OVQA_OK || db == nullptr) return rc;
-  return colsum_bf16(dy, lddy, db, M, N, accumulate_db, st);
+  hipLaunchKernelGGL(gemm_bf16_wgrad_kernel, dim3(g.tiles_r * g.tiles_c), dim3(256), 4 * TILE_BYTES, st, g,
+                     MEpiWgrad{dw, K, accumulate, db, accumulate_db});
+  return ovqa_check_launch("linear_bwd_weight(mfma)");
 }
 
 int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, hipStream_t st) {

@@ -43,9 +43,9 @@ def _flush_wgrads():
 def _wgrad(arena, dy, x, w_params, b_params):
     """dW/db of a (possibly packed) linear into the arena's grad buffer.
 
-    bf16: the bias gradient (an HBM-bound column sum) runs now; the weight gradient is queued and
-    computed at the END of the backward pass by one grouped launch over all linears (each product
-    alone has only 16-64 output tiles, far fewer than the chip's 256 CUs).  The queued ``dy``/``x``
+    bf16: weight AND bias gradient are queued and computed at the END of the backward pass by one
+    grouped launch over all linears (each product alone has only 16-64 output tiles, far fewer than
+    the chip's 256 CUs); the bias gradient falls out of the same kernel (ones-fragment MFMA).  The queued ``dy``/``x``
     are never written afterwards (backward never updates a gradient tensor in place)."""
     global _wgrad_queue
     gw, acc_w = arena.grad_views(w_params)
@@ -55,13 +55,11 @@ def _wgrad(arena, dy, x, w_params, b_params):
     if not defer:
         ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc_w, accumulate_db=acc_b)
         return
-    if gb is not None:
-        ops.bias_grad(dy, gb, accumulate=acc_b)
     if _wgrad_queue is None:
         _wgrad_queue = ops.WgradQueue()
     if not _wgrad_queue.items:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    _wgrad_queue.add(dy, x, gw, acc_w)
+    _wgrad_queue.add(dy, x, gw, acc_w, gb, acc_b)  # bias gradient = fused column sums of dy
 
 
 # ------------------------------------------------------------------ prologue

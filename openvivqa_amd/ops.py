@@ -160,14 +160,16 @@ class WgradQueue:
         self._cache = None
         self._event = None
 
-    def add(self, dy, x, dw, accumulate):
+    def add(self, dy, x, dw, accumulate, db=None, accumulate_db=False):
         lddy, M = _rows(dy)
         ldx, Mx = _rows(x)
         assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous()
         if any(it[2].data_ptr() == dw.data_ptr() for it in self.items):
             # the same weight used twice in one backward pass: its two contributions must be ordered
             self.flush()
-        self.items.append((dy, x, dw, lddy, ldx, M, dy.shape[-1], x.shape[-1], int(bool(accumulate))))
+        assert db is None or (db.dtype == torch.float32 and db.numel() == dy.shape[-1])
+        flags = int(bool(accumulate)) | (int(bool(accumulate_db)) << 1)
+        self.items.append((dy, x, dw, lddy, ldx, M, dy.shape[-1], x.shape[-1], flags, db))
 
     def flush(self):
         if not self.items:
@@ -177,8 +179,8 @@ class WgradQueue:
         dev = items[0][0].device
         probs = (_lib.WgradProblem * len(items))()
         tiles = []
-        for i, (dy, x, dw, lddy, ldx, M, N, K, acc) in enumerate(items):
-            probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), lddy, ldx, M, N, K, acc)
+        for i, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
+            probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), _p(db), lddy, ldx, M, N, K, acc)
             tn, tk = (N + self.TILE - 1) // self.TILE, (K + self.TILE - 1) // self.TILE
             tiles.extend((M, i, c, r) for c in range(tn) for r in range(tk))
         tiles.sort(key=lambda t: -t[0])  # longest reductions first

@@ -77,13 +77,13 @@ class WgradQueue:
     def __init__(self):
         self.items = []
 
-    def add(self, dy, x, dw, accumulate):
-        self.items.append((dy, x, dw, accumulate))
+    def add(self, dy, x, dw, accumulate, db=None, accumulate_db=False):
+        self.items.append((dy, x, dw, accumulate, db, accumulate_db))
 
     def flush(self):
         items, self.items = self.items, []
-        for dy, x, dw, acc in items:
-            linear_bwd_weight(dy, x, dw, None, accumulate=acc)
+        for dy, x, dw, acc, db, acc_b in items:
+            linear_bwd_weight(dy, x, dw, db, accumulate=acc, accumulate_db=acc_b)
 
 
 def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, accumulate_db=None):

@@ -116,18 +116,20 @@ def test_grouped_wgrad_and_bias_grad():
     for i, (M, N, K) in enumerate(specs):
         dy, x = rnd(M, N, dtype=BF16, scale=M ** -0.5, seed=i), rnd(M, K, dtype=BF16, seed=10 + i)
         dw = torch.full((N, K), 3.0, device=DEV)
+        dbq = torch.full((N,), 5.0, device=DEV)
         acc = i % 2 == 1
-        q.add(dy, x, dw, acc)
-        refs.append(dy.double().t() @ x.double() + (3.0 if acc else 0.0))
-        outs.append(dw)
+        q.add(dy, x, dw, acc, dbq, not acc)
+        refs.append((dy.double().t() @ x.double() + (3.0 if acc else 0.0), dy.double().sum(0) + (0.0 if acc else 5.0)))
+        outs.append((dw, dbq))
         db = torch.full((N,), 2.0, device=DEV)
         o.bias_grad(dy, db)
         assert nerr(db, dy.double().sum(0)) < 1e-2
         o.bias_grad(dy, db, accumulate=True)
         assert nerr(db, 2 * dy.double().sum(0)) < 2e-2
     q.flush()
-    for (M, N, K), dw, ref in zip(specs, outs, refs):
+    for (M, N, K), (dw, dbq), (ref, refb) in zip(specs, outs, refs):
         assert nerr(dw, ref) < 1e-2, (M, N, K, nerr(dw, ref))
+        assert nerr(dbq, refb) < 1e-2, (M, N, K, "bias", nerr(dbq, refb))
     assert not q.items
 
 
