@@ -23,6 +23,8 @@
 //     MFMAs of tile t and written after them; one barrier per K-tile.  Loads are unconditional
 //     (clamped addresses + zero select), fully unrolled: everything stays in VGPRs.
 //   * blockIdx is remapped so that the workgroups sharing a Q row-panel run on the same XCD.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -196,6 +198,148 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
   }
 }
 
+
+// ---- direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write -------------------
+// One wave-instruction writes 1 KiB linearly (LDS base is wave-uniform, lane l lands at +16 l), so the LDS
+// image stays linear and the XOR swizzle is applied to the per-lane SOURCE address (same involution as
+// the swizzled fragment reads).  Requires full K tiles (K % 64 == 0); rows are clamped per lane.
+// NW = 4 or 8 waves per 128x128 tile: with 8 waves (4 along c x 2 along r, 32x64 each) every wave issues half
+// the loads and half the MFMAs, so inside ONE workgroup a wave's load-issue bubble (~100 cycles per
+// LDS-DMA instruction) is covered by its SIMD partner's MFMAs -- what matters when the grid is too small
+// to put two workgroups on a CU (most launches of this model: M = 1280 or N = 512).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <bool KMAJOR, int NW>
+__device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ Op, int64_t ld, int row0, int rows,
+                                           int k0, int lane, int wave) {
+  constexpr int PER = 16 / NW;  // 1 KiB chunks of the 16 KiB tile per wave
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int ci = wave * PER + i;
+    const bf16* src;
+    if (!KMAJOR) {
+      const int row = ci * 8 + (lane >> 3), pos = lane & 7;
+      int grow = row0 + row;
+      grow = grow < rows ? grow : rows - 1;
+      src = Op + (int64_t)grow * ld + k0 + ((pos ^ (row & 7)) << 3);
+    } else {
+      const int krow = ci * 4 + (lane >> 4), pos = lane & 15;
+      const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int c = ((((pos >> 1) ^ f) << 1) | (pos & 1));
+      int col = row0 + c * 8;
+      col = col <= rows - 8 ? col : rows - 8;
+      src = Op + (int64_t)(k0 + krow) * ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + ci * 1024), 16, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 4 || N == 8 || N == 16, "unsupported count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW>
+__device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
+  constexpr int NI = 16 / NW;        // c sub-tiles (16 wide) per wave: 4 (NW=4) or 2 (NW=8)
+  constexpr int WSPAN = NI * 16;     // c extent per wave
+  constexpr int LOADS = 2 * (16 / NW);  // LDS-DMA instructions per wave per K tile (both operands)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wr = wave & 1;
+
+  f32x4 acc[4][NI];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool do_colsum = false;
+  if constexpr (COLSUM) do_colsum = r0 == 0 && wr == 0 && epi.wants_colsum();
+  f32x4 cs[NI];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < NI; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
+
+  const int nkt = g.K / BK;
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt % NBUF) * 2 * TILE_BYTES;
+    stage_glds<P_KMAJOR, NW>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
+    stage_glds<Q_KMAJOR, NW>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+  };
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nkt) issue(p);
+
+  for (int kt = 0; kt < nkt; kt++) {
+    // tile kt has landed (all but the youngest NBUF-2 tiles' loads are done), and -- after the barrier --
+    // every wave has finished reading the buffer that the next issue overwrites
+    if (NBUF == 2 || kt + NBUF - 2 >= nkt) wait_vmcnt<0>();
+    else wait_vmcnt<LOADS * (NBUF - 2)>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
+    const char* Ps = smem + (kt % NBUF) * 2 * TILE_BYTES;
+    const char* Qs = Ps + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 pf[4], qf[NI];
+#pragma unroll
+      for (int j = 0; j < 4; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < NI; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * WSPAN + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+      if constexpr (COLSUM) {
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < NI; i++) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, qf[i], cs[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if constexpr (COLSUM) {
+    if (do_colsum && lane < 16) {
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const int c = c0 + wc * WSPAN + i * 16 + lane;
+        if (c < g.C) epi.colsum(c, cs[i][0]);
+      }
+    }
+  }
+  epi.init();
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int c = c0 + wc * WSPAN + i * 16 + (lane & 15);
+    if (c >= g.C) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int r = r0 + wr * 64 + j * 16 + (lane >> 4) * 4;
+      if (r < g.R) epi(c, r, acc[j][i]);
+    }
+  }
+}
+
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nwg = g.tiles_r * g.tiles_c;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW>(g, tc * BT, tr * BT, epi, smem);
+}
+
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
@@ -307,13 +451,53 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWg
   gemm_tile<true, true, MEpiWgrad, true>(g, tc * BT, tr * BT, epi, smem);
 }
 
+inline int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_VARIANT");
+    v = e ? atoi(e) : 12;
+  }
+  return v;
+}
+
+template <typename K>
+inline int set_max_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      ovqa_set_error("hipFuncSetAttribute(%zu): %s", bytes, hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+  }
+  return OVQA_OK;
+}
+
+// variant 0: register-staged (any K % 8 == 0); NBUF = variant % 10 in {2,3}: direct-to-LDS ring (K % 64 == 0);
+// variant >= 10: 8 waves per tile instead of 4.
 template <bool PK, bool QK, typename Epi>
 int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, int64_t C, int64_t K, Epi epi,
            hipStream_t st, const char* what) {
   GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
              (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
-  const size_t lds = 4 * TILE_BYTES;  // 64 KiB
-  hipLaunchKernelGGL((gemm_bf16_kernel<PK, QK, Epi>), dim3(g.tiles_r * g.tiles_c), dim3(256), lds, st, g, epi);
+  const dim3 grid(g.tiles_r * g.tiles_c);
+  const int variant = (K % BK == 0) ? gemm_variant() : 0;
+#define OVQA_GLDS(NBUF, NW)                                                                                   \
+  {                                                                                                           \
+    const size_t lds = (size_t)NBUF * 2 * TILE_BYTES;                                                         \
+    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW>, lds);                                  \
+    if (rc != OVQA_OK) return rc;                                                                             \
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW>), grid, dim3(NW * 64), lds, st, g, epi); \
+  }
+  switch (variant) {
+    case 2: OVQA_GLDS(2, 4) break;
+    case 3: OVQA_GLDS(3, 4) break;
+    case 12: OVQA_GLDS(2, 8) break;
+    case 13: OVQA_GLDS(3, 8) break;
+    default:
+      hipLaunchKernelGGL((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
+  }
+#undef OVQA_GLDS
   return ovqa_check_launch(what);
 }
 
