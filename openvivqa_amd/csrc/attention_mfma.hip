@@ -25,15 +25,48 @@ __device__ __forceinline__ int xs(int row) { return ((row >> 2) & 3) | (((row >>
 // byte offset of 16-byte chunk `ch` (0..7) of row `row` in a [rows][64 bf16] image
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 128 + ((ch ^ xs(row)) << 4); }
 
-// cooperative load of `rows` x 64 bf16 (row stride ld) into an image of `rows_pad` rows, zero padded
-__device__ __forceinline__ void load_image(char* img, const bf16* __restrict__ src, int64_t ld, int rows, int rows_pad,
-                                           int tid, int nthreads) {
-  for (int e = tid; e < rows_pad * 8; e += nthreads) {
-    const int row = e >> 3, ch = e & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + ch * 8);
-    *reinterpret_cast<uint4*>(img + img_off(row, ch)) = v;
+// One [rows_pad][64] bf16 LDS image to fill from `rows` rows of global memory (row stride ld), zero padded.
+struct ImgDesc {
+  char* img;
+  const bf16* src;
+  int64_t ld;
+  int rows, rows_pad;
+};
+
+// Cooperative staging of N images.  All 16-byte loads of a pass (up to 4 per image per thread) are issued
+// before the first LDS store: the staging phase is pure latency (a (b,h) problem is only 10-60 KB), so the
+// number of loads in flight is what matters.
+template <int N>
+__device__ __forceinline__ void load_images(const ImgDesc (&d)[N], int tid) {
+  int maxtot = 0;
+#pragma unroll
+  for (int n = 0; n < N; n++) maxtot = max(maxtot, d[n].rows_pad * 8);
+  for (int e0 = tid; e0 < maxtot; e0 += 4 * 256) {
+    uint4 v[N][4];
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * 256;
+        const int row = e >> 3, ch = e & 7;
+        v[n][u] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < d[n].rows_pad * 8 && row < d[n].rows)
+          v[n][u] = *reinterpret_cast<const uint4*>(d[n].src + (int64_t)row * d[n].ld + ch * 8);
+      }
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + u * 256;
+        if (e < d[n].rows_pad * 8) *reinterpret_cast<uint4*>(d[n].img + img_off(e >> 3, e & 7)) = v[n][u];
+      }
   }
+}
+
+// key-padding masks (msq == 0: one fp32 row per (b,h)) are staged in LDS once per problem; keys beyond nk
+// get -inf so the bound check folds into the same add.  Other mask shapes are read from global memory.
+__device__ __forceinline__ void load_mask_row(float* dst, const float* mask, int nk, int nk_pad, int tid) {
+  for (int j = tid; j < nk_pad; j += 256) dst[j] = j < nk ? (mask ? mask[j] : 0.f) : -INFINITY;
 }
 
 // k-contiguous 32-row operand fragment (A or B of 32x32x16): lane -> row base+(lane&31), k = 16*ks + 8*(lane>>5) + j
@@ -64,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = 32 * W;                         // query rows staged per problem
-  const int prob_bytes = (q_rows + 2 * NKT * 32) * 128;
+  const int prob_bytes = (q_rows + 2 * NKT * 32) * 128 + NKT * 32 * 4;  // Q | K | V | mask row
   const int slot = wave / W, tq = wave % W;
   const int q_blk0 = blockIdx.y * q_rows;
 
@@ -74,13 +107,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
     if (pid >= (int64_t)a.B * a.H) break;
     const int b = (int)(pid / a.H), h = (int)(pid % a.H);
     char* base = smem + g * prob_bytes;
-    const bf16* q = (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64;
-    const bf16* k = (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64;
-    const bf16* v = (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64;
     const int qr = min(q_rows, nq - q_blk0);
-    load_image(base, q, a.ldq, qr, q_rows, tid, 256);
-    load_image(base + q_rows * 128, k, a.ldk, nk, NKT * 32, tid, 256);
-    load_image(base + (q_rows + NKT * 32) * 128, v, a.ldv, nk, NKT * 32, tid, 256);
+    const ImgDesc d[3] = {
+        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows},
+        {base + q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, NKT * 32},
+        {base + (q_rows + NKT * 32) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, NKT * 32}};
+    load_images<3>(d, tid);
+    if (a.msq == 0)
+      load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * 128),
+                    a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, NKT * 32, tid);
   }
   __syncthreads();
 
@@ -92,6 +127,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   const char* Qs = smem + slot * prob_bytes;
   const char* Ks = Qs + q_rows * 128;
   const char* Vs = Ks + NKT * 32 * 128;
+  const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * 128);
+  const bool row_mask = a.msq == 0;
 
   // ---- S^T = K Q^T  (rows = keys, columns = this wave's 32 queries)
   bf16x8 qf[4];
@@ -117,8 +154,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int key = t * 32 + acc_row(r, lane);
-      float s = -INFINITY;
-      if (key < nk) s = st[t][r] * a.scale + (mrow ? mrow[key] : 0.f);
+      float s;
+      if (row_mask) {
+        s = st[t][r] * a.scale + mlds[key];
+      } else {
+        s = -INFINITY;
+        if (key < nk) s = st[t][r] * a.scale + (mrow ? mrow[key] : 0.f);
+      }
       st[t][r] = s;
       mx = fmaxf(mx, s);
     }
@@ -186,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = 32 * W, k_rows = nkt * 32;
-  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128;  // Q | dO | K | V
+  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128 + k_rows * 4;  // Q | dO | K | V | mask row
   const int slot = wave / W, tq = wave % W;
   const int q_blk0 = blockIdx.y * q_rows;
 
@@ -196,12 +238,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
     const int b = (int)(pid / a.H), h = (int)(pid % a.H);
     char* base = smem + g * prob_bytes;
     const int qr = min(q_rows, nq - q_blk0);
-    load_image(base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows, tid, 256);
-    load_image(base + q_rows * 128, (const bf16*)a.d_o + ((int64_t)b * nq + q_blk0) * a.lddo + h * 64, a.lddo, qr,
-               q_rows, tid, 256);
-    load_image(base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows, tid, 256);
-    load_image(base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk,
-               k_rows, tid, 256);
+    const ImgDesc d[4] = {
+        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows},
+        {base + q_rows * 128, (const bf16*)a.d_o + ((int64_t)b * nq + q_blk0) * a.lddo + h * 64, a.lddo, qr, q_rows},
+        {base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
+        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
+    load_images<4>(d, tid);
+    if (a.msq == 0)
+      load_mask_row(reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * 128),
+                    a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
   }
   __syncthreads();
 
@@ -214,6 +259,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   const char* Gs = Qs + q_rows * 128;
   const char* Ks = Gs + q_rows * 128;
   const char* Vs = Ks + k_rows * 128;
+  const float* mlds = reinterpret_cast<const float*>(Vs + k_rows * 128);
+  const bool row_mask = a.msq == 0;
 
   const int q = q0 + (lane & 31);
   const bool qok = q < nq;
@@ -262,8 +309,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int key = t * 32 + acc_row(r, lane);
-      float p = 0.f;
-      if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+      float p;
+      if (row_mask) {
+        p = exp2f((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
+      } else {
+        p = 0.f;
+        if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+      }
       ds[r] = p * (dp[r] - delta);
     }
 #pragma unroll
@@ -308,12 +360,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
     const int b = (int)(pid / a.H), h = (int)(pid % a.H);
     char* base = smem + g * prob_bytes;
     const int kr = min(k_rows, nk - k_blk0);
-    load_image(base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows, tid, 256);
-    load_image(base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows, tid, 256);
-    load_image(base + 2 * q_rows * 128, (const bf16*)a.k + ((int64_t)b * nk + k_blk0) * a.ldk + h * 64, a.ldk, kr,
-               k_rows, tid, 256);
-    load_image(base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + ((int64_t)b * nk + k_blk0) * a.ldv + h * 64, a.ldv,
-               kr, k_rows, tid, 256);
+    const ImgDesc d[4] = {
+        {base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
+        {base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
+        {base + 2 * q_rows * 128, (const bf16*)a.k + ((int64_t)b * nk + k_blk0) * a.ldk + h * 64, a.ldk, kr, k_rows},
+        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + ((int64_t)b * nk + k_blk0) * a.ldv + h * 64, a.ldv, kr,
+         k_rows}};
+    load_images<4>(d, tid);
     float* ls = reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * 128);
     for (int i = tid; i < q_rows; i += 256) {
       ls[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
@@ -336,6 +389,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
   const int key = k0 + (lane & 31);
   const bool kok = key < nk;
   const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
+  const bool row_mask = a.msq == 0;  // key-padding mask: one value per key column, i.e. per lane
+  const float mconst = (row_mask && mcol) ? mcol[0] : 0.f;
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -363,8 +418,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
     for (int r = 0; r < 16; r++) {
       const int qi = t * 32 + acc_row(r, lane);
       float pv = 0.f;
-      if (qi < nq && kok)
-        pv = exp2f((s_[r] * a.scale + (mcol ? mcol[(int64_t)qi * a.msq] : 0.f) - ls[qi]) * LOG2E);
+      if (qi < nq && kok) {
+        const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)qi * a.msq] : 0.f);
+        pv = exp2f((s_[r] * a.scale + mv - ls[qi]) * LOG2E);
+      }
       p[r] = pv;
       ds[r] = pv * (dp[r] - ls[q_rows + qi]);
     }
@@ -429,7 +486,7 @@ int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
   int W = (a.nq + 31) / 32;
   if (W > 4) W = 4;
   if (W == 3) W = 4;
-  const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * 128;
+  const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * 128 + NKT * 32 * 4;
   const int G = pack_factor(W, prob);
   const size_t lds = (size_t)G * prob;
   int rc = ensure_lds(attn_fwd_mfma_kernel<NKT>, lds, "attention_fwd(mfma)");
@@ -447,7 +504,7 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     if (W > 4) W = 4;
     if (W == 3) W = 4;
     const int nkt = (a.nk + 31) / 32;
-    const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * 128;
+    const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * 128 + nkt * 32 * 4;
     const int G = pack_factor(W, prob);
     const size_t lds = (size_t)G * prob;
     int rc = ensure_lds(attn_bwd_dq_mfma_kernel, lds, "attention_bwd(mfma,dq)");

@@ -241,7 +241,7 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
                  const DropArgs& da, void* ws, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
   int nblocks = (int)((M + 3) / 4);
-  if (nblocks > 256) nblocks = 256;
+  if (nblocks > 1024) nblocks = 1024;
   OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
   float* partial = (float*)ws;
   const size_t smem = (size_t)3 * 2 * D * sizeof(float);
@@ -265,9 +265,10 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
       return OVQA_ERR_LAUNCH;
     }
   }
-  const int groups = (nblocks + 15) / 16;
+  const int rows_per_group = 64;
+  const int groups = (nblocks + rows_per_group - 1) / rows_per_group;
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64), groups), dim3(256), 0, st, partial,
-                     nblocks, (int)D, dgamma, dbeta, 16);
+                     nblocks, (int)D, dgamma, dbeta, rows_per_group);
   return ovqa_check_launch("layernorm_bwd_reduce");
 }
 
