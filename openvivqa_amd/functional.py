@@ -37,7 +37,15 @@ _wgrad_queue = None
 
 def _flush_wgrads():
     if _wgrad_queue is not None:
-        _wgrad_queue.flush()
+        _wgrad_queue.finish()
+
+
+def wgrad_queue():
+    """The process-wide deferred weight-gradient queue (created on first use)."""
+    global _wgrad_queue
+    if _wgrad_queue is None:
+        _wgrad_queue = ops.WgradQueue()
+    return _wgrad_queue
 
 
 def _wgrad(arena, dy, x, w_params, b_params):
@@ -55,11 +63,10 @@ def _wgrad(arena, dy, x, w_params, b_params):
     if not defer:
         ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc_w, accumulate_db=acc_b)
         return
-    if _wgrad_queue is None:
-        _wgrad_queue = ops.WgradQueue()
-    if not _wgrad_queue.items:
+    q = wgrad_queue()
+    if not q.items and not q.inflight:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-    _wgrad_queue.add(dy, x, gw, acc_w, gb, acc_b)  # bias gradient = fused column sums of dy
+    q.add(dy, x, gw, acc_w, gb, acc_b)  # bias gradient = fused column sums of dy
 
 
 # ------------------------------------------------------------------ prologue

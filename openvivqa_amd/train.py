@@ -162,6 +162,8 @@ class TrainStep:
             self._discover_foreign()
             for _ in range(2):  # warm-up: allocator pools, lazy arenas, workspace
                 self._fwd_bwd()
+            from . import functional as _fn
+            _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW launches of the capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.use_graph:

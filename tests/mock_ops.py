@@ -76,6 +76,13 @@ def bias_grad(dy, db, accumulate=False):
 class WgradQueue:
     def __init__(self):
         self.items = []
+        self.inflight = []
+
+    def finish(self):
+        self.flush()
+
+    def reserve(self, n):
+        pass
 
     def add(self, dy, x, dw, accumulate, db=None, accumulate_db=False):
         self.items.append((dy, x, dw, accumulate, db, accumulate_db))

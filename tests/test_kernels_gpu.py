@@ -126,11 +126,12 @@ def test_grouped_wgrad_and_bias_grad():
         assert nerr(db, dy.double().sum(0)) < 1e-2
         o.bias_grad(dy, db, accumulate=True)
         assert nerr(db, 2 * dy.double().sum(0)) < 2e-2
-    q.flush()
+    q.finish()
+    torch.cuda.synchronize()
     for (M, N, K), (dw, dbq), (ref, refb) in zip(specs, outs, refs):
         assert nerr(dw, ref) < 1e-2, (M, N, K, nerr(dw, ref))
         assert nerr(dbq, refb) < 1e-2, (M, N, K, "bias", nerr(dbq, refb))
-    assert not q.items
+    assert not q.items and not q.inflight
 
 
 def ln_ref(x, g, b, eps=1e-5):
