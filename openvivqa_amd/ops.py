@@ -162,7 +162,7 @@ class WgradQueue:
     chain.  The default therefore defers everything to the end (OVQA_WGRAD_FLUSH_TILES overrides)."""
 
     TILE = 128
-    FLUSH_TILES = int(__import__("os").environ.get("OVQA_WGRAD_FLUSH_TILES", "1300"))
+    FLUSH_TILES = int(__import__("os").environ.get("OVQA_WGRAD_FLUSH_TILES", str(1 << 30)))
 
     def __init__(self):
         self.items = []
