@@ -45,14 +45,17 @@ def parse():
 
 
 def gemm_launch_list(B, NV, NT, D, DFF, L):
-    """(M, N, K, epilogue) of every forward GEMM launch of one step, grouped by kernel family."""
+    """(M, N, K[, flag]) of every MFMA GEMM launch of one step, grouped by kernel family.
+    Forward families: y[M,N] = x[M,K] w[N,K]^T (+epilogue).  dX family: dx[M,K] = dy[M,N] w[N,K] with
+    flag 'g' (fused dropout*GELU' epilogue, FFN seam), 'a' (residual-branch addend) or ''."""
     mv, mt = B * NV, B * NT
-    bias, gelu, resid = [], [], []
+    bias, gelu, resid, dx = [], [], [], []
     for _ in range(L):  # text EncoderLayer
         bias.append((mt, 3 * D, D))
         resid.append((mt, D, D))
         gelu.append((mt, DFF, D))
         resid.append((mt, D, DFF))
+        dx += [(mt, D, DFF, "g"), (mt, DFF, D, "a"), (mt, D, D, ""), (mt, 3 * D, D, "a")]
     for _ in range(L):  # GuidedEncoderLayer
         bias.append((mv, 3 * D, D))
         resid.append((mv, D, D))
@@ -61,32 +64,60 @@ def gemm_launch_list(B, NV, NT, D, DFF, L):
         resid.append((mv, D, D))
         gelu.append((mv, DFF, D))
         resid.append((mv, D, DFF))
-    return {"bias": bias, "gelu": gelu, "residual": resid}
+        dx += [(mv, D, DFF, "g"), (mv, DFF, D, "a"), (mv, D, D, ""), (mv, D, D, "a"), (mt, 2 * D, D, ""),
+               (mv, D, D, ""), (mv, 3 * D, D, "a")]
+    return {"bias": bias, "gelu": gelu, "residual": resid, "dx": dx}
+
+
+KERNEL_OF_FAMILY = {
+    "bias": "gemm_bf16_glds_kernel<false, false, MEpiBias,",
+    "gelu": "gemm_bf16_glds_kernel<false, false, MEpiBiasGelu,",
+    "residual": "gemm_bf16_glds_kernel<false, false, MEpiBiasResidual,",
+    "dx": "gemm_bf16_glds_kernel<true, false, MEpiBwdData,",
+}
+
+
+def pmc_traffic(kernel_prefix):
+    """Per-launch HBM bytes of a kernel from the committed PMC pass (profiles/r01_traffic.json, produced by
+    scripts/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950, KB -> bytes)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    key = kernel_prefix.replace("(anonymous namespace)::", "")
+    for name, v in json.load(open(path)).items():
+        if key in name.replace("(anonymous namespace)::", ""):
+            return round(v["hbm_bytes_per_launch"])
+    return None
 
 
 def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
-    """Time the dominant kernel family (forward MFMA GEMM with fused epilogue) over exactly the
-    launch list of one step, with HIP events on the launch stream."""
+    """Time every MFMA GEMM kernel family over exactly the launch list of one step (hipGraph replay of the
+    list, HIP events on the replay stream) and report the one that takes the most time per step."""
     from openvivqa_amd import ops
     fam = gemm_launch_list(B, NV, NT, D, DFF, L)
     results = {}
     for name, shapes in fam.items():
-        epi = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "residual": ops.EPI_BIAS_RESIDUAL}[name]
         bufs = {}
-        for (M, N, K) in set(shapes):
-            x = torch.randn(M, K, device=device).bfloat16()
-            w = (torch.randn(N, K, device=device) * K ** -0.5).bfloat16()
-            b = torch.randn(N, device=device)
-            r = torch.randn(M, N, device=device).bfloat16()
-            y = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-            u = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-            bufs[(M, N, K)] = (x, w, b, r, y, u)
+        for sh in set(shapes):
+            M, N, K = sh[:3]
+            bufs[sh] = dict(x=torch.randn(M, K, device=device).bfloat16(),
+                            w=(torch.randn(N, K, device=device) * K ** -0.5).bfloat16(),
+                            b=torch.randn(N, device=device), r=torch.randn(M, N, device=device).bfloat16(),
+                            y=torch.empty(M, N, device=device, dtype=torch.bfloat16),
+                            u=torch.empty(M, N, device=device, dtype=torch.bfloat16),
+                            dx=torch.empty(M, K, device=device, dtype=torch.bfloat16),
+                            pre=torch.randn(M, K, device=device).bfloat16())
 
         def run_all():
-            for s in shapes:
-                x, w, b, r, y, u = bufs[s]
-                ops.linear_fwd(x, w, b, epi, residual=r if name == "residual" else None, out=y,
-                               preact_out=u if name == "gelu" else None)
+            for sh in shapes:
+                t = bufs[sh]
+                if name == "dx":
+                    ops.linear_bwd_data(t["r"], t["w"], preact=t["pre"] if sh[3] == "g" else None, out=t["dx"],
+                                        addend=t["x"] if sh[3] == "a" else None)
+                else:
+                    epi = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "residual": ops.EPI_BIAS_RESIDUAL}[name]
+                    ops.linear_fwd(t["x"], t["w"], t["b"], epi, residual=t["r"] if name == "residual" else None,
+                                   out=t["y"], preact_out=t["u"] if name == "gelu" else None)
         # replay the launch list from a hipGraph so that host launch latency is not what is timed
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -107,7 +138,7 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
         e1.record(st)
         torch.cuda.synchronize()
         total_s = e0.elapsed_time(e1) * 1e-3 / reps
-        flops = sum(2.0 * M * N * K for (M, N, K) in shapes)
+        flops = sum(2.0 * sh[0] * sh[1] * sh[2] for sh in shapes)
         results[name] = dict(launches=len(shapes), time_s=total_s, flops=flops,
                              avg_launch_us=total_s / len(shapes) * 1e6)
     dom = max(results, key=lambda k: results[k]["time_s"])
@@ -115,9 +146,10 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
     achieved = r["flops"] / r["time_s"] / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
-        "kernel": f"gemm_nt_bf16_kernel<{dom}>", "launches_per_step": r["launches"],
+        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic(KERNEL_OF_FAMILY[dom]),
+        "kernel": KERNEL_OF_FAMILY[dom] + " 2, 8>", "launches_per_step": r["launches"],
         "avg_launch_us": round(r["avg_launch_us"], 2),
+        "algorithmic_flops_per_launch": round(r["flops"] / r["launches"]),
         "families": {k: {"avg_launch_us": round(v["avg_launch_us"], 2),
                          "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in results.items()},
     }

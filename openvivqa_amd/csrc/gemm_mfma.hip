@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
                                                                       const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int4 t = tiles[blockIdx.x];
+  if (t.x < 0) return;  // padding entry (keeps the host's blockIdx % 8 -> XCD grouping aligned)
   const ovqa_wgrad_problem pr = probs[t.x];
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};

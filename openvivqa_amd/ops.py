@@ -203,13 +203,26 @@ class WgradQueue:
         items, self.items, self.ntiles = self.items, [], 0
         dev = items[0][0].device
         probs = (_lib.WgradProblem * len(items))()
-        tiles = []
+        per_problem = []
         for i, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
             probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), _p(db), lddy, ldx, M, N, K, acc)
             tn, tk = (N + self.TILE - 1) // self.TILE, (K + self.TILE - 1) // self.TILE
-            tiles.extend((M, i, c, r) for c in range(tn) for r in range(tk))
-        tiles.sort(key=lambda t: -t[0])  # longest reductions first
-        tile_arr = np.array([(i, c, r, 0) for (_, i, c, r) in tiles], dtype=np.int32)
+            per_problem.append((M * tn * tk, M, [(i, c, r, 0) for c in range(tn) for r in range(tk)]))
+        # XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD
+        # group), each XCD has a private L2, and all tiles of one problem stream the same dY / X panels.
+        # Whole problems are therefore binned per XCD (longest-processing-time first) and the bins are
+        # interleaved; without this every XCD fetches every panel (measured: 2.9 GB of L2 misses per launch).
+        bins = [[0, []] for _ in range(8)]
+        for work, M, tl in sorted(per_problem, key=lambda t: (-t[1], -t[0])):
+            b = min(bins, key=lambda bb: bb[0])
+            b[0] += work
+            b[1].extend(tl)
+        depth = max(len(b[1]) for b in bins)
+        tile_arr = np.full((depth * 8, 4), -1, dtype=np.int32)  # -1 = padding entry (kernel returns)
+        for xcd, b in enumerate(bins):
+            if b[1]:
+                tile_arr[xcd:xcd + 8 * len(b[1]):8] = np.array(b[1], dtype=np.int32)
+        tiles = tile_arr
         prob_bytes = np.frombuffer(bytes(probs), dtype=np.uint8)
         pad = (-prob_bytes.size) % 16  # keep the int4 tile table 16-byte aligned
         if pad:
