@@ -97,12 +97,16 @@ class MultiHeadAttention(Module):
         queries = queries.to(T)
         keys = queries if same_all else keys.to(T)
         values = keys if same_kv else values.to(T)
-        if self.can_be_stateful and self._is_stateful:  # attentions.py:320-325
+        mask = _as_mask(attention_mask)
+        if self.can_be_stateful and self._is_stateful:
+            if (type(self.attention) is ScaledDotProductAttention and not torch.is_grad_enabled()
+                    and self.attention.h * self.attention.d_k == self.attention.h * self.attention.d_v == keys.shape[-1]):
+                return self._stateful_step(arena, queries, keys, values, mask)
+            # reference behaviour (attentions.py:320-325): cache the raw inputs, re-project the whole prefix
             self.running_keys = torch.cat([self.running_keys.to(T), keys], 1)
             keys = self.running_keys
             self.running_values = torch.cat([self.running_values.to(T), values], 1)
             values = self.running_values
-        mask = _as_mask(attention_mask)
         if type(self.attention) is ScaledDotProductAttention:
             params = list(self.attention.parameters()) + list(self.layer_norm.parameters())
             st = dict(arena=arena, att=self.attention, ln=self.layer_norm, params=params,
@@ -111,9 +115,35 @@ class MultiHeadAttention(Module):
         else:  # other registered attention kernels: unfused composition
             out, _ = self.attention(queries, keys, values, mask, **kwargs)
             out = Fn.prologue(queries + self.dropout(out.to(T)), self.layer_norm, None, arena, T)
+        return self._aoa(arena, queries, out)
+
+    def _aoa(self, arena, queries, out):
         if self.use_aoa:  # attentions.py:333-337
             z = torch.cat([queries, out], dim=-1)
             i = Fn.linear(z, self.informative_attention, arena)
             g = Fn.linear(z, self.gated_attention, arena)
             out = i * torch.sigmoid(g)
         return out
+
+    def _stateful_step(self, arena, queries, keys, values, mask):
+        """Autoregressive decode step with a PROJECTED K/V cache.
+
+        The reference appends the raw d_model inputs to ``running_keys/values`` and re-applies fc_k / fc_v to
+        the whole prefix at every step (attentions.py:320-325: O(T^2) projections per sequence).  Here only
+        the new positions are projected and the projections are what the state buffers hold -- same buffer
+        names, same (B, t, H*d) shape (so beam search's ``apply_to_states`` reorder works unchanged), same
+        outputs."""
+        from .. import ops
+        from .._lib import EPI_BIAS_RESIDUAL
+        a, ln = self.attention, self.layer_norm
+        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
+        k_new = ops.linear_fwd(keys.contiguous(), arena.compute(a.fc_k.weight), arena.master_of(a.fc_k.bias))
+        v_new = ops.linear_fwd(values.contiguous(), arena.compute(a.fc_v.weight), arena.master_of(a.fc_v.bias))
+        self.running_keys = torch.cat([self.running_keys.to(q.dtype), k_new], 1)
+        self.running_values = torch.cat([self.running_values.to(q.dtype), v_new], 1)
+        o, _, _ = ops.attention_fwd(q, self.running_keys, self.running_values, mask, a.h, save_lse=False)
+        pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
+                             residual=queries.contiguous())
+        out, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps,
+                                      save_stats=False)
+        return self._aoa(arena, queries, out)

@@ -140,3 +140,61 @@ def test_sdpa_direct_with_differentiable_att(mode):
     v, l, vm, lm = _inputs(B=2)
     _compare("sdpa", mode, o, h, lambda m, i: m(i["x"], i["kv"], i["kv"], i["mask"]),
              {"x": v, "kv": l, "mask": lm}, ["x", "kv"])
+
+
+def test_decoder_config5_shapes(mode):
+    """BASELINE config 5 shapes: Decoder L=3, T=20 answer tokens, 237 encoder positions (197 ViT patches +
+    40 question tokens), d=512 -- teacher-forced forward + backward vs the oracle, then stateful greedy
+    stepping (projected K/V cache) vs the teacher-forced log-probs of the same prefix."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+
+    class Vocab:
+        max_answer_length, padding_idx, bos_idx, eos_idx = 20, 0, 1, 2
+
+        def __len__(self):
+            return 1000
+    cfg = ConfigNode(dict(
+        ARCHITECTURE="Decoder", D_MODEL=512, LAYERS=3,
+        ATTENTION=dict(SELF_ATTENTION=_cfg(can_be_stateful=True), ENC_ATTENTION=_cfg()),
+        TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=512, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                            WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+    torch.manual_seed(8)
+    o, h = O.OracleDecoder(cfg, Vocab()), M.Decoder(cfg, Vocab())
+    h.load_state_dict(o.state_dict(), strict=False)
+    o.eval()
+    h = h.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    toks = torch.randint(3, 1000, (4, 20), generator=g)
+    toks[:, 0] = 1
+    toks[1, 15:] = 0
+    toks[3, 9:] = 0
+    enc = torch.randn(4, 237, 512, generator=g)
+    enc[2, 200:] = 0
+    emask = O.padding_mask(enc, 0)
+    w = torch.randn(4, 20, 1000, generator=g)
+    eo = enc.clone().requires_grad_(True)
+    lo = o(toks, eo, emask)
+    (lo * w).sum().backward()
+    eh = enc.clone().to(DEV).requires_grad_(True)
+    lh = h(toks.to(DEV), eh, emask.to(DEV))
+    (lh * w.to(DEV)).sum().backward()
+    tol_f, tol_g = (1e-4, 5e-4) if mode == F32 else (2e-2, 3e-2)
+    assert rel_l2(lh, lo) < tol_f, rel_l2(lh, lo)
+    assert rel_l2(eh.grad, eo.grad) < tol_g, rel_l2(eh.grad, eo.grad)
+    go = dict(o.named_parameters())
+    for k, p in h.named_parameters():
+        if k.endswith("fc_k.bias") or go[k].grad is None or not p.requires_grad:
+            continue
+        assert rel_l2(p.grad, go[k].grad) < (tol_g if mode == F32 else 6e-2), (k, rel_l2(p.grad, go[k].grad))
+    # stateful decoding: feed the first 9 (non-padding) tokens one by one
+    with torch.no_grad():
+        with h.statefulness(4):
+            steps = [h(toks[:, t:t + 1].to(DEV), enc.to(DEV), emask.to(DEV)) for t in range(9)]
+            assert tuple(h.layers[0].self_attn.running_keys.shape) == (4, 9, 512)
+            # beam-search style reorder of every state buffer
+            perm = torch.tensor([2, 0, 3, 1], device=DEV)
+            h.apply_to_states(lambda s: s.index_select(0, perm) if s.shape[0] == 4 else s)
+            assert tuple(h.layers[0].self_attn.running_keys.shape) == (4, 9, 512)
+    assert rel_l2(torch.cat(steps, 1), lo[:, :9]) < (1e-4 if mode == F32 else 2e-2)
