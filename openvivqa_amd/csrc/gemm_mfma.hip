@@ -210,10 +210,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <bool KMAJOR, int NW>
+template <bool KMAJOR, int NW, int NCHUNK = 16>
 __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ Op, int64_t ld, int row0, int rows,
                                            int k0, int lane, int wave) {
-  constexpr int PER = 16 / NW;  // 1 KiB chunks of the 16 KiB tile per wave
+  static_assert(!KMAJOR || NCHUNK == 16, "k-major images are always 128 wide");
+  constexpr int PER = NCHUNK / NW;  // 1 KiB chunks of the tile per wave
 #pragma unroll
   for (int i = 0; i < PER; i++) {
     const int ci = wave * PER + i;
@@ -237,24 +238,33 @@ __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ 
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 4 || N == 8 || N == 16, "unsupported count");
+  static_assert(N == 0 || N == 3 || N == 4 || N == 8 || N == 16, "unsupported count");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW>
+// BC = rows of the c (Q) operand per tile: 128, or 64 for problems with few tiles (more workgroups, fewer
+// bytes per K-step and CU: the per-CU L2->LDS path, not the matrix pipe, bounds these kernels).
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128>
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
-  constexpr int NI = 16 / NW;        // c sub-tiles (16 wide) per wave: 4 (NW=4) or 2 (NW=8)
-  constexpr int WSPAN = NI * 16;     // c extent per wave
-  constexpr int LOADS = 2 * (16 / NW);  // LDS-DMA instructions per wave per K tile (both operands)
+  static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR), "unsupported tile");
+  constexpr int WC = NW == 8 ? (BC >= 64 ? 4 : BC / 16) : 2;  // wave grid: WC along c x WR along r
+  constexpr int WR = NW / WC;
+  constexpr int NI = BC / (16 * WC);   // 16-wide c sub-tiles per wave
+  constexpr int NJ = 128 / (16 * WR);  // 16-wide r sub-tiles per wave
+  constexpr int QCH = BC / 8;          // 1 KiB chunks of the Q tile
+  constexpr int QPER = (QCH + NW - 1) / NW;
+  constexpr int STAGE = TILE_BYTES + BC * BK * 2;  // bytes of one ring stage (P tile + Q tile)
+  constexpr int LOADS = 16 / NW + QPER;  // LDS-DMA instructions per (loading) wave per K tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave >> 1, wr = wave & 1;
+  const int wc = wave / WR, wr = wave % WR;
 
-  f32x4 acc[4][NI];
+  f32x4 acc[NJ][NI];
 #pragma unroll
-  for (int j = 0; j < 4; j++)
+  for (int j = 0; j < NJ; j++)
 #pragma unroll
     for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   bool do_colsum = false;
@@ -268,9 +278,13 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
 
   const int nkt = g.K / BK;
   auto issue = [&](int kt) {
-    char* buf = smem + (kt % NBUF) * 2 * TILE_BYTES;
+    char* buf = smem + (kt % NBUF) * STAGE;
     stage_glds<P_KMAJOR, NW>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
-    stage_glds<Q_KMAJOR, NW>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+    if constexpr (QCH >= NW) {
+      stage_glds<Q_KMAJOR, NW, QCH>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+    } else {  // fewer Q chunks than waves (BC = 32): the first QCH waves load one chunk each
+      if (wave < QCH) stage_glds<Q_KMAJOR, QCH, QCH>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+    }
   };
 #pragma unroll
   for (int p = 0; p < NBUF - 1; p++)
@@ -283,17 +297,17 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     else wait_vmcnt<LOADS * (NBUF - 2)>();
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
-    const char* Ps = smem + (kt % NBUF) * 2 * TILE_BYTES;
+    const char* Ps = smem + (kt % NBUF) * STAGE;
     const char* Qs = Ps + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      bf16x8 pf[4], qf[NI];
+      bf16x8 pf[NJ], qf[NI];
 #pragma unroll
-      for (int j = 0; j < 4; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * 64 + j * 16, ks, lane);
+      for (int j = 0; j < NJ; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * (NJ * 16) + j * 16, ks, lane);
 #pragma unroll
-      for (int i = 0; i < NI; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * WSPAN + i * 16, ks, lane);
+      for (int i = 0; i < NI; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * (NI * 16) + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int i = 0; i < NI; i++)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
@@ -309,7 +323,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     if (do_colsum && lane < 16) {
 #pragma unroll
       for (int i = 0; i < NI; i++) {
-        const int c = c0 + wc * WSPAN + i * 16 + lane;
+        const int c = c0 + wc * (NI * 16) + i * 16 + lane;
         if (c < g.C) epi.colsum(c, cs[i][0]);
       }
     }
@@ -317,17 +331,17 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   epi.init();
 #pragma unroll
   for (int i = 0; i < NI; i++) {
-    const int c = c0 + wc * WSPAN + i * 16 + (lane & 15);
+    const int c = c0 + wc * (NI * 16) + i * 16 + (lane & 15);
     if (c >= g.C) continue;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int r = r0 + wr * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < NJ; j++) {
+      const int r = r0 + wr * (NJ * 16) + j * 16 + (lane >> 4) * 4;
       if (r < g.R) epi(c, r, acc[j][i]);
     }
   }
 }
 
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW>
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = g.tiles_r * g.tiles_c;
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW>(g, tc * BT, tr * BT, epi, smem);
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC>(g, tc * BC, tr * BT, epi, smem);
 }
 
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
@@ -452,6 +466,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWg
   gemm_tile<true, true, MEpiWgrad, true>(g, tc * BT, tr * BT, epi, smem);
 }
 
+inline int small_tile_threshold() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_SMALL_TILES");
+    v = e ? atoi(e) : 320;
+  }
+  return v;
+}
+
+inline int tiny_tile_threshold() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_TINY_TILES");
+    v = e ? atoi(e) : 330;
+  }
+  return v;
+}
+
 inline int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -481,20 +513,34 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
            hipStream_t st, const char* what) {
   GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
              (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
-  const dim3 grid(g.tiles_r * g.tiles_c);
   const int variant = (K % BK == 0) ? gemm_variant() : 0;
-#define OVQA_GLDS(NBUF, NW)                                                                                   \
-  {                                                                                                           \
-    const size_t lds = (size_t)NBUF * 2 * TILE_BYTES;                                                         \
-    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW>, lds);                                  \
-    if (rc != OVQA_OK) return rc;                                                                             \
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW>), grid, dim3(NW * 64), lds, st, g, epi); \
+  // few 128x128 tiles (the M = 1280 question stack): halve the c tile -> twice the workgroups
+  const bool small_c = !QK && variant >= 10 && g.tiles_r * g.tiles_c <= small_tile_threshold();
+  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold();
+  if (small_c) g.tiles_c = (int)((C + (tiny_c ? 31 : 63)) / (tiny_c ? 32 : 64));
+  const dim3 grid(g.tiles_r * g.tiles_c);
+#define OVQA_GLDS(NBUF, NW, BCV)                                                                                   \
+  {                                                                                                                \
+    const size_t lds = (size_t)NBUF * (TILE_BYTES + BCV * BK * 2);                                                 \
+    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>, lds);                                  \
+    if (rc != OVQA_OK) return rc;                                                                                  \
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>), grid, dim3(NW * 64), lds, st, g, epi); \
+  }
+  if constexpr (!QK) {
+    if (tiny_c) {
+      OVQA_GLDS(2, 8, 32)
+      return ovqa_check_launch(what);
+    }
+    if (small_c) {
+      OVQA_GLDS(2, 8, 64)
+      return ovqa_check_launch(what);
+    }
   }
   switch (variant) {
-    case 2: OVQA_GLDS(2, 4) break;
-    case 3: OVQA_GLDS(3, 4) break;
-    case 12: OVQA_GLDS(2, 8) break;
-    case 13: OVQA_GLDS(3, 8) break;
+    case 2: OVQA_GLDS(2, 4, 128) break;
+    case 3: OVQA_GLDS(3, 4, 128) break;
+    case 12: OVQA_GLDS(2, 8, 128) break;
+    case 13: OVQA_GLDS(3, 8, 128) break;
     default:
       hipLaunchKernelGGL((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
   }
