@@ -84,10 +84,12 @@ def pmc_traffic(kernel_prefix):
     if not os.path.exists(path):
         return None
     key = kernel_prefix.replace("(anonymous namespace)::", "")
-    for name, v in json.load(open(path)).items():
+    tot_bytes, tot_n = 0.0, 0
+    for name, v in json.load(open(path)).items():  # a family = all tile-size instantiations of the kernel
         if key in name.replace("(anonymous namespace)::", ""):
-            return round(v["hbm_bytes_per_launch"])
-    return None
+            tot_bytes += v["hbm_bytes_per_launch"] * v["launches"]
+            tot_n += v["launches"]
+    return round(tot_bytes / tot_n) if tot_n else None
 
 
 def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
@@ -147,7 +149,7 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic(KERNEL_OF_FAMILY[dom]),
-        "kernel": KERNEL_OF_FAMILY[dom] + " 2, 8>", "launches_per_step": r["launches"],
+        "kernel": KERNEL_OF_FAMILY[dom] + " 2, 8, {128|64|32}>", "launches_per_step": r["launches"],
         "avg_launch_us": round(r["avg_launch_us"], 2),
         "algorithmic_flops_per_launch": round(r["flops"] / r["launches"]),
         "families": {k: {"avg_launch_us": round(v["avg_launch_us"], 2),
