@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--overlap-mb", type=float, default=32.0,
+                    help="N>1: release a gradient segment to the all-reduce stream every this many MB (fp32) of "
+                         "finished gradients during backward; 0 = one exchange after backward")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
+                         "single-rank group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
@@ -204,6 +210,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+    elif args.rehearse_comm:
+        import tempfile
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(), "rdv"),
+                                rank=0, world_size=1, device_id=device)
     else:
         dist = None
 
@@ -238,7 +249,8 @@ def main():
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,
-                   comm_dtype=comm, compute_dtype=dtype)
+                   comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
+                   force_comm=args.rehearse_comm)
     ts.loss = loss_buf
 
     for _ in range(args.warmup):
@@ -271,7 +283,8 @@ def main():
                        "dff=2048, 64 samples/GPU x (100 regions + 20 tokens), padded lengths, dropout 0.1, "
                        "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
                        "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
-                       "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if world > 1 else None},
+                       "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if (world > 1 or args.rehearse_comm) else None,
+                       "grad_segments": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
             "final_loss": round(final_loss, 6),
             "step_tflops": round(value * FLOPS_PER_SAMPLE_FWD_BWD / 1e12, 1),
             "step_frac_of_bf16_peak": round(value * FLOPS_PER_SAMPLE_FWD_BWD / world / PEAK_BF16, 4),

@@ -33,6 +33,7 @@ def _c(t: Optional[torch.Tensor]):
 
 
 _wgrad_queue = None
+wgrad_observer = None  # optional callable(grad_view): told about every weight-gradient product of a backward pass
 
 
 def _flush_wgrads():
@@ -58,6 +59,8 @@ def _wgrad(arena, dy, x, w_params, b_params):
     global _wgrad_queue
     gw, acc_w = arena.grad_views(w_params)
     gb, acc_b = arena.grad_views(b_params) if b_params else (None, False)
+    if wgrad_observer is not None:
+        wgrad_observer(gw)
     defer = (dy.dtype == torch.bfloat16 and dy.is_cuda and dy.shape[-1] % 8 == 0 and x.shape[-1] % 8 == 0
              and os.environ.get("OVQA_DEFER_WGRAD", "1") != "0")
     if not defer:

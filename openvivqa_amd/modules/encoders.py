@@ -101,7 +101,9 @@ class Encoder(_Prologued):
 
     def forward(self, features: torch.Tensor, padding_mask: torch.Tensor):
         out = self._prologue(self.layer_norm, features)
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
+            if i:
+                out = rt.grad_milestone(out)
             out = layer(queries=out, keys=out, values=out, attention_mask=padding_mask)
         return out.to(features.dtype)
 
@@ -124,7 +126,9 @@ class GuidedAttentionEncoder(_Prologued):
                 language_features: torch.Tensor, language_padding_mask: torch.Tensor):
         out = self._prologue(self.layer_norm, vision_features)
         lang = language_features.to(out.dtype)
-        for layer in self.guided_attn_layers:
+        for i, layer in enumerate(self.guided_attn_layers):
+            if i:
+                out = rt.grad_milestone(out)
             out = layer(queries=out, keys=lang, values=lang, self_attention_mask=vision_padding_mask,
                         guided_attention_mask=language_padding_mask)
         return out.to(vision_features.dtype)

@@ -68,6 +68,30 @@ def dropout_spec(p: float, site: int, training: bool, device) -> Optional[ops.Dr
     return ops.DropSpec(p=float(p), seed=seed, site=site, step=step_tensor(device))
 
 
+# ---- backward milestones -------------------------------------------------------------------------------
+# A training harness that overlaps the data-parallel gradient exchange with the rest of backward needs
+# points at which "everything above here has been differentiated".  Stacks mark their layer boundaries
+# with grad_milestone(x); it is the identity unless a harness installed a sink (train.TrainStep with
+# world_size > 1), which may cut the autograd graph there and run backward in phases.
+_milestone_sink = None
+
+
+def set_milestone_sink(sink) -> None:
+    global _milestone_sink
+    _milestone_sink = sink
+
+
+def grad_milestone(x: torch.Tensor, barrier: bool = False) -> torch.Tensor:
+    """Mark ``x`` as a point where backward may be split: everything computed from the returned tensor is
+    differentiated before anything ``x`` was computed from.  ``barrier=True`` is for a tensor consumed by
+    SEVERAL later milestone-delimited sections (the question features every guided layer attends to): the
+    graph must be cut here whenever it is cut at any later milestone."""
+    sink = _milestone_sink
+    if sink is None or not torch.is_grad_enabled() or not x.requires_grad:
+        return x
+    return sink.cut(x, barrier)
+
+
 class ParamArena:
     """Flat fp32 master / fp32 grad / (bf16 shadow) buffers for a set of parameters."""
 
@@ -227,6 +251,11 @@ def collect_groups(module: nn.Module) -> List[List[nn.Parameter]]:
         if id(p) not in seen:
             groups.append([p])
             seen.add(id(p))
+    # layer-contiguous layout: groups ordered by where their first parameter sits in module order, so that
+    # "the gradients of layers i..j" is one range of the flat buffer (one collective of the overlapped
+    # data-parallel exchange)
+    order = {id(p): i for i, p in enumerate(module.parameters())}
+    groups.sort(key=lambda g: order[id(g[0])])
     return groups
 
 

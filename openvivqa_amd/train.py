@@ -66,96 +66,285 @@ class FlatAdam:
 
 
 class GradAllReducer:
-    """Sum-all-reduce of the flat gradient buffer over the default process group.
+    """Sum-all-reduce of the flat gradient buffer over the default process group, in segments.
 
-    ``comm_dtype=torch.bfloat16`` halves the bytes on every xGMI link (the arena is cast by one
-    streaming kernel, reduced, and Adam consumes the fp32 view after a cast back); buckets keep
-    individual collectives at ``bucket_mb`` so RCCL can pipeline them.  Works with the ``gloo``
-    backend on CPU tensors too (used by the world_size-2 CPU tests)."""
+    ``comm_dtype=torch.bfloat16`` halves the bytes on every xGMI link (a segment is cast into a bf16 staging
+    buffer by one streaming kernel, reduced, and cast back into the fp32 gradient buffer Adam reads).
+    ``reduce_ranges`` is asynchronous: cast, collectives and cast-back of a segment run on a communication
+    stream once ``after`` (an event recorded when the segment's gradients are final) has fired, so segments
+    released early in backward travel over xGMI while the rest of backward computes; ``finish`` joins.
+    Collectives are capped at ``bucket_mb`` so RCCL pipelines them.  Works with the ``gloo`` backend on CPU
+    tensors too (world_size-2 CPU tests): there everything is synchronous."""
 
     def __init__(self, numel: int, device, comm_dtype: torch.dtype = torch.float32, bucket_mb: float = 64.0,
-                 group=None):
+                 group=None, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.comm_dtype = comm_dtype
         elt = 2 if comm_dtype == torch.bfloat16 else 4
         self.bucket = max(1, int(bucket_mb * (1 << 20) / elt))
         self.staging = torch.empty(numel, dtype=comm_dtype, device=device) if comm_dtype != torch.float32 else None
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._pending = False
 
-    def bounds(self, numel: int):
-        return [(s, min(s + self.bucket, numel)) for s in range(0, numel, self.bucket)]
+    def bounds(self, numel: int, lo: int = 0):
+        return [(s, min(s + self.bucket, lo + numel)) for s in range(lo, lo + numel, self.bucket)]
+
+    def _reduce(self, grad: torch.Tensor, ranges):
+        for lo, hi in ranges:
+            if hi <= lo:
+                continue
+            buf = grad
+            if self.staging is not None:
+                if grad.is_cuda:
+                    ops.cast(grad[lo:hi], self.staging[lo:hi])
+                else:
+                    self.staging[lo:hi].copy_(grad[lo:hi])
+                buf = self.staging
+            handles = [dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                       for s, e in self.bounds(hi - lo, lo)]
+            for h in handles:
+                h.wait()  # CUDA: orders the current (communication) stream after the collective, no host block
+            if self.staging is not None:
+                if grad.is_cuda:
+                    ops.cast(self.staging[lo:hi], grad[lo:hi])
+                else:
+                    grad[lo:hi].copy_(self.staging[lo:hi])
+
+    def reduce_ranges(self, grad: torch.Tensor, ranges, after=None) -> None:
+        """Start reducing ``grad[lo:hi]`` for every (lo, hi) in ``ranges`` (in place, SUM over ranks)."""
+        if not self.active:
+            return
+        if self.stream is None:
+            self._reduce(grad, ranges)
+            return
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(after)
+        with torch.cuda.stream(self.stream):
+            self._reduce(grad, ranges)
+        self._pending = True
+
+    def finish(self) -> None:
+        """Make the current stream wait for every segment started with ``reduce_ranges``."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._pending = False
 
     def __call__(self, grad: torch.Tensor) -> torch.Tensor:
-        """Returns the buffer holding the SUM over ranks (callers scale by 1/world)."""
-        if self.world == 1:
-            return grad
-        buf = grad
-        if self.staging is not None:
-            if grad.is_cuda:
-                ops.cast(grad, self.staging)
-            else:
-                self.staging.copy_(grad)
-            buf = self.staging
-        handles = [dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for s, e in self.bounds(buf.numel())]
-        for h in handles:
-            h.wait()
-        if self.staging is not None:
-            if grad.is_cuda:
-                ops.cast(self.staging, grad)
-            else:
-                grad.copy_(self.staging)
+        """Whole buffer at once; returns the buffer holding the SUM over ranks (callers scale by 1/world)."""
+        self.reduce_ranges(grad, [(0, grad.numel())])
+        self.finish()
         return grad
 
 
+class _Cuts:
+    """Milestone sink (runtime.grad_milestone): cuts the autograd graph at the ``active`` milestones (indices in
+    forward call order; None = all) by handing the consumer a detached leaf.  TrainStep then differentiates in
+    phases, last cut first, feeding each leaf's accumulated gradient into the graph below its cut."""
+
+    def __init__(self, active=None):
+        self.active = active
+        self.reset()
+
+    def reset(self):
+        self.count = 0
+        self.cuts = []  # (source tensor, detached leaf) in forward order
+        self.barriers = []
+
+    def cut(self, x, barrier=False):
+        i = self.count
+        self.count += 1
+        if barrier:
+            self.barriers.append(i)
+        if self.active is not None and i not in self.active:
+            return x
+        leaf = x.detach().requires_grad_()
+        self.cuts.append((x, leaf))
+        return leaf
+
+
+def _merge(spans, gap=0):
+    out = []
+    for s, e in sorted(spans):
+        if out and s <= out[-1][1] + gap:
+            out[-1][1] = max(out[-1][1], e)
+        else:
+            out.append([s, e])
+    return [(s, e) for s, e in out]
+
+
+def _complement(spans, lo, hi):
+    out, cur = [], lo
+    for s, e in _merge(spans):
+        if s > cur:
+            out.append((cur, s))
+        cur = max(cur, e)
+    if cur < hi:
+        out.append((cur, hi))
+    return out
+
+
 class TrainStep:
-    """forward -> loss -> backward -> all-reduce -> Adam, with the first three captured in a hipGraph.
+    """forward -> loss -> backward -> all-reduce -> Adam, with the first three captured in hipGraphs.
 
     ``forward_loss(*static_inputs)`` must run the model and return ``(outputs, grads)`` where
     ``grads[i]`` is d loss / d outputs[i] (so that the loss kernel can emit its own gradient), or a
     scalar loss tensor (then autograd differentiates it).  It must be capture-safe: no host syncs.
+
+    Data-parallel overlap (world_size > 1): stacks mark their layer boundaries with
+    ``runtime.grad_milestone``.  A discovery pass records which ranges of the flat gradient buffer become
+    final in which backward phase; milestones are kept where at least ``overlap_mb`` of gradients have
+    accumulated, backward is run (and captured: one hipGraph per phase, one shared memory pool) in that many
+    phases, and after each phase its ranges are handed to the GradAllReducer's communication stream while the
+    next phase computes.  Only the last segment's exchange is exposed.  With world_size == 1 no cut is made
+    and the step is a single graph.
     """
 
     def __init__(self, model: nn.Module, forward_loss: Callable, lr: float = 1.0, betas=(0.9, 0.98),
                  lr_lambda: Optional[Callable[[int], float]] = None, use_graph: bool = True,
                  comm_dtype: torch.dtype = torch.float32, bucket_mb: float = 64.0, device=None,
-                 compute_dtype: Optional[torch.dtype] = None):
+                 compute_dtype: Optional[torch.dtype] = None, overlap_mb: float = 32.0,
+                 force_comm: bool = False):
         self.model = model
         self.arena = rt.prepare(model, device=device, compute_dtype=compute_dtype)
         self.arena.overwrite_grads = True
         self.arena.attach_grads()
         self.optim = FlatAdam(self.arena, lr=lr, betas=betas, lr_lambda=lr_lambda)
-        self.reducer = GradAllReducer(self.arena.numel, self.arena.device, comm_dtype, bucket_mb)
+        self.reducer = GradAllReducer(self.arena.numel, self.arena.device, comm_dtype, bucket_mb, force=force_comm)
         self.forward_loss = forward_loss
-        self.use_graph = use_graph
-        self.graph = None
+        self.use_graph = use_graph and self.arena.device.type == "cuda"
+        self.graphs = None
         self.static_inputs = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.drop_step = rt.step_tensor(self.arena.device)
         self._foreign = [(0, self.arena.numel)]  # until the first backward tells which grads the kernels own
+        self.overlap_mb = overlap_mb
+        self._cuts = None            # _Cuts sink when backward is phased
+        self.segments = [[(0, self.arena.numel)]]  # segments[k] = ranges final after phase k
+        self._live = None
 
-    # -- one fwd+bwd on the static inputs (this is what gets captured) ------
-    def _fwd_bwd(self):
-        a = self.arena
-        if a.small_lo < a.numel:  # bias / LayerNorm gradients: atomically reduced, so zero them (one memset)
-            a.grad[a.small_lo:].zero_()
-        for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
-            if s < a.small_lo:
-                a.grad[s:min(e, a.small_lo)].zero_()
-        res = self.forward_loss(*self.static_inputs)
-        if isinstance(res, tuple):
-            outs, grads = res
-            torch.autograd.backward(list(outs), list(grads))
-        else:
-            res.backward()
-            self.loss.copy_(res.detach().float().reshape(1))
+    # -- phases of one fwd+bwd on the static inputs (this is what gets captured) ------
+    def _phase_fns(self):
+        """[phase 0 = zero + forward + first backward, phase 1.., ] as closures sharing ``self._live``."""
+        def first():
+            a = self.arena
+            if a.small_lo < a.numel:  # bias / LayerNorm gradients: atomically reduced, so zero them (one memset)
+                a.grad[a.small_lo:].zero_()
+            for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
+                if s < a.small_lo:
+                    a.grad[s:min(e, a.small_lo)].zero_()
+            if self._cuts is not None:
+                self._cuts.reset()
+                rt.set_milestone_sink(self._cuts)
+            try:
+                res = self.forward_loss(*self.static_inputs)
+            finally:
+                rt.set_milestone_sink(None)
+            cuts = list(self._cuts.cuts) if self._cuts is not None else []
+            if isinstance(res, tuple):
+                outs, grads = list(res[0]), list(res[1])
+            else:
+                outs, grads = [res], [torch.ones_like(res)]
+                self.loss.copy_(res.detach().float().reshape(1))
+            srcs = {id(src) for src, _ in cuts}
+            now = [(o, g) for o, g in zip(outs, grads) if id(o) not in srcs]
+            self._live = {"cuts": cuts, "outs": outs, "grads": grads}
+            if now:
+                torch.autograd.backward([o for o, _ in now], [g for _, g in now])
+
+        def later(k):
+            def run():
+                live = self._live
+                src, leaf = live["cuts"][k]
+                g = leaf.grad
+                for o, og in zip(live["outs"], live["grads"]):  # an output that is itself a cut source
+                    if o is src:
+                        g = og if g is None else g + og
+                if g is not None:
+                    torch.autograd.backward([src], [g])
+                if k == 0:
+                    self._live = None
+            return run
+
+        return first, later
+
+    def _fwd_bwd(self, on_phase=None):
+        """Eager pass over all phases; ``on_phase(k)`` is called after phase k (0-based, backward order)."""
+        first, later = self._phase_fns()
+        first()
+        if on_phase:
+            on_phase(0)
+        ncut = len(self._live["cuts"])
+        for j, k in enumerate(reversed(range(ncut))):
+            later(k)()
+            if on_phase:
+                on_phase(j + 1)
+        self._live = None
 
     def _discover_foreign(self):
-        self._fwd_bwd()
-        self._foreign = self.arena.foreign_ranges()
+        """One eager fwd+bwd that learns (a) which gradient ranges no kernel writes and (b), when the
+        data-parallel exchange is active, which ranges become final in which backward phase."""
+        from . import functional as _fn
+        a = self.arena
+        plan = self.reducer.active and self.overlap_mb > 0
+        log, phase = [], [0]
+        if plan:
+            self._cuts = _Cuts(active=None)
+            base = a.grad.data_ptr()
+
+            def observe(gw):
+                lo = (gw.data_ptr() - base) // 4
+                if 0 <= lo < a.small_lo:
+                    log.append((phase[0], lo, lo + gw.numel()))
+            _fn.wgrad_observer = observe
+        try:
+            self._fwd_bwd(on_phase=lambda k: phase.__setitem__(0, k + 1))
+        finally:
+            _fn.wgrad_observer = None
+        self._foreign = a.foreign_ranges()
+        if not plan:
+            return
+        n_all, barriers = self._cuts.count, list(self._cuts.barriers)
+        nph = phase[0]  # phases executed = cuts + 1; phase j (backward order) ends at cut n_all-1-j (forward order)
+        assert nph == n_all + 1
+        last = {}
+        for ph, lo, hi in log:  # a range belongs to the LAST phase that writes it (shared weights)
+            hi = (hi + rt.ALIGN - 1) // rt.ALIGN * rt.ALIGN  # + alignment padding (never written, zeros)
+            last[(lo, hi)] = max(ph, last.get((lo, hi), -1))
+        per_phase = [[] for _ in range(nph)]
+        for (lo, hi), ph in last.items():
+            per_phase[ph].append((lo, hi))
+        # keep a milestone once >= overlap_mb MB (fp32) of gradients have become final since the previous one
+        thresh = self.overlap_mb * (1 << 20) / 4
+        active, acc_n = set(), 0
+        for j in range(nph - 1):
+            acc_n += sum(hi - lo for lo, hi in per_phase[j])
+            if acc_n >= thresh:
+                active.add(n_all - 1 - j)
+                acc_n = 0
+        for b in barriers:  # a tensor feeding several sections must be cut if any later section boundary is
+            if any(i > b for i in active):
+                active.add(b)
+        segments, acc = [], []
+        for j in range(nph - 1):
+            acc += per_phase[j]
+            if n_all - 1 - j in active:
+                segments.append(_merge(acc))
+                acc = []
+        done = [r for seg in segments for r in seg]
+        segments.append(_complement(done, 0, a.numel))  # everything else: final only when backward has ended
+        self.segments = segments
+        self._cuts = _Cuts(active=active) if active else None
 
     def _capture(self, inputs: Sequence[torch.Tensor]):
         self.static_inputs = [t.clone() for t in inputs]
+        if self.arena.device.type != "cuda":
+            self._discover_foreign()
+            return
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -167,9 +356,23 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.use_graph:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._fwd_bwd()
+            first, later = self._phase_fns()
+            graphs = [torch.cuda.CUDAGraph()]
+            with torch.cuda.graph(graphs[0]):
+                first()
+            for k in reversed(range(len(self._live["cuts"]))):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=graphs[0].pool()):
+                    later(k)()
+                graphs.append(g)
+            self._live = None
+            assert len(graphs) == len(self.segments), (len(graphs), len(self.segments))
+            self.graphs = graphs
+
+    def _release(self, k):
+        """Phase k is enqueued: hand its gradient ranges to the communication stream."""
+        if self.reducer.active and k < len(self.segments):
+            self.reducer.reduce_ranges(self.arena.grad, self.segments[k])
 
     def step(self, *inputs: torch.Tensor) -> torch.Tensor:
         if self.static_inputs is None:
@@ -177,11 +380,17 @@ class TrainStep:
         for dst, src in zip(self.static_inputs, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        if self.graph is not None:
-            self.graph.replay()
+        if self.graphs is not None:
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                self._release(k)
         else:
-            self._fwd_bwd()
-        g = self.reducer(self.arena.grad)
-        self.optim.step(g, grad_scale=1.0 / self.reducer.world)
+            self._fwd_bwd(on_phase=self._release)
+        self.reducer.finish()
+        self.optim.step(self.arena.grad, grad_scale=1.0 / self.reducer.world)
         ops.increment_step(self.drop_step)
         return self.loss
+
+    @property
+    def graph(self):  # single-graph view kept for callers that replay the captured fwd+bwd themselves
+        return self.graphs[0] if self.graphs is not None and len(self.graphs) == 1 else None
