@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--overlap-mb", type=float, default=32.0,
+    ap.add_argument("--overlap-mb", type=float, default=64.0,
                     help="N>1: release a gradient segment to the all-reduce stream every this many MB (fp32) of "
                          "finished gradients during backward; 0 = one exchange after backward")
     ap.add_argument("--rehearse-comm", action="store_true",

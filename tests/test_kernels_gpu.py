@@ -349,6 +349,13 @@ def test_sq_loss_and_cast():
     a = rnd(1000)
     b = torch.empty(1000, dtype=BF16, device=DEV)
     assert torch.equal(o.cast(a, b), a.to(BF16))
+    for n in (8, 1003, 70001):  # vector path + ragged tail, both directions, and an unaligned (scalar) slice
+        a = rnd(n + 1)
+        b = torch.empty(n + 1, dtype=BF16, device=DEV)
+        assert torch.equal(o.cast(a[:n], b[:n]), a[:n].to(BF16))
+        back = torch.empty(n, device=DEV)
+        assert torch.equal(o.cast(b[:n], back), b[:n].float())
+        assert torch.equal(o.cast(a[1:], b[1:]), a[1:].to(BF16))
 
 
 def test_errors_are_loud():
