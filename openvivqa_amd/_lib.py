@@ -26,6 +26,12 @@ class WgradProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class ReduceProblem(C.Structure):
+    """ovqa_reduce_problem (include/ovqa_hip.h)."""
+    _fields_ = [("partial", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
+                ("blocks", C.c_int32), ("D", C.c_int32)]
+
+
 class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("step", C.c_void_p)]
 
@@ -46,6 +52,8 @@ SIGNATURES = {
     "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
     "ovqa_layernorm_bwd": [c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_int, _DP, c_vp, c_vp],
+    "ovqa_layernorm_bwd_blocks": [c_i64],
+    "ovqa_grouped_partial_reduce": [c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_attention_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
                            c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,

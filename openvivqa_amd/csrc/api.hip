@@ -133,6 +133,16 @@ int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, i
                              accumulate, da, ws, as_stream(stream));
 }
 
+int ovqa_layernorm_bwd_blocks(int64_t M) { return ovqa::layernorm_bwd_blocks(M); }
+
+int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_problems, int32_t max_blocks,
+                                int32_t max_D, void* stream) {
+  OVQA_REQUIRE(n_problems >= 0 && max_blocks >= 0 && max_D >= 0, OVQA_ERR_BAD_ARG, "grouped_partial_reduce: bad sizes");
+  OVQA_REQUIRE(n_problems == 0 || problems != nullptr, OVQA_ERR_BAD_ARG, "grouped_partial_reduce: null table");
+  OVQA_REQUIRE(n_problems <= 65535, OVQA_ERR_BAD_ARG, "grouped_partial_reduce: at most 65535 problems per launch");
+  return ovqa::grouped_partial_reduce(problems, n_problems, max_blocks, max_D, as_stream(stream));
+}
+
 int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        const float* mask, int64_t msb, int64_t msh, int64_t msq, void* o, int64_t ldo, float* lse,
                        void* att, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv, float scale,

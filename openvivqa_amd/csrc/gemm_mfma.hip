@@ -238,12 +238,8 @@ __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ 
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 8 || N == 16, "unsupported count");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // BC = rows of the c (Q) operand per tile: 128, or 64 for problems with few tiles (more workgroups, fewer
@@ -293,8 +289,14 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   for (int kt = 0; kt < nkt; kt++) {
     // tile kt has landed (all but the youngest NBUF-2 tiles' loads are done), and -- after the barrier --
     // every wave has finished reading the buffer that the next issue overwrites
-    if (NBUF == 2 || kt + NBUF - 2 >= nkt) wait_vmcnt<0>();
-    else wait_vmcnt<LOADS * (NBUF - 2)>();
+    if (NBUF == 2 || kt + NBUF - 2 >= nkt) {
+      wait_vmcnt<0>();
+    } else if constexpr (QCH >= NW) {
+      wait_vmcnt<LOADS * (NBUF - 2)>();
+    } else {  // waves >= QCH issue no Q loads: their count per stage is smaller (wave-uniform branch)
+      if (wave < QCH) wait_vmcnt<LOADS * (NBUF - 2)>();
+      else wait_vmcnt<(16 / NW) * (NBUF - 2)>();
+    }
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
     const char* Ps = smem + (kt % NBUF) * STAGE;
@@ -484,6 +486,27 @@ inline int tiny_tile_threshold() {
   return v;
 }
 
+// ring depth of the small-tile kernels (latency-bound: few MFMAs per K step, so the round trip of the next
+// tile must be covered by more than one tile in flight).  MEASURED in the MCAN step (operands cold: produced by
+// the previous kernel on other XCDs): (small, tiny) = (2,2) 4.905 ms, (3,3) 4.766, (3,4) 4.721, (4,4) 5.132
+// (BC = 64 with 4 stages leaves one workgroup per CU); an L2-warm microbenchmark prefers 2.
+inline int small_nbuf() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_SMALL_NBUF");
+    v = e ? atoi(e) : 3;
+  }
+  return v;
+}
+inline int tiny_nbuf() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_TINY_NBUF");
+    v = e ? atoi(e) : 4;
+  }
+  return v;
+}
+
 inline int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -528,11 +551,19 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
   }
   if constexpr (!QK) {
     if (tiny_c) {
-      OVQA_GLDS(2, 8, 32)
+      switch (tiny_nbuf()) {
+        case 3: OVQA_GLDS(3, 8, 32) break;
+        case 4: OVQA_GLDS(4, 8, 32) break;
+        default: OVQA_GLDS(2, 8, 32)
+      }
       return ovqa_check_launch(what);
     }
     if (small_c) {
-      OVQA_GLDS(2, 8, 64)
+      switch (small_nbuf()) {
+        case 3: OVQA_GLDS(3, 8, 64) break;
+        case 4: OVQA_GLDS(4, 8, 64) break;
+        default: OVQA_GLDS(2, 8, 64)
+      }
       return ovqa_check_launch(what);
     }
   }

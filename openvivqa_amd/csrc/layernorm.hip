@@ -218,6 +218,28 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   atomicAdd(base + ((i < D) ? i : i - D), s);
 }
 
+// Deferred form of the reduce: every LayerNorm of a backward pass leaves its partials in its own buffer and ONE
+// launch sums them all.  grid (column blocks of 64 over 2*max_D, row groups of 64 partial rows, problems).
+__global__ __launch_bounds__(256) void ln_bwd_grouped_reduce_kernel(const ovqa_reduce_problem* __restrict__ probs) {
+  __shared__ float red[4][64];
+  const ovqa_reduce_problem pr = probs[blockIdx.z];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;  // over 2*D
+  const int D = pr.D;
+  const int b0 = blockIdx.y * 64, b1 = min(pr.blocks, b0 + 64);
+  if (b0 >= pr.blocks || blockIdx.x * 64 >= 2 * D) return;
+  float s = 0.f;
+  if (i < 2 * D)
+    for (int b = b0 + r; b < b1; b += 4) s += pr.partial[(int64_t)b * 2 * D + i];
+  red[r][c] = s;
+  __syncthreads();
+  if (r != 0 || i >= 2 * D) return;
+  s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  float* base = (i < D) ? pr.out0 : pr.out1;
+  if (base == nullptr) return;
+  atomicAdd(base + ((i < D) ? i : i - D), s);
+}
+
 template <typename TIN, typename TOUT>
 int fwd_dispatch(const void* x, const float* gamma, const float* beta, const float* pos, int64_t pos_rows, void* y,
                  float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
@@ -256,6 +278,7 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
 #undef LN_BWD
   int rc = ovqa_check_launch("layernorm_bwd");
   if (rc != OVQA_OK) return rc;
+  if (dgamma == nullptr && dbeta == nullptr) return OVQA_OK;  // partials stay in ws (deferred grouped reduce)
   if (!accumulate) {
     hipError_t e = hipSuccess;
     if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st);
@@ -290,6 +313,18 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
     return fwd_dispatch<float, bf16>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
   ovqa_set_error("layernorm_fwd: unsupported dtype combination in=%d out=%d", in_dtype, dtype);
   return OVQA_ERR_UNSUPPORTED;
+}
+
+int layernorm_bwd_blocks(int64_t M) {
+  int64_t nb = (M + 3) / 4;
+  return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+
+int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_blocks, int max_D, hipStream_t st) {
+  if (n <= 0) return OVQA_OK;
+  dim3 grid((unsigned)((2 * max_D + 63) / 64), (unsigned)((max_blocks + 63) / 64), (unsigned)n);
+  hipLaunchKernelGGL(ln_bwd_grouped_reduce_kernel, grid, dim3(256), 0, st, probs);
+  return ovqa_check_launch("grouped_partial_reduce");
 }
 
 int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,

@@ -66,10 +66,27 @@ def _wgrad(arena, dy, x, w_params, b_params):
     if not defer:
         ops.linear_bwd_weight(dy, x, gw, gb, accumulate=acc_w, accumulate_db=acc_b)
         return
-    q = wgrad_queue()
-    if not q.items and not q.inflight:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    q = _armed_queue()
     q.add(dy, x, gw, acc_w, gb, acc_b)  # bias gradient = fused column sums of dy
+
+
+def _armed_queue():
+    """The deferred-work queue, with its flush registered to run when the current backward pass ends."""
+    q = wgrad_queue()
+    if not q.items and not q.inflight and not q.reduces:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+    return q
+
+
+def _ln_bwd(arena, dy, x, gamma, beta, mean, rstd, drop=None, dx_dtype=None):
+    """LayerNorm backward; dgamma/dbeta go to the arena.  bf16 on the GPU: their cross-row reduction is
+    deferred and done for ALL LayerNorms of the backward pass by one launch at its end (each of the 32
+    reductions of an MCAN step would otherwise be a ~5 us dependent launch on the critical chain)."""
+    gg, acc = arena.grad_views([gamma])
+    gb, _ = arena.grad_views([beta])
+    defer = (dy.dtype == torch.bfloat16 and dy.is_cuda and os.environ.get("OVQA_DEFER_WGRAD", "1") != "0")
+    return ops.layernorm_bwd(dy, x, arena.master_of(gamma), mean, rstd, gg, gb, drop=drop, dx_dtype=dx_dtype,
+                             accumulate=acc, defer=_armed_queue() if defer else None)
 
 
 # ------------------------------------------------------------------ prologue
@@ -90,10 +107,7 @@ class _Prologue(Function):
         arena = st["arena"]
         x, mean, rstd = ctx.saved_tensors
         gamma, beta = st["gamma"], st["beta"]
-        gg, acc = arena.grad_views([gamma])
-        gb, _ = arena.grad_views([beta])
-        dx, _ = ops.layernorm_bwd(_c(dy), x, arena.master_of(gamma), mean, rstd, gg, gb, dx_dtype=x.dtype,
-                                  accumulate=acc)
+        dx, _ = _ln_bwd(arena, _c(dy), x, gamma, beta, mean, rstd, dx_dtype=x.dtype)
         return dx if ctx.needs_input_grad[0] else None, None, None, None
 
 
@@ -160,10 +174,7 @@ class _MHABlock(Function):
         st, mode = ctx.st, ctx.mode
         arena, a, ln, drop = st["arena"], st["att"], st["ln"], st["drop"]
         queries, keys, values, o, lse, pre, mean, rstd, *bufs = ctx.saved_tensors
-        gg, acc = arena.grad_views([ln.weight])
-        gb, _ = arena.grad_views([ln.bias])
-        dpre, dpre_d = ops.layernorm_bwd(_c(dy), pre, arena.master_of(ln.weight), mean, rstd, gg, gb, drop=drop,
-                                         accumulate=acc)
+        dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=drop)
         # fc_o
         _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
         d_o = ops.linear_bwd_data(dpre_d, arena.compute(a.fc_o.weight))
@@ -242,10 +253,7 @@ class _FFNBlock(Function):
         arena, m = st["arena"], st["mod"]
         ln = m.layer_norm
         x, h, u, pre, mean, rstd = ctx.saved_tensors
-        gg, acc = arena.grad_views([ln.weight])
-        gb, _ = arena.grad_views([ln.bias])
-        dpre, dpre_d = ops.layernorm_bwd(_c(dy), pre, arena.master_of(ln.weight), mean, rstd, gg, gb, drop=st["drop2"],
-                                         accumulate=acc)
+        dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=st["drop2"])
         _wgrad(arena, dpre_d, h, [m.fc2.weight], [m.fc2.bias])
         du = ops.linear_bwd_data(dpre_d, arena.compute(m.fc2.weight), preact=u, drop=st["drop1"])
         _wgrad(arena, du, x, [m.fc1.weight], [m.fc1.bias])

@@ -166,6 +166,7 @@ class WgradQueue:
 
     def __init__(self):
         self.items = []
+        self.reduces = []    # deferred LayerNorm dgamma/dbeta reductions: (partial, blocks, D, out0, out1)
         self.ntiles = 0
         self.inflight = []   # references the side-stream launches still need
         self.keepalive = []  # tables/tensors of captured launches must outlive the graph
@@ -194,6 +195,33 @@ class WgradQueue:
         self.ntiles += ((N + self.TILE - 1) // self.TILE) * ((K + self.TILE - 1) // self.TILE)
         if self.ntiles >= self.FLUSH_TILES:
             self.flush()
+
+    def add_reduce(self, partial, blocks, D, out0, out1):
+        assert out0.dtype == torch.float32 and out1.dtype == torch.float32 and partial.dtype == torch.float32
+        self.reduces.append((partial, blocks, D, out0, out1))
+
+    def _flush_reduces(self):
+        """One launch summing the row-slab partials of every queued LayerNorm backward (main stream)."""
+        if not self.reduces:
+            return
+        import numpy as np
+        red, self.reduces = self.reduces, []
+        dev = red[0][0].device
+        probs = (_lib.ReduceProblem * len(red))()
+        for i, (partial, blocks, D, out0, out1) in enumerate(red):
+            probs[i] = _lib.ReduceProblem(_p(partial), _p(out0), _p(out1), blocks, D)
+        raw = np.frombuffer(bytes(probs), dtype=np.uint8)
+        capturing = torch.cuda.is_current_stream_capturing()
+        entry = self._buffers(raw.size, dev, capturing)
+        host, devbuf = entry[0], entry[1]
+        host[:raw.size] = torch.from_numpy(raw.copy())
+        devbuf[:raw.size].copy_(host[:raw.size], non_blocking=True)
+        _lib.check(_lib.load().ovqa_grouped_partial_reduce(devbuf.data_ptr(), len(red), max(r[1] for r in red),
+                                                           max(r[2] for r in red), _stream()),
+                   "grouped_partial_reduce")
+        self._used(entry, torch.cuda.current_stream(dev), capturing)
+        if capturing:
+            self.keepalive.append((host, devbuf, red))
 
     def flush(self):
         """Launch everything queued so far on the side stream (asynchronously w.r.t. the main stream)."""
@@ -229,7 +257,8 @@ class WgradQueue:
             prob_bytes = np.concatenate([prob_bytes, np.zeros(pad, dtype=np.uint8)])
         nbytes = prob_bytes.size + tile_arr.nbytes
         capturing = torch.cuda.is_current_stream_capturing()
-        host, devbuf = self._buffers(nbytes, dev, capturing)
+        entry = self._buffers(nbytes, dev, capturing)
+        host, devbuf = entry[0], entry[1]
         host[:prob_bytes.size] = torch.from_numpy(prob_bytes.copy())
         host[prob_bytes.size:nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
         main = torch.cuda.current_stream(dev)
@@ -240,6 +269,7 @@ class WgradQueue:
             _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
                 OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles),
                 side.cuda_stream), "grouped_linear_bwd_weight")
+        self._used(entry, side, capturing)
         self._used_side = True
         self.inflight.append(items)
         if capturing:
@@ -247,6 +277,7 @@ class WgradQueue:
 
     def finish(self):
         """End of the backward pass: launch the remainder and make the main stream wait for the side stream."""
+        self._flush_reduces()
         self.flush()
         if self._used_side:
             for dev, side in self._side.items():
@@ -255,10 +286,10 @@ class WgradQueue:
         self.inflight = []  # main-stream-ordered frees are safe again after the join
 
     def _buffers(self, nbytes, dev, capturing):
-        """Pinned host + device table buffers.  Pinned allocations are not permitted while a stream is
-        capturing, so buffers are created in the eager warm-up pass and handed to the capture; a buffer is
-        never reused while a previous launch may still read it (captured ones never, eager ones after their
-        event)."""
+        """Cache entry [pinned host, device, event, owned-by-a-graph] for a table upload.  Pinned allocations
+        are not permitted while a stream is capturing, so buffers are created in the eager warm-up pass and
+        handed to the capture; a buffer is never reused while a previous launch may still read it (captured
+        ones never; eager ones after the event the caller records with ``_used`` once its launch is queued)."""
         for entry in self._cache:
             host, devbuf, ev, owned = entry
             if owned or host.numel() < nbytes or devbuf.device != dev:
@@ -269,18 +300,18 @@ class WgradQueue:
                 ev.synchronize()
             if capturing:
                 entry[3] = True  # the graph owns it from now on
-            else:
-                entry[2] = torch.cuda.Event()
-                entry[2].record(self._side_stream(dev))
-            return host, devbuf
+            return entry
         size = max(nbytes * 2, 1 << 16)
         entry = [torch.empty(size, dtype=torch.uint8).pin_memory(), torch.empty(size, dtype=torch.uint8, device=dev),
                  None, capturing]
         self._cache.append(entry)
+        return entry
+
+    @staticmethod
+    def _used(entry, stream, capturing):
         if not capturing:
             entry[2] = torch.cuda.Event()
-            entry[2].record(self._side_stream(dev))
-        return entry[0], entry[1]
+            entry[2].record(stream)
 
     def reserve(self, n):
         """Pre-create ``n`` idle table buffers (call before graph capture)."""
@@ -309,8 +340,11 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False):
-    """Returns (dx, dx_dropped) -- dx_dropped is dx when dropout is off."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False, defer=None):
+    """Returns (dx, dx_dropped) -- dx_dropped is dx when dropout is off.
+
+    ``defer`` (a WgradQueue): dgamma/dbeta are not reduced now; the kernel's row-slab partials go to a buffer
+    of their own and the queue sums the partials of every LayerNorm of the backward pass in one launch."""
     _dev(dy)
     lib = _lib.load()
     assert dy.is_contiguous() and x.is_contiguous()
@@ -320,9 +354,20 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=N
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
     has_drop = drop is not None and drop.p > 0.0
     dxd = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if has_drop else None
+    if defer is not None and M > 0:
+        blocks = lib.ovqa_layernorm_bwd_blocks(M)
+        ws = torch.empty(blocks * 2 * D, dtype=torch.float32, device=x.device)
+        gout, bout = None, None
+    else:
+        ws, gout, bout = workspace(dy.device), dgamma, dbeta
     _lib.check(lib.ovqa_layernorm_bwd(_dt(dy), _DT[dx_dtype], _p(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd),
-                                      _p(dx), _p(dxd), _p(dgamma), _p(dbeta), M, D, int(accumulate), _drop(drop),
-                                      _p(workspace(dy.device)), _stream()), "layernorm_bwd")
+                                      _p(dx), _p(dxd), _p(gout), _p(bout), M, D, int(accumulate), _drop(drop),
+                                      _p(ws), _stream()), "layernorm_bwd")
+    if defer is not None and M > 0:
+        if not accumulate:  # the grouped reduce adds into its outputs
+            dgamma.zero_()
+            dbeta.zero_()
+        defer.add_reduce(ws, blocks, D, dgamma, dbeta)
     return dx, (dxd if has_drop else dx)
 
 

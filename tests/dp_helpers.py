@@ -70,6 +70,6 @@ def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q):
         model, ts = make_step(overlap_mb, torch.bfloat16 if comm_bf16 else torch.float32)
         for _ in range(2):
             ts.step(*batch(rank))
-        q.put((rank, ts.arena.master.clone(), [list(map(list, s)) for s in ts.segments]))
+        q.put((rank, ts.arena.master.clone().numpy(), [list(map(list, s)) for s in ts.segments]))
     finally:
         dist.destroy_process_group()

@@ -119,7 +119,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats
     return y.to(out_dtype or x.dtype), mean.reshape(-1), rstd.reshape(-1)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False, defer=None):
+    assert defer is None
     assert drop is None or drop.p == 0
     D = x.shape[-1]
     xf, df = x.float().reshape(-1, D), dy.float().reshape(-1, D)

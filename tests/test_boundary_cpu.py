@@ -215,7 +215,7 @@ def _dp_worker(rank, world, rdv, comm_bf16, q):
         g = torch.arange(n, dtype=torch.float32) * (rank + 1) / 64.0
         g[100:200] = 0.0  # parameters without gradient (dead cross-attention): zeros on every rank
         out = red(g)
-        q.put((rank, out.clone()))
+        q.put((rank, out.clone().numpy()))  # by value: a shared-memory tensor could outlive its sender
     finally:
         dist.destroy_process_group()
 
@@ -230,7 +230,7 @@ def test_grad_allreduce_gloo_world2(comm_bf16):
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, rdv, comm_bf16, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -258,7 +258,7 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16):
     procs = [ctx.Process(target=H.dp_worker, args=(r, 2, rdv, overlap_mb, comm_bf16, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {r: (w, seg) for r, w, seg in (q.get(timeout=300) for _ in range(2))}
+    res = {r: (torch.from_numpy(w), seg) for r, w, seg in (q.get(timeout=300) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -332,6 +332,32 @@ def test_adam_matches_torch_and_shadow():
     assert torch.equal(shadow[:n], p.to(BF16))
 
 
+def test_layernorm_bwd_deferred_grouped_reduce():
+    """dgamma/dbeta of several LayerNorms via per-call partials + ONE grouped reduce == the immediate form."""
+    from openvivqa_amd.ops import WgradQueue
+    o = ops()
+    q = WgradQueue()
+    cases = [(6400, 512), (1280, 512), (37, 64), (5000, 768)]
+    outs = []
+    for i, (M, D) in enumerate(cases):
+        x, dy = rnd(M, D, dtype=BF16, seed=i), rnd(M, D, dtype=BF16, seed=10 + i)
+        gamma = rnd(D, seed=20 + i)
+        mean, rstd = x.float().mean(-1), (x.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+        g0, b0 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        dx0, _ = o.layernorm_bwd(dy, x, gamma, mean, rstd, g0, b0)
+        acc = i % 2 == 1
+        g1 = torch.full((D,), 3.0 if acc else 7.0, device=DEV)  # 7.0 must be overwritten, 3.0 accumulated into
+        b1 = torch.full((D,), -2.0 if acc else 7.0, device=DEV)
+        dx1, _ = o.layernorm_bwd(dy, x, gamma, mean, rstd, g1, b1, accumulate=acc, defer=q)
+        assert torch.equal(dx0, dx1)
+        outs.append((g0, b0, g1, b1, acc))
+    assert len(q.reduces) == len(cases)
+    q.finish()
+    torch.cuda.synchronize()
+    for g0, b0, g1, b1, acc in outs:
+        assert nerr(g1 - (3.0 if acc else 0.0), g0) < 1e-5 and nerr(b1 - (-2.0 if acc else 0.0), b0) < 1e-5
+
+
 def test_sq_loss_and_cast():
     o = ops()
     for dtype in (F32, BF16):

@@ -90,9 +90,14 @@ def test_phased_backward_with_comm_stream_matches_single_graph(single_rank_group
 def test_graph_replay_equals_eager_steps():
     _, a, batch = _make(2, use_graph=True)
     _, b, _ = _make(2, use_graph=False)
-    for _ in range(3):
+    a.step(*batch)
+    b.step(*batch)
+    torch.cuda.synchronize()
+    # same kernels on the same weights: only the order of the fp32 atomics (bias / LayerNorm gradients) differs
+    assert _rel(a.arena.grad, b.arena.grad) <= 1e-5
+    for _ in range(2):  # afterwards Adam amplifies that noise on parameters with ~zero gradient (fc_k.bias)
         a.step(*batch)
         b.step(*batch)
     torch.cuda.synchronize()
-    assert _rel(a.arena.grad, b.arena.grad) <= 1e-5  # bias / LayerNorm gradients are atomically reduced
-    assert abs(float(a.loss) - float(b.loss)) <= 1e-5 * abs(float(b.loss))
+    assert _rel(a.arena.grad, b.arena.grad) <= 5e-3
+    assert abs(float(a.loss) - float(b.loss)) <= 1e-4 * abs(float(b.loss))
