@@ -116,6 +116,49 @@ def prologue(x, layer_norm, pos, arena, dtype):
     return _Prologue.apply(x, layer_norm.weight, layer_norm.bias, st)
 
 
+# ------------------------------------------------------------------ hoisted K/V projection
+class _KVProjectAll(Function):
+    """fc_k / fc_v of SEVERAL attention modules applied to the same keys in one GEMM: kv[..., s*(nk+nv):...] is
+    module s's [K | V] projection.  In MCAN's guided stack every layer attends to the same final question
+    features (encoders.py:156-162), so the 6 per-layer K/V projections (6 forward GEMMs, 6 dX GEMMs and 5
+    gradient adds on 1280 rows, each a ~5-15 us dependent launch) become one forward and one dX GEMM."""
+
+    @staticmethod
+    def forward(ctx, keys, st, *params):
+        arena = st["arena"]
+        keys = _c(keys)
+        kv = ops.linear_fwd(keys, arena.packed(st["weights"]), arena.packed(st["biases"], "master"))
+        ctx.st = st
+        ctx.save_for_backward(keys)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        st = ctx.st
+        arena = st["arena"]
+        (keys,) = ctx.saved_tensors
+        dkv = _c(dkv)
+        _wgrad(arena, dkv, keys, st["weights"], st["biases"])
+        dkeys = ops.linear_bwd_data(dkv, arena.packed(st["weights"])) if ctx.needs_input_grad[0] else None
+        return dkeys, None, *([None] * (len(st["weights"]) + len(st["biases"])))
+
+
+def kv_project_all(keys, attentions, arena):
+    """[K_0 | V_0 | K_1 | V_1 | ...] projections of ``keys`` for the given ScaledDotProductAttention modules, or
+    None when their fc_k / fc_v parameters are not adjacent in the arena (then callers project per module)."""
+    weights = [w for a in attentions for w in (a.fc_k.weight, a.fc_v.weight)]
+    biases = [b for a in attentions for b in (a.fc_k.bias, a.fc_v.bias)]
+    try:
+        arena.packed(weights)
+        arena.packed(biases, "master")
+    except (RuntimeError, KeyError):
+        return None
+    st = dict(arena=arena, weights=weights, biases=biases)
+    if torch.is_grad_enabled():
+        return _KVProjectAll.apply(keys, st, *weights, *biases)
+    return ops.linear_fwd(_c(keys), arena.packed(weights), arena.packed(biases, "master"))
+
+
 # ------------------------------------------------------------------ MHA block
 def same_tensor(a, b) -> bool:
     return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
@@ -139,6 +182,11 @@ def _project_qkv(st, queries, keys, values):
     wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
     bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
     nqk, nv = wq.shape[0], wv.shape[0]
+    if st.get("pre_kv") is not None:  # keys IS the hoisted projection buffer (kv_project_all), slot = this module
+        slot = st["pre_kv"][0]
+        base = slot * (wk.shape[0] + nv)
+        q = ops.linear_fwd(queries, arena.compute(wq), arena.master_of(bq))
+        return q, keys[..., base:base + wk.shape[0]], keys[..., base + wk.shape[0]:base + wk.shape[0] + nv], "pre", (q,)
     if queries is keys and keys is values:
         qkv = ops.linear_fwd(queries, arena.packed([wq, wk, wv]), arena.packed([bq, bk, bv], "master"))
         return qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:], "self", (qkv,)
@@ -192,6 +240,20 @@ class _MHABlock(Function):
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
             dx = ops.linear_bwd_data(dqkv, arena.packed([wq, wk, wv]), addend=dpre)
             return dx, None, None, None, None, *([None] * len(st["params"]))
+        if mode == "pre":
+            (q,) = bufs
+            slot, shared = st["pre_kv"]
+            base = slot * (wk.shape[0] + wv.shape[0])
+            k, v = keys[..., base:base + wk.shape[0]], keys[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]]
+            if shared.get("dkv") is None:  # one gradient buffer for the whole hoisted projection; every module
+                shared["dkv"] = torch.empty_like(keys)  # fills its slot, module 0 hands it to autograd
+            dkv = shared["dkv"]
+            dq = torch.empty_like(q)
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., base:base + wk.shape[0]],
+                              dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
+            _wgrad(arena, dq, queries, [wq], [bq])
+            dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
+            return dx, (dkv if slot == 0 else None), None, None, None, *([None] * len(st["params"]))
         if mode == "cross":
             q, kv = bufs
             k, v = kv[..., :nqk], kv[..., nqk:]
@@ -214,11 +276,17 @@ class _MHABlock(Function):
         return dx, dkeys, dvalues, None, None, *([None] * len(st["params"]))
 
 
-def mha_block(queries, keys, values, mask, st):
-    """Forward of the fused MHA block; uses autograd only when needed."""
+def mha_block(queries, keys, values, mask, st, projected_kv=None):
+    """Forward of the fused MHA block; uses autograd only when needed.  ``projected_kv = (kv_all, slot, shared)``
+    (from kv_project_all) replaces keys/values by already projected K/V."""
     st = dict(st)
-    st["same"] = ("all" if same_tensor(queries, keys) and same_tensor(keys, values)
-                  else "kv" if same_tensor(keys, values) else "none")
+    if projected_kv is not None:
+        keys = values = projected_kv[0]
+        st["pre_kv"] = (projected_kv[1], projected_kv[2])
+        st["same"] = "kv"
+    else:
+        st["same"] = ("all" if same_tensor(queries, keys) and same_tensor(keys, values)
+                      else "kv" if same_tensor(keys, values) else "none")
     if torch.is_grad_enabled():
         return _MHABlock.apply(queries, keys, values, mask, st, *st["params"])
     arena, a, ln = st["arena"], st["att"], st["ln"]

@@ -7,7 +7,6 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import runtime as rt
 from .builders import build_encoder
 
 
@@ -21,7 +20,7 @@ class MCANEncoderStack(nn.Module):
     def forward(self, vision_features, vision_padding_mask, text_features, text_padding_mask):
         text = self.self_encoder(features=text_features, padding_mask=text_padding_mask)
         vision = self.guided_encoder(vision_features=vision_features, vision_padding_mask=vision_padding_mask,
-                                     language_features=rt.grad_milestone(text, barrier=True),
+                                     language_features=text,
                                      language_padding_mask=text_padding_mask)
         return vision, text
 

@@ -89,9 +89,12 @@ class MultiHeadAttention(Module):
             self.register_state("running_values", torch.zeros((0, d_model)))
         self._site = rt.new_dropout_site()
 
-    def forward(self, queries, keys, values, attention_mask, **kwargs):
+    def forward(self, queries, keys, values, attention_mask, projected_kv=None, **kwargs):
         arena = rt.ensure_arena(self)
         T = arena.compute_dtype
+        if projected_kv is not None and (type(self.attention) is not ScaledDotProductAttention
+                                         or (self.can_be_stateful and self._is_stateful)):
+            projected_kv = None
         same_kv = Fn.same_tensor(keys, values)
         same_all = same_kv and Fn.same_tensor(queries, keys)
         queries = queries.to(T)
@@ -111,7 +114,7 @@ class MultiHeadAttention(Module):
             params = list(self.attention.parameters()) + list(self.layer_norm.parameters())
             st = dict(arena=arena, att=self.attention, ln=self.layer_norm, params=params,
                       drop=rt.dropout_spec(self.dropout.p, self._site, self.training, queries.device))
-            out = Fn.mha_block(queries, keys, values, mask, st)
+            out = Fn.mha_block(queries, keys, values, mask, st, projected_kv=projected_kv)
         else:  # other registered attention kernels: unfused composition
             out, _ = self.attention(queries, keys, values, mask, **kwargs)
             out = Fn.prologue(queries + self.dropout(out.to(T)), self.layer_norm, None, arena, T)

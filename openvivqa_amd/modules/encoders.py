@@ -10,7 +10,7 @@ from torch import nn
 from .. import functional as Fn
 from .. import runtime as rt
 from ..builders.encoder_builder import META_ENCODER
-from .attentions import MultiHeadAttention
+from .attentions import MultiHeadAttention, ScaledDotProductAttention
 from .pos_embeddings import SinusoidPositionalEmbedding
 from .positionwise_feed_forward import PositionWiseFeedForward
 
@@ -36,9 +36,10 @@ class GuidedEncoderLayer(nn.Module):
         self.guided_mhatt = MultiHeadAttention(config)
         self.pwff = PositionWiseFeedForward(config)
 
-    def forward(self, queries, keys, values, self_attention_mask, guided_attention_mask, **kwargs):
+    def forward(self, queries, keys, values, self_attention_mask, guided_attention_mask, projected_kv=None, **kwargs):
         x = self.self_mhatt(queries=queries, keys=queries, values=queries, attention_mask=self_attention_mask, **kwargs)
-        x = self.guided_mhatt(queries=x, keys=keys, values=values, attention_mask=guided_attention_mask, **kwargs)
+        x = self.guided_mhatt(queries=x, keys=keys, values=values, attention_mask=guided_attention_mask,
+                              projected_kv=projected_kv, **kwargs)
         return self.pwff(x)
 
 
@@ -122,14 +123,44 @@ class GuidedAttentionEncoder(_Prologued):
         self.guided_attn_layers = nn.ModuleList(
             [GuidedEncoderLayer(config.GUIDED_ATTENTION) for _ in range(config.LAYERS)])
 
+    def _kv_modules(self):
+        return [layer.guided_mhatt.attention for layer in self.guided_attn_layers]
+
+    def _ovqa_param_groups(self):
+        """Arena adjacency: [K_0 V_0 K_1 V_1 ...] of the guided attentions, so that one GEMM projects the
+        question features for all layers (functional.kv_project_all)."""
+        att = self._kv_modules()
+        if not all(type(a) is ScaledDotProductAttention for a in att):
+            return []
+        return [[w for a in att for w in (a.fc_k.weight, a.fc_v.weight)],
+                [b for a in att for b in (a.fc_k.bias, a.fc_v.bias)]]
+
+    def _hoisted_kv(self, lang):
+        att = self._kv_modules()
+        if len(att) < 2 or not all(type(a) is ScaledDotProductAttention for a in att):
+            return None
+        if any(l.guided_mhatt.can_be_stateful and l.guided_mhatt._is_stateful for l in self.guided_attn_layers):
+            return None
+        if lang.shape[-1] != att[0].fc_k.weight.shape[1] or lang.dim() != 3:
+            return None
+        return Fn.kv_project_all(lang, att, rt.ensure_arena(self))
+
     def forward(self, vision_features: torch.Tensor, vision_padding_mask: torch.Tensor,
                 language_features: torch.Tensor, language_padding_mask: torch.Tensor):
         out = self._prologue(self.layer_norm, vision_features)
         lang = language_features.to(out.dtype)
+        # every layer attends to the same question features: project K/V for all layers in one GEMM
+        kv_all = self._hoisted_kv(lang)
+        shared = {}
+        if kv_all is not None:
+            kv_all = rt.grad_milestone(kv_all, barrier=True)
+        else:
+            lang = rt.grad_milestone(lang, barrier=True)
         for i, layer in enumerate(self.guided_attn_layers):
             if i:
                 out = rt.grad_milestone(out)
             out = layer(queries=out, keys=lang, values=lang, self_attention_mask=vision_padding_mask,
+                        projected_kv=None if kv_all is None else (kv_all, i, shared),
                         guided_attention_mask=language_padding_mask)
         return out.to(vision_features.dtype)
 

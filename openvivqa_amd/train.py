@@ -167,6 +167,21 @@ class _Cuts:
         return leaf
 
 
+def _reaches(start_fn, target_fn) -> bool:
+    """True if autograd node ``target_fn`` is an ancestor of (is reachable through next_functions from)
+    ``start_fn``."""
+    seen, stack = set(), [start_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is target_fn:
+            return True
+        if fn is None or id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        stack.extend(f for f, _ in fn.next_functions if f is not None)
+    return False
+
+
 def _merge(spans, gap=0):
     out = []
     for s, e in sorted(spans):
@@ -256,8 +271,19 @@ class TrainStep:
                 outs, grads = [res], [torch.ones_like(res)]
                 self.loss.copy_(res.detach().float().reshape(1))
             srcs = {id(src) for src, _ in cuts}
+            # an output that later sections were computed FROM (MCAN returns the question features the guided
+            # stack attends to) must wait for their gradient: it joins the phase of the earliest cut below it
+            extra = {}
+            for o, g in zip(outs, grads):
+                if id(o) in srcs or o.grad_fn is None:
+                    continue
+                for k, (src, _) in enumerate(cuts):
+                    if src.grad_fn is not None and _reaches(src.grad_fn, o.grad_fn):
+                        extra.setdefault(k, []).append((o, g))
+                        srcs.add(id(o))
+                        break
             now = [(o, g) for o, g in zip(outs, grads) if id(o) not in srcs]
-            self._live = {"cuts": cuts, "outs": outs, "grads": grads}
+            self._live = {"cuts": cuts, "outs": outs, "grads": grads, "extra": extra}
             if now:
                 torch.autograd.backward([o for o, _ in now], [g for _, g in now])
 
@@ -269,8 +295,12 @@ class TrainStep:
                 for o, og in zip(live["outs"], live["grads"]):  # an output that is itself a cut source
                     if o is src:
                         g = og if g is None else g + og
-                if g is not None:
-                    torch.autograd.backward([src], [g])
+                roots, rgrads = ([src], [g]) if g is not None else ([], [])
+                for o, og in live["extra"].get(k, []):
+                    roots.append(o)
+                    rgrads.append(og)
+                if roots:
+                    torch.autograd.backward(roots, rgrads)
                 if k == 0:
                     self._live = None
             return run
