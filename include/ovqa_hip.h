@@ -240,6 +240,20 @@ int ovqa_increment_step(uint32_t* step_ptr, void* stream);
 /* fp32 -> bf16 / bf16 -> fp32 flat casts (shadow refresh after load_state_dict). */
 int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Embedding step in front of the path ("next" row 2):
+ *   FeatureEmbedding = dropout(gelu(proj(x))) + zero-row padding mask   vision_embeddings.py:10-25
+ *   forward is ovqa_linear_fwd(OVQA_EPI_BIAS_GELU, preact = u); its backward needs
+ *   du[i] = dy[i] * keep(i)/(1-p) * gelu'(u[i])  (flat index i, same dropout site as the forward), after
+ *   which dW/db/dx are ovqa_linear_bwd_weight / ovqa_linear_bwd_data on du.
+ *   ovqa_row_padding_mask: mask[m] = (sum_d x[m,d] == pad_value*D) ? -1e5 : 0, fp32 [M]  (models/utils.py:44-58,
+ *   generate_padding_mask on feature tensors) in one pass over x.
+ * ------------------------------------------------------------------------- */
+int ovqa_gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n,
+                  const ovqa_dropout* drop, void* stream);
+int ovqa_row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D, float pad_value,
+                          void* stream);
+
 /* Materialise the dropout keep-mask the fused kernels use (tests, debugging):
  * out[i] = 1 if element i of a [rows, cols] site is kept. */
 int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream);

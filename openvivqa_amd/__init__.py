@@ -11,5 +11,7 @@ from .builders import (META_ATTENTION, META_DECODER, META_ENCODER, build_attenti
 from .config import ConfigNode, attention_config, get_config  # noqa: F401
 from .runtime import (get_compute_dtype, manual_seed, prepare, set_compute_dtype)  # noqa: F401
 from . import modules  # noqa: F401  (registration)
+from . import models  # noqa: F401  (registration)
+from .builders import META_ARCHITECTURE, build_model  # noqa: F401
 
 __version__ = "0.1.0"

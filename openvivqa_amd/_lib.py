@@ -65,6 +65,8 @@ SIGNATURES = {
     "ovqa_adam_step": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
     "ovqa_increment_step": [c_vp, c_vp],
     "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],
+    "ovqa_gelu_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, _DP, c_vp],
+    "ovqa_row_padding_mask": [c_int, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
     "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
     "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }

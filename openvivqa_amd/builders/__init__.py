@@ -10,9 +10,10 @@ from .encoder_builder import META_ENCODER, build_encoder
 from .decoder_builder import META_DECODER, build_decoder
 from .text_embedding_builder import META_TEXT_EMBEDDING, build_text_embedding
 from .vision_embedding_builder import META_VISION_EMBEDDING, build_vision_embedding
+from .model_builder import META_ARCHITECTURE, build_model
 
 __all__ = [
     "Registry", "META_ATTENTION", "build_attention", "META_ENCODER", "build_encoder",
     "META_DECODER", "build_decoder", "META_TEXT_EMBEDDING", "build_text_embedding",
-    "META_VISION_EMBEDDING", "build_vision_embedding",
+    "META_VISION_EMBEDDING", "build_vision_embedding", "META_ARCHITECTURE", "build_model",
 ]

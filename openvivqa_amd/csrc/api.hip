@@ -220,6 +220,21 @@ int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t 
   return ovqa::cast(src_dtype, dst_dtype, src, dst, n, as_stream(stream));
 }
 
+int ovqa_gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, const ovqa_dropout* drop,
+                  void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "gelu_bwd: bad dtype");
+  OVQA_REQUIRE(n >= 0 && (n == 0 || (dy && u && du)), OVQA_ERR_BAD_ARG, "gelu_bwd: null pointer or bad n");
+  return ovqa::gelu_bwd(dtype, dy, u, du, n, make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D, float pad_value,
+                          void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "row_padding_mask: bad dtype");
+  OVQA_REQUIRE(M >= 0 && D > 0 && D < (1 << 30) && (M == 0 || (x && mask)), OVQA_ERR_BAD_ARG,
+               "row_padding_mask: bad sizes or null pointer");
+  return ovqa::row_padding_mask(dtype, x, mask, M, D, pad_value, as_stream(stream));
+}
+
 int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream) {
   OVQA_REQUIRE(drop && out && n >= 0, OVQA_ERR_BAD_ARG, "dropout_keep_mask: bad argument");
   OVQA_REQUIRE(n < (1ll << 32), OVQA_ERR_UNSUPPORTED, "dropout_keep_mask: more than 2^32 elements");

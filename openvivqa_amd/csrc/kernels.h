@@ -73,6 +73,8 @@ int adam_step(float* param, const float* grad, float* m, float* v, void* shadow,
 int increment_step(uint32_t* step_ptr, hipStream_t st);
 int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st);
 int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st);
+int gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, const DropArgs& da, hipStream_t st);
+int row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D, float pad_value, hipStream_t st);
 int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                     int accumulate_loss, hipStream_t st);
 

@@ -92,6 +92,44 @@ __global__ __launch_bounds__(256) void cast_vec8_kernel(const TS* __restrict__ s
   for (int64_t i = (n8 << 3) + tid; i < n; i += stride) dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
 }
 
+// du = dy * keep/(1-p) * gelu'(u): gradient through dropout(gelu(u)) of a bias+GELU linear whose output is NOT
+// followed by a second fused GEMM (FeatureEmbedding).  8 elements per lane; dropout index = flat element index,
+// as in the forward epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
+                                                       T* __restrict__ du, int64_t n, DropArgs da) {
+  typedef __attribute__((ext_vector_type(8))) T v8;
+  const DropState ds = drop_init(da);
+  const int64_t n8 = n >> 3;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = tid; i < n8; i += stride) {
+    const v8 g = reinterpret_cast<const v8*>(dy)[i];
+    const v8 x = reinterpret_cast<const v8*>(u)[i];
+    v8 o;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      o[k] = from_f32<T>(to_f32<T>(g[k]) * drop_mul(ds, (uint32_t)(i * 8 + k)) * gelu_grad_f(to_f32<T>(x[k])));
+    reinterpret_cast<v8*>(du)[i] = o;
+  }
+  for (int64_t i = (n8 << 3) + tid; i < n; i += stride)
+    du[i] = from_f32<T>(to_f32<T>(dy[i]) * drop_mul(ds, (uint32_t)i) * gelu_grad_f(to_f32<T>(u[i])));
+}
+
+// mask[m] = (sum_d x[m, d] == pad_value * D) ? -1e5 : 0   (models/utils.py:44-58): one wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void row_padding_mask_kernel(const T* __restrict__ x, float* __restrict__ mask,
+                                                               int64_t M, int D, float pad_total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* p = x + row * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += to_f32<T>(p[d]);
+  s = wave_sum(s);
+  if (lane == 0) mask[row] = (s == pad_total) ? -100000.0f : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __restrict__ out, int64_t n) {
   const DropState ds = drop_init(da);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -172,6 +210,30 @@ int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hi
     return OVQA_ERR_BAD_ARG;
   }
   return ovqa_check_launch("cast");
+}
+
+int gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, const DropArgs& da, hipStream_t st) {
+  if (n == 0) return OVQA_OK;
+  OVQA_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)u % 16 == 0) && ((uintptr_t)du % 16 == 0), OVQA_ERR_BAD_ARG,
+               "gelu_bwd: pointers must be 16-byte aligned");
+  OVQA_REQUIRE(n < (1ll << 32), OVQA_ERR_UNSUPPORTED, "gelu_bwd: more than 2^32 elements");
+  dim3 grid(blocks_for((n + 7) / 8)), block(256);
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, grid, block, 0, st, (const bf16*)dy, (const bf16*)u, (bf16*)du, n, da);
+  else
+    hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)u, (float*)du, n, da);
+  return ovqa_check_launch("gelu_bwd");
+}
+
+int row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D, float pad_value, hipStream_t st) {
+  if (M == 0) return OVQA_OK;
+  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  const float total = pad_value * (float)D;
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(row_padding_mask_kernel<bf16>, grid, block, 0, st, (const bf16*)x, mask, M, (int)D, total);
+  else
+    hipLaunchKernelGGL(row_padding_mask_kernel<float>, grid, block, 0, st, (const float*)x, mask, M, (int)D, total);
+  return ovqa_check_launch("row_padding_mask");
 }
 
 int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st) {

@@ -365,6 +365,39 @@ class _Linear(Function):
         return dx, None, *([None] * len(st["params"]))
 
 
+class _LinearGeluDrop(Function):
+    """dropout(gelu(lin(x))): FeatureEmbedding (vision_embeddings.py:20-23).  Forward is one GEMM with the fused
+    bias+GELU+dropout epilogue; backward regenerates the dropout mask and applies gelu' elementwise."""
+
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        arena, lin = st["arena"], st["lin"]
+        x = _c(x)
+        y, u = ops.linear_fwd(x, arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_GELU,
+                              want_preact=True, drop=st["drop"])
+        ctx.st = st
+        ctx.save_for_backward(x, u)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena, lin = st["arena"], st["lin"]
+        x, u = ctx.saved_tensors
+        du = ops.gelu_bwd(_c(dy).reshape(u.shape), u, drop=st["drop"])
+        _wgrad(arena, du, x.reshape(-1, x.shape[-1]), [lin.weight], [lin.bias])
+        dx = ops.linear_bwd_data(du, arena.compute(lin.weight)).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, None, *([None] * len(st["params"]))
+
+
+def linear_gelu_dropout(x, lin, arena, drop):
+    params = [lin.weight, lin.bias]
+    st = dict(arena=arena, lin=lin, params=params, drop=drop)
+    if torch.is_grad_enabled():
+        return _LinearGeluDrop.apply(x, st, *params)
+    return ops.linear_fwd(_c(x), arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_GELU, drop=drop)
+
+
 def linear(x, lin, arena):
     """y = lin(x) through the HIP GEMM (x is cast to the arena's compute dtype by the caller)."""
     params = [lin.weight] + ([lin.bias] if lin.bias is not None else [])

@@ -5,7 +5,7 @@ from .attentions import MultiHeadAttention, ScaledDotProductAttention
 from .positionwise_feed_forward import PositionWiseFeedForward
 from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEncoderLayer, Encoder, EncoderLayer,
                        GuidedAttentionEncoder, GuidedEncoderLayer)
-from .embeddings import FeatureEmbedding, UsualEmbedding
+from .embeddings import FeatureEmbedding, LSTMTextEmbedding, UsualEmbedding
 from .decoders import Decoder, DecoderLayer
 from .pointer import DynamicPointerNetwork, OcrPtrNet
 
@@ -13,5 +13,5 @@ __all__ = [
     "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
     "ScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
     "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
-    "FeatureEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet",
+    "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet",
 ]

@@ -8,9 +8,9 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .. import functional as Fn
 from .. import ops
 from .. import runtime as rt
-from .._lib import EPI_BIAS_GELU
 from ..builders.text_embedding_builder import META_TEXT_EMBEDDING
 from ..builders.vision_embedding_builder import META_VISION_EMBEDDING
 from ..utils import generate_padding_mask, generate_sequential_mask
@@ -26,16 +26,16 @@ class FeatureEmbedding(nn.Module):
         self._site = rt.new_dropout_site()
 
     def forward(self, features):
-        """Inference/feature-extraction form: GEMM with fused bias+GELU+dropout epilogue.
-        (No autograd through this module yet: it sits before the hot path.)"""
-        masks = generate_padding_mask(features, padding_idx=0).to(features.device)
+        """One pass over the features for the zero-row padding mask (models/utils.py:44-58), one GEMM with the
+        fused bias+GELU+dropout epilogue; differentiable (weights, bias and, if required, the features)."""
         arena = rt.ensure_arena(self)
+        if features.dim() == 3:
+            masks = ops.row_padding_mask(features.contiguous(), 0.0)
+        else:  # other ranks: the generic torch helper
+            masks = generate_padding_mask(features, padding_idx=0).to(features.device)
         x = features.to(arena.compute_dtype).contiguous()
         drop = rt.dropout_spec(self.dropout.p, self._site, self.training, x.device)
-        with torch.no_grad():
-            y = ops.linear_fwd(x, arena.compute(self.proj.weight), arena.master_of(self.proj.bias), EPI_BIAS_GELU,
-                               drop=drop)
-        return y, masks
+        return Fn.linear_gelu_dropout(x, self.proj, arena, drop), masks
 
 
 @META_TEXT_EMBEDDING.register()
@@ -51,3 +51,34 @@ class UsualEmbedding(nn.Module):
         padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
         sequential_masks = generate_sequential_mask(tokens.shape[-1]).to(tokens.device)
         return self.components(tokens), (padding_masks, sequential_masks)
+
+
+@META_TEXT_EMBEDDING.register()
+class LSTMTextEmbedding(nn.Module):
+    """Embedding -> Linear -> dropout -> LSTM (text_embeddings.py:222-246).  It sits in front of the hot path:
+    the projection goes through the HIP GEMM, the recurrent part is torch's LSTM (MIOpen on ROCm) -- plumbing,
+    not a kernel of this package."""
+
+    def __init__(self, config, vocab):
+        super().__init__()
+        self.embedding = nn.Embedding(len(vocab), config.D_EMBEDDING, padding_idx=vocab.padding_idx)
+        self.padding_idx = vocab.padding_idx
+        if config.WORD_EMBEDDING is not None:
+            raise NotImplementedError("pretrained word vectors are a data-loading feature outside the hot path")
+        self.proj = nn.Linear(config.D_EMBEDDING, config.D_MODEL)
+        self.dropout = nn.Dropout(config.DROPOUT)
+        self.lstm = nn.LSTM(input_size=config.D_MODEL, hidden_size=config.D_MODEL, batch_first=True)
+
+    def forward(self, tokens):
+        padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
+        sequential_masks = generate_sequential_mask(tokens.shape[-1]).to(tokens.device)
+        arena = rt.ensure_arena(self)
+        x = self.embedding(tokens).to(arena.compute_dtype)
+        x = self.dropout(Fn.linear(x, self.proj, arena)).float()
+        if not self.training and torch.is_grad_enabled() and x.is_cuda:
+            # MIOpen's fused RNN refuses backward in eval mode; the native kernels do not
+            with torch.backends.cudnn.flags(enabled=False):
+                x, _ = self.lstm(x)
+        else:
+            x, _ = self.lstm(x)
+        return x, (padding_masks, sequential_masks)

@@ -475,6 +475,27 @@ def cast(src, dst):
     return dst
 
 
+def gelu_bwd(dy, u, drop=None):
+    """dy * dropout_mask/(1-p) * gelu'(u) (flat dropout index, the forward epilogue's site)."""
+    _dev(dy)
+    assert dy.is_contiguous() and u.is_contiguous() and dy.dtype == u.dtype and dy.numel() == u.numel()
+    du = torch.empty_like(dy)
+    _lib.check(_lib.load().ovqa_gelu_bwd(_dt(dy), _p(dy), _p(u), _p(du), dy.numel(), _drop(drop), _stream()),
+               "gelu_bwd")
+    return du
+
+
+def row_padding_mask(x, pad_value=0.0):
+    """(B, 1, 1, N) additive fp32 mask of the rows of x [B, N, D] whose features sum to pad_value * D."""
+    _dev(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    B, N, D = x.shape
+    mask = torch.empty(B, 1, 1, N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ovqa_row_padding_mask(_dt(x), _p(x), _p(mask), B * N, D, float(pad_value), _stream()),
+               "row_padding_mask")
+    return mask
+
+
 def dropout_keep_mask(drop: DropSpec, n: int, device) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.uint8, device=device)
     _dev(out)

@@ -27,7 +27,8 @@ __all__ = [
     "OracleEncoder", "OracleGuidedAttentionEncoder", "OracleCoAttentionEncoder",
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
     "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
-    "OracleFeatureEmbedding", "noam_lambda", "oracle_train_step", "build_oracle_encoder",
+    "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "OracleMLP", "OracleMCAN",
+    "noam_lambda", "oracle_train_step", "build_oracle_encoder",
 ]
 
 
@@ -498,6 +499,73 @@ class OracleFeatureEmbedding(nn.Module):
 
     def forward(self, features):
         return self.dropout(self.gelu(self.proj(features))), padding_mask(features, 0)
+
+
+class OracleLSTMTextEmbedding(nn.Module):
+    """Embedding -> Linear -> dropout -> LSTM, plus (padding, sequential) masks.
+    models/modules/text_embeddings.py:222-246 (WORD_EMBEDDING: null form)."""
+
+    def __init__(self, cfg, vocab):
+        super().__init__()
+        self.embedding = nn.Embedding(len(vocab), cfg.D_EMBEDDING, padding_idx=vocab.padding_idx)
+        self.padding_idx = vocab.padding_idx
+        self.proj = nn.Linear(cfg.D_EMBEDDING, cfg.D_MODEL)
+        self.dropout = nn.Dropout(cfg.DROPOUT)
+        self.lstm = nn.LSTM(input_size=cfg.D_MODEL, hidden_size=cfg.D_MODEL, batch_first=True)
+
+    def forward(self, tokens):
+        pad = padding_mask(tokens, self.padding_idx)
+        seq = sequential_mask(tokens.shape[-1])
+        x = self.dropout(self.proj(self.embedding(tokens)))
+        x, _ = self.lstm(x)
+        return x, (pad, seq)
+
+
+class OracleMLP(nn.Module):
+    """Attention-pooling scorer of MCAN: fc2(dropout(relu(fc1 x))) -> one logit per position.  models/mcan.py:12-25."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.fc1 = nn.Linear(cfg.D_MODEL, cfg.D_MODEL)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(cfg.DROPOUT)
+        self.fc2 = nn.Linear(cfg.D_MODEL, 1)
+
+    def forward(self, x):
+        return self.fc2(self.dropout(self.relu(self.fc1(x))))
+
+
+class OracleMCAN(nn.Module):
+    """models/mcan.py:27-81: embeddings -> SA stack -> guided stack -> softmax attention pooling over each sequence
+    (dim=1, padded positions included, as the reference) -> LN(proj_v + proj_t) -> classifier -> log_softmax."""
+
+    def __init__(self, cfg, vocab):
+        super().__init__()
+        self.d_model = cfg.D_MODEL
+        self.text_embedding = {"LSTMTextEmbedding": OracleLSTMTextEmbedding,
+                               "UsualEmbedding": OracleUsualEmbedding}[cfg.TEXT_EMBEDDING.ARCHITECTURE](
+            cfg.TEXT_EMBEDDING, vocab)
+        self.vision_embedding = OracleFeatureEmbedding(cfg.VISION_EMBEDDING)
+        self.self_encoder = build_oracle_encoder(cfg.SELF_ENCODER)
+        self.guided_encoder = build_oracle_encoder(cfg.GUIDED_ENCODER)
+        self.vision_attr_reduce = OracleMLP(cfg.VISION_ATTR_REDUCE)
+        self.text_attr_reduce = OracleMLP(cfg.TEXT_ATTR_REDUCE)
+        self.vision_proj = nn.Linear(cfg.D_MODEL, cfg.D_MODEL)
+        self.text_proj = nn.Linear(cfg.D_MODEL, cfg.D_MODEL)
+        self.layer_norm = nn.LayerNorm(cfg.D_MODEL)
+        self.classify = nn.Linear(cfg.D_MODEL, vocab.total_answers)
+
+    def forward(self, input_features):
+        v, vmask = self.vision_embedding(input_features.region_features)
+        t, (tmask, _) = self.text_embedding(input_features.question_tokens)
+        t = self.self_encoder(features=t, padding_mask=tmask)
+        v = self.guided_encoder(vision_features=v, vision_padding_mask=vmask, language_features=t,
+                                language_padding_mask=tmask)
+        av = torch.softmax(self.vision_attr_reduce(v), dim=1)
+        at = torch.softmax(self.text_attr_reduce(t), dim=1)
+        wv, wt = (v * av).sum(dim=1), (t * at).sum(dim=1)
+        out = self.layer_norm(self.vision_proj(wv) + self.text_proj(wt))
+        return torch.log_softmax(self.classify(out), dim=-1)
 
 
 # --------------------------------------------------------------------------

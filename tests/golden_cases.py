@@ -29,6 +29,16 @@ class FakeVocab:
         return 11
 
 
+class ModelVocab:
+    padding_idx = 0
+
+    def __init__(self, n_tokens, total_answers):
+        self.n_tokens, self.total_answers = n_tokens, total_answers
+
+    def __len__(self):
+        return self.n_tokens
+
+
 def load_case(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
     groups = {"in": {}, "w": {}, "out": {}, "lw": {}, "gin": {}, "gw": {}}
@@ -49,7 +59,7 @@ def oracle_namespace():
         Encoder=O.OracleEncoder, GuidedAttentionEncoder=O.OracleGuidedAttentionEncoder,
         CoAttentionEncoder=O.OracleCoAttentionEncoder, CrossModalityEncoder=O.OracleCrossModalityEncoder,
         DecoderLayer=O.OracleDecoderLayer, Decoder=O.OracleDecoder, OcrPtrNet=O.OracleOcrPtrNet,
-        DynamicPointerNetwork=O.OracleDynamicPointerNetwork)
+        DynamicPointerNetwork=O.OracleDynamicPointerNetwork, MCAN=O.OracleMCAN)
 
 
 def hip_namespace():
@@ -60,7 +70,12 @@ def hip_namespace():
         CrossModalityEncoderLayer=M.CrossModalityEncoderLayer, Encoder=M.Encoder,
         GuidedAttentionEncoder=M.GuidedAttentionEncoder, CoAttentionEncoder=M.CoAttentionEncoder,
         CrossModalityEncoder=M.CrossModalityEncoder, DecoderLayer=M.DecoderLayer, Decoder=M.Decoder,
-        OcrPtrNet=M.OcrPtrNet, DynamicPointerNetwork=M.DynamicPointerNetwork)
+        OcrPtrNet=M.OcrPtrNet, DynamicPointerNetwork=M.DynamicPointerNetwork, MCAN=_hip_mcan())
+
+
+def _hip_mcan():
+    from openvivqa_amd.models import MCAN
+    return MCAN
 
 
 def _cfg(case):
@@ -130,6 +145,9 @@ CASES = {
     "G8_ocrptr": (lambda ns, c: ns.OcrPtrNet(c.meta["hidden"]),
                   lambda m, i: {"s3": m(i["q3"], i["k"], i["mask"]), "s2": m(i["q2"], i["k"], i["mask"])},
                   ["q3", "q2", "k"]),
+    "G12_mcan_model": (lambda ns, c: ns.MCAN(_cfg(c), ModelVocab(c.meta["vocab_len"], c.meta["total_answers"])),
+                       lambda m, i: {"logp": m(SimpleNamespace(region_features=i["regions"],
+                                                               question_tokens=i["tokens"]))}, ["regions"]),
     "G8_dynptr_query_axis": (lambda ns, c: ns.DynamicPointerNetwork(ConfigNode(dict(D_MODEL=c.meta["d_model"])),
                                                                     axis="query"),
                              lambda m, i: {"scores": m(i["q"], i["k"], i["qmask"])}, ["q", "k"]),

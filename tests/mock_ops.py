@@ -226,3 +226,16 @@ def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False, target=None):
     else:
         loss.fill_(float(v))
     return (2 * x.float() / x.numel()).to(x.dtype) if want_grad else None
+
+
+def gelu_bwd(dy, u, drop=None):
+    assert drop is None or drop.p == 0
+    uf = u.float()
+    cdf = 0.5 * (1 + torch.erf(uf * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * uf * uf) * 0.3989422804014327
+    return (dy.float() * (cdf + uf * pdf)).to(dy.dtype)
+
+
+def row_padding_mask(x, pad_value=0.0):
+    B, N, D = x.shape
+    return ((x.float().sum(-1) == pad_value * D).float() * -10e4).reshape(B, 1, 1, N)

@@ -86,6 +86,53 @@ def test_block_prologue(mode):
     _compare("prologue", mode, o, h, lambda m, i: m(i["x"], i["mask"]), {"x": v, "mask": vm}, ["x"])
 
 
+def test_feature_embedding(mode):
+    """"next" row 2: FeatureEmbedding (Linear 1024->512 + GELU + dropout, zero-row padding mask) forward, mask,
+    input and weight gradients vs the oracle at the MCAN region-feature size."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    cfg = ConfigNode(dict(D_FEATURE=1024, D_MODEL=512, DROPOUT=0.1))
+    torch.manual_seed(2)
+    o, h = O.OracleFeatureEmbedding(cfg), M.FeatureEmbedding(cfg)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 100, 1024, generator=g)
+    x[1, 90:] = 0
+    x[3, 37:] = 0
+    _compare("feature_embedding", mode, o, h, lambda m, i: m(i["x"])[0], {"x": x}, ["x"])
+    mo, mh = o(x)[1], h.to(DEV)(x.to(DEV))[1]
+    assert mh.shape == mo.shape == (4, 1, 1, 100) and torch.equal(mh.cpu(), mo.float())
+
+
+def test_feature_embedding_train_dropout_consistent():
+    """Train mode (fp32): the backward regenerates the forward's dropout mask -- finite differences agree."""
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    A.set_compute_dtype(F32)
+    try:
+        torch.manual_seed(3)
+        m = M.FeatureEmbedding(ConfigNode(dict(D_FEATURE=64, D_MODEL=32, DROPOUT=0.3))).to(DEV).train()
+        x = torch.randn(2, 5, 64, device=DEV, requires_grad=True)
+        w = torch.randn(2, 5, 32, device=DEV)
+
+        def f(inp):
+            A.manual_seed(77)
+            return (m(inp)[0] * w).sum()
+        f(x).backward()
+        g = x.grad.clone()
+        assert float((m(x)[0] == 0).float().mean()) > 0.15  # dropout is really on
+        for idx in [(0, 0, 0), (1, 3, 7), (0, 4, 63)]:
+            xp, xm = x.detach().clone(), x.detach().clone()
+            xp[idx] += 1e-2
+            xm[idx] -= 1e-2
+            with torch.no_grad():
+                fd = (f(xp) - f(xm)).item() / 2e-2
+            assert abs(fd - g[idx].item()) < 2e-2 * max(1.0, abs(fd)), (idx, fd, g[idx].item())
+    finally:
+        A.set_compute_dtype(BF16)
+
+
 @pytest.mark.parametrize("kind", ["self", "cross", "general"])
 def test_block_mha(mode, kind):
     import oracle as O

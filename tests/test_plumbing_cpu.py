@@ -188,3 +188,26 @@ def test_train_step_harness_matches_reference_trajectory():
             continue
         _close(v, case.out["w2/" + k], 5e-5, "post-step " + k)
     _close(head.weight, case.out["w2/head.weight"], 5e-5, "head")
+
+
+def test_feature_embedding_plumbing_vs_oracle():
+    """FeatureEmbedding's autograd plumbing (fused GELU forward, gelu' backward, mask) against the oracle."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    cfg = ConfigNode(dict(D_FEATURE=48, D_MODEL=32, DROPOUT=0.1))
+    torch.manual_seed(0)
+    o, h = O.OracleFeatureEmbedding(cfg).eval(), M.FeatureEmbedding(cfg).eval()
+    h.load_state_dict(o.state_dict())
+    x = torch.randn(3, 7, 48)
+    x[1, 4:] = 0
+    xo, xh = x.clone().requires_grad_(), x.clone().requires_grad_()
+    (yo, mo), (yh, mh) = o(xo), h(xh)
+    _close(yh, yo, 1e-5, "features")
+    assert torch.equal(mh, mo.float())
+    w = torch.randn_like(yo)
+    (yo * w).sum().backward()
+    (yh * w).sum().backward()
+    _close(xh.grad, xo.grad, 1e-5, "dx")
+    _close(h.proj.weight.grad, o.proj.weight.grad, 1e-5, "dW")
+    _close(h.proj.bias.grad, o.proj.bias.grad, 1e-5, "db")
