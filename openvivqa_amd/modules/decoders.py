@@ -60,7 +60,7 @@ class Decoder(Module):
         b_s, seq_len = answer_tokens.shape
         dev = answer_tokens.device
         pad_mask = generate_padding_mask(answer_tokens, self.padding_idx).to(dev)
-        self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len).to(dev))
+        self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len, device=dev))
         if self._is_stateful:  # decoders.py:55-57
             self.running_mask_self_attention = torch.cat([self.running_mask_self_attention, self_mask], -1)
             self_mask = self.running_mask_self_attention

@@ -49,7 +49,7 @@ class UsualEmbedding(nn.Module):
 
     def forward(self, tokens):
         padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
-        sequential_masks = generate_sequential_mask(tokens.shape[-1]).to(tokens.device)
+        sequential_masks = generate_sequential_mask(tokens.shape[-1], device=tokens.device)
         return self.components(tokens), (padding_masks, sequential_masks)
 
 
@@ -71,7 +71,7 @@ class LSTMTextEmbedding(nn.Module):
 
     def forward(self, tokens):
         padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
-        sequential_masks = generate_sequential_mask(tokens.shape[-1]).to(tokens.device)
+        sequential_masks = generate_sequential_mask(tokens.shape[-1], device=tokens.device)
         arena = rt.ensure_arena(self)
         x = self.embedding(tokens).to(arena.compute_dtype)
         x = self.dropout(Fn.linear(x, self.proj, arena)).float()

@@ -23,9 +23,10 @@ def generate_padding_mask(sequences: Optional[torch.Tensor], padding_idx: int) -
     return (is_pad.long() * MASK_VALUE).unsqueeze(1).unsqueeze(1)
 
 
-def generate_sequential_mask(seq_len: int) -> torch.Tensor:
-    """(1,1,T,T) causal additive mask.  models/utils.py:59-66."""
-    return (torch.triu(torch.ones(seq_len, seq_len), diagonal=1) * MASK_VALUE).unsqueeze(0).unsqueeze(0)
+def generate_sequential_mask(seq_len: int, device=None) -> torch.Tensor:
+    """(1,1,T,T) causal additive mask.  models/utils.py:59-66.  ``device`` (an addition): build it where it
+    is used -- a host tensor + copy is not capturable into a hipGraph."""
+    return (torch.triu(torch.ones(seq_len, seq_len, device=device), diagonal=1) * MASK_VALUE).unsqueeze(0).unsqueeze(0)
 
 
 def generate_self_attention_masks(padding_masks: torch.Tensor, sequential_masks: torch.Tensor) -> torch.Tensor:

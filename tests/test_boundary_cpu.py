@@ -18,6 +18,7 @@ import openvivqa_amd as A
 from openvivqa_amd import _lib
 from openvivqa_amd.builders import Registry
 from openvivqa_amd.config import ConfigNode, attention_config, get_config
+from golden_cases import load_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
@@ -89,6 +90,20 @@ def test_reference_yamls_load_verbatim():
     assert dec.fc.weight.shape == (100, 512) and len(dec.layers) == gen.DECODER.LAYERS
     for name in ("mmf_m4c.yaml", "saaa.yaml"):
         assert "MODEL" in get_config(os.path.join(REF, "configs", name))
+    # the whole MCAN model resolves through build_model from the unmodified YAML (only DEVICE is overridden)
+    mcan_model_cfg = get_config(os.path.join(REF, "configs", "mcan.yaml")).MODEL
+    mcan_model_cfg["DEVICE"] = "cpu"
+
+    class ClsVocab:
+        padding_idx, total_answers = 0, 353
+
+        def __len__(self):
+            return 4000
+    model = A.build_model(mcan_model_cfg, ClsVocab())
+    keys = set(model.state_dict())
+    golden = set(load_case("G12_mcan_model").w)  # the reference model's own state_dict keys (L=2 there, 3 here)
+    assert {k for k in keys if ".2." not in k} == golden
+    assert model.classify.weight.shape == (353, 512) and model.vision_embedding.proj.weight.shape == (512, 1024)
 
 
 def test_product_state_dicts_match_manifest():

@@ -101,3 +101,65 @@ def test_graph_replay_equals_eager_steps():
     torch.cuda.synchronize()
     assert _rel(a.arena.grad, b.arena.grad) <= 5e-3
     assert abs(float(a.loss) - float(b.loss)) <= 1e-4 * abs(float(b.loss))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_mcan_model_two_training_steps_match_oracle(use_graph):
+    """Whole MCAN model (embeddings + both stacks + pooling head + classifier, weights and inputs of golden G12,
+    which came from the reference's own models/mcan.py) trained for two steps by the product's TrainStep in fp32
+    mode: losses and post-step weights follow the oracle's torch.optim.Adam trajectory (row T at model level).
+    LSTM / embedding / head parameters get their gradients from torch, the stacks from the HIP kernels: both
+    kinds live in the same flat arena."""
+    import oracle as O
+    import openvivqa_amd as A
+    from types import SimpleNamespace
+    from golden_cases import ModelVocab, load_case
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.models import MCAN
+    from openvivqa_amd.train import TrainStep
+    case = load_case("G12_mcan_model")
+    cfg = ConfigNode(case.meta["cfg"])
+    vocab = ModelVocab(case.meta["vocab_len"], case.meta["total_answers"])
+    y = torch.tensor([1, 4, 6])
+    nll = torch.nn.NLLLoss()
+    ref = O.OracleMCAN(cfg, vocab)
+    ref.load_state_dict(case.w)
+    ref.eval()  # dropout off on both sides; LSTM on CPU is fine in eval mode
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    inp = SimpleNamespace(region_features=case.inputs["regions"], question_tokens=case.inputs["tokens"])
+    ref_losses = [O.oracle_train_step(None, lambda: nll(ref(inp), y), opt) for _ in range(2)]
+
+    A.set_compute_dtype(torch.float32)
+    try:
+        dev = torch.device("cuda", 0)
+        m = MCAN(cfg, vocab)
+        m.load_state_dict(case.w)
+        m = m.to(dev).train()
+        for mod in m.modules():  # train mode (MIOpen LSTM backward needs it), dropout off
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        yd = y.to(dev)
+
+        def forward_loss(regions, tokens):
+            return nll(m(SimpleNamespace(region_features=regions, question_tokens=tokens)), yd)
+        ts = TrainStep(m, forward_loss, lr=1e-3, betas=(0.9, 0.98), use_graph=use_graph,
+                       compute_dtype=torch.float32)
+        batch = (case.inputs["regions"].to(dev), case.inputs["tokens"].to(dev))
+        losses = [float(ts.step(*batch)) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        A.set_compute_dtype(torch.bfloat16)
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-4, (losses, ref_losses)
+    sd = m.state_dict()
+    num = den = 0.0
+    for k, v in ref.state_dict().items():
+        if k.endswith("fc_k.bias") or k.endswith("attr_reduce.fc2.bias"):
+            continue  # analytically zero gradients: Adam turns rounding noise into +-lr steps
+        d = (sd[k].cpu().double() - v.double()).abs()
+        # Adam normalises every element's step to ~lr, so an element whose gradient is itself rounding noise
+        # (dead ReLU units of the pooling MLP) may differ by a fraction of the 2 x lr it can move at most
+        assert d.max().item() < 1e-3, (k, d.max().item())
+        upd = v.double() - case.w[k].double()
+        num += ((sd[k].cpu().double() - case.w[k].double()) - upd).pow(2).sum().item()
+        den += upd.pow(2).sum().item()
+    assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5  # the two-step update as a whole
