@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
                          "single-rank group")
+    ap.add_argument("--workload", default="stack", choices=["stack", "model"],
+                    help="stack = BASELINE's metric (the two encoder stacks, default); model = SECONDARY diagnostic: "
+                         "the whole MCAN model (FeatureEmbedding + LSTM text embedding + stacks + pooling head + "
+                         "classifier + NLLLoss) on synthetic region features / token ids (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
@@ -248,21 +252,49 @@ def main():
         dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
         return (vo, lo), (dvo, dlo)
 
+    if args.workload == "model":
+        from types import SimpleNamespace
+        from openvivqa_amd.builders import build_model
+
+        class Vocab:
+            padding_idx, total_answers = 0, int(b.ANSWERS)
+
+            def __len__(self):
+                return int(b.VOCAB)
+        torch.manual_seed(b.SEED)
+        model = build_model(cfg.MODEL, Vocab()).train()
+        g = torch.Generator().manual_seed(b.SEED + rank)
+        feats = torch.randn(b.BATCH_PER_GPU, b.REGIONS, int(b.D_FEATURE), generator=g)
+        nreg = torch.randint(b.MIN_REGIONS, b.REGIONS + 1, (b.BATCH_PER_GPU,), generator=g)
+        feats[torch.arange(b.REGIONS)[None, :] >= nreg[:, None]] = 0
+        toks = torch.randint(4, int(b.VOCAB), (b.BATCH_PER_GPU, b.TOKENS), generator=g)
+        ntok = torch.randint(b.MIN_TOKENS, b.TOKENS + 1, (b.BATCH_PER_GPU,), generator=g)
+        toks[torch.arange(b.TOKENS)[None, :] >= ntok[:, None]] = 0
+        ans = torch.randint(0, int(b.ANSWERS), (b.BATCH_PER_GPU,), generator=g).to(device)
+        v, vm, t, tm = feats.to(device=device, dtype=dtype), toks.to(device), None, None
+        nll = torch.nn.NLLLoss()
+
+        def forward_loss(feats_, toks_):  # noqa: F811
+            return nll(model(SimpleNamespace(region_features=feats_, question_tokens=toks_)), ans)
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,
                    comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
                    force_comm=args.rehearse_comm)
-    ts.loss = loss_buf
+    batch = (v, vm, t, tm)
+    if args.workload == "model":
+        batch, loss_buf = (v, vm), ts.loss
+    else:
+        ts.loss = loss_buf
 
     for _ in range(args.warmup):
-        ts.step(v, vm, t, tm)
+        ts.step(*batch)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ts.step(v, vm, t, tm)
+        ts.step(*batch)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -291,6 +323,18 @@ def main():
             "step_tflops": round(value * FLOPS_PER_SAMPLE_FWD_BWD / 1e12, 1),
             "step_frac_of_bf16_peak": round(value * FLOPS_PER_SAMPLE_FWD_BWD / world / PEAK_BF16, 4),
         }
+        if args.workload == "model":  # secondary diagnostic: whole model; no roofline / CPU legs
+            out["metric"] = "SECONDARY: VQA samples/sec fwd+bwd, whole MCAN model (embeddings + stacks + head), L=6, B=64"
+            out["config"]["workload"] = ("secondary (SURVEY 8d model-level): MCAN model via build_model: FeatureEmbedding "
+                                         "1024->512, LSTMTextEmbedding |V|=4000 (torch/MIOpen LSTM), encoder stacks on "
+                                         "the HIP path, attention-pooling head, 353-way classifier, NLLLoss, Adam")
+            for k in ("step_tflops", "step_frac_of_bf16_peak"):
+                out.pop(k)
+            print(json.dumps(out), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         if not args.no_roofline and args.dtype == "bf16":
             sa = cfg.MODEL.SELF_ENCODER.SELF_ATTENTION
             out["roofline"] = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
