@@ -237,6 +237,56 @@ def test_baseline_size_vs_oracle_bf16(B):
         assert torch.equal(vo_h, vo[:32]) and torch.equal(lo_h, lo[:32])
 
 
+@pytest.mark.parametrize("arch", ["CrossModalityEncoder", "CoAttentionEncoder"])
+def test_config3_size_pair_encoders_vs_oracle_bf16(arch):
+    """BASELINE configs[2] (cross_modality_transformer.yaml shape: d=512, L=6, 100 regions x 20 tokens; B=16 here,
+    samples are independent) and its ViLBERT-style sibling: bf16 HIP path vs the fp32 oracle, forward and
+    input/weight gradients (the oracle needs a few seconds at this size)."""
+    import openvivqa_amd as A
+    import openvivqa_amd.utils as U
+    import oracle as O
+    from openvivqa_amd.config import ConfigNode, attention_config
+    A.set_compute_dtype(BF16)
+    sa = attention_config()
+    cfg = ConfigNode(dict(D_MODEL=512, LAYERS=6, VISION_LANGUAGE_ATTENTION=sa, LANGUAGE_VISION_ATTENTION=sa,
+                          VISION_SELF_ATTENTION=sa, LANGUAGE_SELF_ATTENTION=sa))
+    torch.manual_seed(31)
+    ref = getattr(oracle_namespace(), arch)(cfg).eval()
+    hip = getattr(hip_namespace(), arch)(cfg)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV).eval()
+    gen = torch.Generator().manual_seed(6)
+    B = 16
+    v = torch.randn(B, 100, 512, generator=gen)
+    l = torch.randn(B, 20, 512, generator=gen)
+    for i in range(B):
+        v[i, 80 + i:] = 0
+        l[i, 8 + i % 12:] = 0
+    wv, wl = torch.randn(v.shape, generator=gen), torch.randn(l.shape, generator=gen)
+    vo_r, lo_r = v.clone().requires_grad_(), l.clone().requires_grad_()
+    a, b = ref(vo_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
+    ((a * wv).mean() + (b * wl).mean()).backward()
+    vd, ld = v.to(DEV).requires_grad_(), l.to(DEV).requires_grad_()
+    ah, bh = hip(vision_features=vd, vision_padding_mask=U.generate_padding_mask(vd.detach(), 0), language_features=ld,
+                 language_padding_mask=U.generate_padding_mask(ld.detach(), 0))
+    ((ah.float() * wv.to(DEV)).mean() + (bh.float() * wl.to(DEV)).mean()).backward()
+    # L=6 (CoAttention: 24 chained blocks) in bf16: stack-level bars, module docstring
+    assert rel_l2(ah, a) < 1.5e-2 and rel_l2(bh, b) < 1.5e-2, (rel_l2(ah, a), rel_l2(bh, b))
+    assert rel_l2(vd.grad, vo_r.grad) < 4e-2 and rel_l2(ld.grad, lo_r.grad) < 4e-2, \
+        (rel_l2(vd.grad, vo_r.grad), rel_l2(ld.grad, lo_r.grad))
+    gref = dict(ref.named_parameters())
+    gmax = max(float(p.grad.norm()) for p in gref.values() if p.grad is not None)
+    worst = 0.0
+    for k, p in hip.named_parameters():
+        if gref[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if k.endswith("fc_k.bias") or float(gref[k].grad.norm()) < 0.05 * gmax:
+            continue
+        worst = max(worst, rel_l2(p.grad, gref[k].grad))
+    assert worst < 5e-2, worst
+
+
 def test_crossmodality_dead_branch_and_unused_grads(mode):
     """cross-attention parameters exist in the state_dict, get no gradient, and skipping
     their dead compute leaves outputs identical to computing it."""
