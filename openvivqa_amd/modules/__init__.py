@@ -8,10 +8,11 @@ from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEn
 from .embeddings import FeatureEmbedding, LSTMTextEmbedding, UsualEmbedding
 from .decoders import Decoder, DecoderLayer
 from .pointer import DynamicPointerNetwork, OcrPtrNet
+from .mmt import MMT, BertEncoder, PrevPredEmbeddings
 
 __all__ = [
     "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
     "ScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
     "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
-    "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet",
+    "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet", "MMT", "BertEncoder", "PrevPredEmbeddings",
 ]

@@ -1,0 +1,184 @@
+"""M4C multimodal transformer body on the HIP path ("next" row 3 of SURVEY 8f).
+
+``BertEncoder`` here is a drop-in for ``transformers.models.bert.modeling_bert.BertEncoder`` as the reference
+calls it (models/mmf_m4c.py:262-263,287,349-351: ``encoder(hidden, additive_mask, head_mask=[None]*L)[0]``):
+same constructor argument (a BertConfig-like object), same ``state_dict`` keys
+(``layer.{i}.attention.self.query.weight`` ...), so HF / reference checkpoints load.  A layer is exactly the two
+fused blocks of the hot path -- MHA block (QKV GEMM, attention with an additive (B,1,S,S) prefix-LM mask, output
+GEMM + dropout + residual, LayerNorm eps 1e-12) and FFN block (GEMM+GELU, GEMM + dropout + residual, LayerNorm).
+Heads of 96 features (768/8) run on the LDS-resident VALU attention kernel (the MFMA kernel tiles d = 64).
+
+Dropout on the attention PROBABILITIES (attention_probs_dropout_prob, training only) is not implemented by the
+fused attention kernels: training with it raises; evaluation / decoding (BASELINE config 4) is unaffected.
+
+``PrevPredEmbeddings`` / ``MMT``: mmf_m4c.py:399-459 / 282-364.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from .. import runtime as rt
+from ..utils import generate_sequential_mask
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.query = nn.Linear(config.hidden_size, config.hidden_size)
+        self.key = nn.Linear(config.hidden_size, config.hidden_size)
+        self.value = nn.Linear(config.hidden_size, config.hidden_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def _ovqa_param_groups(self):
+        return [[self.query.weight, self.key.weight, self.value.weight],
+                [self.query.bias, self.key.bias, self.value.bias]]
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if getattr(config, "hidden_act", "gelu") != "gelu":
+            raise NotImplementedError("only the exact-erf GELU of BERT is fused")
+        self.heads = config.num_attention_heads
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self._sites = [rt.new_dropout_site() for _ in range(2)]
+
+    def forward(self, hidden_states, attention_mask=None):
+        arena = rt.ensure_arena(self)
+        x = hidden_states.to(arena.compute_dtype)
+        a = self.attention
+        if self.training and a.self.dropout.p > 0 and torch.is_grad_enabled():
+            raise NotImplementedError("attention-probability dropout is not fused; train with "
+                                      "attention_probs_dropout_prob=0 (evaluation / decoding is unaffected)")
+        mask = attention_mask
+        if mask is not None:
+            mask = mask.to(torch.float32)
+            if mask.dim() == 2:  # (B, S) additive
+                mask = mask[:, None, None, :]
+        att = SimpleNamespace(fc_q=a.self.query, fc_k=a.self.key, fc_v=a.self.value, fc_o=a.output.dense, h=self.heads)
+        ln1 = a.output.LayerNorm
+        st = dict(arena=arena, att=att, ln=ln1,
+                  params=[a.self.query.weight, a.self.query.bias, a.self.key.weight, a.self.key.bias,
+                          a.self.value.weight, a.self.value.bias, a.output.dense.weight, a.output.dense.bias,
+                          ln1.weight, ln1.bias],
+                  drop=rt.dropout_spec(a.output.dropout.p, self._sites[0], self.training, x.device))
+        x = Fn.mha_block(x, x, x, mask, st)
+        ffn = SimpleNamespace(fc1=self.intermediate.dense, fc2=self.output.dense, layer_norm=self.output.LayerNorm)
+        st = dict(arena=arena, mod=ffn,
+                  params=[ffn.fc1.weight, ffn.fc1.bias, ffn.fc2.weight, ffn.fc2.bias, ffn.layer_norm.weight,
+                          ffn.layer_norm.bias],
+                  drop1=None, drop2=rt.dropout_spec(self.output.dropout.p, self._sites[1], self.training, x.device))
+        return Fn.ffn_block(x, st)
+
+
+class BertEncoder(nn.Module):
+    """``encoder(hidden_states, attention_mask, head_mask=None) -> (hidden_states,)`` (head masks must be None)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, **kwargs):
+        if head_mask is not None and any(h is not None for h in head_mask):
+            raise NotImplementedError("head masks are not supported (the reference passes [None] * L)")
+        dtype = hidden_states.dtype
+        for layer in self.layer:
+            hidden_states = layer(hidden_states, attention_mask)
+        return (hidden_states.to(dtype),)
+
+
+def _batch_gather(x, inds):
+    """x (B, L, D), inds (B, T) -> (B, T, D)   (mmf_m4c.py:448-459)."""
+    B, L, D = x.shape
+    flat = (torch.arange(B, device=inds.device) * L).unsqueeze(-1) + inds
+    return torch.nn.functional.embedding(flat, x.reshape(B * L, D))
+
+
+class PrevPredEmbeddings(nn.Module):
+    """Embeddings of the previous decoding steps' predictions (mmf_m4c.py:399-446): gather from
+    [LN(fixed answer table); LN(OCR embeddings)] + LN(position + token-type embedding)."""
+
+    def __init__(self, config):
+        super().__init__()
+        hidden, eps = config.hidden_size, config.layer_norm_eps
+        self.position_embeddings = nn.Embedding(100, hidden)
+        self.token_type_embeddings = nn.Embedding(5, hidden)
+        self.ans_layer_norm = nn.LayerNorm(hidden, eps=eps)
+        self.ocr_layer_norm = nn.LayerNorm(hidden, eps=eps)
+        self.emb_layer_norm = nn.LayerNorm(hidden, eps=eps)
+        self.emb_dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, ans_emb, ocr_emb, prev_inds):
+        assert prev_inds.dim() == 2 and prev_inds.dtype == torch.long and ans_emb.dim() == 2
+        arena = rt.ensure_arena(self)
+        T = arena.compute_dtype
+        B, steps = prev_inds.shape
+        ans_num = ans_emb.size(0)
+        ans = Fn.prologue(ans_emb.float().unsqueeze(0), self.ans_layer_norm, None, arena, T)[0]
+        ocr = Fn.prologue(ocr_emb.float(), self.ocr_layer_norm, None, arena, T)
+        cat = torch.cat([ans.unsqueeze(0).expand(B, -1, -1), ocr], dim=1)
+        raw = _batch_gather(cat, prev_inds)
+        pos = self.position_embeddings(torch.arange(steps, device=ocr_emb.device).unsqueeze(0).expand(B, steps))
+        typ = self.token_type_embeddings(prev_inds.ge(ans_num).long())
+        emb = Fn.prologue((pos + typ).float(), self.emb_layer_norm, None, arena, T)
+        return raw + self.emb_dropout(emb)
+
+
+class MMT(nn.Module):
+    """Multimodal transformer of M4C (mmf_m4c.py:282-364): [txt; obj; ocr; dec] under a prefix-LM mask."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.prev_pred_embeddings = PrevPredEmbeddings(config)
+        self.encoder = BertEncoder(config)
+
+    def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds):
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds)
+        steps = dec_emb.size(1)
+        dec_mask = torch.zeros(dec_emb.size(0), 1, 1, steps, dtype=torch.float32, device=dec_emb.device)
+        x = torch.cat([txt_emb.to(dec_emb.dtype), obj_emb.to(dec_emb.dtype), ocr_emb.to(dec_emb.dtype), dec_emb], dim=1)
+        mask = torch.cat([txt_mask, obj_mask, ocr_mask, dec_mask], dim=-1).float()
+        S = mask.size(-1)
+        ext = mask.repeat(1, 1, S, 1)
+        ext[:, :, -steps:, -steps:] = generate_sequential_mask(steps, device=ext.device)
+        out = self.encoder(x, ext, head_mask=[None] * len(self.encoder.layer))[0]
+        nt, no, nc = txt_mask.size(-1), obj_mask.size(-1), ocr_mask.size(-1)
+        return {"mmt_seq_output": out, "mmt_txt_output": out[:, :nt], "mmt_ocr_output": out[:, nt + no:nt + no + nc],
+                "mmt_dec_output": out[:, -steps:]}

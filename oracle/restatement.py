@@ -28,6 +28,7 @@ __all__ = [
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
     "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
     "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "OracleMLP", "OracleMCAN",
+    "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "batch_gather",
     "noam_lambda", "oracle_train_step", "build_oracle_encoder",
 ]
 
@@ -566,6 +567,134 @@ class OracleMCAN(nn.Module):
         wv, wt = (v * av).sum(dim=1), (t * at).sum(dim=1)
         out = self.layer_norm(self.vision_proj(wv) + self.text_proj(wt))
         return torch.log_softmax(self.classify(out), dim=-1)
+
+
+# --------------------------------------------------------------------------
+# M4C multimodal transformer ("next" row 3)     models/mmf_m4c.py:282-364, 399-459
+# --------------------------------------------------------------------------
+# The layer body is THIRD-PARTY arithmetic: Hugging Face `transformers` BertEncoder (mmf_m4c.py:7-12,287; the
+# reference pins no version -- installed here: 5.15.0).  Restated from its published algorithm (post-LN BERT layer)
+# with HF's parameter names, and pinned against the installed library (tests/golden/G13_*, generated by running HF
+# BertEncoder and the reference's own MMT.forward / PrevPredEmbeddings).
+class _BertSelf(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.key = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.value = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.dropout = nn.Dropout(cfg.attention_probs_dropout_prob)
+
+
+class _BertDenseLN(nn.Module):
+    def __init__(self, d_in, cfg):
+        super().__init__()
+        self.dense = nn.Linear(d_in, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.dropout = nn.Dropout(cfg.hidden_dropout_prob)
+
+
+class _BertAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = _BertSelf(cfg)
+        self.output = _BertDenseLN(cfg.hidden_size, cfg)
+
+
+class _BertIntermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+
+
+class _BertLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.heads = cfg.num_attention_heads
+        self.attention = _BertAttention(cfg)
+        self.intermediate = _BertIntermediate(cfg)
+        self.output = _BertDenseLN(cfg.intermediate_size, cfg)
+
+    def forward(self, x, mask):
+        a, B, S, H = self.attention, x.shape[0], x.shape[1], self.heads
+        d = x.shape[-1] // H
+        q = a.self.query(x).view(B, S, H, d).transpose(1, 2)
+        k = a.self.key(x).view(B, S, H, d).transpose(1, 2)
+        v = a.self.value(x).view(B, S, H, d).transpose(1, 2)
+        s = torch.matmul(q, k.transpose(-1, -2)) * d ** -0.5
+        if mask is not None:
+            s = s + mask
+        p = a.self.dropout(torch.softmax(s, dim=-1))
+        ctx = torch.matmul(p, v).transpose(1, 2).reshape(B, S, H * d)
+        x = a.output.LayerNorm(a.output.dropout(a.output.dense(ctx)) + x)
+        h = torch.nn.functional.gelu(self.intermediate.dense(x))
+        return self.output.LayerNorm(self.output.dropout(self.output.dense(h)) + x)
+
+
+class OracleBertEncoder(nn.Module):
+    """transformers BertEncoder as MMT / TextBert call it: encoder(hidden, additive_mask (B,1,S,S) or (B,1,1,S),
+    head_mask=[None]*L) -> (hidden,)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([_BertLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        for layer in self.layer:
+            hidden_states = layer(hidden_states, attention_mask)
+        return (hidden_states,)
+
+
+def batch_gather(x, inds):
+    """x (B,L,D), inds (B,T) -> (B,T,D).  mmf_m4c.py:448-459."""
+    B, L, D = x.shape
+    flat = (torch.arange(B, device=inds.device) * L).unsqueeze(-1) + inds
+    return torch.nn.functional.embedding(flat, x.reshape(B * L, D))
+
+
+class OraclePrevPredEmbeddings(nn.Module):
+    """mmf_m4c.py:399-446."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(100, cfg.hidden_size)
+        self.token_type_embeddings = nn.Embedding(5, cfg.hidden_size)
+        self.ans_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.ocr_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.emb_layer_norm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.emb_dropout = nn.Dropout(cfg.hidden_dropout_prob)
+
+    def forward(self, ans_emb, ocr_emb, prev_inds):
+        B, T = prev_inds.shape
+        ans_num = ans_emb.size(0)
+        cat = torch.cat([self.ans_layer_norm(ans_emb).unsqueeze(0).expand(B, -1, -1), self.ocr_layer_norm(ocr_emb)], 1)
+        raw = batch_gather(cat, prev_inds)
+        pos = self.position_embeddings(torch.arange(T, device=ocr_emb.device).unsqueeze(0).expand(B, T))
+        typ = self.token_type_embeddings(prev_inds.ge(ans_num).long())
+        return raw + self.emb_dropout(self.emb_layer_norm(pos + typ))
+
+
+class OracleMMT(nn.Module):
+    """mmf_m4c.py:282-364: [txt; obj; ocr; dec] through the BERT encoder under a prefix-LM mask (every position sees
+    the encoding steps per their padding masks; decoding steps see each other causally)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.prev_pred_embeddings = OraclePrevPredEmbeddings(cfg)
+        self.encoder = OracleBertEncoder(cfg)
+
+    def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds):
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds)
+        T = dec_emb.size(1)
+        dec_mask = torch.zeros(dec_emb.size(0), 1, 1, T, dtype=torch.float32, device=dec_emb.device)
+        x = torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1)
+        mask = torch.cat([txt_mask, obj_mask, ocr_mask, dec_mask], dim=-1)
+        S = mask.size(-1)
+        ext = mask.repeat(1, 1, S, 1)
+        ext[:, :, -T:, -T:] = sequential_mask(T).to(ext.device)
+        out = self.encoder(x, ext, head_mask=None)[0]
+        nt, no, nc = txt_mask.size(-1), obj_mask.size(-1), ocr_mask.size(-1)
+        return {"mmt_seq_output": out, "mmt_txt_output": out[:, :nt], "mmt_ocr_output": out[:, nt + no:nt + no + nc],
+                "mmt_dec_output": out[:, -T:]}
 
 
 # --------------------------------------------------------------------------

@@ -609,12 +609,81 @@ def g12():
     finish(c)
 
 
+# ---------------------------------------------------------------- G13 M4C multimodal transformer ("next" row 3)
+def bert_cfg():
+    from transformers import BertConfig
+    return BertConfig(hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96)
+
+
+def g13():
+    """(a) the third-party layer body: installed transformers BertEncoder, called as mmf_m4c.py:349-351 does;
+    (b) the reference's PrevPredEmbeddings; (c) the reference's MMT.forward (mask construction, concatenation,
+    slicing) run as an unbound method on a stand-in ``self`` -- MMT.__init__ itself does not run under
+    transformers 5 (init_weights API drift)."""
+    import transformers
+    from transformers.models.bert.modeling_bert import BertEncoder
+    cfg = bert_cfg()
+    meta_cfg = dict(hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                    layer_norm_eps=cfg.layer_norm_eps, hidden_dropout_prob=cfg.hidden_dropout_prob,
+                    attention_probs_dropout_prob=cfg.attention_probs_dropout_prob)
+    # (a)
+    torch.manual_seed(1301)
+    enc = BertEncoder(cfg)
+    with torch.no_grad():
+        for n_, p_ in enc.named_parameters():
+            if n_.endswith("bias"):
+                p_.normal_(0, 0.1)
+            elif "LayerNorm.weight" in n_:
+                p_.uniform_(0.5, 1.5)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(3, 9, 48, generator=gen)
+    pad = torch.zeros(3, 1, 1, 9)
+    pad[1, ..., 5:7] = -10e4
+    ext = pad.repeat(1, 1, 9, 1)
+    ext[:, :, -3:, -3:] = R_utils.generate_sequential_mask(3)
+    c = Case("G13_bert_encoder")
+    c.meta.update(cfg=meta_cfg, transformers=transformers.__version__)
+    run_with_grads(c, enc, {"x": x, "mask": ext},
+                   lambda mod, ins: {"out": mod(ins["x"], ins["mask"], head_mask=[None] * 2)[0]}, ["x"])
+    finish(c)
+    # (b) + (c)
+    torch.manual_seed(1302)
+    prev = R_m4c.PrevPredEmbeddings(cfg)
+    enc2 = BertEncoder(cfg)
+    with torch.no_grad():
+        for ln in (prev.ans_layer_norm, prev.ocr_layer_norm, prev.emb_layer_norm):
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.normal_(0, 0.1)
+    holder = torch.nn.Module()
+    holder.prev_pred_embeddings, holder.encoder = prev, enc2
+    holder.config = cfg
+    txt, obj, ocr = feats(2, 4, 48, gen), feats(2, 5, 48, gen), feats(2, 3, 48, gen)
+    tmask, omask, cmask = torch.zeros(2, 1, 1, 4), torch.zeros(2, 1, 1, 5), torch.zeros(2, 1, 1, 3)
+    tmask[0, ..., 3:] = -10e4
+    omask[1, ..., 2:] = -10e4
+    cmask[1, ..., 2:] = -10e4
+    ans = torch.randn(6, 48, generator=gen)
+    prev_inds = torch.tensor([[1, 7, 0, 3], [5, 6, 8, 2]])  # < 6: fixed vocabulary, >= 6: OCR token
+    c = Case("G13_mmt")
+    c.meta.update(cfg=meta_cfg, transformers=transformers.__version__)
+
+    def call(mod, ins):
+        out = R_m4c.MMT.forward(mod, ins["txt"], ins["tmask"], ins["obj"], ins["omask"], ins["ocr"], ins["cmask"],
+                                ins["ans"], ins["prev_inds"])
+        dec = mod.prev_pred_embeddings(ins["ans"], ins["ocr"], ins["prev_inds"])
+        return {"seq": out["mmt_seq_output"], "txt_out": out["mmt_txt_output"], "ocr_out": out["mmt_ocr_output"],
+                "dec_out": out["mmt_dec_output"], "dec_emb": dec}
+    run_with_grads(c, holder, dict(txt=txt, tmask=tmask, obj=obj, omask=omask, ocr=ocr, cmask=cmask, ans=ans,
+                                   prev_inds=prev_inds), call, ["txt", "obj", "ocr", "ans"])
+    finish(c)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

@@ -59,7 +59,8 @@ def oracle_namespace():
         Encoder=O.OracleEncoder, GuidedAttentionEncoder=O.OracleGuidedAttentionEncoder,
         CoAttentionEncoder=O.OracleCoAttentionEncoder, CrossModalityEncoder=O.OracleCrossModalityEncoder,
         DecoderLayer=O.OracleDecoderLayer, Decoder=O.OracleDecoder, OcrPtrNet=O.OracleOcrPtrNet,
-        DynamicPointerNetwork=O.OracleDynamicPointerNetwork, MCAN=O.OracleMCAN)
+        DynamicPointerNetwork=O.OracleDynamicPointerNetwork, MCAN=O.OracleMCAN,
+        BertEncoder=O.OracleBertEncoder, MMT=O.OracleMMT)
 
 
 def hip_namespace():
@@ -70,7 +71,8 @@ def hip_namespace():
         CrossModalityEncoderLayer=M.CrossModalityEncoderLayer, Encoder=M.Encoder,
         GuidedAttentionEncoder=M.GuidedAttentionEncoder, CoAttentionEncoder=M.CoAttentionEncoder,
         CrossModalityEncoder=M.CrossModalityEncoder, DecoderLayer=M.DecoderLayer, Decoder=M.Decoder,
-        OcrPtrNet=M.OcrPtrNet, DynamicPointerNetwork=M.DynamicPointerNetwork, MCAN=_hip_mcan())
+        OcrPtrNet=M.OcrPtrNet, DynamicPointerNetwork=M.DynamicPointerNetwork, MCAN=_hip_mcan(),
+        BertEncoder=M.BertEncoder, MMT=M.MMT)
 
 
 def _hip_mcan():
@@ -106,6 +108,13 @@ def _call_vl_pair(m, i):
     v, l = m(vision_features=i["vision"], vision_padding_mask=i["vmask"],
              language_features=i["language"], language_padding_mask=i["lmask"])
     return {"vision": v, "language": l}
+
+
+def _call_mmt(m, i):
+    out = m(i["txt"], i["tmask"], i["obj"], i["omask"], i["ocr"], i["cmask"], i["ans"], i["prev_inds"])
+    dec = m.prev_pred_embeddings(i["ans"], i["ocr"], i["prev_inds"])
+    return {"seq": out["mmt_seq_output"], "txt_out": out["mmt_txt_output"], "ocr_out": out["mmt_ocr_output"],
+            "dec_out": out["mmt_dec_output"], "dec_emb": dec}
 
 
 # name -> (build(ns, case), call(module, inputs), grad_inputs)
@@ -148,6 +157,9 @@ CASES = {
     "G12_mcan_model": (lambda ns, c: ns.MCAN(_cfg(c), ModelVocab(c.meta["vocab_len"], c.meta["total_answers"])),
                        lambda m, i: {"logp": m(SimpleNamespace(region_features=i["regions"],
                                                                question_tokens=i["tokens"]))}, ["regions"]),
+    "G13_bert_encoder": (lambda ns, c: ns.BertEncoder(SimpleNamespace(**c.meta["cfg"])),
+                         lambda m, i: {"out": m(i["x"], i["mask"], head_mask=[None] * 2)[0]}, ["x"]),
+    "G13_mmt": (lambda ns, c: ns.MMT(SimpleNamespace(**c.meta["cfg"])), _call_mmt, ["txt", "obj", "ocr", "ans"]),
     "G8_dynptr_query_axis": (lambda ns, c: ns.DynamicPointerNetwork(ConfigNode(dict(D_MODEL=c.meta["d_model"])),
                                                                     axis="query"),
                              lambda m, i: {"scores": m(i["q"], i["k"], i["qmask"])}, ["q", "k"]),

@@ -142,7 +142,7 @@ def test_train_two_steps_trajectory():
         losses.append(O.oracle_train_step(params, loss_fn, optim, sched))
     _close(torch.tensor(losses), case.out["losses"], 1e-5, "losses")
     for k, v in m.state_dict().items():
-        if k.endswith("fc_k.bias"):
+        if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             # d(loss)/d(fc_k.bias) is analytically 0 (softmax is shift-invariant along keys), so its
             # gradient is pure rounding noise which Adam normalises to +-lr: not comparable.
             continue

@@ -57,7 +57,7 @@ def test_plumbing_matches_reference_golden(name):
         _close(gin[k], ref, gtol, f"{name} gin/{k}")
     for k, ref in case.gw.items():
         assert gw[k] is not None, f"{name}: missing grad {k}"
-        if k.endswith("fc_k.bias"):
+        if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             continue
         _close(gw[k], ref, gtol, f"{name} gw/{k}")
     for k in case.meta["grad_none"]:
@@ -88,7 +88,7 @@ def test_fullsize_plumbing_vs_oracle():
     _close(res[1][1], res[0][1], 1e-4, "dv")
     _close(res[1][2], res[0][2], 1e-4, "dl")
     for k, gref in res[0][3].items():
-        if k.endswith("fc_k.bias"):
+        if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             continue
         _close(res[1][3][k], gref, 1e-4, k)
 
@@ -184,7 +184,7 @@ def test_train_step_harness_matches_reference_trajectory():
     losses = [float(ts.step(case.inputs["x"]).item()) for _ in range(2)]
     _close(torch.tensor(losses), case.out["losses"], 1e-5, "losses")
     for k, v in enc.state_dict().items():
-        if k.endswith("fc_k.bias"):
+        if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             continue
         _close(v, case.out["w2/" + k], 5e-5, "post-step " + k)
     _close(head.weight, case.out["w2/head.weight"], 5e-5, "head")
