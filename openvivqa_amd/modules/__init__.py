@@ -1,7 +1,8 @@
 """HIP-backed modules registered under the reference's names."""
 from .containers import Module, ModuleDict, ModuleList
 from .pos_embeddings import SinusoidPositionalEmbedding
-from .attentions import MultiHeadAttention, ScaledDotProductAttention
+from .attentions import (AugmentedMemoryScaledDotProductAttention, MultiHeadAttention,
+                         ScaledDotProductAttention)
 from .positionwise_feed_forward import PositionWiseFeedForward
 from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEncoderLayer, Encoder, EncoderLayer,
                        GuidedAttentionEncoder, GuidedEncoderLayer)
@@ -12,7 +13,7 @@ from .mmt import MMT, BertEncoder, PrevPredEmbeddings
 
 __all__ = [
     "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
-    "ScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
+    "ScaledDotProductAttention", "AugmentedMemoryScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
     "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
     "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet", "MMT", "BertEncoder", "PrevPredEmbeddings",
 ]

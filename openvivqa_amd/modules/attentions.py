@@ -70,6 +70,49 @@ class ScaledDotProductAttention(nn.Module):
         return out.to(in_dtype), att.to(in_dtype)
 
 
+@META_ATTENTION.register()
+class AugmentedMemoryScaledDotProductAttention(nn.Module):
+    """Attention over [keys; m learned memory slots] (attentions.py:129-205, M2-transformer style):
+    K' = [fc_k(keys); sqrt(d_k) m_k], V' = [fc_v(values); sqrt(m) m_v]; the additive mask covers the real keys
+    only.  Same attention kernel, nk + m key columns."""
+
+    def __init__(self, config):
+        super().__init__()
+        d_model, h, d_k, d_v, m = config.D_MODEL, config.HEAD, config.D_KEY, config.D_VALUE, config.MEMORY
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.m_k = nn.Parameter(torch.empty(1, m, h * d_k))
+        self.m_v = nn.Parameter(torch.empty(1, m, h * d_v))
+        self.d_model, self.d_k, self.d_v, self.h, self.m = d_model, d_k, d_v, h, m
+        self.init_weights()
+
+    def init_weights(self):
+        for lin in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.constant_(lin.bias, 0)
+        nn.init.normal_(self.m_k, 0, 1 / self.d_k)
+        nn.init.normal_(self.m_v, 0, 1 / self.m)
+
+    def forward(self, queries, keys, values, attention_mask=None, **kwargs):
+        arena = rt.ensure_arena(self)
+        T, in_dtype = arena.compute_dtype, queries.dtype
+        B, nk = queries.shape[0], keys.shape[1]
+        q = Fn.linear(queries.to(T), self.fc_q, arena)
+        k = Fn.linear(keys.to(T), self.fc_k, arena)
+        v = Fn.linear(values.to(T), self.fc_v, arena)
+        m_k = (self.d_k ** 0.5 * self.m_k).to(T).expand(B, self.m, self.h * self.d_k)
+        m_v = (self.m ** 0.5 * self.m_v).to(T).expand(B, self.m, self.h * self.d_v)
+        k, v = torch.cat([k, m_k], 1), torch.cat([v, m_v], 1)
+        mask = _as_mask(attention_mask)
+        if mask is not None:  # memory slots are never masked
+            mask = torch.cat([mask, mask.new_zeros(*mask.shape[:-1], self.m)], dim=-1).contiguous()
+        o, att = Fn.attention_core(q, k, v, mask, self.h, need_att=True)
+        out = Fn.linear(o, self.fc_o, arena)
+        return out.to(in_dtype), att.to(in_dtype)
+
+
 class MultiHeadAttention(Module):
     """Multi-head attention block with dropout, residual connection and post-LayerNorm."""
 

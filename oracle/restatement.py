@@ -22,7 +22,7 @@ MASK_VALUE = -10e4  # models/utils.py:56,64,71  (== -100000.0)
 __all__ = [
     "MASK_VALUE", "padding_mask", "sequential_mask", "self_attention_masks",
     "sinusoid_positions", "sinusoid_table", "sdpa_core",
-    "OracleSDPA", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
+    "OracleSDPA", "OracleMemorySDPA", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
     "OracleGuidedEncoderLayer", "OracleCrossModalityEncoderLayer",
     "OracleEncoder", "OracleGuidedAttentionEncoder", "OracleCoAttentionEncoder",
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
@@ -121,6 +121,35 @@ class OracleSDPA(nn.Module):
         v = self.fc_v(values).view(b, nk, self.h, self.d_v).transpose(1, 2)
         o, att = sdpa_core(q, k, v, attention_mask, self.d_k)
         o = o.transpose(1, 2).reshape(b, nq, self.h * self.d_v)
+        return self.fc_o(o), att
+
+
+class OracleMemorySDPA(nn.Module):
+    """AugmentedMemoryScaledDotProductAttention.  models/modules/attentions.py:129-205: m learned memory slots are
+    appended to the projected keys/values (scaled by sqrt(d_k) / sqrt(m)); the mask is added to the real keys only."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.d_model, self.h, self.d_k, self.d_v, self.m = cfg.D_MODEL, cfg.HEAD, cfg.D_KEY, cfg.D_VALUE, cfg.MEMORY
+        self.fc_q = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_k = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_v = nn.Linear(self.d_model, self.h * self.d_v)
+        self.fc_o = nn.Linear(self.h * self.d_v, self.d_model)
+        self.m_k = nn.Parameter(torch.randn(1, self.m, self.h * self.d_k) / self.d_k)
+        self.m_v = nn.Parameter(torch.randn(1, self.m, self.h * self.d_v) / self.m)
+
+    def forward(self, queries, keys, values, attention_mask=None, **kw):
+        b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
+        m_k = math.sqrt(self.d_k) * self.m_k.expand(b, -1, -1)
+        m_v = math.sqrt(self.m) * self.m_v.expand(b, -1, -1)
+        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).transpose(1, 2)
+        k = torch.cat([self.fc_k(keys), m_k], 1).view(b, nk + self.m, self.h, self.d_k).transpose(1, 2)
+        v = torch.cat([self.fc_v(values), m_v], 1).view(b, nk + self.m, self.h, self.d_v).transpose(1, 2)
+        att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.d_k)
+        if attention_mask is not None:
+            att = torch.cat([att[..., :nk] + attention_mask, att[..., nk:]], dim=-1)
+        att = torch.softmax(att, dim=-1)
+        o = torch.matmul(att, v).transpose(1, 2).reshape(b, nq, self.h * self.d_v)
         return self.fc_o(o), att
 
 

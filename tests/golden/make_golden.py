@@ -678,12 +678,36 @@ def g13():
     finish(c)
 
 
+# ---------------------------------------------------------------- G14 memory-augmented attention (row 4)
+def g14():
+    torch.manual_seed(1401)
+    cfg = att_cfg()
+    cfg["MEMORY"] = 3
+    m = R_att.AugmentedMemoryScaledDotProductAttention(cfg)
+    with torch.no_grad():
+        for lin in (m.fc_q, m.fc_k, m.fc_v, m.fc_o):
+            lin.bias.normal_(0, 0.1)
+    gen = torch.Generator().manual_seed(17)
+    q = feats(3, 5, D, gen)
+    kv = feats(3, 7, D, gen, pad_rows={1: [5, 6], 2: list(range(7))})
+    mask = R_utils.generate_padding_mask(kv, 0)
+    c = Case("G14_memory_sdpa")
+    c.meta.update(cfg=dict(cfg))
+
+    def call(mod, ins):
+        out, att = mod(ins["queries"], ins["keys"], ins["values"], attention_mask=ins["mask"])
+        return {"out": out, "att": att}
+    run_with_grads(c, m, {"queries": q, "keys": kv, "values": kv.clone(), "mask": mask}, call,
+                   ["queries", "keys", "values"])
+    finish(c)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

@@ -54,7 +54,7 @@ def load_case(name):
 def oracle_namespace():
     import oracle as O
     return SimpleNamespace(
-        SDPA=O.OracleSDPA, MHA=O.OracleMHA, PWFF=O.OraclePWFF, EncoderLayer=O.OracleEncoderLayer,
+        SDPA=O.OracleSDPA, MemorySDPA=O.OracleMemorySDPA, MHA=O.OracleMHA, PWFF=O.OraclePWFF, EncoderLayer=O.OracleEncoderLayer,
         GuidedEncoderLayer=O.OracleGuidedEncoderLayer, CrossModalityEncoderLayer=O.OracleCrossModalityEncoderLayer,
         Encoder=O.OracleEncoder, GuidedAttentionEncoder=O.OracleGuidedAttentionEncoder,
         CoAttentionEncoder=O.OracleCoAttentionEncoder, CrossModalityEncoder=O.OracleCrossModalityEncoder,
@@ -66,7 +66,8 @@ def oracle_namespace():
 def hip_namespace():
     import openvivqa_amd.modules as M
     return SimpleNamespace(
-        SDPA=M.ScaledDotProductAttention, MHA=M.MultiHeadAttention, PWFF=M.PositionWiseFeedForward,
+        SDPA=M.ScaledDotProductAttention, MemorySDPA=M.AugmentedMemoryScaledDotProductAttention,
+        MHA=M.MultiHeadAttention, PWFF=M.PositionWiseFeedForward,
         EncoderLayer=M.EncoderLayer, GuidedEncoderLayer=M.GuidedEncoderLayer,
         CrossModalityEncoderLayer=M.CrossModalityEncoderLayer, Encoder=M.Encoder,
         GuidedAttentionEncoder=M.GuidedAttentionEncoder, CoAttentionEncoder=M.CoAttentionEncoder,
@@ -122,6 +123,7 @@ CASES = {
     "G1_sdpa_5x7": (_sdpa, _call_sdpa, ["queries", "keys", "values"]),
     "G1_sdpa_7x7": (_sdpa, _call_sdpa, ["queries", "keys", "values"]),
     "G1_sdpa_causal": (_sdpa, _call_sdpa_causal, ["queries"]),
+    "G14_memory_sdpa": (lambda ns, c: ns.MemorySDPA(_cfg(c)), _call_sdpa, ["queries", "keys", "values"]),
     "G2_mha_aoa0": (lambda ns, c: ns.MHA(_cfg(c)),
                     lambda m, i: {"out": m(i["queries"], i["keys"], i["values"], i["mask"])},
                     ["queries", "keys", "values"]),
