@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--overlap-mb", type=float, default=64.0,
+    ap.add_argument("--overlap-mb", type=float, default=96.0,
                     help="N>1: release a gradient segment to the all-reduce stream every this many MB (fp32) of "
                          "finished gradients during backward; 0 = one exchange after backward")
     ap.add_argument("--rehearse-comm", action="store_true",
@@ -210,19 +210,41 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
+    # rehearsal on a one-GPU box: OVQA_REHEARSE_BACKEND=gloo runs all ranks on GPU 0 with gloo transporting the
+    # CUDA tensors (RCCL refuses two ranks on one device); the product path (backend nccl = RCCL) is the default
+    backend = os.environ.get("OVQA_REHEARSE_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
-    elif args.rehearse_comm:
-        import tempfile
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(), "rdv"),
-                                rank=0, world_size=1, device_id=device)
-    else:
-        dist = None
+    # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
+    # by pointing fd 1 at stderr while the process group (and its first collective) comes up
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist.init_process_group(backend=backend)
+        elif args.rehearse_comm:
+            import tempfile
+            import torch.distributed as dist
+            dist.init_process_group(backend="nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(), "rdv"),
+                                    rank=0, world_size=1, device_id=device)
+        else:
+            dist = None
+        if dist is not None:
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     import openvivqa_amd as A
     from openvivqa_amd import ops

@@ -227,9 +227,10 @@ int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b,
  *   master weights; also refreshes the bf16 shadow copy used by the kernels.
  *   lr_scale_ptr / step_ptr are device scalars so a captured graph can replay
  *   with a schedule (tasks/base_task.py:73-76).  grad_scale multiplies g first
- *   (1/world_size after a sum all-reduce).
+ *   (1/world_size after a sum all-reduce).  grad_dtype: OVQA_F32 (the arena's gradient buffer) or OVQA_BF16
+ *   (the data-parallel staging buffer the all-reduce ran on -- saves the cast back).
  * ------------------------------------------------------------------------- */
-int ovqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
                    void* shadow_bf16, int64_t n, float lr, const float* lr_scale_ptr,
                    float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, const uint32_t* step_ptr, void* stream);

@@ -200,12 +200,12 @@ int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b, const vo
                                    stride_c, batch, M, N, K, alpha, as_stream(stream));
 }
 
-int ovqa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
-                   float lr, const float* lr_scale_ptr, float beta1, float beta2, float eps, float weight_decay,
-                   float grad_scale, const uint32_t* step_ptr, void* stream) {
-  OVQA_REQUIRE(n >= 0, OVQA_ERR_BAD_ARG, "adam_step: bad n");
+int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                   int64_t n, float lr, const float* lr_scale_ptr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, const uint32_t* step_ptr, void* stream) {
+  OVQA_REQUIRE(n >= 0 && dtype_ok(grad_dtype), OVQA_ERR_BAD_ARG, "adam_step: bad n or gradient dtype");
   OVQA_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), OVQA_ERR_BAD_ARG, "adam_step: null pointer");
-  return ovqa::adam_step(param, grad, exp_avg, exp_avg_sq, shadow_bf16, n, lr, lr_scale_ptr, beta1, beta2, eps,
+  return ovqa::adam_step(param, grad, grad_dtype, exp_avg, exp_avg_sq, shadow_bf16, n, lr, lr_scale_ptr, beta1, beta2, eps,
                          weight_decay, grad_scale, step_ptr, as_stream(stream));
 }
 

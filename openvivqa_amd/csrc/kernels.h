@@ -67,7 +67,7 @@ int layernorm_bwd_blocks(int64_t M);
 int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_blocks, int max_D, hipStream_t st);
 
 // ---- misc.hip ------------------------------------------------------------------
-int adam_step(float* param, const float* grad, float* m, float* v, void* shadow, int64_t n, float lr,
+int adam_step(float* param, const void* grad, int grad_dtype, float* m, float* v, void* shadow, int64_t n, float lr,
               const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
               const uint32_t* step_ptr, hipStream_t st);
 int increment_step(uint32_t* step_ptr, hipStream_t st);

@@ -8,7 +8,10 @@ namespace {
 
 constexpr int kMaxBlocks = 2048;
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// TG = float (the arena's own gradient buffer) or bf16 (the data-parallel staging buffer after the all-reduce:
+// reading it directly saves the cast back to fp32)
+template <typename TG>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const TG* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ shadow, int64_t n, float lr,
                                                    const float* __restrict__ lr_scale_ptr, float b1, float b2,
@@ -24,7 +27,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    typedef __attribute__((ext_vector_type(4))) TG g4_t;
+    const g4_t g4 = reinterpret_cast<const g4_t*>(g)[i];
+    const float4 gg = make_float4(to_f32<TG>(g4[0]), to_f32<TG>(g4[1]), to_f32<TG>(g4[2]), to_f32<TG>(g4[3]));
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
     float* pa = &pp.x;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   // tail (n not a multiple of 4)
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gk = g[i] * grad_scale + wd * p[i];
+    const float gk = to_f32<TG>(g[i]) * grad_scale + wd * p[i];
     const float mk = b1 * m[i] + (1.f - b1) * gk;
     const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
     m[i] = mk;
@@ -166,15 +171,19 @@ inline int blocks_for(int64_t n) {
 
 namespace ovqa {
 
-int adam_step(float* param, const float* grad, float* m, float* v, void* shadow, int64_t n, float lr,
+int adam_step(float* param, const void* grad, int grad_dtype, float* m, float* v, void* shadow, int64_t n, float lr,
               const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
               const uint32_t* step_ptr, hipStream_t st) {
   if (n == 0) return OVQA_OK;
-  OVQA_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+  OVQA_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 8 == 0) && ((uintptr_t)m % 16 == 0) &&
                    ((uintptr_t)v % 16 == 0) && (shadow == nullptr || (uintptr_t)shadow % 8 == 0),
                OVQA_ERR_BAD_ARG, "adam_step: arena pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, grad, m, v, (bf16*)shadow, n,
-                     lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
+  if (grad_dtype == OVQA_BF16)
+    hipLaunchKernelGGL(adam_kernel<bf16>, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, (const bf16*)grad, m, v,
+                       (bf16*)shadow, n, lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
+  else
+    hipLaunchKernelGGL(adam_kernel<float>, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, (const float*)grad, m,
+                       v, (bf16*)shadow, n, lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
   return ovqa_check_launch("adam_step");
 }
 

@@ -458,7 +458,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None,
               weight_decay=0.0, grad_scale=1.0):
     _dev(param)
     lib = _lib.load()
-    _lib.check(lib.ovqa_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(),
+    assert grad.numel() == param.numel()
+    _lib.check(lib.ovqa_adam_step(_p(param), _p(grad), _dt(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(),
                                   float(lr), _p(lr_scale), float(betas[0]), float(betas[1]), float(eps),
                                   float(weight_decay), float(grad_scale), _p(step), _stream()), "adam_step")
 

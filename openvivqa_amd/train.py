@@ -68,8 +68,9 @@ class FlatAdam:
 class GradAllReducer:
     """Sum-all-reduce of the flat gradient buffer over the default process group, in segments.
 
-    ``comm_dtype=torch.bfloat16`` halves the bytes on every xGMI link (a segment is cast into a bf16 staging
-    buffer by one streaming kernel, reduced, and cast back into the fp32 gradient buffer Adam reads).
+    ``comm_dtype=torch.bfloat16`` halves the bytes on every xGMI link: a segment is cast into a bf16 staging
+    buffer by one streaming kernel and reduced there; on the GPU the fused Adam kernel then reads the staging
+    buffer directly (no cast back).
     ``reduce_ranges`` is asynchronous: cast, collectives and cast-back of a segment run on a communication
     stream once ``after`` (an event recorded when the segment's gradients are final) has fired, so segments
     released early in backward travel over xGMI while the rest of backward computes; ``finish`` joins.
@@ -107,11 +108,8 @@ class GradAllReducer:
                        for s, e in self.bounds(hi - lo, lo)]
             for h in handles:
                 h.wait()  # CUDA: orders the current (communication) stream after the collective, no host block
-            if self.staging is not None:
-                if grad.is_cuda:
-                    ops.cast(self.staging[lo:hi], grad[lo:hi])
-                else:
-                    grad[lo:hi].copy_(self.staging[lo:hi])
+            if self.staging is not None and not grad.is_cuda:
+                grad[lo:hi].copy_(self.staging[lo:hi])
 
     def reduce_ranges(self, grad: torch.Tensor, ranges, after=None) -> None:
         """Start reducing ``grad[lo:hi]`` for every (lo, hi) in ``ranges`` (in place, SUM over ranks)."""
@@ -128,16 +126,23 @@ class GradAllReducer:
             self._reduce(grad, ranges)
         self._pending = True
 
-    def finish(self) -> None:
-        """Make the current stream wait for every segment started with ``reduce_ranges``."""
+    def finish(self, grad: torch.Tensor) -> torch.Tensor:
+        """Make the current stream wait for every segment started with ``reduce_ranges``; returns the buffer that
+        holds the summed gradients (``grad`` itself, or the bf16 staging buffer on the GPU: valid only if the
+        segments covered the whole buffer)."""
         if self._pending:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
             self._pending = False
+        if self.active and self.staging is not None and grad.is_cuda:
+            return self.staging
+        return grad
 
     def __call__(self, grad: torch.Tensor) -> torch.Tensor:
         """Whole buffer at once; returns the buffer holding the SUM over ranks (callers scale by 1/world)."""
         self.reduce_ranges(grad, [(0, grad.numel())])
-        self.finish()
+        out = self.finish(grad)
+        if out is not grad:  # callers of the one-shot form get the fp32 buffer back
+            ops.cast(out, grad)
         return grad
 
 
@@ -218,16 +223,17 @@ class TrainStep:
     next phase computes.  Only the last segment's exchange is exposed.  With world_size == 1 no cut is made
     and the step is a single graph.
 
-    MEASURED (MI355X, single-rank rehearsal of the MCAN L=6 step, scripts/gpu_dp_rehearse.sh): every extra
-    phase costs ~50 us of idle time at the graph boundary plus a split grouped-dW launch, 5 segments cost
-    +0.30 ms per step against 1 segment; the exposed tail is set by the LAST segment only, so the default
-    (64 MB) keeps 3 segments: guided layers 5..2 | guided 1..0 + text 5..3 | text 2..0 + 1-D parameters.
+    MEASURED (MI355X, single-rank rehearsal of the MCAN L=6 step, scripts/gpu_reh_sweep.sh; plain N=1 step
+    4.54 ms): 1 segment 4.80 ms, 2 segments 4.88, 4 segments 5.31, 5 segments 5.34 -- every extra phase costs
+    ~50 us of idle time at the graph boundary plus split grouped-dW / LayerNorm-reduce launches, while the exposed
+    tail is set by the LAST segment only.  The default (96 MB) therefore keeps exactly 2 segments for MCAN:
+    all guided layers (57 % of the bytes, exchanged while the question stack is differentiated) | the rest.
     """
 
     def __init__(self, model: nn.Module, forward_loss: Callable, lr: float = 1.0, betas=(0.9, 0.98),
                  lr_lambda: Optional[Callable[[int], float]] = None, use_graph: bool = True,
                  comm_dtype: torch.dtype = torch.float32, bucket_mb: float = 64.0, device=None,
-                 compute_dtype: Optional[torch.dtype] = None, overlap_mb: float = 64.0,
+                 compute_dtype: Optional[torch.dtype] = None, overlap_mb: float = 96.0,
                  force_comm: bool = False):
         self.model = model
         self.arena = rt.prepare(model, device=device, compute_dtype=compute_dtype)
@@ -421,8 +427,8 @@ class TrainStep:
                 self._release(k)
         else:
             self._fwd_bwd(on_phase=self._release)
-        self.reducer.finish()
-        self.optim.step(self.arena.grad, grad_scale=1.0 / self.reducer.world)
+        g = self.reducer.finish(self.arena.grad)
+        self.optim.step(g, grad_scale=1.0 / self.reducer.world)
         ops.increment_step(self.drop_step)
         return self.loss
 

@@ -308,7 +308,8 @@ def test_pointer_score_and_batched_gemm(dtype):
     assert nerr(o.batched_gemm(q, k, trans_b=True), q.double() @ k.double().transpose(1, 2)) < tol(dtype) * 4
 
 
-def test_adam_matches_torch_and_shadow():
+@pytest.mark.parametrize("grad_dtype", [F32, BF16])
+def test_adam_matches_torch_and_shadow(grad_dtype):
     o = ops()
     n = 4099
     p0 = rnd(n)
@@ -320,8 +321,8 @@ def test_adam_matches_torch_and_shadow():
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
     lr_scale = torch.tensor([0.5], device=DEV)
     for it in range(3):
-        g = rnd(n, seed=10 + it)
-        ref.grad = g.cpu().clone() / 4.0
+        g = rnd(n, seed=10 + it).to(grad_dtype)  # bf16: the data-parallel staging buffer is read directly
+        ref.grad = g.float().cpu().clone() / 4.0
         for grp in opt.param_groups:
             grp["lr"] = 0.01 * 0.5
         opt.step()
