@@ -237,25 +237,31 @@ class ParamArena:
 
 def collect_groups(module: nn.Module) -> List[List[nn.Parameter]]:
     """Adjacency groups first (declared by modules via ``_ovqa_param_groups``), then the rest."""
-    seen, groups = set(), []
+    order = {id(p): i for i, p in enumerate(module.parameters())}
+    seen, groups, key = set(), [], {}
     for m in module.modules():
         fn = getattr(m, "_ovqa_param_groups", None)
         if fn is None:
             continue
+        first = next(iter(m.parameters()), None)
         for g in fn():
             g = [p for p in g if id(p) not in seen]
             if g:
                 groups.append(g)
                 seen.update(id(p) for p in g)
+                # a group declared by a CONTAINER (the guided stack's hoisted K/V weights) is used where the
+                # container starts, i.e. before any of its layers
+                key[id(g[0])] = min(order[id(g[0])], order[id(first)] if first is not None else order[id(g[0])])
     for p in module.parameters():
         if id(p) not in seen:
             groups.append([p])
             seen.add(id(p))
-    # layer-contiguous layout: groups ordered by where their first parameter sits in module order, so that
-    # "the gradients of layers i..j" is one range of the flat buffer (one collective of the overlapped
-    # data-parallel exchange)
-    order = {id(p): i for i, p in enumerate(module.parameters())}
-    groups.sort(key=lambda g: order[id(g[0])])
+            key[id(p)] = order[id(p)]
+    # layer-contiguous layout in REVERSE module order: backward differentiates the last modules first, so "the
+    # gradients that are final after the first k sections of backward" is a PREFIX of the matrix region, and the
+    # segment that is final last (the first modules of the model) sits right in front of the 1-D tail -- every
+    # segment of the overlapped data-parallel exchange is one contiguous range (one cast, one collective)
+    groups.sort(key=lambda g: -key[id(g[0])])
     return groups
 
 
