@@ -56,7 +56,8 @@ def parse():
 
 def gemm_launch_list(B, NV, NT, D, DFF, L):
     """(M, N, K[, flag]) of every MFMA GEMM launch of one step, grouped by kernel family.
-    Forward families: y[M,N] = x[M,K] w[N,K]^T (+epilogue).  dX family: dx[M,K] = dy[M,N] w[N,K] with
+    Forward families: y[M,N] = x[M,K] w[N,K]^T (+epilogue).  dX family: dx[M,K] = dy[M,N] w[N,K] (computed
+    from the transposed weight copy wt[K,N], as the training step does) with
     flag 'g' (fused dropout*GELU' epilogue, FFN seam), 'a' (residual-branch addend) or ''."""
     mv, mt = B * NV, B * NT
     bias, gelu, resid, dx = [], [], [], []
@@ -85,7 +86,7 @@ KERNEL_OF_FAMILY = {
     "bias": "gemm_bf16_glds_kernel<false, false, MEpiBias,",
     "gelu": "gemm_bf16_glds_kernel<false, false, MEpiBiasGelu,",
     "residual": "gemm_bf16_glds_kernel<false, false, MEpiBiasResidual,",
-    "dx": "gemm_bf16_glds_kernel<true, false, MEpiBwdData,",
+    "dx": "gemm_bf16_glds_kernel<false, false, MEpiBwdData,",  # reads the transposed weight copy (row-major tile)
 }
 
 
@@ -116,6 +117,7 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
             M, N, K = sh[:3]
             bufs[sh] = dict(x=torch.randn(M, K, device=device).bfloat16(),
                             w=(torch.randn(N, K, device=device) * K ** -0.5).bfloat16(),
+                            wt=(torch.randn(K, N, device=device) * K ** -0.5).bfloat16(),
                             b=torch.randn(N, device=device), r=torch.randn(M, N, device=device).bfloat16(),
                             y=torch.empty(M, N, device=device, dtype=torch.bfloat16),
                             u=torch.empty(M, N, device=device, dtype=torch.bfloat16),
@@ -126,8 +128,8 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
             for sh in shapes:
                 t = bufs[sh]
                 if name == "dx":
-                    ops.linear_bwd_data(t["r"], t["w"], preact=t["pre"] if sh[3] == "g" else None, out=t["dx"],
-                                        addend=t["x"] if sh[3] == "a" else None)
+                    ops.linear_bwd_data_wt(t["r"], t["wt"], preact=t["pre"] if sh[3] == "g" else None, out=t["dx"],
+                                           addend=t["x"] if sh[3] == "a" else None)
                 else:
                     epi = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "residual": ops.EPI_BIAS_RESIDUAL}[name]
                     ops.linear_fwd(t["x"], t["w"], t["b"], epi, residual=t["r"] if name == "residual" else None,

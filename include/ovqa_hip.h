@@ -95,6 +95,29 @@ int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
                          int64_t M, int64_t N, int64_t K,
                          const ovqa_dropout* drop, void* stream);
 
+/* dX from a TRANSPOSED bf16 copy of the weight: wt[K, N] with row stride ldwt (dx[m,i] = sum_n dy[m,n] wt[i,n]).
+ * Same epilogue arguments as ovqa_linear_bwd_data.  The [N, K] form has to stage its weight tile k-major; in the
+ * MCAN step that costs +0.44 ms, so the training harness keeps a transposed shadow of every matrix
+ * (ovqa_grouped_transpose after each optimiser step: one launch, 2 x 88 MB of traffic).
+ * bf16 only; requires N % 8 == 0, K % 8 == 0, lddy % 8 == 0, ldwt % 8 == 0, lddx % 4 == 0. */
+int ovqa_linear_bwd_data_wt(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt,
+                            void* dx, int64_t lddx, const void* gelu_preact,
+                            const void* addend, int64_t ldadd,
+                            int64_t M, int64_t N, int64_t K, const ovqa_dropout* drop, void* stream);
+
+/* dst[c, r] = src[r, c] for many bf16 matrices in one launch (`problems` is a DEVICE array; rows/cols need not
+ * be multiples of the 64x64 tile, ld_src / ld_dst / pointers must allow 16-byte accesses: multiples of 8). */
+typedef struct ovqa_transpose_problem {
+  const void* src;
+  void* dst;
+  int64_t ld_src;
+  int64_t ld_dst;
+  int32_t rows;
+  int32_t cols;
+} ovqa_transpose_problem;
+int ovqa_grouped_transpose(const ovqa_transpose_problem* problems, int32_t n_problems, int32_t max_tiles,
+                           void* stream);
+
 /* dW = dY^T X (fp32 [N,K]), db = column sums of dY (fp32 [N], may be NULL).
  *   accumulate: bit 0 -> dw += (else overwrite), bit 1 -> db += (else overwrite).
  *   ws: scratch of ovqa_workspace_bytes(). */

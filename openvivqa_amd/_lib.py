@@ -26,6 +26,12 @@ class WgradProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class TransposeProblem(C.Structure):
+    """ovqa_transpose_problem (include/ovqa_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int64), ("ld_dst", C.c_int64),
+                ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class ReduceProblem(C.Structure):
     """ovqa_reduce_problem (include/ovqa_hip.h)."""
     _fields_ = [("partial", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
@@ -48,6 +54,9 @@ SIGNATURES = {
     "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_vp],
     "ovqa_bias_grad": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
+    "ovqa_linear_bwd_data_wt": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
+                                _DP, c_vp],
+    "ovqa_grouped_transpose": [c_vp, c_int, c_int, c_vp],
     "ovqa_linear_bwd_weight": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],
     "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
     "ovqa_layernorm_bwd": [c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

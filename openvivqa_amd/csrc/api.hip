@@ -87,6 +87,28 @@ int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M
   return ovqa::colsum_bf16(dy, lddy, db, M, N, accumulate, as_stream(stream));
 }
 
+int ovqa_linear_bwd_data_wt(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, void* dx, int64_t lddx,
+                            const void* gelu_preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
+                            const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "linear_bwd_data_wt: bf16 only");
+  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_bwd_data_wt: bad sizes");
+  if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(dy && wt && dx, OVQA_ERR_BAD_ARG, "linear_bwd_data_wt: null pointer");
+  OVQA_REQUIRE(lddy >= N && lddx >= K && ldwt >= N && (!addend || ldadd >= K), OVQA_ERR_BAD_ARG,
+               "linear_bwd_data_wt: ld smaller than the row length");
+  OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_bwd_data_wt: more than 2^32 elements");
+  OVQA_REQUIRE(ovqa::mfma_gemm_supported(K, M, N, ldwt, lddy) && lddx % 4 == 0, OVQA_ERR_UNSUPPORTED,
+               "linear_bwd_data_wt: needs N, K, lddy, ldwt multiples of 8 and lddx a multiple of 4");
+  return ovqa::mfma_linear_bwd_data_wt(dy, lddy, wt, ldwt, dx, lddx, gelu_preact, addend, ldadd, M, N, K,
+                                       make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_grouped_transpose(const ovqa_transpose_problem* problems, int32_t n_problems, int32_t max_tiles, void* stream) {
+  OVQA_REQUIRE(n_problems >= 0 && max_tiles >= 0 && n_problems <= 65535, OVQA_ERR_BAD_ARG, "grouped_transpose: bad sizes");
+  OVQA_REQUIRE(n_problems == 0 || problems != nullptr, OVQA_ERR_BAD_ARG, "grouped_transpose: null table");
+  return ovqa::grouped_transpose_bf16(problems, n_problems, max_tiles, as_stream(stream));
+}
+
 int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, float* db,
                            int64_t M, int64_t N, int64_t K, int accumulate, void* ws, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_bwd_weight: bad dtype %d", dtype);

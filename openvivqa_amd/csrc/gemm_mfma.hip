@@ -657,6 +657,62 @@ int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, con
   return OVQA_ERR_BAD_ARG;
 }
 
+// dX from a TRANSPOSED weight copy wt[K, N] (row stride ldwt): the forward-type kernel (row-major P tile).
+// MEASURED in the MCAN step: the k-major P staging of the [N, K] form costs +0.44 ms per step (4.55 -> 4.11 ms).
+int mfma_linear_bwd_data_wt(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, void* dx, int64_t lddx,
+                            const void* preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
+                            const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(aligned16(dy) && aligned16(wt) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0) &&
+                   (!addend || ((uintptr_t)addend % 8 == 0 && ldadd % 4 == 0)),
+               OVQA_ERR_BAD_ARG, "linear_bwd_data_wt(bf16): pointer alignment");
+  return launch<false, false>(wt, ldwt, dy, lddy, K, M, N,
+                              MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, (const bf16*)addend, ldadd, da, DropState{}}, st,
+                              "linear_bwd_data_wt(mfma)");
+}
+
+// Grouped transpose of bf16 matrices through LDS: dst[c, r] = src[r, c], 64x64 tiles, 16-byte global accesses.
+// grid (max tiles of any problem, problems).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const ovqa_transpose_problem* __restrict__ probs) {
+  __shared__ bf16 tile[64][64 + 8];
+  const ovqa_transpose_problem pr = probs[blockIdx.y];
+  const int tiles_c = (pr.cols + 63) / 64, tiles_r = (pr.rows + 63) / 64;
+  if ((int)blockIdx.x >= tiles_r * tiles_c) return;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const bf16* src = (const bf16*)pr.src;
+  bf16* dst = (bf16*)pr.dst;
+  const int t = threadIdx.x;
+  // load: 64 rows x 8 chunks of 8 elements; thread -> (row = t / 8 + 32 * pass, chunk = t % 8)
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int r = t / 8 + 32 * pass, ch = t % 8;
+    const int gr = tr * 64 + r, gc = tc * 64 + ch * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (bf16)0.f;
+    if (gr < pr.rows && gc < pr.cols) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)gr * pr.ld_src + gc);
+#pragma unroll
+    for (int e = 0; e < 8; e++) tile[r][ch * 8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int c = t / 8 + 32 * pass, ch = t % 8;  // output row = source column
+    const int gc = tc * 64 + c, gr = tr * 64 + ch * 8;
+    if (gc < pr.cols && gr < pr.rows) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = tile[ch * 8 + e][c];
+      *reinterpret_cast<bf16x8*>(dst + (int64_t)gc * pr.ld_dst + gr) = v;
+    }
+  }
+}
+
+int grouped_transpose_bf16(const ovqa_transpose_problem* probs, int n, int max_tiles, hipStream_t st) {
+  if (n <= 0 || max_tiles <= 0) return OVQA_OK;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)max_tiles, (unsigned)n), dim3(256), 0, st, probs);
+  return ovqa_check_launch("grouped_transpose");
+}
+
 bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx) {
   // dx[m,i] = sum_n dy[m,n] w[n,i]: r = i (R = K), c = m, reduction over N
   return mfma_gemm_supported(K, M, N, K, lddy) && lddx % 4 == 0;

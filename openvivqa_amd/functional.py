@@ -70,6 +70,15 @@ def _wgrad(arena, dy, x, w_params, b_params):
     q.add(dy, x, gw, acc_w, gb, acc_b)  # bias gradient = fused column sums of dy
 
 
+def _dx(arena, dy, ps, **kw):
+    """dX of a (packed) linear: dy @ [W of ps].  bf16: from the arena's transposed weight copy (row-major weight
+    tile for the GEMM); otherwise from the [N, K] weights."""
+    wt = arena.transposed(ps)
+    if wt is not None and ops.linear_bwd_data_wt_ok(dy, wt):
+        return ops.linear_bwd_data_wt(dy, wt, **kw)
+    return ops.linear_bwd_data(dy, arena.packed(ps) if len(ps) > 1 else arena.compute(ps[0]), **kw)
+
+
 def _armed_queue():
     """The deferred-work queue, with its flush registered to run when the current backward pass ends."""
     q = wgrad_queue()
@@ -139,7 +148,7 @@ class _KVProjectAll(Function):
         (keys,) = ctx.saved_tensors
         dkv = _c(dkv)
         _wgrad(arena, dkv, keys, st["weights"], st["biases"])
-        dkeys = ops.linear_bwd_data(dkv, arena.packed(st["weights"])) if ctx.needs_input_grad[0] else None
+        dkeys = _dx(arena, dkv, st["weights"]) if ctx.needs_input_grad[0] else None
         return dkeys, None, *([None] * (len(st["weights"]) + len(st["biases"])))
 
 
@@ -225,7 +234,7 @@ class _MHABlock(Function):
         dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=drop)
         # fc_o
         _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
-        d_o = ops.linear_bwd_data(dpre_d, arena.compute(a.fc_o.weight))
+        d_o = _dx(arena, dpre_d, [a.fc_o.weight])
         nqk = a.fc_q.weight.shape[0]
         wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
         bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
@@ -238,7 +247,7 @@ class _MHABlock(Function):
             ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
                               dv=dqkv[..., 2 * nqk:])
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
-            dx = ops.linear_bwd_data(dqkv, arena.packed([wq, wk, wv]), addend=dpre)
+            dx = _dx(arena, dqkv, [wq, wk, wv], addend=dpre)
             return dx, None, None, None, None, *([None] * len(st["params"]))
         if mode == "pre":
             (q,) = bufs
@@ -252,7 +261,7 @@ class _MHABlock(Function):
             ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., base:base + wk.shape[0]],
                               dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
             _wgrad(arena, dq, queries, [wq], [bq])
-            dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
+            dx = _dx(arena, dq, [wq], addend=dpre)
             return dx, (dkv if slot == 0 else None), None, None, None, *([None] * len(st["params"]))
         if mode == "cross":
             q, kv = bufs
@@ -261,18 +270,18 @@ class _MHABlock(Function):
             dkv = torch.empty_like(kv)
             ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
             _wgrad(arena, dq, queries, [wq], [bq])
-            dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
+            dx = _dx(arena, dq, [wq], addend=dpre)
             _wgrad(arena, dkv, keys, [wk, wv], [bk, bv])
-            dkeys = ops.linear_bwd_data(dkv, arena.packed([wk, wv])) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
+            dkeys = _dx(arena, dkv, [wk, wv]) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
             return dx, dkeys, None, None, None, *([None] * len(st["params"]))
         q, k, v = bufs
         dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h)
         _wgrad(arena, dq, queries, [wq], [bq])
-        dx = ops.linear_bwd_data(dq, arena.compute(wq), addend=dpre)
+        dx = _dx(arena, dq, [wq], addend=dpre)
         _wgrad(arena, dk, keys, [wk], [bk])
         _wgrad(arena, dv, values, [wv], [bv])
-        dkeys = ops.linear_bwd_data(dk, arena.compute(wk)) if ctx.needs_input_grad[1] else None
-        dvalues = ops.linear_bwd_data(dv, arena.compute(wv)) if ctx.needs_input_grad[2] else None
+        dkeys = _dx(arena, dk, [wk]) if ctx.needs_input_grad[1] else None
+        dvalues = _dx(arena, dv, [wv]) if ctx.needs_input_grad[2] else None
         return dx, dkeys, dvalues, None, None, *([None] * len(st["params"]))
 
 
@@ -323,9 +332,9 @@ class _FFNBlock(Function):
         x, h, u, pre, mean, rstd = ctx.saved_tensors
         dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=st["drop2"])
         _wgrad(arena, dpre_d, h, [m.fc2.weight], [m.fc2.bias])
-        du = ops.linear_bwd_data(dpre_d, arena.compute(m.fc2.weight), preact=u, drop=st["drop1"])
+        du = _dx(arena, dpre_d, [m.fc2.weight], preact=u, drop=st["drop1"])
         _wgrad(arena, du, x, [m.fc1.weight], [m.fc1.bias])
-        dx = ops.linear_bwd_data(du, arena.compute(m.fc1.weight), addend=dpre)
+        dx = _dx(arena, du, [m.fc1.weight], addend=dpre)
         return dx, None, *([None] * len(st["params"]))
 
 
@@ -361,7 +370,7 @@ class _Linear(Function):
         (x,) = ctx.saved_tensors
         dy = _c(dy)
         _wgrad(arena, dy, x, [lin.weight], [lin.bias] if lin.bias is not None else [])
-        dx = ops.linear_bwd_data(dy, arena.compute(lin.weight)) if ctx.needs_input_grad[0] else None
+        dx = _dx(arena, dy, [lin.weight]) if ctx.needs_input_grad[0] else None
         return dx, None, *([None] * len(st["params"]))
 
 
@@ -386,7 +395,7 @@ class _LinearGeluDrop(Function):
         x, u = ctx.saved_tensors
         du = ops.gelu_bwd(_c(dy).reshape(u.shape), u, drop=st["drop"])
         _wgrad(arena, du, x.reshape(-1, x.shape[-1]), [lin.weight], [lin.bias])
-        dx = ops.linear_bwd_data(du, arena.compute(lin.weight)).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dx = _dx(arena, du, [lin.weight]).reshape(x.shape) if ctx.needs_input_grad[0] else None
         return dx, None, *([None] * len(st["params"]))
 
 

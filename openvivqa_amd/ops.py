@@ -126,6 +126,38 @@ def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
     return dx
 
 
+def linear_bwd_data_wt_ok(dy, wt) -> bool:
+    """Shapes/strides the transposed-weight dX kernel accepts (bf16, everything a multiple of 8)."""
+    K, N = wt.shape
+    return (dy.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and wt.stride(1) == 1 and N % 8 == 0
+            and K % 8 == 0 and wt.stride(0) % 8 == 0 and _rows(dy)[0] % 8 == 0 and wt.data_ptr() % 16 == 0)
+
+
+def linear_bwd_data_wt(dy, wt, preact=None, drop=None, out=None, addend=None):
+    """dx = dy wt^T [* dropmask * gelu'(preact)] [+ addend] with wt = the TRANSPOSED weight copy [K, N] (rows may
+    be strided: a column block of a wider transposed matrix)."""
+    _dev(dy)
+    lib = _lib.load()
+    lddy, M = _rows(dy)
+    K, N = wt.shape
+    assert dy.shape[-1] == N and wt.dtype == dy.dtype and wt.stride(1) == 1
+    dx = out if out is not None else torch.empty(*dy.shape[:-1], K, dtype=dy.dtype, device=dy.device)
+    lddx, _ = _rows(dx)
+    ldadd = 0
+    if addend is not None:
+        ldadd, ma = _rows(addend)
+        assert ma == M and addend.dtype == dy.dtype and addend.shape[-1] == K
+    _lib.check(lib.ovqa_linear_bwd_data_wt(_dt(dy), _p(dy), lddy, _p(wt), wt.stride(0), _p(dx), lddx, _p(preact),
+                                           _p(addend), ldadd, M, N, K, _drop(drop), _stream()), "linear_bwd_data_wt")
+    return dx
+
+
+def grouped_transpose(table, n, max_tiles):
+    """table: device uint8 tensor holding n ovqa_transpose_problem structs."""
+    _dev(table)
+    _lib.check(_lib.load().ovqa_grouped_transpose(_p(table), n, max_tiles, _stream()), "grouped_transpose")
+
+
 def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, accumulate_db=None):
     """dw (fp32 [N,K]) (+)= dy^T x ; db (fp32 [N]) (+)= colsum(dy)."""
     flags = int(bool(accumulate)) | (int(bool(accumulate if accumulate_db is None else accumulate_db)) << 1)

@@ -60,6 +60,7 @@ class FlatAdam:
         ops.adam_step(a.master, a.grad if grad is None else grad, self.exp_avg, self.exp_avg_sq, a.shadow, self.lr,
                       self.step_t, lr_scale=self.lr_scale, betas=self.betas, eps=self.eps,
                       weight_decay=self.weight_decay, grad_scale=grad_scale)
+        a.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
         self.host_step += 1
         if self.lr_lambda is not None:  # scheduler.step(): value used by the NEXT optimiser step
             self.lr_scale.fill_(self.lr_lambda(self.host_step))

@@ -333,6 +333,49 @@ def test_adam_matches_torch_and_shadow(grad_dtype):
     assert torch.equal(shadow[:n], p.to(BF16))
 
 
+def test_grouped_transpose_and_dx_from_transposed_weights():
+    """ovqa_grouped_transpose (ragged sizes) and ovqa_linear_bwd_data_wt == ovqa_linear_bwd_data, including a
+    column block of a wider transposed matrix, the fused dropout*GELU' epilogue and the addend."""
+    import ctypes as C
+    import numpy as np
+    from openvivqa_amd import _lib
+    from openvivqa_amd.ops import DropSpec
+    o = ops()
+    mats = [rnd(512, 512, dtype=BF16, seed=1), rnd(1536, 512, dtype=BF16, seed=2), rnd(72, 200, dtype=BF16, seed=3)]
+    outs = [torch.zeros(m.shape[1], m.shape[0], dtype=BF16, device=DEV) for m in mats]
+    probs = (_lib.TransposeProblem * len(mats))()
+    for i, (m, t) in enumerate(zip(mats, outs)):
+        probs[i] = _lib.TransposeProblem(m.data_ptr(), t.data_ptr(), m.shape[1], m.shape[0], m.shape[0], m.shape[1])
+    table = torch.from_numpy(np.frombuffer(bytes(probs), dtype=np.uint8).copy()).to(DEV)
+    o.grouped_transpose(table, len(mats), max(((m.shape[0] + 63) // 64) * ((m.shape[1] + 63) // 64) for m in mats))
+    for m, t in zip(mats, outs):
+        assert torch.equal(t, m.t().contiguous())
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for M in (6400, 1280, 72):
+        w = mats[1]                      # packed [1536, 512] weight, wt = [512, 1536]
+        wt = outs[1]
+        dy = rnd(M, 1536, dtype=BF16, seed=4)
+        add = rnd(M, 512, dtype=BF16, seed=5)
+        a = o.linear_bwd_data(dy, w, addend=add)
+        b = o.linear_bwd_data_wt(dy, wt, addend=add)
+        assert nerr(b, a) < 1e-6
+        # column block: the middle 512 weight rows only (a strided [512, 512] view of wt)
+        a = o.linear_bwd_data(dy[:, 512:1024].contiguous(), w[512:1024])
+        blk = wt[:, 512:1024]
+        assert o.linear_bwd_data_wt_ok(dy[:, 512:1024], blk)
+        b = o.linear_bwd_data_wt(dy[:, 512:1024], blk)
+        assert nerr(b, a) < 1e-6
+        # FFN seam: dy [M, 512] x W2 [512, 2048] with dropout * gelu'(u)
+        w2 = rnd(512, 2048, dtype=BF16, seed=6)
+        w2t = w2.t().contiguous()
+        u = rnd(M, 2048, dtype=BF16, seed=7)
+        dyo = rnd(M, 512, dtype=BF16, seed=8)
+        drop = DropSpec(p=0.1, seed=123, site=4, step=step)
+        a = o.linear_bwd_data(dyo, w2, preact=u, drop=drop)
+        b = o.linear_bwd_data_wt(dyo, w2t, preact=u, drop=drop)
+        assert nerr(b, a) < 1e-6
+
+
 def test_layernorm_bwd_deferred_grouped_reduce():
     """dgamma/dbeta of several LayerNorms via per-call partials + ONE grouped reduce == the immediate form."""
     from openvivqa_amd.ops import WgradQueue
