@@ -457,8 +457,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
   const int4 t = tiles[blockIdx.x];
   if (t.x < 0) return;  // padding entry (keeps the host's blockIdx % 8 -> XCD grouping aligned)
   const ovqa_wgrad_problem pr = probs[t.x];
-  GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
+  // (reading both operands row-major from transposed activation copies was timed: no gain for this
+  // register-staged kernel, unlike the direct-to-LDS dX kernels)
+  GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
   gemm_tile<true, true, MEpiWgrad, true>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
