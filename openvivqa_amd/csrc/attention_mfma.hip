@@ -456,6 +456,224 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
   }
 }
 
+
+// ------------------------------------------------------------------------------ merged backward, n_k <= 32
+// Question self-attention (20 x 20) and guided attention (100 queries x 20 question tokens): one key tile, and
+// a workgroup holds ALL queries of its problems, so dQ, dK and dV come out of ONE launch (the two-kernel form
+// costs a second ~5 us dependent launch and stages Q / dO / K / V twice).  One wave = one 32-query tile:
+//   transposed orientation (lane = query):  S^T, dP^T -> dS^T -> dQ^T += K^T dS^T            (as kernel A)
+//   direct orientation     (lane = key):    S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS  (as kernel B)
+// The dK/dV partials of the <= 4 query tiles of a problem are summed in LDS, one wave after the other between
+// workgroup barriers (LDS fp32 atomics were measured 4x slower: ~100 cycles per ds_add_f32 wave-instruction).
+__global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int q_rows = 32 * W, k_rows = 32;
+  const int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
+  const int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | dV^T,dK^T
+  const int slot = wave / W, tq = wave % W;
+
+  for (int g = 0; g < G; g++) {
+    const int64_t pid = (int64_t)blockIdx.x * G + g;
+    if (pid >= (int64_t)a.B * a.H) break;
+    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+    char* base = smem + g * prob_bytes;
+    const ImgDesc d[4] = {
+        {base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
+        {base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
+        {base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
+        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
+    load_images<4>(d, tid);
+    float* mrow_s = reinterpret_cast<float*>(base + img_bytes);
+    if (a.msq == 0)
+      load_mask_row(mrow_s, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
+  }
+  __syncthreads();
+
+  const int64_t pid = (int64_t)blockIdx.x * G + slot;
+  const bool active = slot < G && pid < (int64_t)a.B * a.H && tq * 32 < nq;
+  const int b = active ? (int)(pid / a.H) : 0, h = active ? (int)(pid % a.H) : 0;
+  const char* Qs = smem + (active ? slot : 0) * prob_bytes;
+  const char* Gs = Qs + q_rows * 128;
+  const char* Ks = Gs + q_rows * 128;
+  const char* Vs = Ks + k_rows * 128;
+  float* mlds = reinterpret_cast<float*>(const_cast<char*>(Vs) + k_rows * 128);
+  float* lse_s = mlds + k_rows;
+  float* del_s = lse_s + q_rows;
+  float* red = del_s + q_rows;
+  const bool row_mask = a.msq == 0;
+  f32x16 dvt[2], dkt[2];
+#pragma unroll
+  for (int d = 0; d < 2; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
+
+  if (active) {
+    const int q = tq * 32 + (lane & 31);
+    const bool qok = q < nq;
+    const int qc = qok ? q : nq - 1;
+    float delta = 0.f;
+    {
+      const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * 64 + 32 * (lane >> 5);
+      const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * 64 + 32 * (lane >> 5);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
+        const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
+        const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) delta += (float)g8[e] * (float)oa[e] + (float)g8[4 + e] * (float)ob[e];
+      }
+      delta += __shfl_xor(delta, 32, 64);
+    }
+    const float lse = a.lse[((int64_t)b * a.H + h) * nq + qc];
+    if (lane < 32) {  // row statistics for the direct orientation (read back by this wave only)
+      lse_s[tq * 32 + lane] = lse;
+      del_s[tq * 32 + lane] = delta;
+      if (qok) a.delta[((int64_t)b * a.H + h) * nq + q] = delta;
+    }
+    const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
+
+    bf16x8 qf[4], gf[4], kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
+      gf[ks] = frag_rows(Gs, tq * 32, ks, lane);
+      kf[ks] = frag_rows(Ks, 0, ks, lane);
+      vf[ks] = frag_rows(Vs, 0, ks, lane);
+    }
+    // ---- transposed orientation: dQ
+    {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = acc_row(r, lane);
+        float p;
+        if (row_mask) {
+          p = exp2f((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
+        } else {
+          p = 0.f;
+          if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+        }
+        ds[r] = p * (dp[r] - delta);
+      }
+      f32x16 dqt[2];
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dqt[d][r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 db;
+#pragma unroll
+        for (int j = 0; j < 8; j++) db[j] = (bf16)ds[8 * s2 + j];
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+          dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, 16 * s2, d * 32, lane), db, dqt[d], 0, 0, 0);
+      }
+      if (qok) {
+        bf16* drow = (bf16*)a.dq + ((int64_t)b * nq + q) * a.lddq + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; g4++) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o4[e] = (bf16)(dqt[d][4 * g4 + e] * a.scale);
+            *reinterpret_cast<bf16x4*>(drow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+          }
+      }
+    }
+    // ---- direct orientation: this query tile's share of dK^T / dV^T
+    {
+      const int key = lane & 31;
+      const bool kok = key < nk;
+      const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
+      const float mconst = row_mask ? mlds[key] : 0.f;  // -inf beyond nk
+      f32x16 s_, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s_, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[ks], vf[ks], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ql = tq * 32 + acc_row(r, lane);
+        float pv = 0.f;
+        if (ql < nq && kok) {
+          const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)ql * a.msq] : 0.f);
+          pv = exp2f((s_[r] * a.scale + mv - lse_s[ql]) * LOG2E);
+        }
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - del_s[ql]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 pb, db;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s2 + j]; db[j] = (bf16)ds[8 * s2 + j]; }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, tq * 32 + 16 * s2, d * 32, lane), pb, dvt[d], 0, 0, 0);
+          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, tq * 32 + 16 * s2, d * 32, lane), db, dkt[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // sum over the query tiles of each problem: tile `ph` adds its share in phase `ph` (tile 0 stores)
+  for (int ph = 0; ph < W; ph++) {
+    if (active && tq == ph) {
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float* pv = red + ((0 * 2 + d) * 16 + r) * 64 + lane;
+          float* pk = red + ((1 * 2 + d) * 16 + r) * 64 + lane;
+          if (ph == 0) {
+            *pv = dvt[d][r];
+            *pk = dkt[d][r];
+          } else {
+            *pv += dvt[d][r];
+            *pk += dkt[d][r];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (active && tq == 0) {
+    const int key = lane & 31;
+    if (key < nk) {
+      bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
+      bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 k4, v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v4[e] = (bf16)red[((0 * 2 + d) * 16 + 4 * g4 + e) * 64 + lane];
+            k4[e] = (bf16)(red[((1 * 2 + d) * 16 + 4 * g4 + e) * 64 + lane] * a.scale);
+          }
+          *reinterpret_cast<bf16x4*>(dkrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = k4;
+          *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
+        }
+    }
+  }
+}
+
 template <typename K>
 int ensure_lds(K kernel, size_t bytes, const char* what) {
   if (bytes > 160 * 1024) {
@@ -499,6 +717,22 @@ int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
 
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   const int64_t nprob = (int64_t)a.B * a.H;
+  static int merged = -1;
+  if (merged < 0) {
+    const char* e = getenv("OVQA_ATTN_BWD_MERGED");
+    merged = e ? atoi(e) : 1;
+  }
+  if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
+    int W = (a.nq + 31) / 32;
+    if (W == 3) W = 4;
+    const size_t prob = (size_t)(2 * 32 * W + 2 * 32) * 128 + 32 * 4 + 2 * 32 * W * 4 + 4096 * 4;
+    const int G = pack_factor(W, prob);
+    const size_t lds = (size_t)G * prob;
+    int rc = ensure_lds(attn_bwd_smallk_mfma_kernel, lds, "attention_bwd(mfma,merged)");
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel, dim3((unsigned)((nprob + G - 1) / G)), dim3(256), lds, st, a, W, G);
+    return ovqa_check_launch("attention_bwd(mfma,merged)");
+  }
   {  // dQ: waves over query tiles, all keys resident
     int W = (a.nq + 31) / 32;
     if (W > 4) W = 4;

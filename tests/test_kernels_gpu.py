@@ -183,7 +183,9 @@ def test_layernorm_bwd_dropout_branch(dtype):
 
 
 ATT_SHAPES = [(2, 4, 5, 7, 8), (3, 8, 100, 100, 64), (2, 8, 100, 20, 64), (2, 8, 20, 20, 64), (2, 8, 20, 100, 64),
-              (2, 2, 1, 7, 16), (1, 8, 237, 237, 64), (2, 8, 182, 182, 96)]
+              (2, 2, 1, 7, 16), (1, 8, 237, 237, 64), (2, 8, 182, 182, 96),
+              # merged small-n_k backward: 2 and 3(->4) query tiles, ragged packing (9 problems, 4 per workgroup)
+              (3, 8, 50, 32, 64), (2, 8, 70, 13, 64), (5, 8, 128, 20, 64), (2, 8, 33, 1, 64), (3, 3, 20, 20, 64)]
 
 
 def att_ref(q, k, v, mask, H):
