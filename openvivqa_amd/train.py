@@ -387,6 +387,21 @@ class TrainStep:
         if self.arena.device.type != "cuda":
             self._discover_foreign()
             return
+        try:
+            self._warm_and_capture()
+        except Exception as exc:  # noqa: BLE001 -- the overlap is an optimisation: never lose the step over it
+            if self._cuts is None and len(self.segments) == 1:
+                raise
+            import sys
+            print(f"openvivqa_amd.TrainStep: phased backward failed ({type(exc).__name__}: {exc}); "
+                  "falling back to one gradient exchange after backward", file=sys.stderr)
+            torch.cuda.synchronize()
+            self.overlap_mb = 0.0
+            self._cuts, self._live, self.graphs = None, None, None
+            self.segments = [[(0, self.arena.numel)]]
+            self._warm_and_capture()
+
+    def _warm_and_capture(self):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -408,7 +423,8 @@ class TrainStep:
                     later(k)()
                 graphs.append(g)
             self._live = None
-            assert len(graphs) == len(self.segments), (len(graphs), len(self.segments))
+            if len(graphs) != len(self.segments):
+                raise RuntimeError(f"{len(graphs)} captured phases for {len(self.segments)} gradient segments")
             self.graphs = graphs
 
     def _release(self, k):
