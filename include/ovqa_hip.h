@@ -130,7 +130,9 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy,
  * individual products have 16..64 output tiles each -- far fewer than 256 CUs --
  * so they are deferred and tiled together instead of being split along M).
  * `problems`/`tiles` are DEVICE arrays written by the host side: tiles[i] =
- * {problem index, tile over N (128 rows), tile over K (128 cols), 0}. bf16 only. */
+ * {problem index, tile over N (128 rows), tile over K (128 cols), 0}. bf16 only.
+ * all_m_mult64 != 0 promises that every problem's M is a multiple of 64 (and its pointers 16-byte aligned,
+ * lddy / ldx multiples of 8): the direct-to-LDS 8-wave tile is used then (measured -50 us per MCAN step). */
 typedef struct {
   const void* dy;   /* [M,N], row stride lddy */
   const void* x;    /* [M,K], row stride ldx  */
@@ -141,7 +143,8 @@ typedef struct {
   int32_t accumulate; /* bit 0: dw +=, bit 1: db += */
 } ovqa_wgrad_problem;
 int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev,
-                                   const int32_t* tiles_dev, int64_t n_tiles, void* stream);
+                                   const int32_t* tiles_dev, int64_t n_tiles, int32_t all_m_mult64,
+                                   void* stream);
 /* db (fp32 [N]) (+)= column sums of dy [M,N] (bias gradient on its own). */
 int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N,
                    int accumulate, void* stream);

@@ -52,7 +52,7 @@ SIGNATURES = {
     "ovqa_linear_fwd": [c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                         c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
-    "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_vp],
+    "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_int, c_vp],
     "ovqa_bias_grad": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
     "ovqa_linear_bwd_data_wt": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
                                 _DP, c_vp],

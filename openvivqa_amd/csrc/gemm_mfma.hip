@@ -464,6 +464,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
   gemm_tile<true, true, MEpiWgrad, true>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
+// The same grouped dW on the direct-to-LDS 8-wave tile (both operands k-major); needs M % 64 == 0 for every problem
+__global__ __launch_bounds__(512) void gemm_bf16_grouped_wgrad_glds_kernel(const ovqa_wgrad_problem* __restrict__ probs,
+                                                                           const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int4 t = tiles[blockIdx.x];
+  if (t.x < 0) return;
+  const ovqa_wgrad_problem pr = probs[t.x];
+  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
+  GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
+  gemm_tile_glds<true, true, MEpiWgrad, true, 2, 8, 128>(g, t.y * BT, t.z * BT, epi, smem);
+}
+
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tc = blockIdx.x / g.tiles_r, tr = blockIdx.x % g.tiles_r;
@@ -748,8 +760,19 @@ int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t 
   return ovqa_check_launch("linear_bwd_weight(mfma)");
 }
 
-int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, hipStream_t st) {
+int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, bool direct_to_lds,
+                       hipStream_t st) {
   if (n_tiles == 0) return OVQA_OK;
+  static int allow = -1;
+  if (allow < 0) {
+    const char* e = getenv("OVQA_DW_GLDS");
+    allow = e ? atoi(e) : 1;
+  }
+  if (direct_to_lds && allow) {
+    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_glds_kernel, dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st,
+                       probs_dev, reinterpret_cast<const int4*>(tiles_dev));
+    return ovqa_check_launch("grouped_linear_bwd_weight(mfma,glds)");
+  }
   hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3((unsigned)n_tiles), dim3(256), 4 * TILE_BYTES, st, probs_dev,
                      reinterpret_cast<const int4*>(tiles_dev));
   return ovqa_check_launch("grouped_linear_bwd_weight(mfma)");

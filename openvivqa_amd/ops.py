@@ -298,8 +298,10 @@ class WgradQueue:
         side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
         with torch.cuda.stream(side):
             devbuf[:nbytes].copy_(host[:nbytes], non_blocking=True)
+            fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
+                       and it[1].data_ptr() % 16 == 0 for it in items)
             _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
-                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles),
+                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), int(fast),
                 side.cuda_stream), "grouped_linear_bwd_weight")
         self._used(entry, side, capturing)
         self._used_side = True

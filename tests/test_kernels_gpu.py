@@ -108,9 +108,13 @@ def test_linear_bwd_weight(dtype, M, N, K):
     assert nerr(dw2, rw) < tol(dtype)
 
 
-def test_grouped_wgrad_and_bias_grad():
+@pytest.mark.parametrize("specs", [
+    [(6400, 512, 512), (1280, 1024, 512), (400, 1536, 512), (1280, 2048, 512), (6400, 512, 2048), (37, 32, 64)],
+    # every M a multiple of 64: the direct-to-LDS 8-wave tile (ragged N / K included)
+    [(6400, 512, 512), (1280, 1024, 512), (448, 1536, 512), (64, 72, 40), (128, 8, 2048), (6400, 512, 2048)],
+], ids=["register-staged", "direct-to-lds"])
+def test_grouped_wgrad_and_bias_grad(specs):
     o = ops()
-    specs = [(6400, 512, 512), (1280, 1024, 512), (400, 1536, 512), (1280, 2048, 512), (6400, 512, 2048), (37, 32, 64)]
     q = o.WgradQueue()
     refs, outs = [], []
     for i, (M, N, K) in enumerate(specs):
