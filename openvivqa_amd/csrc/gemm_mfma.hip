@@ -465,6 +465,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
 }
 
 // The same grouped dW on the direct-to-LDS 8-wave tile (both operands k-major); needs M % 64 == 0 for every problem
+template <int NBUF>
 __global__ __launch_bounds__(512) void gemm_bf16_grouped_wgrad_glds_kernel(const ovqa_wgrad_problem* __restrict__ probs,
                                                                            const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_grouped_wgrad_glds_kernel(const
   const ovqa_wgrad_problem pr = probs[t.x];
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
-  gemm_tile_glds<true, true, MEpiWgrad, true, 2, 8, 128>(g, t.y * BT, t.z * BT, epi, smem);
+  gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
@@ -769,7 +770,7 @@ int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles
     allow = e ? atoi(e) : 1;
   }
   if (direct_to_lds && allow) {
-    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_glds_kernel, dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st,
+    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_glds_kernel<2>, dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st,
                        probs_dev, reinterpret_cast<const int4*>(tiles_dev));
     return ovqa_check_launch("grouped_linear_bwd_weight(mfma,glds)");
   }
