@@ -11,7 +11,11 @@
 //   dX        dX[m,i]  = sum_n dY[m,n] W[n,i]     c=m  r=i   P=W  k-major        Q=dY  k-contiguous
 //   dW        dW[n,i]  = sum_m dY[m,n] X[m,i]     c=n  r=i   P=X  k-major        Q=dY  k-major
 //
-// so nn.Linear's [out,in] weights serve all three products without a transposed copy.
+// so nn.Linear's [out,in] weights can serve all three products without a transposed copy.  In practice the
+// training path computes dX from a TRANSPOSED weight copy (mfma_linear_bwd_data_wt: P = W^T k-contiguous): with
+// direct-to-LDS staging the k-major weight tile was ~2x slower per K step in the MCAN step.
+// The direct-to-LDS kernels with a k-contiguous P stage P's rows in a permuted order (perm32) so that a lane's
+// accumulators cover 8 consecutive r: 16-byte epilogue accesses.
 //   * k-contiguous tiles live in LDS as [128 rows][64 k] (128 B rows), 16-byte chunk index XOR (row&7):
 //     ds_write_b128 staging and ds_read_b128 fragment reads are bank-conflict free.
 //   * k-major tiles live as [64 k][128 rows] (256 B rows) and fragments are fetched with the gfx950
@@ -210,10 +214,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int c0, int r0, Epi
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <bool KMAJOR, int NW, int NCHUNK = 16>
+// PERM (row-major P operand of the wide-epilogue kernels): LDS row slot s of every 32-row group holds GLOBAL row
+//   perm32(s) = 8*((s>>2)&3) + 4*(s>>4) + (s&3),
+// so the two 16-row MFMA tiles of a slot group cover global rows {8g..8g+3} and {8g+4..8g+7} in accumulator
+// row-group g: a lane ends up with 8 CONSECUTIVE output features (one 16-byte access per epilogue tensor instead
+// of two 8-byte ones).  Only the source address of the direct-to-LDS load changes; the LDS image, its swizzle
+// and the fragment reads are untouched.
+__device__ __forceinline__ int perm32(int s) { return (s & ~31) | ((s & 12) << 1) | (((s >> 4) & 1) << 2) | (s & 3); }
+
+template <bool KMAJOR, int NW, int NCHUNK = 16, bool PERM = false>
 __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ Op, int64_t ld, int row0, int rows,
                                            int k0, int lane, int wave) {
   static_assert(!KMAJOR || NCHUNK == 16, "k-major images are always 128 wide");
+  static_assert(!(KMAJOR && PERM), "the row permutation is for row-major images");
   constexpr int PER = NCHUNK / NW;  // 1 KiB chunks of the tile per wave
 #pragma unroll
   for (int i = 0; i < PER; i++) {
@@ -221,7 +234,7 @@ __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ 
     const bf16* src;
     if (!KMAJOR) {
       const int row = ci * 8 + (lane >> 3), pos = lane & 7;
-      int grow = row0 + row;
+      int grow = row0 + (PERM ? perm32(row) : row);
       grow = grow < rows ? grow : rows - 1;
       src = Op + (int64_t)grow * ld + k0 + ((pos ^ (row & 7)) << 3);
     } else {
@@ -255,6 +268,8 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   constexpr int QPER = (QCH + NW - 1) / NW;
   constexpr int STAGE = TILE_BYTES + BC * BK * 2;  // bytes of one ring stage (P tile + Q tile)
   constexpr int LOADS = 16 / NW + QPER;  // LDS-DMA instructions per (loading) wave per K tile
+  constexpr bool WIDE = !P_KMAJOR && Epi::kWide;  // 8 consecutive r per lane (see perm32)
+  static_assert(!WIDE || NJ % 2 == 0, "wide epilogue pairs the r sub-tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WR, wr = wave % WR;
 
@@ -275,7 +290,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   const int nkt = g.K / BK;
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
-    stage_glds<P_KMAJOR, NW>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
+    stage_glds<P_KMAJOR, NW, 16, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
     if constexpr (QCH >= NW) {
       stage_glds<Q_KMAJOR, NW, QCH>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
     } else {  // fewer Q chunks than waves (BC = 32): the first QCH waves load one chunk each
@@ -335,10 +350,18 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   for (int i = 0; i < NI; i++) {
     const int c = c0 + wc * (NI * 16) + i * 16 + (lane & 15);
     if (c >= g.C) continue;
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int r = r0 + wr * (NJ * 16) + j * 16 + (lane >> 4) * 4;
-      if (r < g.R) epi(c, r, acc[j][i]);
+      for (int jp = 0; jp < NJ / 2; jp++) {
+        const int r = r0 + wr * (NJ * 16) + jp * 32 + (lane >> 4) * 8;
+        if (r < g.R) epi.wide(c, r, acc[2 * jp][i], acc[2 * jp + 1][i]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int r = r0 + wr * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+        if (r < g.R) epi(c, r, acc[j][i]);
+      }
     }
   }
 }
@@ -380,17 +403,47 @@ __device__ __forceinline__ float4 bias4(const float* bias, int n) {
   return bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int t = 0; t < 8; t++) o[t] = (bf16)v[t];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ void bias8(const float* bias, int n, const f32x4& lo, const f32x4& hi, float (&u)[8]) {
+  const float4 b0 = bias4(bias, n), b1 = bias4(bias ? bias + 4 : nullptr, n);
+  u[0] = lo[0] + b0.x; u[1] = lo[1] + b0.y; u[2] = lo[2] + b0.z; u[3] = lo[3] + b0.w;
+  u[4] = hi[0] + b1.x; u[5] = hi[1] + b1.y; u[6] = hi[2] + b1.z; u[7] = hi[3] + b1.w;
+}
+
+// `wide(m, n, lo, hi)`: 8 consecutive output features n..n+7 of row m (the glds kernels with a row-major P);
+// needs 16-byte aligned rows for every tensor it touches (checked by launch()).
 struct MEpiBias {
+  static constexpr bool kWide = true;
   bf16* y; int64_t ldy; const float* bias;
   __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    bias8(bias, n, lo, hi, u);
+    store8(y + (int64_t)m * ldy + n, u);
+  }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     const float4 b = bias4(bias, n);
     store4(y + (int64_t)m * ldy + n, a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
   }
 };
 struct MEpiBiasGelu {
+  static constexpr bool kWide = true;
   bf16* y; int64_t ldy; const float* bias; bf16* preact; int N; DropArgs da; DropState ds;
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    bias8(bias, n, lo, hi, u);
+    if (preact) store8(preact + (int64_t)m * N + n, u);
+    const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+#pragma unroll
+    for (int t = 0; t < 8; t++) u[t] = gelu_fast(u[t]) * drop_mul(ds, idx + t);
+    store8(y + (int64_t)m * ldy + n, u);
+  }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     const float4 b = bias4(bias, n);
     const float u0 = a[0] + b.x, u1 = a[1] + b.y, u2 = a[2] + b.z, u3 = a[3] + b.w;
@@ -401,8 +454,18 @@ struct MEpiBiasGelu {
   }
 };
 struct MEpiBiasResidual {
+  static constexpr bool kWide = true;
   bf16* y; int64_t ldy; const float* bias; const bf16* res; int64_t ldres; int N; DropArgs da; DropState ds;
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    bias8(bias, n, lo, hi, u);
+    const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + (int64_t)m * ldres + n);
+    const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+#pragma unroll
+    for (int t = 0; t < 8; t++) u[t] = (float)r[t] + u[t] * drop_mul(ds, idx + t);
+    store8(y + (int64_t)m * ldy + n, u);
+  }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     const float4 b = bias4(bias, n);
     const bf16x4 r = *reinterpret_cast<const bf16x4*>(res + (int64_t)m * ldres + n);
@@ -414,8 +477,24 @@ struct MEpiBiasResidual {
 };
 // dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
 struct MEpiBwdData {
+  static constexpr bool kWide = true;
   bf16* dx; int64_t lddx; const bf16* preact; int Kcols; const bf16* addend; int64_t ldadd; DropArgs da; DropState ds;
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (preact) {
+      const bf16x8 u = *reinterpret_cast<const bf16x8*>(preact + (int64_t)m * Kcols + n);
+      const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + (uint32_t)n;
+#pragma unroll
+      for (int t = 0; t < 8; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_fast((float)u[t]);
+    }
+    if (addend) {
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(addend + (int64_t)m * ldadd + n);
+#pragma unroll
+      for (int t = 0; t < 8; t++) v[t] += (float)o[t];
+    }
+    store8(dx + (int64_t)m * lddx + n, v);
+  }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (preact) {
@@ -434,6 +513,7 @@ struct MEpiBwdData {
 };
 // dW (fp32) (+)= acc
 struct MEpiWgrad {
+  static constexpr bool kWide = false;
   float* dw; int64_t ld; int accumulate; float* db; int accumulate_db;
   __device__ __forceinline__ void init() {}
   __device__ __forceinline__ bool wants_colsum() const { return db != nullptr; }
@@ -546,12 +626,14 @@ inline int set_max_lds(K kernel, size_t bytes) {
 
 // variant 0: register-staged (any K % 8 == 0); NBUF = variant % 10 in {2,3}: direct-to-LDS ring (K % 64 == 0);
 // variant >= 10: 8 waves per tile instead of 4.
+// wide_ok: every tensor the epilogue touches has 16-byte aligned rows (the direct-to-LDS kernels with a row-major
+// P use the 8-feature epilogue); otherwise the register-staged kernel (8-byte epilogue accesses) runs.
 template <bool PK, bool QK, typename Epi>
 int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, int64_t C, int64_t K, Epi epi,
-           hipStream_t st, const char* what) {
+           hipStream_t st, const char* what, bool wide_ok = true) {
   GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
              (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
-  const int variant = (K % BK == 0) ? gemm_variant() : 0;
+  const int variant = (K % BK == 0 && (PK || !Epi::kWide || wide_ok)) ? gemm_variant() : 0;
   // few 128x128 tiles (the M = 1280 question stack): halve the c tile -> twice the workgroups
   const bool small_c = !QK && variant >= 10 && g.tiles_r * g.tiles_c <= small_tile_threshold();
   const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold();
@@ -655,18 +737,20 @@ int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, con
   OVQA_REQUIRE(aligned16(x) && aligned16(w) && ((uintptr_t)y % 8 == 0) && (!bias || aligned16(bias)) &&
                    (!residual || (uintptr_t)residual % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0),
                OVQA_ERR_BAD_ARG, "linear_fwd(bf16): pointer alignment (x/w/bias 16 B, y/residual/preact 8 B)");
+  const bool wide = aligned16(y) && ldy % 8 == 0 && (!residual || (aligned16(residual) && ldres % 8 == 0)) &&
+                    (!preact || aligned16(preact));
   switch (epilogue) {
     case OVQA_EPI_BIAS:
-      return launch<false, false>(w, K, x, ldx, N, M, K, MEpiBias{(bf16*)y, ldy, bias}, st, "linear_fwd(mfma,bias)");
+      return launch<false, false>(w, K, x, ldx, N, M, K, MEpiBias{(bf16*)y, ldy, bias}, st, "linear_fwd(mfma,bias)", wide);
     case OVQA_EPI_BIAS_GELU:
       return launch<false, false>(w, K, x, ldx, N, M, K,
                                   MEpiBiasGelu{(bf16*)y, ldy, bias, (bf16*)preact, (int)N, da, DropState{}}, st,
-                                  "linear_fwd(mfma,gelu)");
+                                  "linear_fwd(mfma,gelu)", wide);
     case OVQA_EPI_BIAS_RESIDUAL:
       OVQA_REQUIRE(residual != nullptr, OVQA_ERR_BAD_ARG, "linear_fwd: residual epilogue needs a residual");
       return launch<false, false>(w, K, x, ldx, N, M, K,
                                   MEpiBiasResidual{(bf16*)y, ldy, bias, (const bf16*)residual, ldres, (int)N, da, DropState{}}, st,
-                                  "linear_fwd(mfma,residual)");
+                                  "linear_fwd(mfma,residual)", wide);
   }
   ovqa_set_error("linear_fwd: unknown epilogue %d", epilogue);
   return OVQA_ERR_BAD_ARG;
@@ -680,9 +764,11 @@ int mfma_linear_bwd_data_wt(const void* dy, int64_t lddy, const void* wt, int64_
   OVQA_REQUIRE(aligned16(dy) && aligned16(wt) && ((uintptr_t)dx % 8 == 0) && (!preact || (uintptr_t)preact % 8 == 0) &&
                    (!addend || ((uintptr_t)addend % 8 == 0 && ldadd % 4 == 0)),
                OVQA_ERR_BAD_ARG, "linear_bwd_data_wt(bf16): pointer alignment");
+  const bool wide = aligned16(dx) && lddx % 8 == 0 && (!preact || aligned16(preact)) &&
+                    (!addend || (aligned16(addend) && ldadd % 8 == 0));
   return launch<false, false>(wt, ldwt, dy, lddy, K, M, N,
                               MEpiBwdData{(bf16*)dx, lddx, (const bf16*)preact, (int)K, (const bf16*)addend, ldadd, da, DropState{}}, st,
-                              "linear_bwd_data_wt(mfma)");
+                              "linear_bwd_data_wt(mfma)", wide);
 }
 
 // Grouped transpose of bf16 matrices through LDS: dst[c, r] = src[r, c], 64x64 tiles, 16-byte global accesses.
