@@ -20,6 +20,9 @@ namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 constexpr float LOG2E = 1.4426950408889634f;
+// raw v_exp_f32: the arguments are <= ~0 (score minus row maximum / log-sum-exp), results in [0, 1]; the libm
+// exp2f wraps the instruction in denormal-range fix-ups (~4 extra VALU ops per element of a VALU-bound softmax)
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ int xs(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
 // byte offset of 16-byte chunk `ch` (0..7) of row `row` in a [rows][64 bf16] image
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   for (int t = 0; t < NKT; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float p = exp2f((st[t][r] - mx) * LOG2E);
+      const float p = exp2_fast((st[t][r] - mx) * LOG2E);
       st[t][r] = p;
       sum += p;
     }
@@ -311,10 +314,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
       const int key = t * 32 + acc_row(r, lane);
       float p;
       if (row_mask) {
-        p = exp2f((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
+        p = exp2_fast((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
       } else {
         p = 0.f;
-        if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+        if (key < nk) p = exp2_fast((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
       }
       ds[r] = p * (dp[r] - delta);
     }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
       float pv = 0.f;
       if (qi < nq && kok) {
         const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)qi * a.msq] : 0.f);
-        pv = exp2f((s_[r] * a.scale + mv - ls[qi]) * LOG2E);
+        pv = exp2_fast((s_[r] * a.scale + mv - ls[qi]) * LOG2E);
       }
       p[r] = pv;
       ds[r] = pv * (dp[r] - ls[q_rows + qi]);
@@ -559,10 +562,10 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
         const int key = acc_row(r, lane);
         float p;
         if (row_mask) {
-          p = exp2f((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
+          p = exp2_fast((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
         } else {
           p = 0.f;
-          if (key < nk) p = exp2f((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+          if (key < nk) p = exp2_fast((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
         }
         ds[r] = p * (dp[r] - delta);
       }
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
         float pv = 0.f;
         if (ql < nq && kok) {
           const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)ql * a.msq] : 0.f);
-          pv = exp2f((s_[r] * a.scale + mv - lse_s[ql]) * LOG2E);
+          pv = exp2_fast((s_[r] * a.scale + mv - lse_s[ql]) * LOG2E);
         }
         p[r] = pv;
         ds[r] = pv * (dp[r] - del_s[ql]);
