@@ -440,3 +440,41 @@ def test_errors_are_loud():
         o.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))  # CPU tensors
     with pytest.raises(RuntimeError):
         o.layernorm_fwd(rnd(4, 12), torch.ones(12, device=DEV), torch.zeros(12, device=DEV))  # D % 8 != 0
+
+
+def test_empty_and_limit_shapes():
+    """Edge cases: empty batches go through every entry point (no launch, right shapes); the MFMA attention's
+    limits (n_k = 256 resident keys, then the LDS-resident VALU kernel takes over at 257) and LayerNorm's widest
+    row (D = 2048) agree with the reference math."""
+    o = ops()
+    for dtype in (F32, BF16):
+        x0 = torch.empty(0, 512, dtype=dtype, device=DEV)
+        w = rnd(256, 512, dtype=dtype)
+        b = rnd(256)
+        assert o.linear_fwd(x0, w, b).shape == (0, 256)
+        assert o.linear_bwd_data(torch.empty(0, 256, dtype=dtype, device=DEV), w).shape == (0, 512)
+        dw, db = torch.full((256, 512), 7.0, device=DEV), torch.full((256,), 7.0, device=DEV)
+        o.linear_bwd_weight(torch.empty(0, 256, dtype=dtype, device=DEV), x0, dw, db)
+        assert float(dw.abs().max()) == 0.0 and float(db.abs().max()) == 0.0  # an empty sum overwrites with zeros
+        y, mean, rstd = o.layernorm_fwd(x0, torch.ones(512, device=DEV), torch.zeros(512, device=DEV))
+        assert y.shape == (0, 512)
+        q0 = torch.empty(0, 5, 128, dtype=dtype, device=DEV)
+        out, lse, _ = o.attention_fwd(q0, q0, q0, None, 2)
+        assert out.shape == (0, 5, 128)
+    # n_k at and just above the MFMA kernel's limit, padded keys included
+    for nk in (256, 257):
+        q = rnd(2, 40, 8 * 64, dtype=BF16, seed=1)
+        k = rnd(2, nk, 8 * 64, dtype=BF16, seed=2)
+        v = rnd(2, nk, 8 * 64, dtype=BF16, seed=3)
+        mask = torch.zeros(2, 1, 1, nk, device=DEV)
+        mask[1, ..., nk - 9:] = -1e5
+        out, _, _ = o.attention_fwd(q, k, v, mask, 8)
+        ref, _, _ = att_ref(q, k, v, mask, 8)
+        assert nerr(out, ref) < 1e-2, nk
+    # widest LayerNorm row
+    x = rnd(33, 2048, dtype=BF16, seed=4)
+    g, bb = rnd(2048, seed=5), rnd(2048, seed=6)
+    y, _, _ = o.layernorm_fwd(x, g, bb)
+    assert nerr(y, ln_ref(x, g, bb)[0]) < 1e-2
+    with pytest.raises(RuntimeError):
+        o.layernorm_fwd(rnd(4, 2056, dtype=BF16), torch.ones(2056, device=DEV), torch.zeros(2056, device=DEV))
