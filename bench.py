@@ -311,6 +311,7 @@ def main():
     else:
         ts.loss = loss_buf
 
+    ts.prepare(*batch)  # graph capture happens here, never inside the timed region (even with --warmup 0)
     for _ in range(args.warmup):
         ts.step(*batch)
     if dist is not None:

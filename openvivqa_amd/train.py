@@ -432,6 +432,13 @@ class TrainStep:
         if self.reducer.active and k < len(self.segments):
             self.reducer.reduce_ranges(self.arena.grad, self.segments[k])
 
+    def prepare(self, *inputs: torch.Tensor) -> None:
+        """Discovery, warm-up passes and graph capture on ``inputs`` WITHOUT an optimiser step (gradients are
+        computed and discarded).  ``step`` does this lazily on its first call; benchmarks call it up front so
+        that no timed step pays for the capture."""
+        if self.static_inputs is None:
+            self._capture(inputs)
+
     def step(self, *inputs: torch.Tensor) -> torch.Tensor:
         if self.static_inputs is None:
             self._capture(inputs)
