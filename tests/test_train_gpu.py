@@ -193,3 +193,50 @@ def test_training_reduces_loss_bf16():
     hist = [float(ts.step(v, vm, t, tm)) for _ in range(30)]
     assert all(h == h for h in hist)  # no NaN
     assert sum(hist[-5:]) / 5 < 0.93 * sum(hist[:5]) / 5, hist
+
+
+def test_crossmodality_train_step_with_comm(single_rank_group):
+    """BASELINE configs[2] path: CrossModalityEncoder under TrainStep.  Its dead cross-attention parameters never
+    get a gradient: their ranges of the flat buffer must stay zero -- on every rank alike -- through
+    the data-parallel exchange, and their weights must not move."""
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd import ops
+    from openvivqa_amd.config import ConfigNode, attention_config
+    from openvivqa_amd.mcan_stack import synthetic_batch
+    from openvivqa_amd.train import TrainStep
+    dev = torch.device("cuda", 0)
+    A.set_compute_dtype(torch.bfloat16)
+    sa = attention_config(dropout=0.0)
+    cfg = ConfigNode(dict(D_MODEL=512, LAYERS=2, VISION_LANGUAGE_ATTENTION=sa, LANGUAGE_VISION_ATTENTION=sa,
+                          VISION_SELF_ATTENTION=sa, LANGUAGE_SELF_ATTENTION=sa))
+    results = []
+    for force in (False, True):
+        A.manual_seed(3)
+        torch.manual_seed(3)
+        model = M.CrossModalityEncoder(cfg).to(dev).train()
+        w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        v, vm, t, tm = synthetic_batch(8, 100, 20, 512, 80, 8, 5, dev, torch.bfloat16)
+        g = torch.Generator().manual_seed(3)
+        tv = torch.randn(v.shape, generator=g).to(dev, torch.bfloat16)
+        tt = torch.randn(t.shape, generator=g).to(dev, torch.bfloat16)
+        loss = torch.zeros(1, device=dev)
+
+        def forward_loss(v_, vm_, t_, tm_):
+            vo, lo = model(v_, vm_, t_, tm_)
+            return (vo, lo), (ops.sq_loss_fwd_bwd(vo.detach(), loss, accumulate=False, target=tv),
+                              ops.sq_loss_fwd_bwd(lo.detach(), loss, accumulate=True, target=tt))
+        ts = TrainStep(model, forward_loss, lr=1e-4, betas=(0.9, 0.98), compute_dtype=torch.bfloat16,
+                       force_comm=force, comm_dtype=torch.float32)
+        ts.loss = loss
+        for _ in range(2):
+            ts.step(v, vm, t, tm)
+        torch.cuda.synchronize()
+        dead = [k for k in w0 if "language_vision_mhattn" in k or "vision_language_mhattn" in k]
+        assert dead
+        for k in dead:
+            assert torch.equal(model.state_dict()[k], w0[k]), k  # zero gradient -> Adam leaves them alone
+        moved = [k for k in w0 if k not in dead and not torch.equal(model.state_dict()[k], w0[k])]
+        assert len(moved) > 20
+        results.append((ts.arena.grad.clone(), float(ts.loss)))
+    assert _rel(results[1][0], results[0][0]) <= 1e-5 and abs(results[1][1] - results[0][1]) <= 1e-5 * abs(results[0][1])
