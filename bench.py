@@ -171,6 +171,45 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
     }
 
 
+def attention_probe(device, B, NV, NT, D, H, reps=20):
+    """The attention core against the HBM roofline: algorithmic bytes = bf16 Q, K, V read + O written
+    (+ log-sum-exp) per launch, time from a hipGraph replay of the forward kernel alone with HIP events."""
+    from openvivqa_amd import ops
+    out = {}
+    for name, (nq, nk) in {"image self (100x100)": (NV, NV), "guided (100x20)": (NV, NT),
+                           "question self (20x20)": (NT, NT)}.items():
+        qkv = torch.randn(B, nq, 3 * D, device=device).bfloat16()
+        kv = torch.randn(B, nk, 2 * D, device=device).bfloat16()
+        q = qkv[..., :D]
+        k, v = (qkv[..., D:2 * D], qkv[..., 2 * D:]) if nq == nk else (kv[..., :D], kv[..., D:])
+        mask = torch.zeros(B, 1, 1, nk, device=device)
+        mask[:, :, :, nk - 3:] = -1e5
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.attention_fwd(q, k, v, mask, H)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                ops.attention_fwd(q, k, v, mask, H)
+        g.replay()
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            g.replay()
+        e1.record(st)
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / (reps * 10)
+        nbytes = B * H * (2 * nq + 2 * nk) * (D // H) * 2 + B * H * nq * 4
+        out[name] = {"us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": nbytes,
+                     "achieved_GBps": round(nbytes / t / 1e9, 1), "frac_of_hbm_peak": round(nbytes / t / 8e12, 4)}
+    return {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel": "attn_fwd_mfma_kernel", "shapes": out}
+
+
 def cpu_baseline(cfg, steps):
     """The oracle (plain-PyTorch CPU restatement, fp32, train mode) on the same workload."""
     import oracle as O
@@ -367,6 +406,8 @@ def main():
             sa = cfg.MODEL.SELF_ENCODER.SELF_ATTENTION
             out["roofline"] = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
                                              cfg.MODEL.SELF_ENCODER.LAYERS)
+            # secondary: the (HBM-bound) attention core on its own roofline
+            out["roofline_attention"] = attention_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.HEAD)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
