@@ -215,7 +215,9 @@ class CrossModalityEncoder(_Prologued):
         vdt, ldt = vision_features.dtype, language_features.dtype
         v = self._prologue(self.vision_layer_norm, vision_features)
         l = self._prologue(self.language_layer_norm, language_features)
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
+            if i:  # the two modality chains never mix (the cross-attention results are dead): independent cuts
+                v, l = rt.grad_milestone(v), rt.grad_milestone(l)
             v, l = layer(vision_features=v, vision_padding_mask=vision_padding_mask, language_features=l,
                          language_padding_mask=language_padding_mask)
         return v.to(vdt), l.to(ldt)

@@ -35,13 +35,21 @@ def patch_cpu_ops():
     A.set_compute_dtype(torch.float32)
 
 
-def make_step(overlap_mb, comm_dtype=torch.float32, seed=7):
+CM_CFG = dict(D_MODEL=32, LAYERS=3, VISION_LANGUAGE_ATTENTION=ATT, LANGUAGE_VISION_ATTENTION=ATT,
+              VISION_SELF_ATTENTION=ATT, LANGUAGE_SELF_ATTENTION=ATT)
+
+
+def make_step(overlap_mb, comm_dtype=torch.float32, seed=7, kind="mcan"):
     import mock_ops
     from openvivqa_amd.config import ConfigNode
     from openvivqa_amd.mcan_stack import MCANEncoderStack
     from openvivqa_amd.train import TrainStep
     torch.manual_seed(seed)
-    model = MCANEncoderStack(ConfigNode(CFG))
+    if kind == "mcan":
+        model = MCANEncoderStack(ConfigNode(CFG))
+    else:  # BASELINE configs[2]: LXMERT-style pair encoder (dead cross-attention parameters included)
+        import openvivqa_amd.modules as M
+        model = M.CrossModalityEncoder(ConfigNode(CM_CFG))
     model.train()
     loss_buf = torch.zeros(1)
 
@@ -62,12 +70,12 @@ def batch(rank, B=3, NV=6, NT=4, D=32):
     return v, vm, t, tm, torch.randn(B, NV, D, generator=g), torch.randn(B, NT, D, generator=g)
 
 
-def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q):
+def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q, kind="mcan"):
     import torch.distributed as dist
     patch_cpu_ops()
     dist.init_process_group("gloo", init_method="file://" + rdv, rank=rank, world_size=world)
     try:
-        model, ts = make_step(overlap_mb, torch.bfloat16 if comm_bf16 else torch.float32)
+        model, ts = make_step(overlap_mb, torch.bfloat16 if comm_bf16 else torch.float32, kind=kind)
         for _ in range(2):
             ts.step(*batch(rank))
         q.put((rank, ts.arena.master.clone().numpy(), [list(map(list, s)) for s in ts.segments]))

@@ -259,8 +259,9 @@ def test_grad_allreduce_gloo_world2(comm_bf16):
     assert torch.equal(res[0], res[1])  # every rank ends with identical gradients
 
 
-@pytest.mark.parametrize("overlap_mb,comm_bf16", [(0.0, False), (0.02, False), (0.02, True)])
-def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16):
+@pytest.mark.parametrize("overlap_mb,comm_bf16,kind", [(0.0, False, "mcan"), (0.02, False, "mcan"), (0.02, True, "mcan"),
+                                                       (0.02, False, "crossmodality")])
+def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind):
     """Two ranks x TrainStep on a small MCAN stack (kernel wrappers mocked, gloo): with the gradient exchange
     released segment by segment during a phased backward (overlap_mb > 0) both ranks end with identical weights,
     equal to a single process that averages the two ranks' gradients itself."""
@@ -270,7 +271,7 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     rdv = os.path.join(tempfile.mkdtemp(prefix="ovqa_rdv_"), "store")
-    procs = [ctx.Process(target=H.dp_worker, args=(r, 2, rdv, overlap_mb, comm_bf16, q)) for r in range(2)]
+    procs = [ctx.Process(target=H.dp_worker, args=(r, 2, rdv, overlap_mb, comm_bf16, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = {r: (torch.from_numpy(w), seg) for r, w, seg in (q.get(timeout=300) for _ in range(2))}
@@ -289,7 +290,7 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16):
     saved = (tr.ops, Fn.ops, rt.ops, rt.build_arena, rt.step_tensor)
     try:
         H.patch_cpu_ops()
-        model, ts = H.make_step(0.0)
+        model, ts = H.make_step(0.0, kind=kind)
         assert flat[-1][1] == ts.arena.numel
         ts.static_inputs = [t.clone() for t in H.batch(0)]
         ts._discover_foreign()

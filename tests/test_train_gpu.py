@@ -227,11 +227,12 @@ def test_crossmodality_train_step_with_comm(single_rank_group):
             return (vo, lo), (ops.sq_loss_fwd_bwd(vo.detach(), loss, accumulate=False, target=tv),
                               ops.sq_loss_fwd_bwd(lo.detach(), loss, accumulate=True, target=tt))
         ts = TrainStep(model, forward_loss, lr=1e-4, betas=(0.9, 0.98), compute_dtype=torch.bfloat16,
-                       force_comm=force, comm_dtype=torch.float32)
+                       force_comm=force, comm_dtype=torch.float32, overlap_mb=8.0)
         ts.loss = loss
         for _ in range(2):
             ts.step(v, vm, t, tm)
         torch.cuda.synchronize()
+        assert len(ts.segments) == (1 if not force else len(ts.graphs)) and (not force or len(ts.segments) >= 2)
         dead = [k for k in w0 if "language_vision_mhattn" in k or "vision_language_mhattn" in k]
         assert dead
         for k in dead:
