@@ -314,3 +314,17 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind):
     tol = 1e-5 if not comm_bf16 else 2e-2
     err = ((res[0][0] - ref).abs() * keep).max().item()
     assert err <= tol, err
+
+
+def test_segment_helpers():
+    """Range bookkeeping of the overlapped gradient exchange (train._merge / _complement / _reaches)."""
+    from openvivqa_amd.train import _complement, _merge, _reaches
+    assert _merge([(10, 20), (0, 5), (5, 10), (30, 40)]) == [(0, 20), (30, 40)]
+    assert _merge([(0, 4), (6, 8)], gap=2) == [(0, 8)]
+    assert _complement([(10, 20), (30, 40)], 0, 50) == [(0, 10), (20, 30), (40, 50)]
+    assert _complement([], 0, 7) == [(0, 7)] and _complement([(0, 7)], 0, 7) == []
+    a = torch.randn(3, requires_grad=True)
+    b = (a * 2).sin()
+    c = b + 1
+    d = torch.randn(3, requires_grad=True).cos()
+    assert _reaches(c.grad_fn, b.grad_fn) and not _reaches(b.grad_fn, c.grad_fn) and not _reaches(c.grad_fn, d.grad_fn)
