@@ -677,6 +677,206 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
   }
 }
 
+
+// ------------------------------------------------------- role-split backward, 32 < n_k <= 128 and n_q <= 128
+// Image self-attention (100 x 100): ONE launch, 8 waves.  Q, dO, K, V of a (batch, head) are staged once; waves
+// 0-3 play kernel A (one 32-query tile each, all key tiles: dQ), waves 4-7 play kernel B (one 32-key tile each, all
+// query tiles: dK, dV).  Nothing is reduced across waves; delta = dO . O is computed once per query row during
+// staging.  Saves the second launch (~5 us floor) and the second staging of the same 50 KB.
+__global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt, int nkt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int q_rows = nqt * 32, k_rows = nkt * 32;
+  const int64_t pid = blockIdx.x;
+  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  char* Qs = smem;
+  char* Gs = Qs + q_rows * 128;
+  char* Ks = Gs + q_rows * 128;
+  char* Vs = Ks + k_rows * 128;
+  float* mlds = reinterpret_cast<float*>(Vs + k_rows * 128);  // key-padding mask row (-inf beyond nk)
+  float* lse_s = mlds + k_rows;
+  float* del_s = lse_s + q_rows;
+  {
+    const ImgDesc d[4] = {
+        {Qs, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
+        {Gs, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
+        {Ks, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
+        {Vs, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
+    // load_images strides by 4 * 256 threads: run it as two half-workgroups over two images each
+    if (tid < 256) {
+      const ImgDesc d0[2] = {d[0], d[1]};
+      load_images<2>(d0, tid);
+    } else {
+      const ImgDesc d1[2] = {d[2], d[3]};
+      load_images<2>(d1, tid - 256);
+    }
+    if (a.msq == 0 && tid < 256)
+      load_mask_row(mlds, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
+    // lse and delta = dO . O per query row: 4 lanes per row, 16 features each
+    for (int e = tid; e < q_rows * 4; e += 512) {
+      const int i = e >> 2, part = e & 3;
+      float dl = 0.f;
+      if (i < nq) {
+        const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + i) * a.lddo + h * 64 + 16 * part;
+        const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + i) * a.ldo + h * 64 + 16 * part;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
+          const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
+          const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
+#pragma unroll
+          for (int t = 0; t < 4; t++) dl += (float)g8[t] * (float)oa[t] + (float)g8[4 + t] * (float)ob[t];
+        }
+      }
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      if (part == 0) {
+        del_s[i] = dl;
+        lse_s[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
+        if (i < nq) a.delta[((int64_t)b * a.H + h) * nq + i] = dl;
+      }
+    }
+  }
+  __syncthreads();
+  const bool row_mask = a.msq == 0;
+
+  if (wave < 4) {
+    // ------------------------------------------------ role A: dQ of query tile tq
+    const int tq = wave;
+    if (tq * 32 >= nq) return;
+    const int q = tq * 32 + (lane & 31);
+    const bool qok = q < nq;
+    const int qc = qok ? q : nq - 1;
+    const float lse = lse_s[qc], delta = del_s[qc];
+    const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
+      gf[ks] = frag_rows(Gs, tq * 32, ks, lane);
+    }
+    f32x16 dqt[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dqt[d][r] = 0.f;
+    for (int t = 0; t < nkt; t++) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, t * 32, ks, lane), gf[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = t * 32 + acc_row(r, lane);
+        float p;
+        if (row_mask) {
+          p = exp2_fast((st[r] * a.scale + mlds[key] - lse) * LOG2E);
+        } else {
+          p = 0.f;
+          if (key < nk) p = exp2_fast((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+        }
+        ds[r] = p * (dp[r] - delta);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 db;
+#pragma unroll
+        for (int j = 0; j < 8; j++) db[j] = (bf16)ds[8 * s2 + j];
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+          dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, t * 32 + 16 * s2, d * 32, lane), db, dqt[d], 0, 0, 0);
+      }
+    }
+    if (qok) {
+      bf16* drow = (bf16*)a.dq + ((int64_t)b * nq + q) * a.lddq + h * 64;
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o4[e] = (bf16)(dqt[d][4 * g4 + e] * a.scale);
+          *reinterpret_cast<bf16x4*>(drow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+        }
+    }
+  } else {
+    // ------------------------------------------------ role B: dK / dV of key tile tk
+    const int tk = wave - 4;
+    if (tk * 32 >= nk) return;
+    const int key = tk * 32 + (lane & 31);
+    const bool kok = key < nk;
+    const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
+    const float mconst = row_mask ? mlds[key] : 0.f;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      kf[ks] = frag_rows(Ks, tk * 32, ks, lane);
+      vf[ks] = frag_rows(Vs, tk * 32, ks, lane);
+    }
+    f32x16 dvt[2], dkt[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
+    for (int t = 0; t < nqt; t++) {
+      f32x16 s_, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qi = t * 32 + acc_row(r, lane);
+        float pv = 0.f;
+        if (qi < nq && kok) {
+          const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)qi * a.msq] : 0.f);
+          pv = exp2_fast((s_[r] * a.scale + mv - lse_s[qi]) * LOG2E);
+        }
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - del_s[qi]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 pb, db;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s2 + j]; db[j] = (bf16)ds[8 * s2 + j]; }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, t * 32 + 16 * s2, d * 32, lane), pb, dvt[d], 0, 0, 0);
+          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, t * 32 + 16 * s2, d * 32, lane), db, dkt[d], 0, 0, 0);
+        }
+      }
+    }
+    if (kok) {
+      bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
+      bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 k4, v4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            k4[e] = (bf16)(dkt[d][4 * g4 + e] * a.scale);
+            v4[e] = (bf16)dvt[d][4 * g4 + e];
+          }
+          *reinterpret_cast<bf16x4*>(dkrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = k4;
+          *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
+        }
+    }
+  }
+}
+
 template <typename K>
 int ensure_lds(K kernel, size_t bytes, const char* what) {
   if (bytes > 160 * 1024) {
@@ -724,6 +924,14 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged < 0) {
     const char* e = getenv("OVQA_ATTN_BWD_MERGED");
     merged = e ? atoi(e) : 1;
+  }
+  if (merged && a.nk > 32 && a.nk <= 128 && a.nq <= 128 && merged != 2) {  // one launch, role-split waves
+    const int nqt = (a.nq + 31) / 32, nkt = (a.nk + 31) / 32;
+    const size_t lds = (size_t)(2 * nqt * 32 + 2 * nkt * 32) * 128 + (size_t)(nkt * 32 + 2 * nqt * 32) * 4;
+    int rc = ensure_lds(attn_bwd_roles_mfma_kernel, lds, "attention_bwd(mfma,roles)");
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL(attn_bwd_roles_mfma_kernel, dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+    return ovqa_check_launch("attention_bwd(mfma,roles)");
   }
   if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
     int W = (a.nq + 31) / 32;
