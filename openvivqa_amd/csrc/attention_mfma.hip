@@ -683,7 +683,11 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
 // 0-3 play kernel A (one 32-query tile each, all key tiles: dQ), waves 4-7 play kernel B (one 32-key tile each, all
 // query tiles: dK, dV).  Nothing is reduced across waves; delta = dO . O is computed once per query row during
 // staging.  Saves the second launch (~5 us floor) and the second staging of the same 50 KB.
-__global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt, int nkt) {
+// NQT_T / NKT_T: compile-time tile counts (0 = use the runtime arguments): with constants the two tile loops are
+// fully unrolled and the MFMA chains of different tiles interleave.
+template <int NQT_T, int NKT_T>
+__global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt_rt, int nkt_rt) {
+  const int nqt = NQT_T ? NQT_T : nqt_rt, nkt = NKT_T ? NKT_T : nkt_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
@@ -761,6 +765,7 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     for (int d = 0; d < 2; d++)
 #pragma unroll
       for (int r = 0; r < 16; r++) dqt[d][r] = 0.f;
+#pragma unroll
     for (int t = 0; t < nkt; t++) {
       f32x16 st, dp;
 #pragma unroll
@@ -824,6 +829,7 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     for (int d = 0; d < 2; d++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
+#pragma unroll
     for (int t = 0; t < nqt; t++) {
       f32x16 s_, dp;
 #pragma unroll
@@ -928,9 +934,15 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged && a.nk > 32 && a.nk <= 128 && a.nq <= 128 && merged != 2) {  // one launch, role-split waves
     const int nqt = (a.nq + 31) / 32, nkt = (a.nk + 31) / 32;
     const size_t lds = (size_t)(2 * nqt * 32 + 2 * nkt * 32) * 128 + (size_t)(nkt * 32 + 2 * nqt * 32) * 4;
-    int rc = ensure_lds(attn_bwd_roles_mfma_kernel, lds, "attention_bwd(mfma,roles)");
-    if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL(attn_bwd_roles_mfma_kernel, dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+    if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
+      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4>, lds, "attention_bwd(mfma,roles)");
+      if (rc != OVQA_OK) return rc;
+      hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<4, 4>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+    } else {
+      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<0, 0>, lds, "attention_bwd(mfma,roles)");
+      if (rc != OVQA_OK) return rc;
+      hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<0, 0>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+    }
     return ovqa_check_launch("attention_bwd(mfma,roles)");
   }
   if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
