@@ -463,19 +463,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 // ------------------------------------------------------------------------------ merged backward, n_k <= 32
 // Question self-attention (20 x 20) and guided attention (100 queries x 20 question tokens): one key tile, and
 // a workgroup holds ALL queries of its problems, so dQ, dK and dV come out of ONE launch (the two-kernel form
-// costs a second ~5 us dependent launch and stages Q / dO / K / V twice).  One wave = one 32-query tile:
+// costs a second ~5 us dependent launch and stages Q / dO / K / V twice).  One wave = one 32-query tile (with a
+// single tile per problem the two orientations are split over two waves, see `both` below):
 //   transposed orientation (lane = query):  S^T, dP^T -> dS^T -> dQ^T += K^T dS^T            (as kernel A)
 //   direct orientation     (lane = key):    S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS  (as kernel B)
 // The dK/dV partials of the <= 4 query tiles of a problem are summed in LDS, one wave after the other between
 // workgroup barriers (LDS fp32 atomics were measured 4x slower: ~100 cycles per ds_add_f32 wave-instruction).
-__global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G) {
+__global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = 32 * W, k_rows = 32;
   const int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
   const int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | dV^T,dK^T
-  const int slot = wave / W, tq = wave % W;
+  // 512 threads (W == 1: the 20 x 20 question attention): waves 0-3 take the dQ role, waves 4-7 the dK/dV role of
+  // the same 4 packed problems -- half the dependent chain per wave.  256 threads (W >= 2): every wave does both
+  // (with 4 query tiles per problem the doubled wave count only adds VALU contention: 14.8 vs 18.3 us).
+  const bool both = blockDim.x == 256;
+  const int role = wave >> 2, w4 = wave & 3;
+  const int slot = w4 / W, tq = w4 % W;
 
   for (int g = 0; g < G; g++) {
     const int64_t pid = (int64_t)blockIdx.x * G + g;
@@ -487,10 +493,44 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
         {base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
         {base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
         {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
-    load_images<4>(d, tid);
+    if (both) {
+      load_images<4>(d, tid);
+    } else if (tid < 256) {
+      const ImgDesc d0[2] = {d[0], d[1]};
+      load_images<2>(d0, tid);
+    } else {
+      const ImgDesc d1[2] = {d[2], d[3]};
+      load_images<2>(d1, tid - 256);
+    }
     float* mrow_s = reinterpret_cast<float*>(base + img_bytes);
-    if (a.msq == 0)
+    if (a.msq == 0 && tid < 256)
       load_mask_row(mrow_s, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
+    // lse and delta = dO . O per query row: 4 lanes per row, 16 features each
+    float* lse_g = mrow_s + k_rows;
+    float* del_g = lse_g + q_rows;
+    for (int e = tid; e < q_rows * 4; e += (int)blockDim.x) {
+      const int i = e >> 2, part = e & 3;
+      float dl = 0.f;
+      if (i < nq) {
+        const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + i) * a.lddo + h * 64 + 16 * part;
+        const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + i) * a.ldo + h * 64 + 16 * part;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
+          const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
+          const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
+#pragma unroll
+          for (int t = 0; t < 4; t++) dl += (float)g8[t] * (float)oa[t] + (float)g8[4 + t] * (float)ob[t];
+        }
+      }
+      dl += __shfl_xor(dl, 1, 64);
+      dl += __shfl_xor(dl, 2, 64);
+      if (part == 0) {
+        del_g[i] = dl;
+        lse_g[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
+        if (i < nq) a.delta[((int64_t)b * a.H + h) * nq + i] = dl;
+      }
+    }
   }
   __syncthreads();
 
@@ -516,26 +556,7 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
     const int q = tq * 32 + (lane & 31);
     const bool qok = q < nq;
     const int qc = qok ? q : nq - 1;
-    float delta = 0.f;
-    {
-      const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * 64 + 32 * (lane >> 5);
-      const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * 64 + 32 * (lane >> 5);
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
-        const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
-        const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) delta += (float)g8[e] * (float)oa[e] + (float)g8[4 + e] * (float)ob[e];
-      }
-      delta += __shfl_xor(delta, 32, 64);
-    }
-    const float lse = a.lse[((int64_t)b * a.H + h) * nq + qc];
-    if (lane < 32) {  // row statistics for the direct orientation (read back by this wave only)
-      lse_s[tq * 32 + lane] = lse;
-      del_s[tq * 32 + lane] = delta;
-      if (qok) a.delta[((int64_t)b * a.H + h) * nq + q] = delta;
-    }
+    const float lse = lse_s[qc], delta = del_s[qc];
     const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
 
     bf16x8 qf[4], gf[4], kf[4], vf[4];
@@ -546,8 +567,8 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
       kf[ks] = frag_rows(Ks, 0, ks, lane);
       vf[ks] = frag_rows(Vs, 0, ks, lane);
     }
-    // ---- transposed orientation: dQ
-    {
+    // ---- transposed orientation: dQ (role 0)
+    if (both || role == 0) {
       f32x16 st, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { st[r] = 0.f; dp[r] = 0.f; }
@@ -596,8 +617,8 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
           }
       }
     }
-    // ---- direct orientation: this query tile's share of dK^T / dV^T
-    {
+    // ---- direct orientation: this query tile's share of dK^T / dV^T (role 1)
+    if (both || role == 1) {
       const int key = lane & 31;
       const bool kok = key < nk;
       const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
@@ -637,7 +658,7 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
   }
   // sum over the query tiles of each problem: tile `ph` adds its share in phase `ph` (tile 0 stores)
   for (int ph = 0; ph < W; ph++) {
-    if (active && tq == ph) {
+    if (active && (both || role == 1) && tq == ph) {
 #pragma unroll
       for (int d = 0; d < 2; d++)
 #pragma unroll
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
     }
     __syncthreads();
   }
-  if (active && tq == 0) {
+  if (active && (both || role == 1) && tq == 0) {
     const int key = lane & 31;
     if (key < nk) {
       bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
@@ -953,7 +974,8 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)G * prob;
     int rc = ensure_lds(attn_bwd_smallk_mfma_kernel, lds, "attention_bwd(mfma,merged)");
     if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel, dim3((unsigned)((nprob + G - 1) / G)), dim3(256), lds, st, a, W, G);
+    hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel, dim3((unsigned)((nprob + G - 1) / G)), dim3(W == 1 ? 512 : 256), lds, st,
+                       a, W, G);
     return ovqa_check_launch("attention_bwd(mfma,merged)");
   }
   {  // dQ: waves over query tiles, all keys resident
