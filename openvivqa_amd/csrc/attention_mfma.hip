@@ -94,7 +94,9 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 
 // ------------------------------------------------------------------------------------------ forward
 // grid.x = ceil(B*H / G), grid.y = ceil(nq / (32*W)) ; W = query tiles per problem in this workgroup
-template <int NKT>
+// ROWMASK: the mask is one fp32 row per (b,h) (key padding; staged in LDS, -inf beyond n_k) -- the common case,
+// compiled without the per-element bound checks / global mask reads; WANT_ATT: also write the probabilities.
+template <int NKT, bool ROWMASK, bool WANT_ATT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, int W, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
         {base + q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, NKT * 32},
         {base + (q_rows + NKT * 32) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, NKT * 32}};
     load_images<3>(d, tid);
-    if (a.msq == 0)
+    if (ROWMASK)
       load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * 128),
                     a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, NKT * 32, tid);
   }
@@ -131,7 +133,6 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   const char* Ks = Qs + q_rows * 128;
   const char* Vs = Ks + NKT * 32 * 128;
   const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * 128);
-  const bool row_mask = a.msq == 0;
 
   // ---- S^T = K Q^T  (rows = keys, columns = this wave's 32 queries)
   bf16x8 qf[4];
@@ -155,17 +156,27 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
 #pragma unroll
   for (int t = 0; t < NKT; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int key = t * 32 + acc_row(r, lane);
-      float s;
-      if (row_mask) {
-        s = st[t][r] * a.scale + mlds[key];
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int key0 = t * 32 + 8 * g4 + 4 * (lane >> 5);  // acc_row(4*g4 + e, lane) = key0 + e
+      if constexpr (ROWMASK) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mlds + key0);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float sv = st[t][4 * g4 + e] * a.scale + mm[e];
+          st[t][4 * g4 + e] = sv;
+          mx = fmaxf(mx, sv);
+        }
       } else {
-        s = -INFINITY;
-        if (key < nk) s = st[t][r] * a.scale + (mrow ? mrow[key] : 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int key = key0 + e;
+          float sv = -INFINITY;
+          if (key < nk) sv = st[t][4 * g4 + e] * a.scale + (mrow ? mrow[key] : 0.f);
+          st[t][4 * g4 + e] = sv;
+          mx = fmaxf(mx, sv);
+        }
       }
-      st[t][r] = s;
-      mx = fmaxf(mx, s);
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
   if (qok && a.lse && lane < 32) a.lse[((int64_t)b * a.H + h) * nq + q] = mx + __logf(sum);
-  if (a.att && qok) {
+  if (WANT_ATT && qok) {
     bf16* arow = (bf16*)a.att + (((int64_t)b * a.H + h) * nq + q) * nk;
 #pragma unroll
     for (int t = 0; t < NKT; t++)
@@ -929,20 +940,27 @@ inline int pack_factor(int W, size_t prob_bytes) {
   return G < 1 ? 1 : G;
 }
 
-template <int NKT>
-int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
+template <int NKT, bool ROWMASK, bool WANT_ATT>
+int launch_fwd_t(const ovqa::AttnArgs& a, hipStream_t st) {
   int W = (a.nq + 31) / 32;
   if (W > 4) W = 4;
   if (W == 3) W = 4;
   const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * 128 + NKT * 32 * 4;
   const int G = pack_factor(W, prob);
   const size_t lds = (size_t)G * prob;
-  int rc = ensure_lds(attn_fwd_mfma_kernel<NKT>, lds, "attention_fwd(mfma)");
+  int rc = ensure_lds(attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT>, lds, "attention_fwd(mfma)");
   if (rc != OVQA_OK) return rc;
   const int64_t nprob = (int64_t)a.B * a.H;
   dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel<NKT>, grid, dim3(256), lds, st, a, W, G);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT>), grid, dim3(256), lds, st, a, W, G);
   return ovqa_check_launch("attention_fwd(mfma)");
+}
+
+template <int NKT>
+int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
+  const bool rowmask = a.msq == 0, att = a.att != nullptr;
+  if (rowmask) return att ? launch_fwd_t<NKT, true, true>(a, st) : launch_fwd_t<NKT, true, false>(a, st);
+  return att ? launch_fwd_t<NKT, false, true>(a, st) : launch_fwd_t<NKT, false, false>(a, st);
 }
 
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
