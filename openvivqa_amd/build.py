@@ -15,7 +15,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libovqa_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          "-Wno-unused-result", "-ffp-contract=fast"]
 
 

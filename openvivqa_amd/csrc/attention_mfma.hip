@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
 // Kernel A: one wave = 32 queries (columns).  delta_q = dO_q . O_q ;  for every key tile:
 //   S^T = K Q^T, dP^T = V dO^T, P^T = exp(S^T*scale + mask - lse_q), dS^T = P^T (dP^T - delta_q),
 //   dQ^T += K^T dS^T   (K^T through transposing reads, dS^T straight from the accumulator registers).
+template <bool ROWMASK>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nkt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   const char* Ks = Gs + q_rows * 128;
   const char* Vs = Ks + k_rows * 128;
   const float* mlds = reinterpret_cast<const float*>(Vs + k_rows * 128);
-  const bool row_mask = a.msq == 0;
+  constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
 
   const int q = q0 + (lane & 31);
   const bool qok = q < nq;
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
 // Kernel B: one wave = 32 keys (columns).  For every query tile (rows):
 //   S = Q K^T, dP = dO V^T, P = exp(S*scale + mask - lse_row), dS = P (dP - delta_row),
 //   dV^T += dO^T P ,  dK^T += Q^T dS    (dO^T / Q^T through transposing reads).
+template <bool ROWMASK>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nqt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
   const int key = k0 + (lane & 31);
   const bool kok = key < nk;
   const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
-  const bool row_mask = a.msq == 0;  // key-padding mask: one value per key column, i.e. per lane
+  constexpr bool row_mask = ROWMASK;  // key-padding mask: one value per key column, i.e. per lane
   const float mconst = (row_mask && mcol) ? mcol[0] : 0.f;
 
   bf16x8 kf[4], vf[4];
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 //   direct orientation     (lane = key):    S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS  (as kernel B)
 // The dK/dV partials of the <= 4 query tiles of a problem are summed in LDS, one wave after the other between
 // workgroup barriers (LDS fp32 atomics were measured 4x slower: ~100 cycles per ds_add_f32 wave-instruction).
+template <bool ROWMASK>
 __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
   float* lse_s = mlds + k_rows;
   float* del_s = lse_s + q_rows;
   float* red = del_s + q_rows;
-  const bool row_mask = a.msq == 0;
+  constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
   f32x16 dvt[2], dkt[2];
 #pragma unroll
   for (int d = 0; d < 2; d++)
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
 // staging.  Saves the second launch (~5 us floor) and the second staging of the same 50 KB.
 // NQT_T / NKT_T: compile-time tile counts (0 = use the runtime arguments): with constants the two tile loops are
 // fully unrolled and the MFMA chains of different tiles interleave.
-template <int NQT_T, int NKT_T>
+template <int NQT_T, int NKT_T, bool ROWMASK>
 __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt_rt, int nkt_rt) {
   const int nqt = NQT_T ? NQT_T : nqt_rt, nkt = NKT_T ? NKT_T : nkt_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     }
   }
   __syncthreads();
-  const bool row_mask = a.msq == 0;
+  constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
 
   if (wave < 4) {
     // ------------------------------------------------ role A: dQ of query tile tq
@@ -965,6 +968,7 @@ int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
 
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   const int64_t nprob = (int64_t)a.B * a.H;
+  const bool rowmask = a.msq == 0;
   static int merged = -1;
   if (merged < 0) {
     const char* e = getenv("OVQA_ATTN_BWD_MERGED");
@@ -973,15 +977,18 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged && a.nk > 32 && a.nk <= 128 && a.nq <= 128 && merged != 2) {  // one launch, role-split waves
     const int nqt = (a.nq + 31) / 32, nkt = (a.nk + 31) / 32;
     const size_t lds = (size_t)(2 * nqt * 32 + 2 * nkt * 32) * 128 + (size_t)(nkt * 32 + 2 * nqt * 32) * 4;
+#define OVQA_ROLES(NQ, NK, RM)                                                                                        \
+  {                                                                                                                   \
+    int rc = ensure_lds(attn_bwd_roles_mfma_kernel<NQ, NK, RM>, lds, "attention_bwd(mfma,roles)");                    \
+    if (rc != OVQA_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt); \
+  }
     if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
-      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4>, lds, "attention_bwd(mfma,roles)");
-      if (rc != OVQA_OK) return rc;
-      hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<4, 4>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+      if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
     } else {
-      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<0, 0>, lds, "attention_bwd(mfma,roles)");
-      if (rc != OVQA_OK) return rc;
-      hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<0, 0>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt);
+      if (rowmask) OVQA_ROLES(0, 0, true) else OVQA_ROLES(0, 0, false)
     }
+#undef OVQA_ROLES
     return ovqa_check_launch("attention_bwd(mfma,roles)");
   }
   if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
@@ -990,10 +997,12 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     const size_t prob = (size_t)(2 * 32 * W + 2 * 32) * 128 + 32 * 4 + 2 * 32 * W * 4 + 4096 * 4;
     const int G = pack_factor(W, prob);
     const size_t lds = (size_t)G * prob;
-    int rc = ensure_lds(attn_bwd_smallk_mfma_kernel, lds, "attention_bwd(mfma,merged)");
+    int rc = rowmask ? ensure_lds(attn_bwd_smallk_mfma_kernel<true>, lds, "attention_bwd(mfma,merged)")
+                     : ensure_lds(attn_bwd_smallk_mfma_kernel<false>, lds, "attention_bwd(mfma,merged)");
     if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel, dim3((unsigned)((nprob + G - 1) / G)), dim3(W == 1 ? 512 : 256), lds, st,
-                       a, W, G);
+    const dim3 grid((unsigned)((nprob + G - 1) / G)), block(W == 1 ? 512 : 256);
+    if (rowmask) hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel<true>, grid, block, lds, st, a, W, G);
+    else hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel<false>, grid, block, lds, st, a, W, G);
     return ovqa_check_launch("attention_bwd(mfma,merged)");
   }
   {  // dQ: waves over query tiles, all keys resident
@@ -1004,10 +1013,12 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * 128 + nkt * 32 * 4;
     const int G = pack_factor(W, prob);
     const size_t lds = (size_t)G * prob;
-    int rc = ensure_lds(attn_bwd_dq_mfma_kernel, lds, "attention_bwd(mfma,dq)");
+    int rc = rowmask ? ensure_lds(attn_bwd_dq_mfma_kernel<true>, lds, "attention_bwd(mfma,dq)")
+                     : ensure_lds(attn_bwd_dq_mfma_kernel<false>, lds, "attention_bwd(mfma,dq)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), lds, st, a, W, G, nkt);
+    if (rowmask) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, dim3(256), lds, st, a, W, G, nkt);
+    else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, dim3(256), lds, st, a, W, G, nkt);
     rc = ovqa_check_launch("attention_bwd(mfma,dq)");
     if (rc != OVQA_OK) return rc;
   }
@@ -1019,10 +1030,12 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     const size_t prob = (size_t)(2 * nqt * 32 + 2 * 32 * W) * 128 + 2 * nqt * 32 * 4;
     const int G = pack_factor(W, prob);
     const size_t lds = (size_t)G * prob;
-    int rc = ensure_lds(attn_bwd_dkv_mfma_kernel, lds, "attention_bwd(mfma,dkv)");
+    int rc = rowmask ? ensure_lds(attn_bwd_dkv_mfma_kernel<true>, lds, "attention_bwd(mfma,dkv)")
+                     : ensure_lds(attn_bwd_dkv_mfma_kernel<false>, lds, "attention_bwd(mfma,dkv)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), lds, st, a, W, G, nqt);
+    if (rowmask) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, dim3(256), lds, st, a, W, G, nqt);
+    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, dim3(256), lds, st, a, W, G, nqt);
     return ovqa_check_launch("attention_bwd(mfma,dkv)");
   }
 }
