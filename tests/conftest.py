@@ -27,3 +27,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is a build artefact (git-ignored): build it once if this checkout has none and a hipcc is
+    around (the CPU container cross-compiles gfx950; on the GPU box the prebuilt file travels with the snapshot)."""
+    from openvivqa_amd import build as B
+    if not os.path.exists(B.LIB):
+        try:
+            B.build(verbose=False)
+        except Exception as exc:  # noqa: BLE001 -- the tests that need it will say so themselves
+            print(f"conftest: could not build {B.LIB}: {exc}", file=sys.stderr)
+    yield
