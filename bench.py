@@ -287,6 +287,12 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
+    from openvivqa_amd import build as _build
+    if not os.path.exists(_build.LIB):  # a snapshot without the build artefact: compile it (hipcc is in the image)
+        if rank == 0:
+            _build.build(verbose=False)
+        if dist is not None:
+            dist.barrier()
     import openvivqa_amd as A
     from openvivqa_amd import ops
     from openvivqa_amd.mcan_stack import MCANEncoderStack, synthetic_batch
