@@ -7,6 +7,7 @@ tensors and raises otherwise -- there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -129,6 +130,8 @@ def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
 def linear_bwd_data_wt_ok(dy, wt) -> bool:
     """Shapes/strides the transposed-weight dX kernel accepts (bf16, everything a multiple of 8)."""
     K, N = wt.shape
+    if os.environ.get("OVQA_FORCE_SIMPLE", "0") not in ("", "0"):
+        return False  # cross-check mode: everything through the VALU reference kernels
     return (dy.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and wt.stride(1) == 1 and N % 8 == 0
             and K % 8 == 0 and wt.stride(0) % 8 == 0 and _rows(dy)[0] % 8 == 0 and wt.data_ptr() % 16 == 0)
 
