@@ -244,11 +244,33 @@ def cpu_baseline(cfg, steps):
             f"fwd+bwd+Adam step, fp32, train mode; {dt:.2f} s/step"}
 
 
+def ensure_library(local_rank):
+    """The C-ABI library is a build artefact.  Decide about it BEFORE anything touches the GPU or the process group
+    (hipcc must never run in a process that initialised HIP, and never under a profiler): local rank 0 compiles a
+    missing / stale library, the other ranks of the node wait for the file; OVQA_NO_BUILD=1 (set by the profiling
+    scripts, which build first) turns a missing library into an error."""
+    from openvivqa_amd import build as _build
+    if not _build.needs_build():
+        return
+    if os.environ.get("OVQA_NO_BUILD", "0") == "1":
+        raise SystemExit(f"bench.py: {_build.LIB} is missing or older than its sources; "
+                         "run `python -m openvivqa_amd.build` first (OVQA_NO_BUILD=1 forbids building here)")
+    if local_rank == 0:
+        _build.build(verbose=False)
+        return
+    deadline = time.time() + 900
+    while _build.needs_build():
+        if time.time() > deadline:
+            raise SystemExit("bench.py: timed out waiting for local rank 0 to build libovqa_hip.so")
+        time.sleep(1.0)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ensure_library(local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
     # rehearsal on a one-GPU box: OVQA_REHEARSE_BACKEND=gloo runs all ranks on GPU 0 with gloo transporting the
@@ -287,12 +309,6 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
-    from openvivqa_amd import build as _build
-    if not os.path.exists(_build.LIB):  # a snapshot without the build artefact: compile it (hipcc is in the image)
-        if rank == 0:
-            _build.build(verbose=False)
-        if dist is not None:
-            dist.barrier()
     import openvivqa_amd as A
     from openvivqa_amd import ops
     from openvivqa_amd.mcan_stack import MCANEncoderStack, synthetic_batch

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 1
+#define OVQA_ABI_VERSION 2
 
 typedef enum {
   OVQA_OK = 0,
@@ -60,6 +60,11 @@ typedef struct {
 
 int ovqa_abi_version(void);
 const char* ovqa_last_error(void);
+/* Which kernel family the last entry point called on this thread ran: "mfma" (gfx950 matrix-core kernels), "simple"
+ * (VALU reference-grade kernels: the fp32 mode, and bf16 shapes the MFMA kernels do not tile) or "" (kernels with a
+ * single form).  With OVQA_REQUIRE_MFMA=1 in the environment a bf16 call that would fall back returns
+ * OVQA_ERR_UNSUPPORTED instead, so a test can assert which kernel it validated. */
+const char* ovqa_last_dispatch(void);
 /* Scratch bytes the caller must provide to the entry points that take `ws`. */
 int64_t ovqa_workspace_bytes(void);
 
@@ -81,6 +86,24 @@ int ovqa_linear_fwd(int dtype, int epilogue,
                     void* y, int64_t ldy, void* preact,
                     int64_t M, int64_t N, int64_t K,
                     const ovqa_dropout* drop, void* stream);
+
+/* fp32 residual stream of the bf16 mode (the post-LN residual chain of attentions.py:330-331 and
+ * positionwise_feed_forward.py:25-26 kept in fp32 between blocks, so that a 6-layer stack stays within 1e-2 of the
+ * fp32 reference):
+ *     pre[m,n] = res(m,n) + drop(x W^T + b)[m,n]          x, w bf16; bias, residual, pre fp32
+ * `ln` == NULL: res = residual[m,n].  Otherwise `residual` is the PREVIOUS block's fp32 pre-LayerNorm sum and
+ *     res(m,n) = (residual[m,n] - ln->mean[m]) * ln->rstd[m] * ln->gamma[n] + ln->beta[n]
+ * i.e. the previous block's LayerNorm output is recomputed in fp32 on the fly instead of being stored. */
+typedef struct ovqa_ln_ref {
+  const float* mean;   /* [M] */
+  const float* rstd;   /* [M] */
+  const float* gamma;  /* [N] */
+  const float* beta;   /* [N] */
+} ovqa_ln_ref;
+int ovqa_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias,
+                          const float* residual, int64_t ldres, const ovqa_ln_ref* ln,
+                          float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K,
+                          const ovqa_dropout* drop, void* stream);
 
 /* dX = dY W  (autograd of nn.Linear w.r.t. its input).
  *   dy [M,N] (lddy), w [N,K], dx [M,K] (lddx).
@@ -157,19 +180,23 @@ int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M
  *             the encoder prologue LN(x) + SinusoidPositionalEmbedding(x)
  *             (encoders.py:113,154,192-193,243-244; pos_embeddings.py:58-72).
  *   x [M,D] of `in_dtype`, y [M,D] of `dtype`; gamma/beta fp32 [D];
+ *   y_f32 [M,D] fp32 or NULL: the same result unrounded (the fp32 residual stream of the bf16 mode: the
+ *   encoder prologue hands the first block both the bf16 GEMM operand and the fp32 residual);
  *   mean/rstd fp32 [M] (saved for backward, may be NULL);
  *   pos fp32 [pos_rows, D] or NULL: y[m] += pos[m % pos_rows].
+ *   Supported (in_dtype -> dtype): f32->f32, bf16->bf16, f32->bf16.
  * ------------------------------------------------------------------------- */
 int ovqa_layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma,
                        const float* beta, const float* pos, int64_t pos_rows,
-                       void* y, float* mean, float* rstd,
+                       void* y, float* y_f32, float* mean, float* rstd,
                        int64_t M, int64_t D, float eps, void* stream);
 
 /* dx = LN backward; dgamma/dbeta fp32 [D] (accumulate flag as above).
  *   If drop != NULL and drop->p > 0, `dx_dropped` [M,D] additionally receives
  *   dx * keep/(1-p): the gradient flowing into the branch that went through
  *   dropout before the residual add (attentions.py:330, pwff.py:25).
- *   dx_dtype is the dtype of dx (fp32 for the prologue whose input was fp32). */
+ *   dx_dtype is the dtype of dx (fp32 for the prologue whose input was fp32).
+ *   Supported (dy, x, dx): (f32,f32,f32), (bf16,bf16,bf16), (bf16,f32,bf16) [fp32 pre-LN sum], (bf16,f32,f32). */
 int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype,
                        const float* gamma, const float* mean, const float* rstd,
                        void* dx, void* dx_dropped, float* dgamma, float* dbeta,

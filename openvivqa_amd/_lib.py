@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -38,6 +38,11 @@ class ReduceProblem(C.Structure):
                 ("blocks", C.c_int32), ("D", C.c_int32)]
 
 
+class LnRef(C.Structure):
+    """ovqa_ln_ref (include/ovqa_hip.h): a LayerNorm to recompute in the fp32 residual epilogue."""
+    _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p)]
+
+
 class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("step", C.c_void_p)]
 
@@ -48,9 +53,12 @@ _DP = C.POINTER(Dropout)
 SIGNATURES = {
     "ovqa_abi_version": [],
     "ovqa_last_error": [],
+    "ovqa_last_dispatch": [],
     "ovqa_workspace_bytes": [],
     "ovqa_linear_fwd": [c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                         c_i64, c_i64, c_i64, _DP, c_vp],
+    "ovqa_linear_fwd_res32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, C.POINTER(LnRef), c_vp, c_i64, c_i64, c_i64, c_i64,
+                              _DP, c_vp],
     "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_int, c_vp],
     "ovqa_bias_grad": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
@@ -58,7 +66,8 @@ SIGNATURES = {
                                 _DP, c_vp],
     "ovqa_grouped_transpose": [c_vp, c_int, c_int, c_vp],
     "ovqa_linear_bwd_weight": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp],
-    "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_layernorm_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32,
+                           c_vp],
     "ovqa_layernorm_bwd": [c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_int, _DP, c_vp, c_vp],
     "ovqa_layernorm_bwd_blocks": [c_i64],
@@ -79,7 +88,7 @@ SIGNATURES = {
     "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
     "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }
-_RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_workspace_bytes": C.c_int64}
+_RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_last_dispatch": C.c_char_p, "ovqa_workspace_bytes": C.c_int64}
 
 _lock = threading.Lock()
 _lib = None
@@ -109,6 +118,12 @@ def load(path: str | None = None):
         if path is None:
             _lib = lib
         return lib
+
+
+def last_dispatch() -> str:
+    """Kernel family ("mfma" | "simple" | "") the last C-ABI call of this thread ran (ovqa_last_dispatch)."""
+    v = load().ovqa_last_dispatch()
+    return v.decode() if v else ""
 
 
 def check(rc: int, what: str = "") -> None:

@@ -20,6 +20,27 @@ void ovqa_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// which kernel family the last entry point called on this thread ran ("mfma" = the gfx950 matrix-core kernels,
+// "simple" = the VALU reference-grade kernels, "stream" = elementwise / reduction kernels with a single form)
+static thread_local const char* g_dispatch = "";
+
+// OVQA_REQUIRE_MFMA=1: a bf16 call that would fall back to the VALU kernels is an error instead (tests of the
+// BASELINE shapes run with it, so a silent fallback cannot pass for the MFMA path)
+static bool require_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_REQUIRE_MFMA");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+#define OVQA_FALLBACK(what)                                                                            \
+  do {                                                                                                 \
+    g_dispatch = "simple";                                                                             \
+    OVQA_REQUIRE(!(dtype == OVQA_BF16 && require_mfma() && !force_simple()), OVQA_ERR_UNSUPPORTED,     \
+                 what ": shape/alignment not covered by the MFMA kernels and OVQA_REQUIRE_MFMA=1");    \
+  } while (0)
+
 static bool force_simple() {
   static int v = -1;
   if (v < 0) {
@@ -35,6 +56,7 @@ extern "C" {
 
 int ovqa_abi_version(void) { return OVQA_ABI_VERSION; }
 const char* ovqa_last_error(void) { return g_err; }
+const char* ovqa_last_dispatch(void) { return g_dispatch; }
 int64_t ovqa_workspace_bytes(void) { return ovqa::kWorkspaceBytes; }
 
 int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
@@ -49,9 +71,37 @@ int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const v
   OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_fwd: more than 2^32 elements");
   const DropArgs da = make_drop_args(drop);
   hipStream_t st = as_stream(stream);
-  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_fwd_supported(epilogue, M, N, K, ldx, ldy, ldres))
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_fwd_supported(epilogue, M, N, K, ldx, ldy, ldres)) {
+    g_dispatch = "mfma";
     return ovqa::mfma_linear_fwd(epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
+  }
+  OVQA_FALLBACK("linear_fwd");
   return ovqa::simple_linear_fwd(dtype, epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
+}
+
+int ovqa_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
+                          int64_t ldres, const ovqa_ln_ref* ln, float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K,
+                          const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_fwd_res32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
+               (long long)N, (long long)K);
+  if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && w && residual && pre, OVQA_ERR_BAD_ARG, "linear_fwd_res32: null pointer");
+  OVQA_REQUIRE(ldx >= K && ldpre >= N && ldres >= N, OVQA_ERR_BAD_ARG, "linear_fwd_res32: ld smaller than the row length");
+  OVQA_REQUIRE(!ln || (ln->mean && ln->rstd && ln->gamma && ln->beta), OVQA_ERR_BAD_ARG,
+               "linear_fwd_res32: incomplete LayerNorm reference");
+  OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_fwd_res32: more than 2^32 elements");
+  const DropArgs da = make_drop_args(drop);
+  const float *mean = ln ? ln->mean : nullptr, *rstd = ln ? ln->rstd : nullptr;
+  const float *gamma = ln ? ln->gamma : nullptr, *beta = ln ? ln->beta : nullptr;
+  if (!force_simple() && ovqa::mfma_gemm_supported(N, M, K, K, ldx) && ldpre % 4 == 0 && ldres % 4 == 0) {
+    g_dispatch = "mfma";
+    return ovqa::mfma_linear_fwd_res32(x, ldx, w, bias, residual, ldres, mean, rstd, gamma, beta, pre, ldpre, M, N, K, da,
+                                       as_stream(stream));
+  }
+  const int dtype = OVQA_BF16;
+  OVQA_FALLBACK("linear_fwd_res32");
+  return ovqa::simple_linear_fwd_res32(x, ldx, w, bias, residual, ldres, mean, rstd, gamma, beta, pre, ldpre, M, N, K, da,
+                                       as_stream(stream));
 }
 
 int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
@@ -64,9 +114,12 @@ int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
   OVQA_REQUIRE(lddy >= N && lddx >= K && (!addend || ldadd >= K), OVQA_ERR_BAD_ARG,
                "linear_bwd_data: ld smaller than the row length");
   OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_bwd_data: more than 2^32 elements");
-  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_data_supported(M, N, K, lddy, lddx))
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_data_supported(M, N, K, lddy, lddx)) {
+    g_dispatch = "mfma";
     return ovqa::mfma_linear_bwd_data(dy, lddy, w, dx, lddx, gelu_preact, addend, ldadd, M, N, K, make_drop_args(drop),
                                       as_stream(stream));
+  }
+  OVQA_FALLBACK("linear_bwd_data");
   return ovqa::simple_linear_bwd_data(dtype, dy, lddy, w, dx, lddx, gelu_preact, addend, ldadd, M, N, K,
                                       make_drop_args(drop), as_stream(stream));
 }
@@ -77,6 +130,7 @@ int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems
   OVQA_REQUIRE(n_tiles >= 0 && (n_tiles == 0 || (problems_dev && tiles_dev)), OVQA_ERR_BAD_ARG,
                "grouped_linear_bwd_weight: bad argument");
   OVQA_REQUIRE(n_tiles < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: too many tiles");
+  g_dispatch = "mfma";
   return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, all_m_mult64 != 0 && !force_simple(), as_stream(stream));
 }
 
@@ -99,6 +153,7 @@ int ovqa_linear_bwd_data_wt(int dtype, const void* dy, int64_t lddy, const void*
   OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_bwd_data_wt: more than 2^32 elements");
   OVQA_REQUIRE(ovqa::mfma_gemm_supported(K, M, N, ldwt, lddy) && lddx % 4 == 0, OVQA_ERR_UNSUPPORTED,
                "linear_bwd_data_wt: needs N, K, lddy, ldwt multiples of 8 and lddx a multiple of 4");
+  g_dispatch = "mfma";
   return ovqa::mfma_linear_bwd_data_wt(dy, lddy, wt, ldwt, dx, lddx, gelu_preact, addend, ldadd, M, N, K,
                                        make_drop_args(drop), as_stream(stream));
 }
@@ -126,19 +181,23 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy, const void* 
     }
     return OVQA_OK;
   }
-  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_weight_supported(M, N, K, lddy, ldx))
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_linear_bwd_weight_supported(M, N, K, lddy, ldx)) {
+    g_dispatch = "mfma";
     return ovqa::mfma_linear_bwd_weight(dy, lddy, x, ldx, dw, db, M, N, K, acc_w, acc_b, as_stream(stream));
+  }
+  OVQA_FALLBACK("linear_bwd_weight");
   return ovqa::simple_linear_bwd_weight(dtype, dy, lddy, x, ldx, dw, db, M, N, K, acc_w, acc_b, as_stream(stream));
 }
 
 int ovqa_layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta,
-                       const float* pos, int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D,
-                       float eps, void* stream) {
+                       const float* pos, int64_t pos_rows, void* y, float* y_f32, float* mean, float* rstd, int64_t M,
+                       int64_t D, float eps, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(in_dtype), OVQA_ERR_BAD_ARG, "layernorm_fwd: bad dtype");
   OVQA_REQUIRE(M >= 0 && D > 0, OVQA_ERR_BAD_ARG, "layernorm_fwd: bad sizes");
   OVQA_REQUIRE(M == 0 || (x && gamma && beta && y), OVQA_ERR_BAD_ARG, "layernorm_fwd: null pointer");
   OVQA_REQUIRE(pos == nullptr || pos_rows > 0, OVQA_ERR_BAD_ARG, "layernorm_fwd: pos_rows must be > 0");
-  return ovqa::layernorm_fwd(dtype, in_dtype, x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps,
+  g_dispatch = "";
+  return ovqa::layernorm_fwd(dtype, in_dtype, x, gamma, beta, pos, pos_rows, y, y_f32, mean, rstd, M, D, eps,
                              as_stream(stream));
 }
 
@@ -178,8 +237,11 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
   OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_fwd: B*H too large");
   ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, msq, o, ldo, lse, att,
                    (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
-  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_supported(a))
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_supported(a)) {
+    g_dispatch = "mfma";
     return ovqa::mfma_attention_fwd(a, as_stream(stream));
+  }
+  OVQA_FALLBACK("attention_fwd");
   return ovqa::simple_attention_fwd(dtype, a, as_stream(stream));
 }
 
@@ -195,8 +257,11 @@ int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, 
   OVQA_REQUIRE(d_o && q && k && v && o && dq && dk_ && dv_, OVQA_ERR_BAD_ARG, "attention_bwd: null pointer");
   ovqa::AttnBwdArgs a{d_o, q, k, v, o, d_att, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
                       lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
-  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_bwd_supported(a))
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_bwd_supported(a)) {
+    g_dispatch = "mfma";
     return ovqa::mfma_attention_bwd(a, as_stream(stream));
+  }
+  OVQA_FALLBACK("attention_bwd");
   return ovqa::simple_attention_bwd(dtype, a, as_stream(stream));
 }
 
@@ -207,6 +272,7 @@ int ovqa_pointer_score(int dtype, const void* q, const void* k, const float* add
   OVQA_REQUIRE(B >= 0 && T >= 0 && Nk >= 0 && D > 0, OVQA_ERR_BAD_ARG, "pointer_score: bad sizes");
   if (B == 0 || T == 0 || Nk == 0) return OVQA_OK;
   OVQA_REQUIRE(q && k && scores, OVQA_ERR_BAD_ARG, "pointer_score: null pointer");
+  g_dispatch = "simple";
   return ovqa::simple_pointer_score(dtype, q, k, add_mask, key_fill, query_fill, scores, B, T, Nk, D, scale,
                                     as_stream(stream));
 }
@@ -218,6 +284,7 @@ int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b, const vo
   OVQA_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, OVQA_ERR_BAD_ARG, "batched_gemm: bad sizes");
   if (batch == 0 || M == 0 || N == 0) return OVQA_OK;
   OVQA_REQUIRE(A && Bm && C, OVQA_ERR_BAD_ARG, "batched_gemm: null pointer");
+  g_dispatch = "simple";
   return ovqa::simple_batched_gemm(dtype, c_dtype, trans_a, trans_b, A, lda, stride_a, Bm, ldb, stride_b, C, ldc,
                                    stride_c, batch, M, N, K, alpha, as_stream(stream));
 }

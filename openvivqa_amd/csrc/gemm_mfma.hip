@@ -475,6 +475,56 @@ struct MEpiBiasResidual {
            (float)r[3] + (a[3] + b.w) * drop_mul(ds, idx + 3));
   }
 };
+// fp32 residual stream (bf16 mode): pre32 = res + drop(x W^T + b), written in fp32.  The residual
+// is either a plain fp32 tensor (mean == nullptr) or the LayerNorm of the PREVIOUS block's fp32 pre-LN sum, recomputed
+// here from that sum and its saved row statistics -- (v - mean) * rstd * gamma + beta, the expression ln_fwd_kernel
+// evaluates -- so a block's fp32 output never has to be written to HBM: ln_fwd_kernel stores only the bf16 GEMM operand.
+struct MEpiBiasRes32 {
+  static constexpr bool kWide = true;
+  float* pre; int64_t ldpre; const float* bias; const float* res; int64_t ldres;
+  const float* mean; const float* rstd; const float* gamma; const float* beta;
+  int N; DropArgs da; DropState ds;
+  __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    bias8(bias, n, lo, hi, u);
+    const float4 r0 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n);
+    const float4 r1 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n + 4);
+    float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    if (mean) {
+      const float mu = mean[m], rs = rstd[m];
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + n), g1 = *reinterpret_cast<const float4*>(gamma + n + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(beta + n), b1 = *reinterpret_cast<const float4*>(beta + n + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int t = 0; t < 8; t++) r[t] = (r[t] - mu) * rs * g[t] + b[t];
+    }
+    const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+#pragma unroll
+    for (int t = 0; t < 8; t++) r[t] += u[t] * drop_mul(ds, idx + t);
+    float* o = pre + (int64_t)m * ldpre + n;
+    *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+  }
+  __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
+    const float4 bb = bias4(bias, n);
+    const float4 r0 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n);
+    float r[4] = {r0.x, r0.y, r0.z, r0.w};
+    if (mean) {
+      const float mu = mean[m], rs = rstd[m];
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + n), b0 = *reinterpret_cast<const float4*>(beta + n);
+      const float g[4] = {g0.x, g0.y, g0.z, g0.w}, b[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+      for (int t = 0; t < 4; t++) r[t] = (r[t] - mu) * rs * g[t] + b[t];
+    }
+    const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+    const float u[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
+#pragma unroll
+    for (int t = 0; t < 4; t++) r[t] += u[t] * drop_mul(ds, idx + t);
+    *reinterpret_cast<float4*>(pre + (int64_t)m * ldpre + n) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+};
 // dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
 struct MEpiBwdData {
   static constexpr bool kWide = true;
@@ -754,6 +804,17 @@ int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, con
   }
   ovqa_set_error("linear_fwd: unknown epilogue %d", epilogue);
   return OVQA_ERR_BAD_ARG;
+}
+
+int mfma_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
+                          int64_t ldres, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(aligned16(x) && aligned16(w) && aligned16(pre) && aligned16(residual) && (!bias || aligned16(bias)) &&
+                   (!gamma || (aligned16(gamma) && aligned16(beta))) && ldpre % 4 == 0 && ldres % 4 == 0,
+               OVQA_ERR_BAD_ARG, "linear_fwd_res32: pointers must be 16-byte aligned, ldpre / ldres multiples of 4");
+  return launch<false, false>(w, K, x, ldx, N, M, K,
+                              MEpiBiasRes32{pre, ldpre, bias, residual, ldres, mean, rstd, gamma, beta, (int)N, da, DropState{}},
+                              st, "linear_fwd_res32(mfma)", true);
 }
 
 // dX from a TRANSPOSED weight copy wt[K, N] (row stride ldwt): the forward-type kernel (row-major P tile).

@@ -131,6 +131,17 @@ struct EpiBiasResidual {
     y[(int64_t)m * ldy + n] = from_f32<T>(to_f32<T>(res[(int64_t)m * ldres + n]) + v);
   }
 };
+// fp32 residual stream: pre32 = res + drop(acc + bias), res = plain fp32 or LayerNorm(res; mean, rstd, gamma, beta)
+struct EpiBiasRes32 {
+  float* pre; int64_t ldpre; const float* bias; const float* res; int64_t ldres;
+  const float* mean; const float* rstd; const float* gamma; const float* beta; int N; DropArgs da;
+  __device__ void operator()(int, int m, int n, float acc) const {
+    const DropState ds = drop_init(da);
+    float r = res[(int64_t)m * ldres + n];
+    if (mean) r = (r - mean[m]) * rstd[m] * gamma[n] + beta[n];
+    pre[(int64_t)m * ldpre + n] = r + (acc + (bias ? bias[n] : 0.f)) * drop_mul(ds, (uint32_t)m * (uint32_t)N + n);
+  }
+};
 // dX = dY W [* dropmask * gelu'(u)]
 template <typename T>
 struct EpiBwdData {
@@ -230,6 +241,14 @@ int simple_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const
   if (dtype == OVQA_F32)
     return linear_fwd_t<float>(epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
   return linear_fwd_t<bf16>(epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
+}
+
+int simple_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
+                            int64_t ldres, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st) {
+  return launch<bf16, false, true>(x, ldx, 0, w, K, 0, 1, M, N, K,
+                                   EpiBiasRes32{pre, ldpre, bias, residual, ldres, mean, rstd, gamma, beta, (int)N, da}, st,
+                                   "linear_fwd_res32");
 }
 
 int simple_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,

@@ -10,6 +10,9 @@ constexpr int64_t kWorkspaceBytes = 64ll << 20;  // scratch the caller provides 
 int simple_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
                       const void* residual, int64_t ldres, void* y, int64_t ldy, void* preact,
                       int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
+int simple_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
+                            int64_t ldres, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
 int simple_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,
                            const void* preact, const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K,
                            const DropArgs& da, hipStream_t st);
@@ -58,7 +61,7 @@ int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st);
 
 // ---- layernorm.hip -----------------------------------------------------------
 int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta, const float* pos,
-                  int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                  int64_t pos_rows, void* y, float* y32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                   hipStream_t st);
 int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,
                   const float* mean, const float* rstd, void* dx, void* dx_dropped, float* dgamma, float* dbeta,
@@ -98,5 +101,9 @@ bool mfma_linear_fwd_supported(int epilogue, int64_t M, int64_t N, int64_t K, in
 int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, const float* bias, const void* residual,
                     int64_t ldres, void* y, int64_t ldy, void* preact, int64_t M, int64_t N, int64_t K,
                     const DropArgs& da, hipStream_t st);
+
+int mfma_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
+                          int64_t ldres, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
 
 }  // namespace ovqa

@@ -43,8 +43,9 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[VEC]) {
 template <typename TIN, typename TOUT, int CHUNKS>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ pos,
-                                                     int pos_rows, TOUT* __restrict__ y, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, int M, int D, float eps) {
+                                                     int pos_rows, TOUT* __restrict__ y, float* __restrict__ y32,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
+                                                     int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
         for (int i = 0; i < VEC; i++) o[i] += p[i];
       }
       store8<TOUT>(yr + col, o);
+      if (y32) store8<float>(y32 + (int64_t)row * D + col, o);
     }
   }
 }
@@ -242,12 +244,12 @@ __global__ __launch_bounds__(256) void ln_bwd_grouped_reduce_kernel(const ovqa_r
 
 template <typename TIN, typename TOUT>
 int fwd_dispatch(const void* x, const float* gamma, const float* beta, const float* pos, int64_t pos_rows, void* y,
-                 float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
+                 float* y32, float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
   dim3 grid((unsigned)((M + 3) / 4)), block(256);
 #define LN_FWD(C)                                                                                              \
   hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, C>), grid, block, 0, st, (const TIN*)x, gamma, beta, pos,      \
-                     (int)(pos ? pos_rows : 1), (TOUT*)y, mean, rstd, (int)M, (int)D, eps)
+                     (int)(pos ? pos_rows : 1), (TOUT*)y, y32, mean, rstd, (int)M, (int)D, eps)
   switch (chunks) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -300,17 +302,17 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
 namespace ovqa {
 
 int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, const float* beta, const float* pos,
-                  int64_t pos_rows, void* y, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                  int64_t pos_rows, void* y, float* y32, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                   hipStream_t st) {
   OVQA_REQUIRE(D % VEC == 0 && D <= 64 * VEC * MAX_CHUNKS, OVQA_ERR_UNSUPPORTED,
                "layernorm: D=%lld must be a multiple of 8 and <= 2048", (long long)D);
   if (M == 0) return OVQA_OK;
   if (dtype == OVQA_F32 && in_dtype == OVQA_F32)
-    return fwd_dispatch<float, float>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+    return fwd_dispatch<float, float>(x, gamma, beta, pos, pos_rows, y, y32, mean, rstd, M, D, eps, st);
   if (dtype == OVQA_BF16 && in_dtype == OVQA_BF16)
-    return fwd_dispatch<bf16, bf16>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+    return fwd_dispatch<bf16, bf16>(x, gamma, beta, pos, pos_rows, y, y32, mean, rstd, M, D, eps, st);
   if (dtype == OVQA_BF16 && in_dtype == OVQA_F32)
-    return fwd_dispatch<float, bf16>(x, gamma, beta, pos, pos_rows, y, mean, rstd, M, D, eps, st);
+    return fwd_dispatch<float, bf16>(x, gamma, beta, pos, pos_rows, y, y32, mean, rstd, M, D, eps, st);
   ovqa_set_error("layernorm_fwd: unsupported dtype combination in=%d out=%d", in_dtype, dtype);
   return OVQA_ERR_UNSUPPORTED;
 }
@@ -338,6 +340,8 @@ int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_
     return bwd_dispatch<float, float, float>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
   if (dtype == OVQA_BF16 && x_dtype == OVQA_BF16 && dx_dtype == OVQA_BF16)
     return bwd_dispatch<bf16, bf16, bf16>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
+  if (dtype == OVQA_BF16 && x_dtype == OVQA_F32 && dx_dtype == OVQA_BF16)  // fp32 pre-LN sum of the residual stream
+    return bwd_dispatch<bf16, float, bf16>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
   if (dtype == OVQA_BF16 && x_dtype == OVQA_F32 && dx_dtype == OVQA_F32)
     return bwd_dispatch<bf16, float, float>(dy, x, gamma, mean, rstd, dx, dx_dropped, dgamma, dbeta, M, D, accumulate, da, ws, st);
   ovqa_set_error("layernorm_bwd: unsupported dtype combination dy=%d x=%d dx=%d", dtype, x_dtype, dx_dtype);

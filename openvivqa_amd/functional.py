@@ -98,14 +98,77 @@ def _ln_bwd(arena, dy, x, gamma, beta, mean, rstd, drop=None, dx_dtype=None):
                              accumulate=acc, defer=_armed_queue() if defer else None)
 
 
+# ------------------------------------------------------------------ fp32 residual stream (bf16 mode)
+# The post-LN residual chain (attentions.py:330-331, positionwise_feed_forward.py:25-26) is kept in fp32 between
+# blocks: a block's bf16 output (the next GEMM's operand) carries, as the attribute ``_ovqa_res``, either its fp32
+# twin (prologue) or an ops.LnRef from which the next block's epilogue recomputes it (block outputs: the fp32 values
+# are never written to HBM).  The attribute is plumbing, not an autograd edge: the gradient of both uses flows through
+# the bf16 tensor, exactly as before.  A tensor without the attribute falls back to its own values cast to fp32.
+def residual_of(x):
+    res = getattr(x, "_ovqa_res", None)
+    if res is None:
+        return x.float()
+    return res
+
+
+def _attach(y, st):
+    res = st.pop("_res_out", None)
+    if res is not None:
+        y._ovqa_res = res
+    return y
+
+
+def carry_residual(dst, src):
+    """Hand ``src``'s fp32 twin to ``dst`` (a detached / re-rooted alias of the same values)."""
+    res = getattr(src, "_ovqa_res", None)
+    if res is not None:
+        dst._ovqa_res = res
+    return dst
+
+
+class _WithValue(Function):
+    """forward: ``value`` (the fp32 twin of x); backward: the gradient goes to x."""
+
+    @staticmethod
+    def forward(ctx, x, value):
+        ctx.dt = x.dtype
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt), None
+
+
+def finalize(out, dtype):
+    """Stack output in the caller's dtype: an fp32 caller of the bf16 mode gets the unrounded fp32 stream."""
+    res = getattr(out, "_ovqa_res", None)
+    if dtype == torch.float32 and out.dtype != torch.float32 and res is not None:
+        y32 = res.materialize() if isinstance(res, ops.LnRef) else res
+        return _WithValue.apply(out, y32) if out.requires_grad else y32
+    return out.to(dtype)
+
+
+def _ln_out(pre, ln, arena, st, save_stats=True):
+    """LayerNorm of the fp32 pre-LN sum -> bf16 operand; leaves the lazy fp32 twin in st["_res_out"]."""
+    gamma, beta = arena.master_of(ln.weight), arena.master_of(ln.bias)
+    y, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=arena.compute_dtype)
+    st["_res_out"] = ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps)
+    return y, mean, rstd
+
+
 # ------------------------------------------------------------------ prologue
 class _Prologue(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, st):
         arena, T = st["arena"], st["dtype"]
         x = _c(x)
-        y, mean, rstd = ops.layernorm_fwd(x, arena.master_of(gamma), arena.master_of(beta), st["eps"], out_dtype=T,
-                                          pos=st["pos"])
+        if T == torch.bfloat16:
+            y, y32, mean, rstd = ops.layernorm_fwd(x, arena.master_of(gamma), arena.master_of(beta), st["eps"],
+                                                   out_dtype=T, pos=st["pos"], want_f32=True)
+            st["_res_out"] = y32
+        else:
+            y, mean, rstd = ops.layernorm_fwd(x, arena.master_of(gamma), arena.master_of(beta), st["eps"], out_dtype=T,
+                                              pos=st["pos"])
         ctx.st = st
         ctx.save_for_backward(x, mean, rstd)
         return y
@@ -122,7 +185,7 @@ class _Prologue(Function):
 
 def prologue(x, layer_norm, pos, arena, dtype):
     st = dict(arena=arena, dtype=dtype, eps=layer_norm.eps, pos=pos, gamma=layer_norm.weight, beta=layer_norm.bias)
-    return _Prologue.apply(x, layer_norm.weight, layer_norm.bias, st)
+    return _attach(_Prologue.apply(x, layer_norm.weight, layer_norm.bias, st), st)
 
 
 # ------------------------------------------------------------------ hoisted K/V projection
@@ -218,9 +281,14 @@ class _MHABlock(Function):
         q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
         o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h)
         drop = st["drop"]
-        pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
-                             residual=queries, drop=drop)
-        y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
+        if queries.dtype == torch.bfloat16:  # fp32 residual stream: fp32 pre-LN sum, bf16 operand out
+            pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
+                                       drop=drop)
+            y, mean, rstd = _ln_out(pre, ln, arena, st)
+        else:
+            pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
+                                 residual=queries, drop=drop)
+            y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
         ctx.st, ctx.mode = st, mode
         ctx.mask = mask
         ctx.save_for_backward(queries, keys, values, o, lse, pre, mean, rstd, *bufs)
@@ -296,12 +364,20 @@ def mha_block(queries, keys, values, mask, st, projected_kv=None):
     else:
         st["same"] = ("all" if same_tensor(queries, keys) and same_tensor(keys, values)
                       else "kv" if same_tensor(keys, values) else "none")
+    bf16 = queries.dtype == torch.bfloat16
+    if bf16:
+        st["res"] = residual_of(queries)
     if torch.is_grad_enabled():
-        return _MHABlock.apply(queries, keys, values, mask, st, *st["params"])
+        return _attach(_MHABlock.apply(queries, keys, values, mask, st, *st["params"]), st)
     arena, a, ln = st["arena"], st["att"], st["ln"]
     queries, keys, values = _canon(queries, keys, values, st["same"])
     q, k, v, _, _ = _project_qkv(st, queries, keys, values)
     o, _, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=False)
+    if bf16:
+        pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
+                                   drop=st["drop"])
+        y, _, _ = _ln_out(pre, ln, arena, st)
+        return _attach(y, st)
     pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
                          residual=queries, drop=st["drop"])
     y, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps, save_stats=False)
@@ -316,10 +392,15 @@ class _FFNBlock(Function):
         x = _c(x)
         h, u = ops.linear_fwd(x, arena.compute(m.fc1.weight), arena.master_of(m.fc1.bias), EPI_BIAS_GELU,
                               want_preact=True, drop=st["drop1"])
-        pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL,
-                             residual=x, drop=st["drop2"])
         ln = m.layer_norm
-        y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
+        if x.dtype == torch.bfloat16:
+            pre = ops.linear_fwd_res32(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), st.pop("res"),
+                                       drop=st["drop2"])
+            y, mean, rstd = _ln_out(pre, ln, arena, st)
+        else:
+            pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL,
+                                 residual=x, drop=st["drop2"])
+            y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
         ctx.st = st
         ctx.save_for_backward(x, h, u, pre, mean, rstd)
         return y
@@ -339,14 +420,23 @@ class _FFNBlock(Function):
 
 
 def ffn_block(x, st):
+    st = dict(st)
+    bf16 = x.dtype == torch.bfloat16
+    if bf16:
+        st["res"] = residual_of(x)
     if torch.is_grad_enabled():
-        return _FFNBlock.apply(x, st, *st["params"])
+        return _attach(_FFNBlock.apply(x, st, *st["params"]), st)
     arena, m = st["arena"], st["mod"]
     x = _c(x)
     h = ops.linear_fwd(x, arena.compute(m.fc1.weight), arena.master_of(m.fc1.bias), EPI_BIAS_GELU, drop=st["drop1"])
+    ln = m.layer_norm
+    if bf16:
+        pre = ops.linear_fwd_res32(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), st.pop("res"),
+                                   drop=st["drop2"])
+        y, _, _ = _ln_out(pre, ln, arena, st)
+        return _attach(y, st)
     pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL, residual=x,
                          drop=st["drop2"])
-    ln = m.layer_norm
     y, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps, save_stats=False)
     return y
 

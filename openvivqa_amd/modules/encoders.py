@@ -106,7 +106,7 @@ class Encoder(_Prologued):
             if i:
                 out = rt.grad_milestone(out)
             out = layer(queries=out, keys=out, values=out, attention_mask=padding_mask)
-        return out.to(features.dtype)
+        return Fn.finalize(out, features.dtype)
 
 
 @META_ENCODER.register()
@@ -162,7 +162,7 @@ class GuidedAttentionEncoder(_Prologued):
             out = layer(queries=out, keys=lang, values=lang, self_attention_mask=vision_padding_mask,
                         projected_kv=None if kv_all is None else (kv_all, i, shared),
                         guided_attention_mask=language_padding_mask)
-        return out.to(vision_features.dtype)
+        return Fn.finalize(out, vision_features.dtype)
 
 
 @META_ENCODER.register()
@@ -195,7 +195,7 @@ class CoAttentionEncoder(_Prologued):
             l = lv(queries=l, keys=v, values=v, attention_mask=vision_padding_mask)
             v = vs(queries=v, keys=v, values=v, attention_mask=vision_padding_mask)
             l = ls(queries=l, keys=l, values=l, attention_mask=language_padding_mask)
-        return v.to(vdt), l.to(ldt)
+        return Fn.finalize(v, vdt), Fn.finalize(l, ldt)
 
 
 @META_ENCODER.register()
@@ -220,4 +220,4 @@ class CrossModalityEncoder(_Prologued):
                 v, l = rt.grad_milestone(v), rt.grad_milestone(l)
             v, l = layer(vision_features=v, vision_padding_mask=vision_padding_mask, language_features=l,
                          language_padding_mask=language_padding_mask)
-        return v.to(vdt), l.to(ldt)
+        return Fn.finalize(v, vdt), Fn.finalize(l, ldt)

@@ -109,6 +109,46 @@ def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=Fa
     return (y, preact) if want_preact else y
 
 
+class LnRef:
+    """A LayerNorm whose fp32 output is recomputed on the fly from its fp32 input ``pre`` (see ovqa_ln_ref)."""
+
+    def __init__(self, pre, mean, rstd, gamma, beta, eps):
+        self.pre, self.mean, self.rstd, self.gamma, self.beta, self.eps = pre, mean, rstd, gamma, beta, eps
+
+    def c(self):
+        return C.byref(_lib.LnRef(_p(self.mean), _p(self.rstd), _p(self.gamma), _p(self.beta)))
+
+    def materialize(self):
+        """The fp32 LayerNorm output itself (one extra launch; used where a plain tensor is needed)."""
+        y = torch.empty_like(self.pre)
+        lib = _lib.load()
+        D = self.pre.shape[-1]
+        _lib.check(lib.ovqa_layernorm_fwd(OVQA_F32, OVQA_F32, _p(self.pre), _p(self.gamma), _p(self.beta), None, 0, _p(y),
+                                          None, None, None, self.pre.numel() // D, D, float(self.eps), _stream()),
+                   "layernorm_fwd")
+        return y
+
+
+def linear_fwd_res32(x, w, bias, residual, drop=None):
+    """pre32 = res + drop(x w^T + bias) in fp32; ``residual`` is an fp32 tensor [.., N] or an LnRef (the previous
+    block's LayerNorm, recomputed in the epilogue).  x, w bf16."""
+    _dev(x)
+    lib = _lib.load()
+    ldx, M = _rows(x)
+    N, K = w.shape
+    assert x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype == torch.bfloat16
+    ln = None
+    if isinstance(residual, LnRef):
+        ln, residual = residual.c(), residual.pre
+    assert residual.dtype == torch.float32 and residual.shape[-1] == N
+    ldres, mr = _rows(residual)
+    assert mr == M
+    pre = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ovqa_linear_fwd_res32(_p(x), ldx, _p(w), _p(bias), _p(residual), ldres, ln, _p(pre), N, M, N, K,
+                                         _drop(drop), _stream()), "linear_fwd_res32")
+    return pre
+
+
 def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
     """dx = dy w  [* dropmask * gelu'(preact)]  [+ addend]   (addend may alias out)."""
     _dev(dy)
@@ -208,6 +248,8 @@ class WgradQueue:
         self._cache = []
         self._side = {}
         self._used_side = False
+        self.defer_uploads = False  # capture mode of a harness: tables are uploaded ONCE after the capture
+        self._deferred = []         # (pinned host, device, nbytes) of tables a captured launch reads
 
     def _side_stream(self, dev):
         st = self._side.get(dev)
@@ -250,7 +292,7 @@ class WgradQueue:
         entry = self._buffers(raw.size, dev, capturing)
         host, devbuf = entry[0], entry[1]
         host[:raw.size] = torch.from_numpy(raw.copy())
-        devbuf[:raw.size].copy_(host[:raw.size], non_blocking=True)
+        self._upload(host, devbuf, raw.size, capturing)
         _lib.check(_lib.load().ovqa_grouped_partial_reduce(devbuf.data_ptr(), len(red), max(r[1] for r in red),
                                                            max(r[2] for r in red), _stream()),
                    "grouped_partial_reduce")
@@ -297,20 +339,41 @@ class WgradQueue:
         host[:prob_bytes.size] = torch.from_numpy(prob_bytes.copy())
         host[prob_bytes.size:nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev)
-        side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
+        # a side stream only when launches are meant to overlap the rest of backward (FLUSH_TILES set); the default
+        # single launch at the end stays on the main stream: a fork/join in a captured graph turns every node
+        # boundary of the replay into a cross-queue dependency (scripts/boundary_bench.py: 1.6 us per dependent
+        # launch on one queue)
+        overlapping = self.FLUSH_TILES < (1 << 30) or os.environ.get("OVQA_WGRAD_SIDE", "0") == "1"
+        side = self._side_stream(dev) if overlapping else main
+        if overlapping:
+            side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
         with torch.cuda.stream(side):
-            devbuf[:nbytes].copy_(host[:nbytes], non_blocking=True)
+            self._upload(host, devbuf, nbytes, capturing)
             fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
                        and it[1].data_ptr() % 16 == 0 for it in items)
             _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
                 OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), int(fast),
                 side.cuda_stream), "grouped_linear_bwd_weight")
         self._used(entry, side, capturing)
-        self._used_side = True
+        self._used_side = self._used_side or overlapping
         self.inflight.append(items)
         if capturing:
             self.keepalive.append((host, devbuf, items))
+
+    def _upload(self, host, devbuf, nbytes, capturing):
+        """Host table -> device.  Inside a harness capture (defer_uploads) the copy is NOT recorded as a memcpy node:
+        the captured launches read device addresses that never change between replays, so ``upload_deferred``
+        copies each table once, right after the capture."""
+        if capturing and self.defer_uploads:
+            self._deferred.append((host, devbuf, nbytes))
+        else:
+            devbuf[:nbytes].copy_(host[:nbytes], non_blocking=True)
+
+    def upload_deferred(self):
+        for host, devbuf, nbytes in self._deferred:
+            devbuf[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        self._deferred = []
+        torch.cuda.synchronize()
 
     def finish(self):
         """End of the backward pass: launch the remainder and make the main stream wait for the side stream."""
@@ -338,6 +401,12 @@ class WgradQueue:
             if capturing:
                 entry[3] = True  # the graph owns it from now on
             return entry
+        if capturing:
+            raise RuntimeError(
+                f"WgradQueue: no idle table buffer of {nbytes} bytes is available while a stream is capturing (pinned "
+                "memory cannot be allocated during capture); run the backward pass eagerly once and call "
+                "wgrad_queue().reserve(n) before the capture")
+        self._max_nbytes = max(getattr(self, "_max_nbytes", 0), nbytes)
         size = max(nbytes * 2, 1 << 16)
         entry = [torch.empty(size, dtype=torch.uint8).pin_memory(), torch.empty(size, dtype=torch.uint8, device=dev),
                  None, capturing]
@@ -351,14 +420,21 @@ class WgradQueue:
             entry[2].record(stream)
 
     def reserve(self, n):
-        """Pre-create ``n`` idle table buffers (call before graph capture)."""
+        """Pre-create ``n`` idle table buffers (call after the eager warm-up passes and a device synchronise, before
+        graph capture).  They are sized from the largest table the warm-up passes built; buffers of finished eager
+        launches are recycled (their events have fired once the device is idle)."""
         dev = torch.device("cuda", torch.cuda.current_device())
-        while sum(1 for e in self._cache if not e[3] and e[2] is None) < n:
-            self._cache.append([torch.empty(1 << 17, dtype=torch.uint8).pin_memory(),
-                                torch.empty(1 << 17, dtype=torch.uint8, device=dev), None, False])
+        size = max(1 << 17, 2 * getattr(self, "_max_nbytes", 0))
+        for e in self._cache:
+            if not e[3] and e[2] is not None and e[2].query():
+                e[2] = None
+        while sum(1 for e in self._cache if not e[3] and e[2] is None and e[0].numel() >= size) < n:
+            self._cache.append([torch.empty(size, dtype=torch.uint8).pin_memory(),
+                                torch.empty(size, dtype=torch.uint8, device=dev), None, False])
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True, want_f32=False):
+    """Returns (y, mean, rstd), or (y, y_f32, mean, rstd) with ``want_f32`` (the unrounded fp32 result next to y)."""
     _dev(x)
     lib = _lib.load()
     assert x.is_contiguous()
@@ -366,6 +442,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats
     M = x.numel() // D
     out_dtype = out_dtype or x.dtype
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     pos_rows = 0
@@ -373,8 +450,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats
         assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == D
         pos_rows = pos.shape[0]
     _lib.check(lib.ovqa_layernorm_fwd(_DT[out_dtype], _dt(x), _p(x), _p(gamma), _p(beta), _p(pos), pos_rows, _p(y),
-                                      _p(mean), _p(rstd), M, D, float(eps), _stream()), "layernorm_fwd")
-    return y, mean, rstd
+                                      _p(y32), _p(mean), _p(rstd), M, D, float(eps), _stream()), "layernorm_fwd")
+    return (y, y32, mean, rstd) if want_f32 else (y, mean, rstd)
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=None, accumulate=False, defer=None):

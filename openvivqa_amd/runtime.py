@@ -137,6 +137,7 @@ class ParamArena:
         self._tr_table = None
         self.overwrite_grads = False  # harness mode: backward always overwrites the grad buffer
         self.kernel_written = set()   # ids of parameters whose gradient the HIP kernels produce
+        self._written_pass = set()    # harness mode: ids written so far in the CURRENT backward pass
         with torch.no_grad():
             for p in self.params:
                 o = self.offsets[id(p)]
@@ -249,6 +250,17 @@ class ParamArena:
                 merged.append([s, e])
         return [(s, e) for s, e in merged]
 
+    def begin_backward_pass(self) -> None:
+        """Harness mode: a new forward+backward starts (every matrix gradient is overwritten by its first product)."""
+        self._written_pass = set()
+
+    def end_backward_pass(self) -> None:
+        """Harness mode: zero the gradient of every kernel-owned matrix that this pass did NOT write (a branch that
+        was skipped this time), so that a stale gradient of an earlier step never reaches the optimiser."""
+        for p in self.params:
+            if p.dim() >= 2 and id(p) in self.kernel_written and id(p) not in self._written_pass:
+                self.grad_of(p).zero_()
+
     def attach_grads(self) -> None:
         for p in self.params:
             p.grad = self.grad_of(p)
@@ -261,12 +273,21 @@ class ParamArena:
         views = [self.grad_of(p) for p in ps]
         self.kernel_written.update(id(p) for p in ps)
         if self.overwrite_grads:
-            # harness mode: matrices are overwritten; the 1-D tail was zeroed for this step and is
+            # harness mode: the FIRST product of a pass overwrites a matrix, later products of the same pass (a
+            # weight applied twice in one forward) accumulate; the 1-D tail was zeroed for this step and is always
             # accumulated into (atomic column sums)
             for p, v in zip(ps, views):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
-            return self.packed(ps, "grad"), ps[0].dim() < 2
+            if ps[0].dim() < 2:
+                return self.packed(ps, "grad"), True
+            seen = [id(p) in self._written_pass for p in ps]
+            if any(seen) and not all(seen):  # a packed group of which only some members were written before
+                for p, v, was in zip(ps, views, seen):
+                    if not was:
+                        v.zero_()
+            self._written_pass.update(id(p) for p in ps)
+            return self.packed(ps, "grad"), any(seen)
         if all(p.grad is None for p in ps):
             for p, v in zip(ps, views):
                 p.grad = v

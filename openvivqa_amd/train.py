@@ -22,6 +22,7 @@ MI355X-first choices:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -53,6 +54,24 @@ class FlatAdam:
         self.host_step = 0
         if lr_lambda is not None:
             self.lr_scale.fill_(lr_lambda(0))
+
+    def state_dict(self) -> dict:
+        """Moments by parameter name-free arena offset (flat fp32), step counters and the LR scale: what
+        tasks/base_task.py:97-112 stores as ``optimizer`` / ``scheduler`` so that a run can resume."""
+        return {"exp_avg": self.exp_avg.detach().cpu().clone(), "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(),
+                "step": int(self.step_t.item()), "host_step": self.host_step, "lr_scale": float(self.lr_scale.item()),
+                "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "numel": self.arena.numel}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd["numel"] != self.arena.numel:
+            raise RuntimeError("FlatAdam.load_state_dict: arena layout differs from the checkpoint's")
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_t.fill_(int(sd["step"]))
+        self.host_step = int(sd["host_step"])
+        self.lr_scale.fill_(float(sd["lr_scale"]))
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
 
     def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
         a = self.arena
@@ -168,7 +187,8 @@ class _Cuts:
             self.barriers.append(i)
         if self.active is not None and i not in self.active:
             return x
-        leaf = x.detach().requires_grad_()
+        from .functional import carry_residual
+        leaf = carry_residual(x.detach().requires_grad_(), x)  # the fp32 twin of the residual stream follows the cut
         self.cuts.append((x, leaf))
         return leaf
 
@@ -259,6 +279,7 @@ class TrainStep:
         """[phase 0 = zero + forward + first backward, phase 1.., ] as closures sharing ``self._live``."""
         def first():
             a = self.arena
+            a.begin_backward_pass()
             if a.small_lo < a.numel:  # bias / LayerNorm gradients: atomically reduced, so zero them (one memset)
                 a.grad[a.small_lo:].zero_()
             for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
@@ -293,6 +314,8 @@ class TrainStep:
             self._live = {"cuts": cuts, "outs": outs, "grads": grads, "extra": extra}
             if now:
                 torch.autograd.backward([o for o, _ in now], [g for _, g in now])
+            if not cuts:
+                a.end_backward_pass()
 
         def later(k):
             def run():
@@ -310,6 +333,7 @@ class TrainStep:
                     torch.autograd.backward(roots, rgrads)
                 if k == 0:
                     self._live = None
+                    self.arena.end_backward_pass()
             return run
 
         return first, later
@@ -387,19 +411,46 @@ class TrainStep:
         if self.arena.device.type != "cuda":
             self._discover_foreign()
             return
+        err = None
         try:
             self._warm_and_capture()
         except Exception as exc:  # noqa: BLE001 -- the overlap is an optimisation: never lose the step over it
             if self._cuts is None and len(self.segments) == 1:
                 raise
+            err = exc
+        # the plan (number and bounds of the gradient segments) must be the SAME on every rank, or the all-reduce
+        # sequences diverge: agree on success across the group, fall back everywhere or nowhere
+        if not self._agree(err is None):
             import sys
-            print(f"openvivqa_amd.TrainStep: phased backward failed ({type(exc).__name__}: {exc}); "
-                  "falling back to one gradient exchange after backward", file=sys.stderr)
+            why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
+            print(f"openvivqa_amd.TrainStep: phased backward failed ({why}); "
+                  "falling back to one gradient exchange after backward on every rank", file=sys.stderr)
             torch.cuda.synchronize()
             self.overlap_mb = 0.0
             self._cuts, self._live, self.graphs = None, None, None
             self.segments = [[(0, self.arena.numel)]]
             self._warm_and_capture()
+        self._check_plan_identical()
+
+    def _agree(self, ok: bool) -> bool:
+        """True iff every rank of the group reports ``ok`` (MIN all-reduce of a flag on the device)."""
+        if not self.reducer.active or self.reducer.world <= 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.arena.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.reducer.group)
+        return bool(flag.item())
+
+    def _check_plan_identical(self):
+        """Assert once that the gradient segments have identical bounds on every rank."""
+        if not self.reducer.active or self.reducer.world <= 1:
+            return
+        import zlib
+        sig = zlib.crc32(repr([[tuple(r) for r in seg] for seg in self.segments]).encode()) & 0x7FFFFFFF
+        t = torch.tensor([sig, -sig], dtype=torch.int64, device=self.arena.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        if int(t[0].item()) != sig or int(-t[1].item()) != sig:
+            raise RuntimeError("TrainStep: gradient-exchange segments differ between ranks "
+                               f"(this rank: {len(self.segments)} segments); the models or inputs are not replicas")
 
     def _warm_and_capture(self):
         side = torch.cuda.Stream()
@@ -408,20 +459,26 @@ class TrainStep:
             self._discover_foreign()
             for _ in range(2):  # warm-up: allocator pools, lazy arenas, workspace
                 self._fwd_bwd()
-            from . import functional as _fn
-            _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW launches of the capture
+        from . import functional as _fn
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW / LayerNorm-reduce launches of the capture
         if self.use_graph:
             first, later = self._phase_fns()
             graphs = [torch.cuda.CUDAGraph()]
-            with torch.cuda.graph(graphs[0]):
-                first()
-            for k in reversed(range(len(self._live["cuts"]))):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=graphs[0].pool()):
-                    later(k)()
-                graphs.append(g)
+            q = _fn.wgrad_queue()
+            q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graphs
+            try:
+                with torch.cuda.graph(graphs[0]):
+                    first()
+                for k in reversed(range(len(self._live["cuts"]))):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=graphs[0].pool()):
+                        later(k)()
+                    graphs.append(g)
+            finally:
+                q.defer_uploads = False
+            q.upload_deferred()
             self._live = None
             if len(graphs) != len(self.segments):
                 raise RuntimeError(f"{len(graphs)} captured phases for {len(self.segments)} gradient segments")
@@ -439,9 +496,21 @@ class TrainStep:
         if self.static_inputs is None:
             self._capture(inputs)
 
+    def state_dict(self) -> dict:
+        """Optimiser + dropout-counter state (the model's own ``state_dict`` holds the fp32 master weights)."""
+        return {"optim": self.optim.state_dict(), "drop_step": int(self.drop_step.item())}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.optim.load_state_dict(sd["optim"])
+        self.drop_step.fill_(int(sd["drop_step"]))
+        self.arena.refresh_shadow()
+
     def step(self, *inputs: torch.Tensor) -> torch.Tensor:
         if self.static_inputs is None:
             self._capture(inputs)
+        # model.load_state_dict() between steps rewrites the fp32 masters in place: the bf16 shadows a captured graph
+        # reads must follow (the Python forward that would notice does not run during a replay)
+        self.arena.sync_if_stale()
         for dst, src in zip(self.static_inputs, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)

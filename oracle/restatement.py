@@ -20,7 +20,7 @@ from torch.nn import functional as F
 MASK_VALUE = -10e4  # models/utils.py:56,64,71  (== -100000.0)
 
 __all__ = [
-    "MASK_VALUE", "padding_mask", "sequential_mask", "self_attention_masks",
+    "emulate_bf16", "MASK_VALUE", "padding_mask", "sequential_mask", "self_attention_masks",
     "sinusoid_positions", "sinusoid_table", "sdpa_core",
     "OracleSDPA", "OracleMemorySDPA", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
     "OracleGuidedEncoderLayer", "OracleCrossModalityEncoderLayer",
@@ -31,6 +31,43 @@ __all__ = [
     "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "batch_gather",
     "noam_lambda", "oracle_train_step", "build_oracle_encoder",
 ]
+
+
+# --------------------------------------------------------------------------
+# bf16 emulation mode (bug detector for the HIP bf16 path, not a second reference)
+# --------------------------------------------------------------------------
+# Inside ``with emulate_bf16():`` the oracle rounds to bf16 exactly where the HIP bf16 path STORES bf16 (DESIGN.md
+# section 3): nn.Linear weights, every GEMM input operand, the projected q / k / v, the attention output o, the
+# un-normalised softmax numerators that feed the P.V matrix product, the FFN hidden activation h.  Everything the HIP
+# path keeps in fp32 stays fp32 here: accumulators, biases, softmax statistics, the residual stream (pre-LayerNorm sums
+# and LayerNorm outputs), LayerNorm statistics.  The roundings are straight-through for autograd.  The gap between
+# the HIP path and this mode is what the KERNELS add (accumulation order, fast exp / erf); the gap between this mode
+# and the plain fp32 oracle is the price of bf16 storage.
+_EMU = {"on": False}
+
+
+@contextmanager
+def emulate_bf16(on: bool = True):
+    prev = _EMU["on"]
+    _EMU["on"] = bool(on)
+    try:
+        yield
+    finally:
+        _EMU["on"] = prev
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    """bf16 storage round trip (identity outside emulate_bf16); straight-through gradient."""
+    if not _EMU["on"]:
+        return t
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def _lin(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear as the MFMA GEMM sees it: bf16 input and weight, fp32 accumulate, fp32 bias."""
+    if not _EMU["on"]:
+        return lin(x)
+    return F.linear(_r(x), _r(lin.weight), lin.bias)
 
 
 # --------------------------------------------------------------------------
@@ -95,6 +132,10 @@ def sdpa_core(q, k, v, mask, d_k):
     att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d_k)
     if mask is not None:
         att = att + mask
+    if _EMU["on"]:  # the kernel feeds bf16 exp(s - max) to the second matrix product and divides by the fp32 row sum
+        e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
+        den = e.sum(dim=-1, keepdim=True)
+        return torch.matmul(_r(e), v) / den, e / den
     att = torch.softmax(att, dim=-1)
     return torch.matmul(att, v), att
 
@@ -116,12 +157,12 @@ class OracleSDPA(nn.Module):
 
     def forward(self, queries, keys, values, attention_mask=None, **kw):
         b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
-        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).transpose(1, 2)
-        k = self.fc_k(keys).view(b, nk, self.h, self.d_k).transpose(1, 2)
-        v = self.fc_v(values).view(b, nk, self.h, self.d_v).transpose(1, 2)
+        q = _r(_lin(self.fc_q, queries)).view(b, nq, self.h, self.d_k).transpose(1, 2)
+        k = _r(_lin(self.fc_k, keys)).view(b, nk, self.h, self.d_k).transpose(1, 2)
+        v = _r(_lin(self.fc_v, values)).view(b, nk, self.h, self.d_v).transpose(1, 2)
         o, att = sdpa_core(q, k, v, attention_mask, self.d_k)
-        o = o.transpose(1, 2).reshape(b, nq, self.h * self.d_v)
-        return self.fc_o(o), att
+        o = _r(o.transpose(1, 2).reshape(b, nq, self.h * self.d_v))
+        return _lin(self.fc_o, o), att
 
 
 class OracleMemorySDPA(nn.Module):
@@ -253,8 +294,8 @@ class OraclePWFF(nn.Module):
         self.layer_norm = nn.LayerNorm(cfg.D_MODEL)
 
     def forward(self, x):
-        h = self.dropout_1(F.gelu(self.fc1(x)))
-        return self.layer_norm(x + self.dropout_2(self.fc2(h)))
+        h = _r(self.dropout_1(F.gelu(_lin(self.fc1, x))))
+        return self.layer_norm(x + self.dropout_2(_lin(self.fc2, h)))
 
 
 # --------------------------------------------------------------------------

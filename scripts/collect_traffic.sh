@@ -3,6 +3,9 @@
 # MI355X_MICROARCH.md "rocprofv3 PMC slots" prescribes: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2).
 mkdir -p gpurun_out/traffic; rm -rf gpurun_out/traffic/*
 export PYTHONDONTWRITEBYTECODE=1
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

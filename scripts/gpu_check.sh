@@ -2,6 +2,9 @@
 set -o pipefail
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 timeout -k 10 600 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/tests.log 2>&1
 echo "gpu tests exit $?"; grep -E "^(FAILED|ERROR)" gpurun_out/tests.log | head -30; tail -2 gpurun_out/tests.log
 timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log

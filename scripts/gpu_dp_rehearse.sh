@@ -1,4 +1,7 @@
 #!/bin/bash
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 # GPU: harness tests, then the bench in its normal N=1 form and with the N>1 code path rehearsed on one rank.
 set -e
 mkdir -p gpurun_out

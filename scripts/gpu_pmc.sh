@@ -1,6 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out/pmc
 export PYTHONDONTWRITEBYTECODE=1
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for shape in "6400 512 2048 fwd" "6400 2048 512 fwd" "6400 2048 512 dx"; do

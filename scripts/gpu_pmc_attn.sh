@@ -2,6 +2,9 @@
 mkdir -p gpurun_out/pmc
 rm -rf gpurun_out/pmc/*
 export PYTHONDONTWRITEBYTECODE=1
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 R=$GRAFT_REPO_ROOT
 for s in "100 100" "100 20" "20 20"; do python3 $R/scripts/one_attn.py $s time 2>&1 | grep -v amdgpu; done
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,7 @@
 #!/bin/bash
+# never compile from a profiled run (hipcc under the profiler preload would be an exec after GPU init): build first
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_reh

@@ -53,6 +53,26 @@ def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=Fa
     return (y, pre) if want_preact else y
 
 
+class LnRef:
+    def __init__(self, pre, mean, rstd, gamma, beta, eps):
+        self.pre, self.mean, self.rstd, self.gamma, self.beta, self.eps = pre, mean, rstd, gamma, beta, eps
+
+    def materialize(self):
+        D = self.pre.shape[-1]
+        x = self.pre.reshape(-1, D)
+        return ((x - self.mean[:, None]) * self.rstd[:, None] * self.gamma + self.beta).reshape(self.pre.shape)
+
+
+def linear_fwd_res32(x, w, bias, residual, drop=None):
+    assert drop is None or drop.p == 0
+    u = x.float() @ w.float().t()
+    if bias is not None:
+        u = u + bias
+    res = residual.materialize() if isinstance(residual, LnRef) else residual
+    assert res.dtype == torch.float32
+    return res + u
+
+
 def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
     dx = dy.float() @ w.float()
     if preact is not None:
@@ -108,7 +128,7 @@ def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, accumulate_db=None):
             db.copy_(s.view_as(db))
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats=True, want_f32=False):
     xf = x.float()
     mean = xf.mean(-1)
     var = xf.var(-1, unbiased=False)
@@ -116,6 +136,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=None, pos=None, save_stats
     y = (xf - mean[..., None]) * rstd[..., None] * gamma + beta
     if pos is not None:
         y = y + pos[None]
+    if want_f32:
+        return y.to(out_dtype or x.dtype), y, mean.reshape(-1), rstd.reshape(-1)
     return y.to(out_dtype or x.dtype), mean.reshape(-1), rstd.reshape(-1)
 
 
@@ -150,7 +172,12 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
     if mask is not None:
         s = s + mask
     p = torch.softmax(s, -1)
-    o = (p @ vh).transpose(1, 2).reshape(q.shape[0], q.shape[1], -1).to(q.dtype)
+    if q.dtype == torch.bfloat16:  # like the MFMA kernel: bf16 exp(s - max) into P.V, fp32 row sum
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        o = (e.bfloat16().float() @ vh) / e.sum(-1, keepdim=True)
+    else:
+        o = p @ vh
+    o = o.transpose(1, 2).reshape(q.shape[0], q.shape[1], -1).to(q.dtype)
     return o, torch.logsumexp(s, -1), (p.to(q.dtype) if need_att else None)
 
 

@@ -211,3 +211,84 @@ def test_feature_embedding_plumbing_vs_oracle():
     _close(xh.grad, xo.grad, 1e-5, "dx")
     _close(h.proj.weight.grad, o.proj.weight.grad, 1e-5, "dW")
     _close(h.proj.bias.grad, o.proj.bias.grad, 1e-5, "db")
+
+
+def _cpu_train_step(net, loss_fn, **kw):
+    from openvivqa_amd.train import TrainStep
+    ts = TrainStep(net, loss_fn, use_graph=False, **kw)
+
+    def capture_cpu(inputs):  # no CUDA streams/graphs on CPU: same steps minus the stream plumbing
+        ts.static_inputs = [t.clone() for t in inputs]
+        ts._discover_foreign()
+    ts._capture = capture_cpu
+    return ts
+
+
+def test_train_step_shared_weight_accumulates():
+    """A Linear applied TWICE in one forward under TrainStep (harness mode overwrites gradients): the second
+    product must accumulate into the first, not replace it (runtime.grad_views)."""
+    import openvivqa_amd.functional as Fn
+    import openvivqa_amd.runtime as rt
+
+    class Twice(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(16, 16)
+            self.other = torch.nn.Linear(16, 16)  # used only when flag is set: a branch that can be skipped
+            self.use_other = True
+
+        def forward(self, x):
+            arena = rt.ensure_arena(self)
+            h = Fn.linear(Fn.linear(x, self.lin, arena), self.lin, arena)
+            return Fn.linear(h, self.other, arena) if self.use_other else h
+
+    torch.manual_seed(3)
+    net, ref = Twice(), Twice()
+    ref.load_state_dict(net.state_dict())
+    x = torch.randn(5, 16)
+    tgt = torch.randn(5, 16)
+    ts = _cpu_train_step(net, lambda x_: (net(x_) - tgt).pow(2).mean(), lr=0.0, compute_dtype=torch.float32)
+    ts.step(x)
+    (ref.other(ref.lin(ref.lin(x))) - tgt).pow(2).mean().backward()
+    _close(ts.arena.grad_of(net.lin.weight), ref.lin.weight.grad, 1e-5, "shared dW")
+    _close(ts.arena.grad_of(net.lin.bias), ref.lin.bias.grad, 1e-5, "shared db")
+    _close(ts.arena.grad_of(net.other.weight), ref.other.weight.grad, 1e-5, "other dW")
+    # second step, same result (the first product of a pass overwrites: nothing carried over)
+    ts.step(x)
+    _close(ts.arena.grad_of(net.lin.weight), ref.lin.weight.grad, 1e-5, "shared dW, step 2")
+    # a kernel-owned matrix whose backward is skipped this step must not keep last step's gradient
+    net.use_other = False
+    ts.step(x)
+    assert float(ts.arena.grad_of(net.other.weight).abs().max()) == 0.0
+
+
+def test_bf16_mode_residual_stream_plumbing(monkeypatch):
+    """bf16 mode with the mocked kernels: the fp32 residual stream (lazy LayerNorm twins handed from block to block,
+    prologue twin, finalize) computes the same function as the oracle in bf16-emulation mode; forward and gradients."""
+    import openvivqa_amd as A
+    import oracle as O
+    from test_modules_helpers import mcan_pair
+    A.set_compute_dtype(torch.bfloat16)
+    te_o, ve_o = mcan_pair(O, 2, 5, d=64, heads=4, dff=128)
+    import openvivqa_amd.modules as M
+    te, ve = mcan_pair(M, 2, 6, d=64, heads=4, dff=128)
+    te.load_state_dict(te_o.state_dict())
+    ve.load_state_dict(ve_o.state_dict())
+    te.eval(), ve.eval(), te_o.eval(), ve_o.eval()
+    g = torch.Generator().manual_seed(1)
+    v, l = torch.randn(3, 10, 64, generator=g), torch.randn(3, 6, 64, generator=g)
+    v[1, 7:] = 0
+    vm, lm = O.padding_mask(v, 0), O.padding_mask(l, 0)
+    v1, v2 = v.clone().requires_grad_(), v.clone().requires_grad_()
+    with O.emulate_bf16():
+        lo_r = te_o(l, lm)
+        vo_r = ve_o(v1, vm, lo_r, lm)
+    lo = te(l, lm.float())
+    vo = ve(v2, vm.float(), lo, lm.float())
+    assert vo.dtype == torch.float32  # fp32 caller gets the unrounded stream
+    _close(lo, lo_r, 2e-3, "text out")
+    _close(vo, vo_r, 2e-3, "vision out")
+    w = torch.randn(vo.shape, generator=g)
+    (vo_r * w).mean().backward()
+    (vo * w).mean().backward()
+    assert ((v2.grad - v1.grad).norm() / v1.grad.norm()).item() < 2e-2

@@ -87,19 +87,31 @@ def test_phased_backward_with_comm_stream_matches_single_graph(single_rank_group
     assert moved <= 6.5e-4
 
 
+def _without_fc_k_bias(model, arena):
+    """Index mask of the flat gradient buffer minus every fc_k.bias: its gradient is analytically zero (softmax
+    shift invariance), what is there is rounding noise that Adam turns into +-lr steps."""
+    keep = torch.ones(arena.numel, dtype=torch.bool, device=arena.grad.device)
+    for name, p in model.named_parameters():
+        if name.endswith("fc_k.bias"):
+            o = arena.offsets[id(p)]
+            keep[o:o + p.numel()] = False
+    return keep
+
+
 def test_graph_replay_equals_eager_steps():
-    _, a, batch = _make(2, use_graph=True)
-    _, b, _ = _make(2, use_graph=False)
+    ma, a, batch = _make(2, use_graph=True)
+    mb, b, _ = _make(2, use_graph=False)
     a.step(*batch)
     b.step(*batch)
     torch.cuda.synchronize()
     # same kernels on the same weights: only the order of the fp32 atomics (bias / LayerNorm gradients) differs
     assert _rel(a.arena.grad, b.arena.grad) <= 1e-5
-    for _ in range(2):  # afterwards Adam amplifies that noise on parameters with ~zero gradient (fc_k.bias)
+    for _ in range(2):
         a.step(*batch)
         b.step(*batch)
     torch.cuda.synchronize()
-    assert _rel(a.arena.grad, b.arena.grad) <= 5e-3
+    ka, kb = _without_fc_k_bias(ma, a.arena), _without_fc_k_bias(mb, b.arena)
+    assert _rel(a.arena.grad[ka], b.arena.grad[kb]) <= 5e-3
     assert abs(float(a.loss) - float(b.loss)) <= 1e-4 * abs(float(b.loss))
 
 
