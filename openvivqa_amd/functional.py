@@ -111,6 +111,17 @@ def residual_of(x):
     return res
 
 
+def to_compute(x, dtype):
+    """``x`` in the compute dtype; an fp32 input of the bf16 mode stays available as the fp32 twin of its bf16 cast
+    (embedding sums entering a decoder, fp32 features entering an attention block directly)."""
+    if x.dtype == dtype:
+        return x
+    y = x.to(dtype)
+    if dtype == torch.bfloat16 and x.dtype == torch.float32:
+        y._ovqa_res = x.detach()
+    return y
+
+
 def _attach(y, st):
     res = st.pop("_res_out", None)
     if res is not None:

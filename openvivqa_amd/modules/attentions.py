@@ -140,7 +140,7 @@ class MultiHeadAttention(Module):
             projected_kv = None
         same_kv = Fn.same_tensor(keys, values)
         same_all = same_kv and Fn.same_tensor(queries, keys)
-        queries = queries.to(T)
+        queries = Fn.to_compute(queries, T)
         keys = queries if same_all else keys.to(T)
         values = keys if same_kv else values.to(T)
         mask = _as_mask(attention_mask)
@@ -188,8 +188,15 @@ class MultiHeadAttention(Module):
         self.running_keys = torch.cat([self.running_keys.to(q.dtype), k_new], 1)
         self.running_values = torch.cat([self.running_values.to(q.dtype), v_new], 1)
         o, _, _ = ops.attention_fwd(q, self.running_keys, self.running_values, mask, a.h, save_lse=False)
-        pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
-                             residual=queries.contiguous())
-        out, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps,
-                                      save_stats=False)
+        if q.dtype == torch.bfloat16:  # fp32 residual stream, as in the fused block
+            pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias),
+                                       Fn.residual_of(queries))
+            gamma, beta = arena.master_of(ln.weight), arena.master_of(ln.bias)
+            out, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=q.dtype)
+            out._ovqa_res = ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps)
+        else:
+            pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
+                                 residual=queries.contiguous())
+            out, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps,
+                                          save_stats=False)
         return self._aoa(arena, queries, out)

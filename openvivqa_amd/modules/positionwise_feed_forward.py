@@ -23,7 +23,7 @@ class PositionWiseFeedForward(nn.Module):
 
     def forward(self, input):
         arena = rt.ensure_arena(self)
-        x = input.to(arena.compute_dtype)
+        x = Fn.to_compute(input, arena.compute_dtype)
         st = dict(arena=arena, mod=self, params=list(self.parameters()),
                   drop1=rt.dropout_spec(self.dropout_1.p, self._site1, self.training, x.device),
                   drop2=rt.dropout_spec(self.dropout_2.p, self._site2, self.training, x.device))

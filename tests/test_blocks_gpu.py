@@ -227,7 +227,7 @@ def test_decoder_config5_shapes(mode):
     eh = enc.clone().to(DEV).requires_grad_(True)
     lh = h(toks.to(DEV), eh, emask.to(DEV))
     (lh * w.to(DEV)).sum().backward()
-    tol_f, tol_g = (1e-4, 5e-4) if mode == F32 else (2e-2, 3e-2)
+    tol_f, tol_g = (1e-4, 5e-4) if mode == F32 else (1e-2, 3e-2)
     assert rel_l2(lh, lo) < tol_f, rel_l2(lh, lo)
     assert rel_l2(eh.grad, eo.grad) < tol_g, rel_l2(eh.grad, eo.grad)
     go = dict(o.named_parameters())
@@ -244,7 +244,7 @@ def test_decoder_config5_shapes(mode):
             perm = torch.tensor([2, 0, 3, 1], device=DEV)
             h.apply_to_states(lambda s: s.index_select(0, perm) if s.shape[0] == 4 else s)
             assert tuple(h.layers[0].self_attn.running_keys.shape) == (4, 9, 512)
-    assert rel_l2(torch.cat(steps, 1), lo[:, :9]) < (1e-4 if mode == F32 else 2e-2)
+    assert rel_l2(torch.cat(steps, 1), lo[:, :9]) < (1e-4 if mode == F32 else 1e-2)
 
 
 def test_mmt_config4_size(mode):

@@ -64,6 +64,79 @@ def test_linear_fwd_epilogues(dtype, M, N, K):
     assert nerr(o.linear_fwd(x, w, b, o.EPI_BIAS_RESIDUAL, residual=res), u + rd) < tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K", [(37, 48, 40), (256, 128, 64), (6400, 512, 512), (1280, 512, 2048), (300, 768, 3072)])
+@pytest.mark.parametrize("lazy", [False, True], ids=["plain-residual", "lazy-layernorm-residual"])
+def test_linear_fwd_res32(M, N, K, lazy):
+    """fp32 residual stream epilogue: pre32 = res + drop(x W^T + b) in fp32; res either a plain fp32 tensor or the
+    LayerNorm of the previous block's fp32 pre-LN sum, recomputed from its saved row statistics.  fp32 OUTPUT of a
+    bf16 product: held to 2e-3 normalised (bf16 inputs are exact in the fp64 reference, only accumulation order and
+    the fp32 epilogue differ)."""
+    o = ops()
+    x, w = rnd(M, K, dtype=BF16), rnd(N, K, dtype=BF16, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2)
+    u = x.double() @ w.double().t() + b.double()
+    if lazy:
+        prev = rnd(M, N, scale=2.0, seed=3) + 0.3
+        g, be = rnd(N, seed=4) * 0.2 + 1.0, rnd(N, seed=5) * 0.1
+        yb, y32, mean, rstd = o.layernorm_fwd(prev, g, be, 1e-5, out_dtype=BF16, want_f32=True)
+        ry, _, _ = ln_ref(prev, g, be)
+        assert nerr(y32, ry) < 1e-5 and torch.equal(yb, y32.bfloat16())  # the bf16 operand is the rounded twin
+        res = o.LnRef(prev, mean, rstd, g, be, 1e-5)
+        assert nerr(res.materialize(), ry) < 1e-5
+        rres = ry
+    else:
+        res = rnd(M, N, scale=2.0, seed=3)
+        rres = res.double()
+    pre = o.linear_fwd_res32(x, w, b, res)
+    assert pre.dtype == F32 and nerr(pre, rres + u) < 2e-3
+    if K % 8 == 0 and N % 8 == 0:
+        from openvivqa_amd import _lib
+        assert _lib.last_dispatch() == "mfma"
+    d = o.DropSpec(p=0.3, seed=9, site=11, step=torch.tensor([3], dtype=torch.int32, device=DEV))
+    keep = o.dropout_keep_mask(d, M * N, DEV).view(M, N).double() / 0.7
+    assert nerr(o.linear_fwd_res32(x, w, b, res, drop=d), rres + u * keep) < 2e-3
+
+
+def test_layernorm_bwd_fp32_input_bf16_gradient():
+    """LayerNorm backward of the residual stream: bf16 dy, fp32 x (the pre-LN sum), bf16 dx (+ dropped branch)."""
+    o = ops()
+    M, D = 77, 512
+    x = rnd(M, D, scale=2.0) + 0.5
+    g, b = rnd(D, seed=1) * 0.2 + 1.0, rnd(D, seed=2) * 0.1
+    _, mean, rstd = o.layernorm_fwd(x, g, b, 1e-5, out_dtype=BF16)
+    dy = rnd(M, D, dtype=BF16, seed=9)
+    xd = x.double().detach().cpu().requires_grad_(True)
+    gd, bd = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5).backward(dy.double().cpu())
+    dg, dbt = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    drop = o.DropSpec(p=0.25, seed=123, site=7, step=torch.tensor([5], dtype=torch.int32, device=DEV))
+    dx, dxd = o.layernorm_bwd(dy, x, g, mean, rstd, dg, dbt, drop=drop)
+    assert dx.dtype == BF16 and dxd.dtype == BF16
+    assert nerr(dx, xd.grad) < 1e-2 and nerr(dg, gd.grad) < 1e-2 and nerr(dbt, bd.grad) < 1e-2
+    keep = o.dropout_keep_mask(drop, M * D, DEV).view(M, D).double()
+    assert nerr(dxd, dx.double() * keep / 0.75) < 1e-2
+
+
+def test_dispatch_hook_reports_kernel_family():
+    """ovqa_last_dispatch(): BASELINE shapes run the MFMA kernels, fp32 / ragged shapes the VALU ones."""
+    from openvivqa_amd import _lib
+    o = ops()
+    x, w = rnd(6400, 512, dtype=BF16), rnd(1536, 512, dtype=BF16, scale=0.04, seed=1)
+    o.linear_fwd(x, w, None)
+    assert _lib.last_dispatch() == "mfma"
+    o.linear_fwd(x.float(), w.float(), None)
+    assert _lib.last_dispatch() == "simple"
+    o.linear_fwd(rnd(37, 29, dtype=BF16), rnd(50, 29, dtype=BF16, seed=1), None)  # K % 8 != 0
+    assert _lib.last_dispatch() == "simple"
+    for nq, nk in ((100, 100), (100, 20), (20, 20)):
+        q = rnd(64, nq, 1536, dtype=BF16, seed=2)
+        kv = rnd(64, nk, 1024, dtype=BF16, seed=3)
+        out, lse, _ = o.attention_fwd(q[..., :512], kv[..., :512], kv[..., 512:], None, 8)
+        assert _lib.last_dispatch() == "mfma"
+        o.attention_bwd(rnd(64, nq, 512, dtype=BF16, seed=4), q[..., :512], kv[..., :512], kv[..., 512:], out, lse, None, 8)
+        assert _lib.last_dispatch() == "mfma"
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_linear_fwd_strided_and_3d(dtype):
     o = ops()

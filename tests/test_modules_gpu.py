@@ -2,12 +2,11 @@
 oracle on seeded inputs at BASELINE sizes.  Everything goes through the C ABI.
 
 Bars (north star): fp32 mode <= 1e-3, bf16 mode <= 1e-2, both as normalised max
-error max|a-b| / max(1, max|b|); bf16 gradients <= 3e-2 relative L2.
-Deep stacks in bf16 (>= 8 chained blocks: the L=6 MCAN stack, the L=2 co-attention stack) sit AT
-the bf16 noise floor of the algorithm itself -- rounding the fp32 oracle's weights and
-activations to bf16 already gives 1.4e-2 normalised max / 0.8e-2 relative L2 at L=6
-(tests/bf16_noise_floor.py) -- so for those the bar is relative L2 <= 1e-2 and normalised
-max <= 2e-2.
+error max|a-b| / max(1, max|b|), at every depth (the residual stream is kept in fp32 between
+blocks: tests/bf16_noise_floor.py); bf16 gradients <= 3e-2 relative L2.
+On top of that the bf16 path is held to <= 3e-3 against the oracle in bf16-EMULATION mode
+(oracle.emulate_bf16: rounds where the HIP path stores bf16), which is the bug detector: what is
+left between the two is accumulation order and fast exp / erf.
 """
 import json
 import os
@@ -50,13 +49,9 @@ def mode(request):
 def test_hip_modules_match_reference_golden(name, mode):
     case, outs, gin, gw, _ = run_case(hip_namespace(), name, device=DEV)
     fwd_tol = 1e-3 if mode == F32 else 1e-2
-    deep = name in ("G5_coattention_encoder",)  # 8 chained blocks: bf16 noise floor, see module docstring
     for k, ref in case.out.items():
         if k in outs and outs[k] is not None:
-            if mode == BF16 and deep:
-                assert rel_l2(outs[k], ref) < 1e-2 and nerr(outs[k], ref) < 2e-2, f"{name} out/{k}"
-            else:
-                assert nerr(outs[k], ref) < fwd_tol, f"{name} out/{k}: {nerr(outs[k], ref):.3e}"
+            assert nerr(outs[k], ref) < fwd_tol, f"{name} out/{k}: {nerr(outs[k], ref):.3e}"
     for k, ref in case.gin.items():
         e = nerr(gin[k], ref) if mode == F32 else rel_l2(gin[k], ref)
         assert e < (1e-3 if mode == F32 else 3e-2), f"{name} gin/{k}: {e:.3e}"
@@ -131,7 +126,7 @@ def test_decoder_stateful_steps(mode):
         with m.statefulness(2):
             steps = [m(toks[:, t:t + 1], enc, emask) for t in range(4)]
             assert torch.equal(m.running_seq.cpu(), case.out["running_seq_final"])
-    assert nerr(torch.cat(steps, 1), case.out["step_logp"]) < (1e-3 if mode == F32 else 2e-2)
+    assert nerr(torch.cat(steps, 1), case.out["step_logp"]) < (1e-3 if mode == F32 else 1e-2)
 
 
 def _mcan_pair(ns, layers, seed):
@@ -164,7 +159,7 @@ def test_fullsize_mcan_against_reference_checksum(mode):
     wl = torch.randn(lo.shape, generator=gen).to(DEV)
     loss = (vo.float() * wv).mean() + (lo.float() * wl).mean()
     loss.backward()
-    tol = 1e-3 if mode == F32 else 2e-2  # bf16 at L=6: noise floor, see module docstring
+    tol = 1e-3 if mode == F32 else 1e-2
     assert abs(loss.item() - c.out["loss"].item()) < tol
     assert nerr(vo[:, ::17, ::61], c.out["vision_sample"]) < tol
     assert nerr(lo[:, ::3, ::61], c.out["language_sample"]) < tol
@@ -227,14 +222,67 @@ def test_baseline_size_vs_oracle_bf16(B):
         vm, lm = U.generate_padding_mask(vd, 0), U.generate_padding_mask(ld, 0)
         lo = te(features=ld, padding_mask=lm)
         vo = ve(vision_features=vd, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
-        # L=6 in bf16: relative L2 <= 1e-2 and normalised max <= 2e-2 (noise floor, module docstring)
+        # north star: 1e-2 in bf16, at L=6 too
+        assert nerr(lo, lo_ref) < 1e-2 and nerr(vo, vo_ref) < 1e-2, (nerr(lo, lo_ref), nerr(vo, vo_ref))
         assert rel_l2(lo, lo_ref) < 1e-2 and rel_l2(vo, vo_ref) < 1e-2, (rel_l2(lo, lo_ref), rel_l2(vo, vo_ref))
-        assert nerr(lo, lo_ref) < 2e-2 and nerr(vo, vo_ref) < 2e-2, (nerr(lo, lo_ref), nerr(vo, vo_ref))
+        # bug detector: against the oracle rounding where the HIP path stores bf16
+        with O.emulate_bf16():
+            lo_emu = te_o(l, O.padding_mask(l, 0))
+            vo_emu = ve_o(v, O.padding_mask(v, 0), lo_emu, O.padding_mask(l, 0))
+        assert nerr(lo, lo_emu) < 3e-3 and nerr(vo, vo_emu) < 3e-3, (nerr(lo, lo_emu), nerr(vo, vo_emu))
         # property: samples are independent (data-parallel shardability): a half batch gives the same rows
         lo_h = te(features=ld[:32], padding_mask=lm[:32])
         vo_h = ve(vision_features=vd[:32], vision_padding_mask=vm[:32], language_features=lo_h,
                   language_padding_mask=lm[:32])
         assert torch.equal(vo_h, vo[:32]) and torch.equal(lo_h, lo[:32])
+
+
+def test_l6_forward_and_gradients_vs_bf16_emulating_oracle():
+    """The bug detector at depth: MCAN stacks L=6, B=16, 100x20 -- HIP bf16 path against the oracle in bf16-emulation
+    mode (rounds where the HIP path stores bf16, fp32 everywhere else).  Forward <= 3e-3 normalised max; gradients
+    (HIP keeps them in bf16 between kernels, the emulation differentiates in fp32) <= 1e-2 relative L2 for the input
+    gradients and for every weight gradient that is not itself at noise level."""
+    import openvivqa_amd as A
+    import openvivqa_amd.utils as U
+    import oracle as O
+    A.set_compute_dtype(BF16)
+    te_o, ve_o = _mcan_pair(oracle_namespace(), 6, 41)
+    te, ve = _mcan_pair(hip_namespace(), 6, 42)
+    te.load_state_dict(te_o.state_dict())
+    ve.load_state_dict(ve_o.state_dict())
+    te, ve = te.to(DEV).eval(), ve.to(DEV).eval()
+    te_o.eval(), ve_o.eval()
+    gen = torch.Generator().manual_seed(8)
+    B = 16
+    v, l = torch.randn(B, 100, 512, generator=gen), torch.randn(B, 20, 512, generator=gen)
+    for i in range(B):
+        v[i, 84 + i:] = 0
+        l[i, 8 + i % 12:] = 0
+    wv, wl = torch.randn(v.shape, generator=gen), torch.randn(l.shape, generator=gen)
+    v_r, l_r = v.clone().requires_grad_(), l.clone().requires_grad_()
+    with O.emulate_bf16():
+        lo_r = te_o(l_r, O.padding_mask(l, 0))
+        vo_r = ve_o(v_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
+    ((vo_r * wv).mean() + (lo_r * wl).mean()).backward()
+    vd, ld = v.to(DEV).requires_grad_(), l.to(DEV).requires_grad_()
+    vm, lm = U.generate_padding_mask(vd.detach(), 0), U.generate_padding_mask(ld.detach(), 0)
+    lo = te(features=ld, padding_mask=lm)
+    vo = ve(vision_features=vd, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
+    ((vo.float() * wv.to(DEV)).mean() + (lo.float() * wl.to(DEV)).mean()).backward()
+    assert nerr(lo, lo_r) < 3e-3 and nerr(vo, vo_r) < 3e-3, (nerr(lo, lo_r), nerr(vo, vo_r))
+    assert rel_l2(vd.grad, v_r.grad) < 1e-2 and rel_l2(ld.grad, l_r.grad) < 1e-2, \
+        (rel_l2(vd.grad, v_r.grad), rel_l2(ld.grad, l_r.grad))
+    worst = ("", 0.0)
+    for (pre, hip_m, ref_m) in (("self_encoder.", te, te_o), ("guided_encoder.", ve, ve_o)):
+        gref = dict(ref_m.named_parameters())
+        gmax = max(float(p.grad.norm()) for p in gref.values() if p.grad is not None)
+        for k, p in hip_m.named_parameters():
+            if k.endswith("fc_k.bias") or float(gref[k].grad.norm()) < 0.05 * gmax:
+                continue
+            e = rel_l2(p.grad, gref[k].grad)
+            if e > worst[1]:
+                worst = (pre + k, e)
+    assert worst[1] < 1e-2, worst
 
 
 @pytest.mark.parametrize("arch", ["CrossModalityEncoder", "CoAttentionEncoder"])
@@ -270,8 +318,9 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch):
     ah, bh = hip(vision_features=vd, vision_padding_mask=U.generate_padding_mask(vd.detach(), 0), language_features=ld,
                  language_padding_mask=U.generate_padding_mask(ld.detach(), 0))
     ((ah.float() * wv.to(DEV)).mean() + (bh.float() * wl.to(DEV)).mean()).backward()
-    # L=6 (CoAttention: 24 chained blocks) in bf16: stack-level bars, module docstring
-    assert rel_l2(ah, a) < 1.5e-2 and rel_l2(bh, b) < 1.5e-2, (rel_l2(ah, a), rel_l2(bh, b))
+    # L=6 (CoAttention: 24 chained blocks) in bf16
+    assert nerr(ah, a) < 1e-2 and nerr(bh, b) < 1e-2, (nerr(ah, a), nerr(bh, b))
+    assert rel_l2(ah, a) < 1e-2 and rel_l2(bh, b) < 1e-2, (rel_l2(ah, a), rel_l2(bh, b))
     assert rel_l2(vd.grad, vo_r.grad) < 4e-2 and rel_l2(ld.grad, lo_r.grad) < 4e-2, \
         (rel_l2(vd.grad, vo_r.grad), rel_l2(ld.grad, lo_r.grad))
     gref = dict(ref.named_parameters())
@@ -339,3 +388,41 @@ def test_train_mode_dropout_runs_and_is_consistent():
         assert torch.equal(a, b)
     finally:
         A.set_compute_dtype(BF16)
+
+
+@pytest.mark.parametrize("axis", ["key", "query"])
+def test_dynamic_pointer_network_module_vs_oracle(axis, mode):
+    """a17 at the M4C size (D_MODEL 768, 12 decode positions x 50 OCR tokens): the key-axis variant of
+    models/m4c.py:19-33 (boolean mask over the OCR tokens -> -inf columns) and the query-axis variant of
+    models/iterative_m4c.py:18-32 (-inf rows), module level, forward and gradients, against the oracle."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    cfg = ConfigNode(dict(D_MODEL=768))
+    torch.manual_seed(17)
+    ref = O.OracleDynamicPointerNetwork(cfg, axis)
+    hip = M.DynamicPointerNetwork(cfg, axis)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    B, T, No = 4, 12, 50
+    q, k = torch.randn(B, T, 768, generator=g), torch.randn(B, No, 768, generator=g)
+    n = No if axis == "key" else T
+    mask = torch.zeros(B, 1, 1, n, dtype=torch.bool)
+    mask[1, ..., n - 7:] = True
+    mask[3, ..., n // 2:] = True
+    qr, kr = q.clone().requires_grad_(), k.clone().requires_grad_()
+    s_r = ref(qr, kr, mask)
+    qh, kh = q.to(DEV).requires_grad_(), k.to(DEV).requires_grad_()
+    s_h = hip(qh, kh, mask.to(DEV))
+    assert s_h.shape == s_r.shape == (B, T, No)
+    assert torch.equal(torch.isinf(s_h).cpu(), torch.isinf(s_r))
+    assert nerr(s_h, s_r) < (1e-3 if mode == F32 else 1e-2), nerr(s_h, s_r)
+    w = torch.randn(s_r.shape, generator=g)
+    fin = torch.isfinite(s_r)
+    (torch.where(fin, s_r, torch.zeros_like(s_r)) * w).sum().backward()
+    (torch.where(fin.to(DEV), s_h, torch.zeros_like(s_h)) * w.to(DEV)).sum().backward()
+    gt = 1e-3 if mode == F32 else 3e-2
+    assert rel_l2(qh.grad, qr.grad) < gt and rel_l2(kh.grad, kr.grad) < gt
+    for name, p in hip.named_parameters():
+        assert rel_l2(p.grad, dict(ref.named_parameters())[name].grad) < gt, name
