@@ -118,7 +118,7 @@ def to_compute(x, dtype):
         return x
     y = x.to(dtype)
     if dtype == torch.bfloat16 and x.dtype == torch.float32:
-        y._ovqa_res = x.detach()
+        y._ovqa_res = x.detach().contiguous()
     return y
 
 

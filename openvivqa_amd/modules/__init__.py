@@ -9,11 +9,11 @@ from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEn
 from .embeddings import FeatureEmbedding, LSTMTextEmbedding, UsualEmbedding
 from .decoders import Decoder, DecoderLayer
 from .pointer import DynamicPointerNetwork, OcrPtrNet
-from .mmt import MMT, BertEncoder, PrevPredEmbeddings
+from .mmt import MMT, BertEncoder, M4CDecodingHead, PrevPredEmbeddings
 
 __all__ = [
     "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
     "ScaledDotProductAttention", "AugmentedMemoryScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
     "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
-    "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet", "MMT", "BertEncoder", "PrevPredEmbeddings",
+    "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet", "MMT", "BertEncoder", "PrevPredEmbeddings", "M4CDecodingHead",
 ]

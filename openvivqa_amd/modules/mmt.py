@@ -80,7 +80,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None):
         arena = rt.ensure_arena(self)
-        x = hidden_states.to(arena.compute_dtype)
+        x = Fn.to_compute(hidden_states, arena.compute_dtype)
         a = self.attention
         if self.training and a.self.dropout.p > 0 and torch.is_grad_enabled():
             raise NotImplementedError("attention-probability dropout is not fused; train with "
@@ -120,7 +120,7 @@ class BertEncoder(nn.Module):
         dtype = hidden_states.dtype
         for layer in self.layer:
             hidden_states = layer(hidden_states, attention_mask)
-        return (hidden_states.to(dtype),)
+        return (Fn.finalize(hidden_states, dtype),)
 
 
 def _batch_gather(x, inds):
@@ -182,3 +182,50 @@ class MMT(nn.Module):
         nt, no, nc = txt_mask.size(-1), obj_mask.size(-1), ocr_mask.size(-1)
         return {"mmt_seq_output": out, "mmt_txt_output": out[:, :nt], "mmt_ocr_output": out[:, nt + no:nt + no + nc],
                 "mmt_dec_output": out[:, -steps:]}
+
+
+class M4CDecodingHead(nn.Module):
+    """Output scorer and greedy decoder of M4C (mmf_m4c.py:221-256): scores = [classifier(dec) | OcrPtrNet(dec, ocr)],
+    and at evaluation time ``max_iter`` passes of the multimodal transformer, each feeding the arg-max of the previous
+    pass back as ``prev_inds`` (fixed-vocabulary index, or ``num_choices + i`` for OCR token i), with the reference's
+    early exit once every sample has produced ``eos_idx``.
+
+    No key/value reuse across the passes: in the reference the encoding positions attend to the decoding positions
+    too (``dec_mask`` is all zeros and the masks are ADDITIVE, mmf_m4c.py:310-313,333-340), so every hidden state of
+    every layer changes from pass to pass; caching the [txt; obj; ocr] prefix would change the results."""
+
+    def __init__(self, hidden_size: int, num_choices: int):
+        super().__init__()
+        from .pointer import OcrPtrNet
+        self.classifier = nn.Linear(hidden_size, num_choices)
+        self.ocr_ptr_net = OcrPtrNet(hidden_size)
+
+    def scores(self, mmt_results, ocr_mask):
+        """mmf_m4c.py:221-229 (_forward_output)."""
+        dec, ocr = mmt_results["mmt_dec_output"], mmt_results["mmt_ocr_output"]
+        arena = rt.ensure_arena(self.classifier)
+        fixed = Fn.linear(dec.to(arena.compute_dtype), self.classifier, arena).float()
+        dynamic = self.ocr_ptr_net(dec, ocr, ocr_mask)
+        return torch.cat([fixed, dynamic], dim=-1)
+
+    @torch.no_grad()
+    def greedy_decode(self, mmt, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, max_iter: int, bos_idx: int,
+                      eos_idx: int):
+        """mmf_m4c.py:236-256.  Returns (scores of the last pass (B, max_iter, num_choices + n_ocr), prev_inds,
+        number of passes run)."""
+        B, dev = txt_emb.shape[0], txt_emb.device
+        prev_inds = torch.zeros((B, max_iter), dtype=torch.long, device=dev)
+        prev_inds[:, 0] = bos_idx
+        last_ids = torch.zeros((B,), device=dev)
+        scores, passes = None, 0
+        for ith in range(max_iter):
+            res = mmt(txt_emb=txt_emb, txt_mask=txt_mask, obj_emb=obj_emb, obj_mask=obj_mask, ocr_emb=ocr_emb,
+                      ocr_mask=ocr_mask, fixed_ans_emb=self.classifier.weight, prev_inds=prev_inds)
+            scores = self.scores(res, ocr_mask)
+            passes += 1
+            argmax_inds = scores.argmax(dim=-1)
+            prev_inds[:, 1:] = argmax_inds[:, :-1]
+            last_ids = torch.where(last_ids == eos_idx, last_ids, argmax_inds[:, ith].to(last_ids.dtype))
+            if last_ids.mean() == eos_idx:  # one host sync per pass, as in the reference
+                break
+        return scores, prev_inds, passes

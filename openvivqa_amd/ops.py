@@ -141,6 +141,8 @@ def linear_fwd_res32(x, w, bias, residual, drop=None):
     if isinstance(residual, LnRef):
         ln, residual = residual.c(), residual.pre
     assert residual.dtype == torch.float32 and residual.shape[-1] == N
+    if not residual.is_contiguous() and (residual.stride(-1) != 1 or residual.dim() > 2):
+        residual = residual.contiguous()
     ldres, mr = _rows(residual)
     assert mr == M
     pre = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)

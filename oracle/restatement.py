@@ -28,7 +28,7 @@ __all__ = [
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
     "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
     "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "OracleMLP", "OracleMCAN",
-    "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "batch_gather",
+    "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "OracleM4CDecodingHead", "batch_gather",
     "noam_lambda", "oracle_train_step", "build_oracle_encoder",
 ]
 
@@ -56,18 +56,51 @@ def emulate_bf16(on: bool = True):
         _EMU["on"] = prev
 
 
+class _StoreBf16(torch.autograd.Function):
+    """A tensor the HIP path stores in bf16: its value is rounded in forward, and so is its gradient in backward
+    (the HIP backward kernels hand gradients from kernel to kernel in bf16 as well)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _GradBf16(torch.autograd.Function):
+    """Value untouched (kept in fp32 by the HIP path), gradient rounded to bf16 (LayerNorm backward writes bf16)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 def _r(t: torch.Tensor) -> torch.Tensor:
-    """bf16 storage round trip (identity outside emulate_bf16); straight-through gradient."""
+    """bf16 storage round trip of a value and of its gradient (identity outside emulate_bf16)."""
     if not _EMU["on"]:
         return t
-    return t + (t.bfloat16().float() - t).detach()
+    return _StoreBf16.apply(t) if t.requires_grad else t.bfloat16().float()
+
+
+def _gr(t: torch.Tensor) -> torch.Tensor:
+    """fp32 value whose GRADIENT the HIP path stores in bf16 (the pre-LayerNorm sums of the residual stream)."""
+    if not _EMU["on"] or not t.requires_grad:
+        return t
+    return _GradBf16.apply(t)
 
 
 def _lin(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """nn.Linear as the MFMA GEMM sees it: bf16 input and weight, fp32 accumulate, fp32 bias."""
     if not _EMU["on"]:
         return lin(x)
-    return F.linear(_r(x), _r(lin.weight), lin.bias)
+    w = lin.weight
+    return F.linear(_r(x), w + (w.bfloat16().float() - w).detach(), lin.bias)  # weight gradients stay fp32
 
 
 # --------------------------------------------------------------------------
@@ -275,7 +308,7 @@ class OracleMHA(_Stateful):
             self.running_values = torch.cat([self.running_values, values], 1)
             keys, values = self.running_keys, self.running_values
         out, _ = self.attention(queries, keys, values, attention_mask, **kw)
-        out = self.layer_norm(queries + self.dropout(out))  # :330-331
+        out = self.layer_norm(_gr(queries + self.dropout(out)))  # :330-331
         if self.use_aoa:  # :333-337
             z = torch.cat([queries, out], dim=-1)
             out = self.informative_attention(z) * torch.sigmoid(self.gated_attention(z))
@@ -295,7 +328,7 @@ class OraclePWFF(nn.Module):
 
     def forward(self, x):
         h = _r(self.dropout_1(F.gelu(_lin(self.fc1, x))))
-        return self.layer_norm(x + self.dropout_2(_lin(self.fc2, h)))
+        return self.layer_norm(_gr(x + self.dropout_2(_lin(self.fc2, h))))
 
 
 # --------------------------------------------------------------------------
@@ -765,6 +798,38 @@ class OracleMMT(nn.Module):
         nt, no, nc = txt_mask.size(-1), obj_mask.size(-1), ocr_mask.size(-1)
         return {"mmt_seq_output": out, "mmt_txt_output": out[:, :nt], "mmt_ocr_output": out[:, nt + no:nt + no + nc],
                 "mmt_dec_output": out[:, -T:]}
+
+
+class OracleM4CDecodingHead(nn.Module):
+    """classifier || OcrPtrNet scores and the greedy decoding loop.  mmf_m4c.py:221-256."""
+
+    def __init__(self, hidden_size, num_choices):
+        super().__init__()
+        self.classifier = nn.Linear(hidden_size, num_choices)
+        self.ocr_ptr_net = OracleOcrPtrNet(hidden_size)
+
+    def scores(self, mmt_results, ocr_mask):  # :221-229
+        dec, ocr = mmt_results["mmt_dec_output"], mmt_results["mmt_ocr_output"]
+        return torch.cat([self.classifier(dec), self.ocr_ptr_net(dec, ocr, ocr_mask)], dim=-1)
+
+    @torch.no_grad()
+    def greedy_decode(self, mmt, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, max_iter, bos_idx, eos_idx):
+        B = txt_emb.shape[0]
+        prev_inds = torch.zeros((B, max_iter)).long()  # :241-242
+        prev_inds[:, 0] = bos_idx
+        last_ids = torch.zeros((B,))  # :245
+        scores, passes, trace = None, 0, []
+        for ith in range(max_iter):  # :246-256
+            trace.append(prev_inds.clone())
+            res = mmt(txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, self.classifier.weight, prev_inds)
+            scores = self.scores(res, ocr_mask)
+            passes += 1
+            argmax_inds = scores.argmax(dim=-1)
+            prev_inds[:, 1:] = argmax_inds[:, :-1]
+            last_ids = torch.where(last_ids == eos_idx, last_ids, argmax_inds[:, ith].to(last_ids.dtype))
+            if last_ids.mean() == eos_idx:
+                break
+        return scores, prev_inds, passes, trace
 
 
 # --------------------------------------------------------------------------

@@ -21,7 +21,7 @@ def timeit(fn, reps=30):
     return e0.elapsed_time(e1) * 1e-3 / (reps * 10)
 
 shapes = [(6400, 2048, 512), (6400, 512, 2048), (6400, 1536, 512), (6400, 512, 512), (1280, 2048, 512),
-          (1280, 512, 2048), (1280, 1536, 512), (1280, 1024, 512), (1280, 512, 512), (8192, 4096, 4096)]
+          (1280, 512, 2048), (1280, 1536, 512), (1280, 6144, 512), (1280, 512, 512), (8192, 4096, 4096)]
 which = sys.argv[1:] or ["fwd", "bwd_data", "bwd_weight"]
 for (M, N, K) in shapes:
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
@@ -38,7 +38,8 @@ for (M, N, K) in shapes:
             t = timeit(fn); row[name] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
         t = timeit(lambda: torch.nn.functional.linear(x, w)); row["torch"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
     if "bwd_data" in which and M < 8000:
-        t = timeit(lambda: ops.linear_bwd_data(dy, w, out=dx)); row["dX"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
+        wt = w.t().contiguous()
+        t = timeit(lambda: ops.linear_bwd_data_wt(dy, wt, out=dx)); row["dX_wt"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
         t = timeit(lambda: torch.matmul(dy, w)); row["torch_dX"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
     if "bwd_weight" in which and M < 8000:
         t = timeit(lambda: ops.linear_bwd_weight(dy, x, dw, db)); row["dW"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"

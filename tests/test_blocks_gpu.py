@@ -276,3 +276,56 @@ def test_mmt_config4_size(mode):
     def call(m, i):
         return m(i["txt"], i["tmask"], i["obj"], i["omask"], i["ocr"], i["cmask"], i["ans"], i["prev"])["mmt_seq_output"]
     _compare("mmt", mode, o, h, call, ins, ["txt", "obj", "ocr"])
+
+
+def test_m4c_greedy_decode_config4(mode):
+    """BASELINE configs[3] (mmf_m4c.yaml: 50 OCR + 100 region tokens + 20 question tokens, hidden 768, 4 layers x 8
+    heads, 12 decoding iterations, classifier || OcrPtrNet(768) scores): the product's greedy decoding loop
+    (modules/mmt.py M4CDecodingHead, mmf_m4c.py:221-256) against the oracle running the same loop.  fp32 mode: the
+    two loops make the same number of passes, emit the same tokens and the same final scores.  bf16 mode: near-tied
+    arg-maxes may flip, so every pass of the oracle's loop is replayed with ITS prev_inds and the scores are compared;
+    the product's own loop must terminate within max_iter passes."""
+    from types import SimpleNamespace
+    import oracle as O
+    import openvivqa_amd.modules as M
+    cfg = SimpleNamespace(hidden_size=768, num_hidden_layers=4, num_attention_heads=8, intermediate_size=3072,
+                          layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    num_choices, max_iter, bos, eos = 300, 12, 1, 2
+    torch.manual_seed(14)
+    mmt_o, head_o = O.OracleMMT(cfg).eval(), O.OracleM4CDecodingHead(768, num_choices).eval()
+    with torch.no_grad():
+        for m in (mmt_o, head_o):
+            for n, p in m.named_parameters():
+                if p.dim() == 2:
+                    p.normal_(0, 0.02)
+        head_o.classifier.weight.normal_(0, 0.05)
+        head_o.classifier.bias[eos] = 0.5  # eos reachable: the early exit of the loop is exercised for some seeds
+    mmt_h, head_h = M.MMT(cfg), M.M4CDecodingHead(768, num_choices)
+    mmt_h.load_state_dict(mmt_o.state_dict())
+    head_h.load_state_dict(head_o.state_dict())
+    mmt_h, head_h = mmt_h.to(DEV).eval(), head_h.to(DEV).eval()
+    g = torch.Generator().manual_seed(9)
+    B = 4
+    txt, obj, ocr = (torch.randn(B, n, 768, generator=g) for n in (20, 100, 50))
+    tmask, omask, cmask = torch.zeros(B, 1, 1, 20), torch.zeros(B, 1, 1, 100), torch.zeros(B, 1, 1, 50)
+    tmask[0, ..., 14:] = -10e4
+    omask[1, ..., 60:] = -10e4
+    cmask[2, ..., 30:] = -10e4
+    s_o, prev_o, n_o, trace = head_o.greedy_decode(mmt_o, txt, tmask, obj, omask, ocr, cmask, max_iter, bos, eos)
+    dev = lambda t: t.to(DEV)
+    s_h, prev_h, n_h = head_h.greedy_decode(mmt_h, dev(txt), dev(tmask), dev(obj), dev(omask), dev(ocr), dev(cmask),
+                                            max_iter, bos, eos)
+    assert s_h.shape == s_o.shape == (B, max_iter, num_choices + 50) and 1 <= n_h <= max_iter
+    if mode == F32:
+        assert n_h == n_o and torch.equal(prev_h.cpu(), prev_o)
+        assert rel_l2(s_h, s_o) < 1e-4
+    with torch.no_grad():  # every pass of the oracle's loop, replayed on the HIP path with the same prev_inds
+        for prev in trace:
+            r_o = head_o.scores(mmt_o(txt, tmask, obj, omask, ocr, cmask, head_o.classifier.weight, prev), cmask)
+            r_h = head_h.scores(mmt_h(dev(txt), dev(tmask), dev(obj), dev(omask), dev(ocr), dev(cmask),
+                                      head_h.classifier.weight, dev(prev)), dev(cmask))
+            fin = torch.isfinite(r_o)
+            assert torch.equal(torch.isfinite(r_h).cpu(), fin)
+            a, b = torch.where(fin, r_h.cpu(), torch.zeros_like(r_o)), torch.where(fin, r_o, torch.zeros_like(r_o))
+            e = ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
+            assert e < (1e-3 if mode == F32 else 1e-2), e
