@@ -232,28 +232,35 @@ int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_p
  *         uniform distribution).
  *   lse fp32 [B,H,nq] (may be NULL); att [B,H,nq,nk] probabilities of `dtype`
  *   (NULL unless the caller wants the second return value of the reference).
+ *   att_drop (may be NULL / p == 0): dropout on the attention PROBABILITIES, p~ = p * keep/(1-p) with the
+ *   element index ((b*H+h)*nq+i)*nk+j -- what transformers' BertSelfAttention does inside M4C's multimodal
+ *   transformer (models/mmf_m4c.py:349-351); `att` then holds p~.  The reference's own attention modules have
+ *   none (attentions.py:56-57).  Runs on the VALU kernels (the MFMA kernels cover p == 0).
  * ------------------------------------------------------------------------- */
 int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, const float* mask,
                        int64_t msb, int64_t msh, int64_t msq,
                        void* o, int64_t ldo, float* lse, void* att,
                        int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
-                       float scale, void* stream);
+                       float scale, const ovqa_dropout* att_drop, void* stream);
 
 /* Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
  * the caller (rowsum(P*dP)); dq/dk/dv use the same [b,n,h*d+c] addressing.
  * d_att [B,H,nq,nk] (dtype, may be NULL) is the gradient w.r.t. the returned
  * attention weights -- the reference's second return value is differentiable
- * (attentions.py:56,60). */
+ * (attentions.py:56,60).  d_lse fp32 [B,H,nq] (may be NULL) is the gradient w.r.t. the returned log-sum-exp
+ * (d lse_i / d S_ij = P_ij): callers that extend the softmax by extra columns of their own -- the per-query
+ * language-signal key of AdaptiveScaledDotProductAttention, attentions.py:262-277 -- merge through lse.
+ * att_drop: the forward call's dropout on the probabilities. */
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo,
                        const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, const void* o, int64_t ldo,
                        const void* d_att, const float* lse, const float* mask,
                        int64_t msb, int64_t msh, int64_t msq,
                        void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv,
-                       float* delta,
+                       float* delta, const float* d_lse,
                        int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
-                       float scale, void* stream);
+                       float scale, const ovqa_dropout* att_drop, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Pointer scorer: scores[b,t,n] = q[b,t,:].k[b,n,:] * scale (+ mask | -inf fill).

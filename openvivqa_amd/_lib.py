@@ -73,10 +73,10 @@ SIGNATURES = {
     "ovqa_layernorm_bwd_blocks": [c_i64],
     "ovqa_grouped_partial_reduce": [c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_attention_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
-                           c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+                           c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
     "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
-                           c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
-                           c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+                           c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                           c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
     "ovqa_pointer_score": [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_batched_gemm": [c_int, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                           c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],

@@ -227,7 +227,7 @@ int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_p
 int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        const float* mask, int64_t msb, int64_t msh, int64_t msq, void* o, int64_t ldo, float* lse,
                        void* att, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv, float scale,
-                       void* stream) {
+                       const ovqa_dropout* att_drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_fwd: bad dtype %d", dtype);
   OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_fwd: bad sizes");
   if (B == 0 || nq == 0) return OVQA_OK;
@@ -235,8 +235,10 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
   OVQA_REQUIRE(ldq >= H * dk && ldk >= H * dk && ldv >= H * dv && ldo >= H * dv, OVQA_ERR_BAD_ARG,
                "attention_fwd: row stride smaller than H*d");
   OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_fwd: B*H too large");
+  OVQA_REQUIRE(B * H * nq * nk < (1ll << 32) || !att_drop || att_drop->p <= 0.f, OVQA_ERR_UNSUPPORTED,
+               "attention_fwd: dropout on more than 2^32 probabilities");
   ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, msq, o, ldo, lse, att,
-                   (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+                   (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale, make_drop_args(att_drop)};
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_supported(a)) {
     g_dispatch = "mfma";
     return ovqa::mfma_attention_fwd(a, as_stream(stream));
@@ -249,14 +251,15 @@ int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, 
                        const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_att, const float* lse,
                        const float* mask, int64_t msb, int64_t msh, int64_t msq, void* dq, int64_t lddq, void* dk_,
                        int64_t lddk,
-                       void* dv_, int64_t lddv, float* delta, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk,
-                       int64_t dv, float scale, void* stream) {
+                       void* dv_, int64_t lddv, float* delta, const float* d_lse, int64_t B, int64_t H, int64_t nq,
+                       int64_t nk, int64_t dk, int64_t dv, float scale, const ovqa_dropout* att_drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_bwd: bad dtype %d", dtype);
   OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_bwd: bad sizes");
   if (B == 0 || nq == 0) return OVQA_OK;
   OVQA_REQUIRE(d_o && q && k && v && o && dq && dk_ && dv_, OVQA_ERR_BAD_ARG, "attention_bwd: null pointer");
   ovqa::AttnBwdArgs a{d_o, q, k, v, o, d_att, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
-                      lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale};
+                      lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale,
+                      make_drop_args(att_drop), d_lse};
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_bwd_supported(a)) {
     g_dispatch = "mfma";
     return ovqa::mfma_attention_bwd(a, as_stream(stream));

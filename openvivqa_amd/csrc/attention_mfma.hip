@@ -1047,7 +1047,9 @@ namespace ovqa {
 bool mfma_attention_bwd_supported(const AttnBwdArgs& a) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   auto al8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
-  return a.d_att == nullptr && a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.nq <= 256 &&
+  // gradients of the returned attention weights / log-sum-exp and dropout on the probabilities: VALU kernels
+  return a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && a.dk == 64 && a.dv == 64 && a.nk >= 1 &&
+         a.nk <= 256 && a.nq >= 1 && a.nq <= 256 &&
          a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.lddo % 8 == 0 && a.ldo % 4 == 0 && a.lddq % 4 == 0 &&
          a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && al(a.d_o) && al8(a.o) && al8(a.dq) &&
          al8(a.dk_) && al8(a.dv_) && a.lse && a.delta;
@@ -1057,7 +1059,8 @@ int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st) { return launch_bwd
 
 bool mfma_attention_supported(const AttnArgs& a) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  return a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.ldq % 8 == 0 && a.ldk % 8 == 0 &&
+  return a.drop.p <= 0.f && a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.ldq % 8 == 0 &&
+         a.ldk % 8 == 0 &&
          a.ldv % 8 == 0 && a.ldo % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && (((uintptr_t)a.o & 7) == 0);
 }
 

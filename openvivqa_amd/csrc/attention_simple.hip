@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(ovqa::AttnArgs a) 
   const T* v = (const T*)a.v;
   T* o = (T*)a.o;
   T* att = (T*)a.att;
+  const DropState ds = drop_init(a.drop);
 
   for (int e = tid; e < nk * dk; e += 256) {
     const int j = e / dk, c = e % dk;
@@ -75,7 +76,12 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(ovqa::AttnArgs a) 
       }
     }
     sum = wave_sum(sum);
-    const float inv = 1.f / sum;
+    float inv = 1.f / sum;
+    if (live && ds.on) {  // dropout on the probabilities (HF BertSelfAttention): p~ = p * keep / (1 - p_drop)
+      const uint32_t base = (uint32_t)((((int64_t)b * a.H + h) * nq + i) * nk);
+      for (int j = lane; j < nk; j += 64) sw[j] = sw[j] * inv * drop_mul(ds, base + j);
+      inv = 1.f;
+    }
     __syncthreads();
     if (live) {
       if (a.lse && lane == 0) a.lse[((int64_t)b * a.H + h) * nq + i] = mx + __logf(sum);
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(ovqa::AttnBwdAr
   const T* d_o = (const T*)a.d_o;
   const T* datt = (const T*)a.d_att;
   T* dq = (T*)a.dq;
+  const DropState ds = drop_init(a.drop);
 
   for (int e = tid; e < nk * dk; e += 256) {
     const int j = e / dk, c = e % dk;
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(ovqa::AttnBwdAr
         for (int c = 0; c < dk; c++) s = fmaf(qw[c], kr[c], s);
         for (int c = 0; c < dv; c++) dp = fmaf(dw[c], vr[c], dp);
         if (datt) dp += to_f32<T>(datt[(((int64_t)b * a.H + h) * nq + i) * nk + j]);
+        dp *= drop_mul(ds, (uint32_t)((((int64_t)b * a.H + h) * nq + i) * nk + j));  // d p = d p~ * keep/(1-p_drop)
         s = s * a.scale + mask_at(a.mask, a.msb, a.msh, a.msq, b, h, i, j);
         const float p = __expf(s - lse);
         sw[j] = p;
@@ -154,7 +162,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_simple_kernel(ovqa::AttnBwdAr
         dsum += p * dp;
       }
     }
-    const float delta = wave_sum(dsum);
+    // d lse / d S_ij = P_ij: the gradient of the returned log-sum-exp folds into delta (dS = P (dP - delta))
+    float delta = wave_sum(dsum);
+    if (live && a.d_lse) delta -= a.d_lse[((int64_t)b * a.H + h) * nq + i];
     if (live) {
       if (lane == 0) a.delta[((int64_t)b * a.H + h) * nq + i] = delta;
       for (int j = lane; j < nk; j += 64) sw[j] = sw[j] * (pw[j] - delta);
@@ -193,6 +203,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(ovqa::AttnBwdA
   const T* datt = (const T*)a.d_att;
   T* dkp = (T*)a.dk_;
   T* dvp = (T*)a.dv_;
+  const DropState ds = drop_init(a.drop);
 
   for (int e = tid; e < nq * dk; e += 256) {
     const int i = e / dk, c = e % dk;
@@ -229,9 +240,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_simple_kernel(ovqa::AttnBwdA
         for (int c = 0; c < dk; c++) s = fmaf(qr[c], kw[c], s);
         for (int c = 0; c < dv; c++) dp = fmaf(gr[c], vw[c], dp);
         if (datt) dp += to_f32<T>(datt[(((int64_t)b * a.H + h) * nq + i) * nk + j]);
+        const float dm = drop_mul(ds, (uint32_t)((((int64_t)b * a.H + h) * nq + i) * nk + j));
+        dp *= dm;
         s = s * a.scale + mask_at(a.mask, a.msb, a.msh, a.msq, b, h, i, j);
         const float p = __expf(s - lse_s[i]);
-        pw[i] = p;
+        pw[i] = p * dm;  // dV = P~^T dO
         dsw[i] = p * (dp - del_s[i]);
       }
     }

@@ -55,10 +55,13 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- dropout: stateless counter hash ---------------------------------------
 // keep(idx) is a pure function of (seed, site, step, idx); forward and backward
-// regenerate it.  fmix32 of murmur3 over idx * golden ^ key.
+// regenerate it.  One 32-bit hash (fmix32 of murmur3 over pair * golden ^ key) serves the element PAIR
+// {2j, 2j+1}: each element compares its own 16 bits with a 16-bit threshold (p is resolved to 2^-16).  The fused
+// epilogues own 8 consecutive elements per lane, i.e. 4 hashes instead of 8: the epilogues are VALU-bound and the
+// 32-bit integer multiplies of the hash were a third of their instruction stream.
 struct DropState {
   uint32_t key;
-  uint32_t thresh;  // drop iff hash < thresh
+  uint32_t thresh;  // drop iff (16-bit field of the hash) < thresh, thresh = round(p * 65536)
   float inv_keep;   // 1/(1-p)
   bool on;
 };
@@ -86,18 +89,35 @@ __device__ __forceinline__ DropState drop_init(const DropArgs& a) {
   s.on = a.p > 0.f;
   uint32_t step = (a.step != nullptr) ? *a.step : 0u;
   s.key = ovqa_fmix32(a.seed ^ ovqa_fmix32(a.site * 0x9E3779B1u + step * 0x7F4A7C15u + 0x1234567u));
-  double t = (double)a.p * 4294967296.0;
-  s.thresh = (a.p >= 1.f) ? 0xFFFFFFFFu : (uint32_t)t;
+  s.thresh = (a.p >= 1.f) ? 0x10000u : (uint32_t)(a.p * 65536.f + 0.5f);
   s.inv_keep = (a.p < 1.f) ? 1.f / (1.f - a.p) : 0.f;
   return s;
 }
+__device__ __forceinline__ uint32_t drop_pair_hash(const DropState& s, uint32_t pair) {
+  return ovqa_fmix32(pair * 0x9E3779B1u ^ s.key);
+}
 __device__ __forceinline__ bool drop_keep(const DropState& s, uint32_t idx) {
-  return ovqa_fmix32(idx * 0x9E3779B1u ^ s.key) >= s.thresh;
+  const uint32_t h = drop_pair_hash(s, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= s.thresh;
 }
 // multiplier applied to a value that went through dropout (1 when off)
 __device__ __forceinline__ float drop_mul(const DropState& s, uint32_t idx) {
   if (!s.on) return 1.f;
   return drop_keep(s, idx) ? s.inv_keep : 0.f;
+}
+// multipliers of 8 consecutive elements idx .. idx+7 (idx EVEN): 4 hashes
+__device__ __forceinline__ void drop_mul8(const DropState& s, uint32_t idx, float (&m)[8]) {
+  if (!s.on) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) m[t] = 1.f;
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const uint32_t h = drop_pair_hash(s, (idx >> 1) + t);
+    m[2 * t] = (h & 0xFFFFu) >= s.thresh ? s.inv_keep : 0.f;
+    m[2 * t + 1] = (h >> 16) >= s.thresh ? s.inv_keep : 0.f;
+  }
 }
 
 // ---- exact GELU (erf form, F.gelu default) ----------------------------------
@@ -113,7 +133,7 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 // Returns erf(u / sqrt(2)) and e = exp(-u*u/2) (shared with the Gaussian pdf of the GELU derivative).
 __device__ __forceinline__ float erf_sqrt2_fast(float u, float& e) {
   const float x = fabsf(u) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));  // raw v_rcp_f32 (1 ulp): not the IEEE division sequence
   e = __expf(-x * x);
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);

@@ -549,8 +549,10 @@ struct MEpiBiasGelu {
     bias8(bias, n, lo, hi, u);
     if (preact) store8(preact + (int64_t)m * N + n, u);
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+    float dm[8];
+    drop_mul8(ds, idx, dm);
 #pragma unroll
-    for (int t = 0; t < 8; t++) u[t] = gelu_fast(u[t]) * drop_mul(ds, idx + t);
+    for (int t = 0; t < 8; t++) u[t] = gelu_fast(u[t]) * dm[t];
     store8(y + (int64_t)m * ldy + n, u);
   }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
@@ -571,8 +573,10 @@ struct MEpiBiasResidual {
     bias8(bias, n, lo, hi, u);
     const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + (int64_t)m * ldres + n);
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+    float dm[8];
+    drop_mul8(ds, idx, dm);
 #pragma unroll
-    for (int t = 0; t < 8; t++) u[t] = (float)r[t] + u[t] * drop_mul(ds, idx + t);
+    for (int t = 0; t < 8; t++) u[t] = (float)r[t] + u[t] * dm[t];
     store8(y + (int64_t)m * ldy + n, u);
   }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
@@ -610,8 +614,10 @@ struct MEpiBiasRes32 {
       for (int t = 0; t < 8; t++) r[t] = (r[t] - mu) * rs * g[t] + b[t];
     }
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+    float dm[8];
+    drop_mul8(ds, idx, dm);
 #pragma unroll
-    for (int t = 0; t < 8; t++) r[t] += u[t] * drop_mul(ds, idx + t);
+    for (int t = 0; t < 8; t++) r[t] += u[t] * dm[t];
     float* o = pre + (int64_t)m * ldpre + n;
     *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
     *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
@@ -644,8 +650,10 @@ struct MEpiBwdData {
     if (preact) {
       const bf16x8 u = *reinterpret_cast<const bf16x8*>(preact + (int64_t)m * Kcols + n);
       const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + (uint32_t)n;
+      float dm[8];
+      drop_mul8(ds, idx, dm);
 #pragma unroll
-      for (int t = 0; t < 8; t++) v[t] *= drop_mul(ds, idx + t) * gelu_grad_fast((float)u[t]);
+      for (int t = 0; t < 8; t++) v[t] *= dm[t] * gelu_grad_fast((float)u[t]);
     }
     if (addend) {
       const bf16x8 o = *reinterpret_cast<const bf16x8*>(addend + (int64_t)m * ldadd + n);

@@ -38,6 +38,7 @@ struct AttnArgs {
   void* att;
   int B, H, nq, nk, dk, dv;
   float scale;
+  DropArgs drop;  // dropout on the attention probabilities (p == 0: off); element index ((b*H+h)*nq+i)*nk+j
 };
 struct AttnBwdArgs {
   const void *d_o, *q, *k, *v, *o, *d_att;
@@ -49,6 +50,8 @@ struct AttnBwdArgs {
   float* delta;
   int B, H, nq, nk, dk, dv;
   float scale;
+  DropArgs drop;       // as in AttnArgs
+  const float* d_lse;  // gradient w.r.t. the returned log-sum-exp [B,H,nq] or nullptr
 };
 int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
 int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);

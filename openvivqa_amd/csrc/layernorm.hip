@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         for (int i = 0; i < VEC; i++) o[i] = rs * (d[c][i] - c1 - xh[c][i] * c2);
         store8<TDX>(dx + (int64_t)row * D + col, o);
         if (dx_dropped) {
+          float dm[VEC];
+          drop_mul8(ds, (uint32_t)row * (uint32_t)D + col, dm);  // D and col are multiples of 8: even index
 #pragma unroll
-          for (int i = 0; i < VEC; i++) o[i] *= drop_mul(ds, (uint32_t)row * (uint32_t)D + col + i);
+          for (int i = 0; i < VEC; i++) o[i] *= dm[i];
           store8<TDY>(dx_dropped + (int64_t)row * D + col, o);
         }
       }

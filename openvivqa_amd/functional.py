@@ -290,7 +290,7 @@ class _MHABlock(Function):
         arena, a, ln = st["arena"], st["att"], st["ln"]
         queries, keys, values = _canon(queries, keys, values, st["same"])
         q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
-        o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h)
+        o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, att_drop=st.get("att_drop"))
         drop = st["drop"]
         if queries.dtype == torch.bfloat16:  # fp32 residual stream: fp32 pre-LN sum, bf16 operand out
             pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
@@ -323,7 +323,7 @@ class _MHABlock(Function):
             (qkv,) = bufs
             q, k, v = qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:]
             dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
                               dv=dqkv[..., 2 * nqk:])
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
             dx = _dx(arena, dqkv, [wq, wk, wv], addend=dpre)
@@ -337,7 +337,7 @@ class _MHABlock(Function):
                 shared["dkv"] = torch.empty_like(keys)  # fills its slot, module 0 hands it to autograd
             dkv = shared["dkv"]
             dq = torch.empty_like(q)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., base:base + wk.shape[0]],
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., base:base + wk.shape[0]],
                               dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
             _wgrad(arena, dq, queries, [wq], [bq])
             dx = _dx(arena, dq, [wq], addend=dpre)
@@ -347,14 +347,14 @@ class _MHABlock(Function):
             k, v = kv[..., :nqk], kv[..., nqk:]
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
             _wgrad(arena, dq, queries, [wq], [bq])
             dx = _dx(arena, dq, [wq], addend=dpre)
             _wgrad(arena, dkv, keys, [wk, wv], [bk, bv])
             dkeys = _dx(arena, dkv, [wk, wv]) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
             return dx, dkeys, None, None, None, *([None] * len(st["params"]))
         q, k, v = bufs
-        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h)
+        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"))
         _wgrad(arena, dq, queries, [wq], [bq])
         dx = _dx(arena, dq, [wq], addend=dpre)
         _wgrad(arena, dk, keys, [wk], [bk])
@@ -383,7 +383,7 @@ def mha_block(queries, keys, values, mask, st, projected_kv=None):
     arena, a, ln = st["arena"], st["att"], st["ln"]
     queries, keys, values = _canon(queries, keys, values, st["same"])
     q, k, v, _, _ = _project_qkv(st, queries, keys, values)
-    o, _, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=False)
+    o, _, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=False, att_drop=st.get("att_drop"))
     if bf16:
         pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
                                    drop=st["drop"])
@@ -520,30 +520,79 @@ def linear(x, lin, arena):
 
 # ------------------------------------------------------------------ attention core on projected tensors
 class _AttentionCore(Function):
-    """(o, att) = attention(q, k, v); both outputs are differentiable, like the reference's."""
+    """(o, att, lse) = attention(q, k, v); all three outputs are differentiable (the reference's second return value
+    is; the log-sum-exp lets a caller merge extra softmax columns of its own, e.g. the adaptive attention)."""
 
     @staticmethod
     def forward(ctx, q, k, v, mask, h, need_att):
         o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att)
         ctx.h, ctx.mask, ctx.need_att = h, mask, need_att
         ctx.save_for_backward(q, k, v, o, lse)
-        return (o, att) if need_att else (o, None)
+        return o, att, lse
 
     @staticmethod
-    def backward(ctx, d_o, d_att):
+    def backward(ctx, d_o, d_att, d_lse):
         q, k, v, o, lse = ctx.saved_tensors
         if d_o is None:
             d_o = torch.zeros_like(o)
         if d_att is not None:
             d_att = d_att.to(q.dtype).contiguous()
-        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h, d_att=d_att)
+        if d_lse is not None:
+            d_lse = d_lse.float().contiguous()
+        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h, d_att=d_att, d_lse=d_lse)
         return dq, dk, dv, None, None, None
 
 
-def attention_core(q, k, v, mask, h, need_att=False):
+def attention_core(q, k, v, mask, h, need_att=False, need_lse=False):
+    """Returns (o, att) -- or (o, att, lse) with ``need_lse`` -- of the attention core on projected tensors."""
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-        return _AttentionCore.apply(q, k, v, mask, h, need_att)
-    o, _, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att, save_lse=False)
+        o, att, lse = _AttentionCore.apply(q, k, v, mask, h, need_att)
+    else:
+        o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att, save_lse=need_lse)
+    return (o, att, lse) if need_lse else (o, att)
+
+
+class _BiasedAttentionCore(Function):
+    """attention(q, k, v) with a LEARNED additive score bias (B, H, nq, nk) -- the log-geometry term of the
+    geometry-aware attention.  The kernels take the bias as their mask; its gradient is dS = P (dP - rowsum(P dP)),
+    assembled here from the returned probabilities with stock batched ops (the bias path is small: H x nq x nk)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, h):
+        o, lse, att = ops.attention_fwd(q, k, v, bias, h, need_att=True)
+        ctx.h = h
+        ctx.save_for_backward(q, k, v, o, lse, att, bias)
+        return o, att
+
+    @staticmethod
+    def backward(ctx, d_o, d_att):
+        q, k, v, o, lse, att, bias = ctx.saved_tensors
+        h = ctx.h
+        if d_o is None:
+            d_o = torch.zeros_like(o)
+        d_o = _c(d_o)
+        if d_att is not None:
+            d_att = d_att.to(q.dtype).contiguous()
+        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, bias, h, d_att=d_att)
+        dbias = None
+        if ctx.needs_input_grad[3]:
+            B, nq, nk = q.shape[0], q.shape[1], k.shape[1]
+            dv_ = v.shape[-1] // h
+            g = d_o.float().view(B, nq, h, dv_).transpose(1, 2)
+            vh = v.float().reshape(B, nk, h, dv_).transpose(1, 2)
+            dp = g @ vh.transpose(-1, -2)
+            if d_att is not None:
+                dp = dp + d_att.float()
+            p = att.float()
+            dbias = p * (dp - (p * dp).sum(-1, keepdim=True))
+        return dq, dk, dv, dbias, None
+
+
+def attention_core_with_bias(q, k, v, bias, h):
+    """(o, att) with a differentiable additive score bias (fp32, contiguous (B, H, nq, nk))."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad or bias.requires_grad):
+        return _BiasedAttentionCore.apply(q, k, v, bias, h)
+    o, _, att = ops.attention_fwd(q, k, v, bias, h, need_att=True, save_lse=False)
     return o, att
 
 

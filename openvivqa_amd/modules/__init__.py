@@ -1,8 +1,8 @@
 """HIP-backed modules registered under the reference's names."""
 from .containers import Module, ModuleDict, ModuleList
 from .pos_embeddings import SinusoidPositionalEmbedding
-from .attentions import (AugmentedMemoryScaledDotProductAttention, MultiHeadAttention,
-                         ScaledDotProductAttention)
+from .attentions import (AdaptiveScaledDotProductAttention, AugmentedGeometryScaledDotProductAttention,
+                         AugmentedMemoryScaledDotProductAttention, MultiHeadAttention, ScaledDotProductAttention)
 from .positionwise_feed_forward import PositionWiseFeedForward
 from .encoders import (CoAttentionEncoder, CrossModalityEncoder, CrossModalityEncoderLayer, Encoder, EncoderLayer,
                        GuidedAttentionEncoder, GuidedEncoderLayer)
@@ -13,7 +13,8 @@ from .mmt import MMT, BertEncoder, M4CDecodingHead, PrevPredEmbeddings
 
 __all__ = [
     "Module", "ModuleDict", "ModuleList", "SinusoidPositionalEmbedding", "MultiHeadAttention",
-    "ScaledDotProductAttention", "AugmentedMemoryScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
+    "ScaledDotProductAttention", "AugmentedMemoryScaledDotProductAttention", "AdaptiveScaledDotProductAttention",
+    "AugmentedGeometryScaledDotProductAttention", "PositionWiseFeedForward", "CoAttentionEncoder", "CrossModalityEncoder",
     "CrossModalityEncoderLayer", "Encoder", "EncoderLayer", "GuidedAttentionEncoder", "GuidedEncoderLayer",
     "FeatureEmbedding", "LSTMTextEmbedding", "UsualEmbedding", "Decoder", "DecoderLayer", "DynamicPointerNetwork", "OcrPtrNet", "MMT", "BertEncoder", "PrevPredEmbeddings", "M4CDecodingHead",
 ]

@@ -113,6 +113,121 @@ class AugmentedMemoryScaledDotProductAttention(nn.Module):
         return out.to(in_dtype), att.to(in_dtype)
 
 
+def _split_extras(args, kwargs, key, is_signal):
+    """The reference's variant attentions take their extra signal as the 4th POSITIONAL argument
+    (``forward(q, k, v, boxes, attention_mask=None)``) while MultiHeadAttention passes the mask there
+    (attentions.py:326): accept both orders -- an extra positional tensor is the signal if ``is_signal`` says so,
+    else the mask."""
+    signal, mask = kwargs.pop(key, None), kwargs.pop("attention_mask", None)
+    for a in args:
+        if a is None:
+            continue
+        if signal is None and is_signal(a):
+            signal = a
+        else:
+            mask = a
+    return signal, mask
+
+
+@META_ATTENTION.register()
+class AugmentedGeometryScaledDotProductAttention(nn.Module):
+    """Geometry-aware self-attention over boxes (attentions.py:62-137, models/utils.py:102-162):
+    softmax(log(clamp(relu(fc_g(geometry)), 1e-6)) + Q K^T / sqrt(d_k) + mask) V, one fc_g per head.
+
+    Built WORKING: upstream's forward ends in two lines that read an undefined ``att`` (attentions.py:126-137,
+    NameError on every call) and adds the mask to that same undefined name; the intended computation (the
+    log-geometry-biased softmax ``mn`` applied to V, returned with its weights) is what runs here."""
+
+    def __init__(self, config):
+        super().__init__()
+        d_model, h, d_k, d_v = config.D_MODEL, config.HEAD, config.D_KEY, config.D_VALUE
+        self.trignometric_embedding = config.TRIGNOMETRIC_EMBEDDING
+        self.d_g = d_model // h if self.trignometric_embedding else 4
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.fc_gs = nn.ModuleList([nn.Linear(self.d_g, 1) for _ in range(h)])
+        self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
+        self.init_weights()
+
+    def init_weights(self):
+        for lin in (self.fc_q, self.fc_k, self.fc_v, self.fc_o, *self.fc_gs):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.constant_(lin.bias, 0)
+
+    def forward(self, queries, keys, values, *args, **kwargs):
+        from ..utils import box_relational_embedding
+        boxes, attention_mask = _split_extras(args, kwargs, "boxes", lambda t: t.dim() == 3 and t.shape[-1] == 4)
+        arena = rt.ensure_arena(self)
+        T, in_dtype = arena.compute_dtype, queries.dtype
+        emb = box_relational_embedding(boxes.float(), dim_g=self.d_g, trignometric_embedding=self.trignometric_embedding)
+        wg = torch.cat([g.weight for g in self.fc_gs], 0).float()  # (H, d_g): the H heads' 1-output linears at once
+        bg = torch.cat([g.bias for g in self.fc_gs], 0).float()
+        geo = torch.relu(emb @ wg.t() + bg).permute(0, 3, 1, 2)  # (B, H, nk, nk)
+        bias = torch.log(torch.clamp(geo, min=1e-6))
+        mask = _as_mask(attention_mask)
+        if mask is not None:
+            bias = bias + mask
+        q = Fn.linear(queries.to(T), self.fc_q, arena)
+        k = Fn.linear(keys.to(T), self.fc_k, arena)
+        v = Fn.linear(values.to(T), self.fc_v, arena)
+        o, att = Fn.attention_core_with_bias(q, k, v, bias.contiguous(), self.h)
+        out = Fn.linear(o, self.fc_o, arena)
+        return out.to(in_dtype), att.to(in_dtype)
+
+
+@META_ATTENTION.register()
+class AdaptiveScaledDotProductAttention(nn.Module):
+    """Adaptive attention (attentions.py:210-291): every query i sees the nk keys plus ONE extra key/value of its
+    own, the projected language signal s_i = fc_s(language_signals)_i (score q_i . s_i / sqrt(d_k), value s_i).
+
+    The extra column differs per query, so it cannot be appended to K/V; instead the attention kernel runs over the
+    keys and returns its output, probabilities and log-sum-exp (all differentiable), and the extra column is merged
+    in closed form: with sigma_i = sigmoid(lse_i - e_i), out_i = sigma_i o_i + (1 - sigma_i) s_i and the combined
+    weights are [sigma_i p_i, 1 - sigma_i].  Returns (out, list of nq (B,H,1,nk+1) weight tensors) like upstream."""
+
+    def __init__(self, config):
+        super().__init__()
+        d_model, h, d_k, d_v = config.D_MODEL, config.HEAD, config.D_KEY, config.D_VALUE
+        assert d_k == d_v, "the language signal is used as key AND value (attentions.py:262,274): d_k must equal d_v"
+        self.fc_q = nn.Linear(d_model, h * d_k)
+        self.fc_k = nn.Linear(d_model, h * d_k)
+        self.fc_v = nn.Linear(d_model, h * d_v)
+        self.fc_s = nn.Linear(d_model, h * d_k)
+        self.fc_o = nn.Linear(h * d_v, d_model)
+        self.dropout = nn.Dropout(config.DROPOUT)  # constructed and never applied upstream (attentions.py:228)
+        self.d_model, self.d_k, self.d_v, self.h = d_model, d_k, d_v, h
+        self.init_weights()
+
+    def init_weights(self):
+        for lin in (self.fc_q, self.fc_k, self.fc_v, self.fc_o, self.fc_s):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.constant_(lin.bias, 0)
+
+    def forward(self, queries, keys, values, *args, **kwargs):
+        d_model = self.d_model
+        signals, attention_mask = _split_extras(args, kwargs, "language_signals",
+                                                lambda t: t.dim() == 3 and t.shape[-1] == d_model)
+        arena = rt.ensure_arena(self)
+        T, in_dtype = arena.compute_dtype, queries.dtype
+        B, nq = queries.shape[:2]
+        q = Fn.linear(queries.to(T), self.fc_q, arena)
+        k = Fn.linear(keys.to(T), self.fc_k, arena)
+        v = Fn.linear(values.to(T), self.fc_v, arena)
+        s = Fn.linear(signals.to(T), self.fc_s, arena)
+        o, att, lse = Fn.attention_core(q, k, v, _as_mask(attention_mask), self.h, need_att=True, need_lse=True)
+        qh = q.float().view(B, nq, self.h, self.d_k)
+        sh = s.float().view(B, nq, self.h, self.d_k)
+        e = (qh * sh).sum(-1) / (self.d_k ** 0.5)              # (B, nq, H): score of query i against ITS signal
+        sigma = torch.sigmoid(lse.float().transpose(1, 2) - e)  # weight kept by the nk keys
+        out = sigma.unsqueeze(-1) * o.float().view(B, nq, self.h, self.d_v) + (1 - sigma).unsqueeze(-1) * sh
+        out = Fn.linear(out.reshape(B, nq, self.h * self.d_v).to(T), self.fc_o, arena)
+        sig = sigma.transpose(1, 2).unsqueeze(-1)               # (B, H, nq, 1)
+        combined = torch.cat([att.float() * sig, 1 - sig], dim=-1).to(in_dtype)
+        return out.to(in_dtype), [combined[:, :, i:i + 1] for i in range(nq)]
+
+
 class MultiHeadAttention(Module):
     """Multi-head attention block with dropout, residual connection and post-LayerNorm."""
 

@@ -8,8 +8,8 @@ fused blocks of the hot path -- MHA block (QKV GEMM, attention with an additive 
 GEMM + dropout + residual, LayerNorm eps 1e-12) and FFN block (GEMM+GELU, GEMM + dropout + residual, LayerNorm).
 Heads of 96 features (768/8) run on the LDS-resident VALU attention kernel (the MFMA kernel tiles d = 64).
 
-Dropout on the attention PROBABILITIES (attention_probs_dropout_prob, training only) is not implemented by the
-fused attention kernels: training with it raises; evaluation / decoding (BASELINE config 4) is unaffected.
+Dropout on the attention PROBABILITIES (attention_probs_dropout_prob, training only) runs inside the VALU attention
+kernels (ovqa_attention_fwd/bwd ``att_drop``); evaluation / decoding (BASELINE config 4) has none.
 
 ``PrevPredEmbeddings`` / ``MMT``: mmf_m4c.py:399-459 / 282-364.
 """
@@ -76,15 +76,12 @@ class BertLayer(nn.Module):
         self.attention = BertAttention(config)
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
-        self._sites = [rt.new_dropout_site() for _ in range(2)]
+        self._sites = [rt.new_dropout_site() for _ in range(3)]
 
     def forward(self, hidden_states, attention_mask=None):
         arena = rt.ensure_arena(self)
         x = Fn.to_compute(hidden_states, arena.compute_dtype)
         a = self.attention
-        if self.training and a.self.dropout.p > 0 and torch.is_grad_enabled():
-            raise NotImplementedError("attention-probability dropout is not fused; train with "
-                                      "attention_probs_dropout_prob=0 (evaluation / decoding is unaffected)")
         mask = attention_mask
         if mask is not None:
             mask = mask.to(torch.float32)
@@ -96,7 +93,9 @@ class BertLayer(nn.Module):
                   params=[a.self.query.weight, a.self.query.bias, a.self.key.weight, a.self.key.bias,
                           a.self.value.weight, a.self.value.bias, a.output.dense.weight, a.output.dense.bias,
                           ln1.weight, ln1.bias],
-                  drop=rt.dropout_spec(a.output.dropout.p, self._sites[0], self.training, x.device))
+                  drop=rt.dropout_spec(a.output.dropout.p, self._sites[0], self.training, x.device),
+                  # dropout on the attention probabilities (HF BertSelfAttention): training only, VALU attention kernels
+                  att_drop=rt.dropout_spec(a.self.dropout.p, self._sites[2], self.training, x.device))
         x = Fn.mha_block(x, x, x, mask, st)
         ffn = SimpleNamespace(fc1=self.intermediate.dense, fc2=self.output.dense, layer_norm=self.output.LayerNorm)
         st = dict(arena=arena, mod=ffn,

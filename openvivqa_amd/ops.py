@@ -500,8 +500,9 @@ def _mask_strides(mask, B, H, nq, nk):
     return mask, sb, sh, sq
 
 
-def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
-    """q [B,nq,H*dk], k [B,nk,H*dk], v [B,nk,H*dv] (row-strided views allowed) -> o [B,nq,H*dv], lse, att."""
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None):
+    """q [B,nq,H*dk], k [B,nk,H*dk], v [B,nk,H*dv] (row-strided views allowed) -> o [B,nq,H*dv], lse, att.
+    ``att_drop`` (DropSpec): dropout on the attention probabilities (BERT-style; VALU kernels)."""
     _dev(q)
     lib = _lib.load()
     B, nq = q.shape[0], q.shape[1]
@@ -516,11 +517,13 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
     att = torch.empty(B, H, nq, nk, dtype=q.dtype, device=q.device) if need_att else None
     mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
     _lib.check(lib.ovqa_attention_fwd(_dt(q), _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(mask), sb, sh, sq, _p(o), H * dv,
-                                      _p(lse), _p(att), B, H, nq, nk, dk, dv, float(scale), _stream()), "attention_fwd")
+                                      _p(lse), _p(att), B, H, nq, nk, dk, dv, float(scale), _drop(att_drop), _stream()),
+               "attention_fwd")
     return o, lse, att
 
 
-def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None):
+def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
+                  att_drop=None):
     _dev(q)
     lib = _lib.load()
     B, nq = q.shape[0], q.shape[1]
@@ -534,10 +537,12 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
     mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
     if d_att is not None:
         assert d_att.is_contiguous() and d_att.dtype == q.dtype and d_att.shape == (B, H, nq, nk)
+    if d_lse is not None:
+        assert d_lse.is_contiguous() and d_lse.dtype == torch.float32 and d_lse.shape == (B, H, nq)
     _lib.check(lib.ovqa_attention_bwd(
         _dt(q), _p(d_o), _rows(d_o)[0], _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v), _rows(v)[0], _p(o), _rows(o)[0],
         _p(d_att), _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
-        B, H, nq, nk, dkk, dvv, float(scale), _stream()), "attention_bwd")
+        _p(d_lse), B, H, nq, nk, dkk, dvv, float(scale), _drop(att_drop), _stream()), "attention_bwd")
     return dq, dk, dv
 
 

@@ -45,3 +45,26 @@ def sinusoid_encoding_table(max_len: int, d_model: int, padding_idx: Optional[in
     if padding_idx is not None:
         out[padding_idx] = 0
     return out
+
+
+def box_relational_embedding(boxes: torch.Tensor, dim_g: int = 64, wave_len: float = 1000.0,
+                             trignometric_embedding: bool = True) -> torch.Tensor:
+    """Pairwise box geometry (B, N, N, dim_g) of the geometry-aware attention.  models/utils.py:102-162: log-scaled
+    centre offsets (clamped at 1e-3) and log size ratios of boxes (x_min, y_min, x_max, y_max), optionally expanded
+    to sin/cos features over dim_g/8 wavelengths (positions scaled by 100).  O(B*N*N) elementwise work."""
+    B = boxes.size(0)
+    x_min, y_min, x_max, y_max = torch.chunk(boxes, 4, dim=-1)
+    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
+    w, h = (x_max - x_min) + 1.0, (y_max - y_min) + 1.0
+    dx = torch.log(torch.clamp(torch.abs((cx - cx.view(B, 1, -1)) / w), min=1e-3))
+    dy = torch.log(torch.clamp(torch.abs((cy - cy.view(B, 1, -1)) / h), min=1e-3))
+    dw = torch.log(w / w.view(B, 1, -1))
+    dh = torch.log(h / h.view(B, 1, -1))
+    pos = torch.stack((dx, dy, dw, dh), dim=-1)  # (B, N, N, 4)
+    if not trignometric_embedding:
+        return pos
+    feat = torch.arange(dim_g / 8, device=boxes.device)
+    dim_mat = 1.0 / torch.pow(torch.tensor(float(wave_len), device=boxes.device), feat / (dim_g / 8))
+    mul = (100.0 * pos).unsqueeze(-1) * dim_mat.view(1, 1, 1, 1, -1)
+    mul = mul.reshape(B, pos.size(1), pos.size(2), -1)
+    return torch.cat((torch.sin(mul), torch.cos(mul)), dim=-1)

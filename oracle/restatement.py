@@ -22,7 +22,7 @@ MASK_VALUE = -10e4  # models/utils.py:56,64,71  (== -100000.0)
 __all__ = [
     "emulate_bf16", "MASK_VALUE", "padding_mask", "sequential_mask", "self_attention_masks",
     "sinusoid_positions", "sinusoid_table", "sdpa_core",
-    "OracleSDPA", "OracleMemorySDPA", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
+    "OracleSDPA", "OracleMemorySDPA", "OracleGeometrySDPA", "OracleAdaptiveSDPA", "box_relational_embedding", "OracleMHA", "OraclePWFF", "OracleEncoderLayer",
     "OracleGuidedEncoderLayer", "OracleCrossModalityEncoderLayer",
     "OracleEncoder", "OracleGuidedAttentionEncoder", "OracleCoAttentionEncoder",
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
@@ -225,6 +225,91 @@ class OracleMemorySDPA(nn.Module):
         att = torch.softmax(att, dim=-1)
         o = torch.matmul(att, v).transpose(1, 2).reshape(b, nq, self.h * self.d_v)
         return self.fc_o(o), att
+
+
+def box_relational_embedding(f_g, dim_g=64, wave_len=1000, trignometric_embedding=True):
+    """Pairwise box geometry (B, N, N, dim_g).  models/utils.py:102-162."""
+    bs = f_g.size(0)
+    x_min, y_min, x_max, y_max = torch.chunk(f_g, chunks=4, dim=-1)
+    cx, cy = (x_min + x_max) * 0.5, (y_min + y_max) * 0.5
+    w, h = (x_max - x_min) + 1.0, (y_max - y_min) + 1.0
+    delta_x = torch.log(torch.clamp(torch.abs((cx - cx.view(bs, 1, -1)) / w), min=1e-3))  # :126-128
+    delta_y = torch.log(torch.clamp(torch.abs((cy - cy.view(bs, 1, -1)) / h), min=1e-3))  # :130-132
+    delta_w = torch.log(w / w.view(bs, 1, -1))  # :134
+    delta_h = torch.log(h / h.view(bs, 1, -1))  # :135
+    n = delta_h.size(1)
+    position_mat = torch.cat([d.view(bs, n, n, 1) for d in (delta_x, delta_y, delta_w, delta_h)], -1)  # :143
+    if not trignometric_embedding:
+        return position_mat
+    feat_range = torch.arange(dim_g / 8).to(f_g.device)  # :146-148
+    dim_mat = 1.0 / torch.pow(wave_len, feat_range / (dim_g / 8))
+    mul_mat = (100.0 * position_mat.view(bs, n, n, 4, -1)) * dim_mat.view(1, 1, 1, -1)  # :150-154
+    mul_mat = mul_mat.view(bs, n, n, -1)
+    return torch.cat((torch.sin(mul_mat), torch.cos(mul_mat)), -1)  # :156-158
+
+
+class OracleGeometrySDPA(nn.Module):
+    """AugmentedGeometryScaledDotProductAttention, models/modules/attentions.py:62-137, as INTENDED: upstream's
+    forward raises NameError on every call (``att`` is read but never assigned, :124,134-137); the computation it
+    spells out up to there -- mn = softmax(log(clamp(relu(g), 1e-6)) + QK^T/sqrt(d_k) [+ mask]), out = fc_o(mn V) --
+    is what is restated, returning (out, mn).  Constructor and parameter names follow :68-110."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.d_model, self.h, self.d_k, self.d_v = cfg.D_MODEL, cfg.HEAD, cfg.D_KEY, cfg.D_VALUE
+        self.trignometric_embedding = cfg.TRIGNOMETRIC_EMBEDDING
+        self.d_g = self.d_model // self.h if self.trignometric_embedding else 4
+        self.fc_q = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_k = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_v = nn.Linear(self.d_model, self.h * self.d_v)
+        self.fc_o = nn.Linear(self.h * self.d_v, self.d_model)
+        self.fc_gs = nn.ModuleList([nn.Linear(self.d_g, 1) for _ in range(self.h)])
+
+    def forward(self, queries, keys, values, boxes, attention_mask=None, **kw):
+        emb = box_relational_embedding(boxes, dim_g=self.d_g, trignometric_embedding=self.trignometric_embedding)
+        bs, nk = emb.shape[:2]
+        flat = emb.view(-1, self.d_g)
+        g = F.relu(torch.cat([fc(flat).view(bs, 1, nk, nk) for fc in self.fc_gs], dim=1))  # :113-118
+        b, nq = queries.shape[:2]
+        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)
+        k = self.fc_k(keys).view(b, nk, self.h, self.d_k).permute(0, 2, 3, 1)
+        v = self.fc_v(values).view(b, nk, self.h, self.d_v).permute(0, 2, 1, 3)
+        a = torch.matmul(q, k) / math.sqrt(self.d_k)  # :125
+        if attention_mask is not None:
+            a = a + attention_mask
+        mn = torch.softmax(torch.log(torch.clamp(g, min=1e-6)) + a, dim=-1)  # :129-131
+        out = torch.matmul(mn, v).permute(0, 2, 1, 3).contiguous().view(b, nq, self.h * self.d_v)
+        return self.fc_o(out), mn
+
+
+class OracleAdaptiveSDPA(nn.Module):
+    """AdaptiveScaledDotProductAttention.  models/modules/attentions.py:210-291: per query one extra softmax column,
+    its score against its own projected language signal, whose value is that signal."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.d_model, self.h, self.d_k, self.d_v = cfg.D_MODEL, cfg.HEAD, cfg.D_KEY, cfg.D_VALUE
+        self.fc_q = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_k = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_v = nn.Linear(self.d_model, self.h * self.d_v)
+        self.fc_s = nn.Linear(self.d_model, self.h * self.d_k)
+        self.fc_o = nn.Linear(self.h * self.d_v, self.d_model)
+        self.dropout = nn.Dropout(cfg.DROPOUT)
+
+    def forward(self, queries, keys, values, language_signals, attention_mask=None):
+        b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
+        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)
+        s = self.fc_s(language_signals).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)  # :262
+        k = self.fc_k(keys).view(b, nk, self.h, self.d_k).permute(0, 2, 3, 1)
+        v = self.fc_v(values).view(b, nk, self.h, self.d_v).permute(0, 2, 1, 3)
+        attn = torch.matmul(q, k) / math.sqrt(self.d_k)
+        if attention_mask is not None:
+            attn = attn + attention_mask
+        lang = (q * s).sum(-1) / math.sqrt(self.d_k)  # the diagonal of q s^T, :271-272
+        comb = torch.softmax(torch.cat([attn, lang.unsqueeze(-1)], dim=-1), dim=-1)  # :274-275, row by row
+        out = torch.matmul(comb[..., :nk], v) + comb[..., nk:] * s  # :277-281
+        out = out.permute(0, 2, 1, 3).contiguous().view(b, nq, self.h * self.d_v)
+        return self.fc_o(out), [comb[:, :, i:i + 1] for i in range(nq)]
 
 
 class _Stateful(nn.Module):

@@ -702,12 +702,51 @@ def g14():
     finish(c)
 
 
+# ---------------------------------------------------------------- G15 adaptive / geometry attention (row 4)
+def g15():
+    """Adaptive attention: the real class, forward + gradients.  Geometry attention: upstream's forward raises
+    NameError on every call (attentions.py:134-137), so what the reference CAN give is pinned: its own
+    box_relational_embedding outputs (both embedding forms) and its constructor's parameter shapes."""
+    torch.manual_seed(1501)
+    cfg = att_cfg()
+    m = R_att.AdaptiveScaledDotProductAttention(cfg)
+    with torch.no_grad():
+        for lin in (m.fc_q, m.fc_k, m.fc_v, m.fc_o, m.fc_s):
+            lin.bias.normal_(0, 0.1)
+    gen = torch.Generator().manual_seed(19)
+    q = feats(3, 5, D, gen)
+    kv = feats(3, 7, D, gen, pad_rows={1: [5, 6]})
+    sig = feats(3, 5, D, gen)
+    mask = R_utils.generate_padding_mask(kv, 0)
+    c = Case("G15_adaptive_sdpa")
+    c.meta.update(cfg=dict(cfg))
+
+    def call(mod, ins):
+        out, att = mod(ins["queries"], ins["keys"], ins["values"], ins["signals"], attention_mask=ins["mask"])
+        return {"out": out, "att": torch.cat(att, dim=2)}
+    run_with_grads(c, m, {"queries": q, "keys": kv, "values": kv.clone(), "signals": sig, "mask": mask}, call,
+                   ["queries", "keys", "values", "signals"])
+    finish(c)
+
+    c = Case("G15_box_geometry")
+    boxes = torch.rand(2, 6, 4, generator=gen)
+    boxes[..., 2:] = boxes[..., :2] + 0.05 + boxes[..., 2:] * 0.5  # x_max > x_min, y_max > y_min
+    c.add("in", "boxes", boxes)
+    c.add("out", "trig", R_utils.box_relational_embedding(boxes, dim_g=DK, trignometric_embedding=True))
+    c.add("out", "plain", R_utils.box_relational_embedding(boxes, dim_g=4, trignometric_embedding=False))
+    gcfg = att_cfg()
+    gcfg["TRIGNOMETRIC_EMBEDDING"] = True
+    gm = R_att.AugmentedGeometryScaledDotProductAttention(gcfg)
+    c.meta.update(cfg=dict(gcfg), dim_g=DK, state_dict_shapes={k: list(v.shape) for k, v in gm.state_dict().items()})
+    finish(c)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

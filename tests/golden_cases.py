@@ -54,7 +54,8 @@ def load_case(name):
 def oracle_namespace():
     import oracle as O
     return SimpleNamespace(
-        SDPA=O.OracleSDPA, MemorySDPA=O.OracleMemorySDPA, MHA=O.OracleMHA, PWFF=O.OraclePWFF, EncoderLayer=O.OracleEncoderLayer,
+        SDPA=O.OracleSDPA, MemorySDPA=O.OracleMemorySDPA, AdaptiveSDPA=O.OracleAdaptiveSDPA,
+        GeometrySDPA=O.OracleGeometrySDPA, MHA=O.OracleMHA, PWFF=O.OraclePWFF, EncoderLayer=O.OracleEncoderLayer,
         GuidedEncoderLayer=O.OracleGuidedEncoderLayer, CrossModalityEncoderLayer=O.OracleCrossModalityEncoderLayer,
         Encoder=O.OracleEncoder, GuidedAttentionEncoder=O.OracleGuidedAttentionEncoder,
         CoAttentionEncoder=O.OracleCoAttentionEncoder, CrossModalityEncoder=O.OracleCrossModalityEncoder,
@@ -67,6 +68,7 @@ def hip_namespace():
     import openvivqa_amd.modules as M
     return SimpleNamespace(
         SDPA=M.ScaledDotProductAttention, MemorySDPA=M.AugmentedMemoryScaledDotProductAttention,
+        AdaptiveSDPA=M.AdaptiveScaledDotProductAttention, GeometrySDPA=M.AugmentedGeometryScaledDotProductAttention,
         MHA=M.MultiHeadAttention, PWFF=M.PositionWiseFeedForward,
         EncoderLayer=M.EncoderLayer, GuidedEncoderLayer=M.GuidedEncoderLayer,
         CrossModalityEncoderLayer=M.CrossModalityEncoderLayer, Encoder=M.Encoder,
@@ -124,6 +126,10 @@ CASES = {
     "G1_sdpa_7x7": (_sdpa, _call_sdpa, ["queries", "keys", "values"]),
     "G1_sdpa_causal": (_sdpa, _call_sdpa_causal, ["queries"]),
     "G14_memory_sdpa": (lambda ns, c: ns.MemorySDPA(_cfg(c)), _call_sdpa, ["queries", "keys", "values"]),
+    "G15_adaptive_sdpa": (lambda ns, c: ns.AdaptiveSDPA(_cfg(c)),
+                          lambda m, i: (lambda r: {"out": r[0], "att": torch.cat(r[1], dim=2)})(
+                              m(i["queries"], i["keys"], i["values"], i["signals"], attention_mask=i["mask"])),
+                          ["queries", "keys", "values", "signals"]),
     "G2_mha_aoa0": (lambda ns, c: ns.MHA(_cfg(c)),
                     lambda m, i: {"out": m(i["queries"], i["keys"], i["values"], i["mask"])},
                     ["queries", "keys", "values"]),

@@ -165,7 +165,8 @@ def _heads(t, H):
     return t.float().reshape(B, n, H, F // H).transpose(1, 2)
 
 
-def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None):
+    assert att_drop is None or att_drop.p == 0
     qh, kh, vh = _heads(q, H), _heads(k, H), _heads(v, H)
     scale = scale or 1.0 / math.sqrt(qh.shape[-1])
     s = qh @ kh.transpose(-1, -2) * scale
@@ -181,7 +182,9 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True):
     return o, torch.logsumexp(s, -1), (p.to(q.dtype) if need_att else None)
 
 
-def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None):
+def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
+                  att_drop=None):
+    assert att_drop is None or att_drop.p == 0
     qh, kh, vh, gh = _heads(q, H), _heads(k, H), _heads(v, H), _heads(d_o, H)
     scale = scale or 1.0 / math.sqrt(qh.shape[-1])
     s = qh @ kh.transpose(-1, -2) * scale
@@ -191,7 +194,10 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
     dp = gh @ vh.transpose(-1, -2)
     if d_att is not None:
         dp = dp + d_att.float()
-    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    delta = (p * dp).sum(-1, keepdim=True)
+    if d_lse is not None:
+        delta = delta - d_lse[..., None].float()
+    ds = p * (dp - delta)
     rdq = (ds @ kh * scale).transpose(1, 2).reshape(q.shape)
     rdk = (ds.transpose(-1, -2) @ qh * scale).transpose(1, 2).reshape(k.shape)
     rdv = (p.transpose(-1, -2) @ gh).transpose(1, 2).reshape(v.shape)

@@ -552,3 +552,35 @@ def test_empty_and_limit_shapes():
     assert nerr(y, ln_ref(x, g, bb)[0]) < 1e-2
     with pytest.raises(RuntimeError):
         o.layernorm_fwd(rnd(4, 2056, dtype=BF16), torch.ones(2056, device=DEV), torch.zeros(2056, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,H,nq,nk,d", [(2, 4, 9, 11, 16), (2, 8, 182, 182, 96), (2, 8, 20, 20, 64)])
+def test_attention_probability_dropout_and_lse_gradient(dtype, B, H, nq, nk, d):
+    """Dropout on the attention probabilities (transformers' BertSelfAttention inside M4C's MMT) and the gradient
+    w.r.t. the returned log-sum-exp (d_lse), against fp64 autograd with the kernel's own keep mask injected."""
+    o = ops()
+    q, k, v = rnd(B, nq, H * d, dtype=dtype, seed=1), rnd(B, nk, H * d, dtype=dtype, seed=2), rnd(B, nk, H * d, dtype=dtype, seed=3)
+    mask = torch.zeros(B, 1, 1, nk, device=DEV)
+    mask[0, ..., nk - 3:] = -1e5
+    drop = o.DropSpec(p=0.2, seed=77, site=5, step=torch.tensor([9], dtype=torch.int32, device=DEV))
+    keep = o.dropout_keep_mask(drop, B * H * nq * nk, DEV).view(B, H, nq, nk).double().cpu() / 0.8
+
+    def ref(qd, kd, vd):
+        qh = qd.view(B, nq, H, d).transpose(1, 2)
+        kh = kd.view(B, nk, H, d).transpose(1, 2)
+        vh = vd.view(B, nk, H, d).transpose(1, 2)
+        s = qh @ kh.transpose(-1, -2) / math.sqrt(d) + mask.double().cpu()
+        p = torch.softmax(s, -1) * keep
+        return (p @ vh).transpose(1, 2).reshape(B, nq, H * d), p, torch.logsumexp(s, -1)
+    out, lse, att = o.attention_fwd(q, k, v, mask, H, need_att=True, att_drop=drop)
+    qd, kd, vd = (t.double().cpu().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ro, rp, rl = ref(qd, kd, vd)
+    t = tol(dtype)
+    assert nerr(out, ro) < t and nerr(att, rp) < t and nerr(lse, rl) < 1e-2
+    d_o = rnd(B, nq, H * d, dtype=dtype, seed=5)
+    d_lse = rnd(B, H, nq, seed=6) * 0.3
+    ((ro * d_o.double().cpu()).sum() + (rl * d_lse.double().cpu()).sum()).backward()
+    dq, dk, dv = o.attention_bwd(d_o, q, k, v, out, lse, mask, H, d_lse=d_lse, att_drop=drop)
+    t = t * (3 if dtype == BF16 else 1)
+    assert nerr(dq, qd.grad) < t and nerr(dk, kd.grad) < t and nerr(dv, vd.grad) < t

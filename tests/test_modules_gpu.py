@@ -431,3 +431,54 @@ def test_dynamic_pointer_network_module_vs_oracle(axis, mode):
     assert rel_l2(qh.grad, qr.grad) < gt and rel_l2(kh.grad, kr.grad) < gt
     for name, p in hip.named_parameters():
         assert rel_l2(p.grad, dict(ref.named_parameters())[name].grad) < gt, name
+
+
+@pytest.mark.parametrize("trig", [True, False])
+def test_geometry_attention_vs_oracle(trig, mode):
+    """AugmentedGeometryScaledDotProductAttention built working (upstream's forward raises NameError): the
+    log-geometry-biased softmax on the HIP attention kernel (bias = per-head additive mask) against the oracle's
+    restatement of the intended computation, forward, input gradients and the fc_g / projection weight gradients."""
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode, attention_config
+    cfg = attention_config(d_model=512, head=8, d_key=64, d_value=64)
+    cfg["TRIGNOMETRIC_EMBEDDING"] = trig
+    torch.manual_seed(21)
+    ref = O.OracleGeometrySDPA(cfg)
+    with torch.no_grad():
+        for g_ in ref.fc_gs:
+            g_.bias.fill_(0.3)  # keep a good share of the relu alive
+    hip = M.AugmentedGeometryScaledDotProductAttention(cfg)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 36
+    x = torch.randn(B, N, 512, generator=g)
+    boxes = torch.rand(B, N, 4, generator=g)
+    boxes[..., 2:] = boxes[..., :2] + 0.05 + boxes[..., 2:] * 0.5
+    mask = torch.zeros(B, 1, 1, N)
+    mask[1, ..., 30:] = -10e4
+    xr = x.clone().requires_grad_()
+    out_r, att_r = ref(xr, xr, xr, boxes, attention_mask=mask)
+    xh = x.to(DEV).requires_grad_()
+    out_h, att_h = hip(xh, xh, xh, boxes.to(DEV), attention_mask=mask.to(DEV))
+    out_h2, _ = hip(xh, xh, xh, mask.to(DEV), boxes=boxes.to(DEV))  # the order MultiHeadAttention uses
+    assert torch.equal(out_h2, out_h)
+    tol = 1e-3 if mode == F32 else 1e-2
+    assert nerr(out_h, out_r) < tol and nerr(att_h, att_r) < tol, (nerr(out_h, out_r), nerr(att_h, att_r))
+    w = torch.randn(out_r.shape, generator=g)
+    (out_r * w).sum().backward()
+    (out_h.float() * w.to(DEV)).sum().backward()
+    gt = 1e-3 if mode == F32 else 3e-2
+    assert rel_l2(xh.grad, xr.grad) < gt, rel_l2(xh.grad, xr.grad)
+    gref = dict(ref.named_parameters())
+    for k, p in hip.named_parameters():
+        if k.endswith("fc_k.bias"):
+            continue
+        assert p.grad is not None, k
+        if k.startswith("fc_gs"):  # 8 heads x d_g weights: compare them together
+            continue
+        assert rel_l2(p.grad, gref[k].grad) < gt, (k, rel_l2(p.grad, gref[k].grad))
+    gh = torch.cat([p.grad.flatten() for k, p in hip.named_parameters() if k.startswith("fc_gs")])
+    gr = torch.cat([p.grad.flatten() for k, p in ref.named_parameters() if k.startswith("fc_gs")])
+    assert rel_l2(gh, gr) < gt, rel_l2(gh, gr)

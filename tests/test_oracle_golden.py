@@ -203,3 +203,27 @@ def test_state_dict_manifest_matches_reference():
     for name, mod in built.items():
         got = {k: list(v.shape) for k, v in mod.state_dict().items()}
         assert got == man[name], name
+
+
+def test_box_geometry_and_geometry_attention_contract():
+    """G15_box_geometry: the reference's OWN box_relational_embedding outputs (both forms) pin the oracle's and the
+    product's restatement bit-for-bit-close; the geometry attention's parameter shapes follow the reference
+    constructor (its forward is unrunnable upstream: NameError, attentions.py:134-137)."""
+    import numpy as np
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.utils import box_relational_embedding as prod_emb
+    from golden_cases import load_case
+    c = load_case("G15_box_geometry")
+    boxes = c.inputs["boxes"]
+    for name, trig, dim in (("trig", True, c.meta["dim_g"]), ("plain", False, 4)):
+        ref = c.out[name]
+        for fn in (O.box_relational_embedding, prod_emb):
+            got = fn(boxes, dim_g=dim, trignometric_embedding=trig)
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) < 1e-5, (name, fn.__module__)
+    cfg = ConfigNode(c.meta["cfg"])
+    for cls in (O.OracleGeometrySDPA, M.AugmentedGeometryScaledDotProductAttention):
+        shapes = {k: list(v.shape) for k, v in cls(cfg).state_dict().items()}
+        assert shapes == c.meta["state_dict_shapes"], cls
