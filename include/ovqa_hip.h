@@ -316,6 +316,23 @@ int ovqa_gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n,
 int ovqa_row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D, float pad_value,
                           void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Beam-search state reorder for ALL state buffers of a decoder in one launch ("next" row 1):
+ *   replaces: BeamSearch._expand_state applied through Module.apply_to_states
+ *             models/modules/beam_search.py:19-34, models/modules/containers.py:26-31
+ *             (one torch.gather with an expanded index tensor per running K/V cache / mask / position buffer).
+ *   Every problem is a row-major buffer src [b_s*cur_beam, row_bytes] -> dst [b_s*beam, row_bytes] (any dtype,
+ *   out of place):  dst[b*beam + j] = src[b*cur_beam + sel[b*beam + j]],  sel int32 [b_s*beam] in [0, cur_beam).
+ *   `problems` and `sel` are DEVICE arrays.
+ * ------------------------------------------------------------------------- */
+typedef struct ovqa_gather_problem {
+  const void* src;
+  void* dst;
+  int64_t row_bytes;
+} ovqa_gather_problem;
+int ovqa_grouped_row_gather(const ovqa_gather_problem* problems, int32_t n_problems, const int32_t* sel,
+                            int32_t b_s, int32_t cur_beam, int32_t beam, void* stream);
+
 /* Materialise the dropout keep-mask the fused kernels use (tests, debugging):
  * out[i] = 1 if element i of a [rows, cols] site is kept. */
 int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream);

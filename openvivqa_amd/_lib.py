@@ -43,6 +43,11 @@ class LnRef(C.Structure):
     _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p)]
 
 
+class GatherProblem(C.Structure):
+    """ovqa_gather_problem (include/ovqa_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
+
+
 class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("step", C.c_void_p)]
 
@@ -86,6 +91,7 @@ SIGNATURES = {
     "ovqa_gelu_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, _DP, c_vp],
     "ovqa_row_padding_mask": [c_int, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],
     "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
+    "ovqa_grouped_row_gather": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
 }
 _RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_last_dispatch": C.c_char_p, "ovqa_workspace_bytes": C.c_int64}

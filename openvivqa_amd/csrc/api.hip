@@ -327,6 +327,16 @@ int ovqa_row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int6
   return ovqa::row_padding_mask(dtype, x, mask, M, D, pad_value, as_stream(stream));
 }
 
+int ovqa_grouped_row_gather(const ovqa_gather_problem* problems, int32_t n_problems, const int32_t* sel, int32_t b_s,
+                            int32_t cur_beam, int32_t beam, void* stream) {
+  OVQA_REQUIRE(n_problems >= 0 && n_problems <= 65535 && b_s >= 0 && cur_beam >= 1 && beam >= 1, OVQA_ERR_BAD_ARG,
+               "grouped_row_gather: bad sizes");
+  OVQA_REQUIRE(n_problems == 0 || b_s == 0 || (problems && sel), OVQA_ERR_BAD_ARG, "grouped_row_gather: null pointer");
+  OVQA_REQUIRE((int64_t)b_s * beam < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_row_gather: too many rows");
+  g_dispatch = "";
+  return ovqa::grouped_row_gather(problems, n_problems, sel, b_s, cur_beam, beam, as_stream(stream));
+}
+
 int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, void* stream) {
   OVQA_REQUIRE(drop && out && n >= 0, OVQA_ERR_BAD_ARG, "dropout_keep_mask: bad argument");
   OVQA_REQUIRE(n < (1ll << 32), OVQA_ERR_UNSUPPORTED, "dropout_keep_mask: more than 2^32 elements");

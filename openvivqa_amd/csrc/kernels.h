@@ -84,6 +84,10 @@ int row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D
 int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                     int accumulate_loss, hipStream_t st);
 
+// ---- gather.hip -----------------------------------------------------------------
+int grouped_row_gather(const ovqa_gather_problem* probs, int n_problems, const int32_t* sel, int b_s, int cur, int beam,
+                       hipStream_t st);
+
 // ---- gemm_mfma.hip (bf16, MFMA) ----------------------------------------------
 bool mfma_gemm_supported(int64_t R, int64_t C, int64_t K, int64_t ld_p, int64_t ld_q);
 bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx);

@@ -43,6 +43,40 @@ class Module(nn.Module):
         for child in self._stateful_children():
             child.apply_to_states(fn)
 
+    def _state_slots(self):
+        for name in self._state_names:
+            yield self, name
+        for child in self._stateful_children():
+            yield from child._state_slots()
+
+    def reorder_states(self, selected_beam: torch.Tensor, b_s: int, cur_beam_size: int, beam_size: int) -> None:
+        """Beam-search reorder of EVERY state buffer in one kernel launch: what ``apply_to_states(
+        BeamSearch._expand_state(selected_beam, cur_beam_size))`` does with one torch.gather (and one expanded index
+        tensor) per buffer (beam_search.py:19-34).  ``selected_beam`` is (b_s, beam_size).  State tensors that are not
+        on the GPU, or whose leading dimension is not b_s * cur_beam_size, take the reference's gather."""
+        from .. import ops
+        slots = [(m, n) for m, n in self._state_slots() if m._buffers[n] is not None]
+        fused = [(m, n) for m, n in slots
+                 if m._buffers[n].is_cuda and m._buffers[n].dim() >= 1 and m._buffers[n].shape[0] == b_s * cur_beam_size
+                 and m._buffers[n].numel() > 0]
+        if fused:
+            outs = ops.grouped_row_gather([m._buffers[n].contiguous() for m, n in fused], selected_beam, b_s,
+                                          cur_beam_size, beam_size)
+            for (m, n), o in zip(fused, outs):
+                m._buffers[n] = o
+        done = {(id(m), n) for m, n in fused}
+        for m, n in slots:
+            if (id(m), n) in done:
+                continue
+            s = m._buffers[n]
+            shape = [int(x) for x in s.shape]
+            beam = selected_beam
+            for _ in shape[1:]:
+                beam = beam.unsqueeze(-1)
+            s = torch.gather(s.view(*([b_s, cur_beam_size] + shape[1:])), 1,
+                             beam.expand(*([b_s, beam_size] + shape[1:])))
+            m._buffers[n] = s.view(*([-1] + shape[1:]))
+
     def _fresh(self, name: str, batch_size: Optional[int]):
         default = self._state_defaults[name]
         if default is None:

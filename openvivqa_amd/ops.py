@@ -618,6 +618,28 @@ def row_padding_mask(x, pad_value=0.0):
     return mask
 
 
+def grouped_row_gather(states, selected_beam, b_s, cur_beam, beam):
+    """Beam reorder of many state buffers in ONE launch: for every tensor s of ``states`` (leading dimension
+    b_s * cur_beam, contiguous) returns a new tensor with leading dimension b_s * beam whose row b*beam + j is row
+    b*cur_beam + selected_beam[b, j] of s (beam_search.py:19-34)."""
+    import numpy as np
+    dev = states[0].device
+    _dev(states[0])
+    sel = selected_beam.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
+    assert sel.numel() == b_s * beam
+    outs, probs = [], (_lib.GatherProblem * len(states))()
+    for i, s in enumerate(states):
+        assert s.is_cuda and s.is_contiguous() and s.shape[0] == b_s * cur_beam, (tuple(s.shape), b_s, cur_beam)
+        o = torch.empty((b_s * beam,) + tuple(s.shape[1:]), dtype=s.dtype, device=dev)
+        row_bytes = (s.numel() // max(1, s.shape[0])) * s.element_size()
+        probs[i] = _lib.GatherProblem(_p(s), _p(o), row_bytes)
+        outs.append(o)
+    table = torch.from_numpy(np.frombuffer(bytes(probs), dtype=np.uint8).copy()).to(dev)
+    _lib.check(_lib.load().ovqa_grouped_row_gather(_p(table), len(states), _p(sel), b_s, cur_beam, beam, _stream()),
+               "grouped_row_gather")
+    return outs
+
+
 def dropout_keep_mask(drop: DropSpec, n: int, device) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.uint8, device=device)
     _dev(out)

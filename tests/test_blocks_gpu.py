@@ -329,3 +329,54 @@ def test_m4c_greedy_decode_config4(mode):
             a, b = torch.where(fin, r_h.cpu(), torch.zeros_like(r_o)), torch.where(fin, r_o, torch.zeros_like(r_o))
             e = ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
             assert e < (1e-3 if mode == F32 else 1e-2), e
+
+
+def test_fused_beam_reorder_equals_reference_gather():
+    """Module.reorder_states (one grouped row-gather launch over every state buffer) == the reference's
+    BeamSearch._expand_state applied through apply_to_states (beam_search.py:19-34), on a stateful decoder after a
+    few decoding steps: K/V caches of every layer (bf16), the running self-attention mask (bool) and the running
+    position counter (int64), first with cur_beam 1 -> beam 3 (t = 0), then beam 3 -> 3."""
+    import copy
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+
+    class Vocab:
+        max_answer_length, padding_idx, bos_idx, eos_idx = 20, 0, 1, 2
+
+        def __len__(self):
+            return 50
+    A.set_compute_dtype(BF16)
+    cfg = ConfigNode(dict(
+        ARCHITECTURE="Decoder", D_MODEL=512, LAYERS=3,
+        ATTENTION=dict(SELF_ATTENTION=_cfg(can_be_stateful=True), ENC_ATTENTION=_cfg()),
+        TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=512, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                            WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+    torch.manual_seed(2)
+    dec = M.Decoder(cfg, Vocab()).to(DEV).eval()
+    b_s, beam = 4, 3
+    enc = torch.randn(b_s, 30, 512, device=DEV)
+    emask = torch.zeros(b_s, 1, 1, 30, device=DEV)
+    g = torch.Generator().manual_seed(1)
+
+    def reference_expand(selected_beam, cur):
+        def fn(s):
+            shape = [int(sh) for sh in s.shape]
+            bm = selected_beam
+            for _ in shape[1:]:
+                bm = bm.unsqueeze(-1)
+            s = torch.gather(s.view(*([b_s, cur] + shape[1:])), 1, bm.expand(*([b_s, beam] + shape[1:])))
+            return s.view(*([-1] + shape[1:]))
+        return fn
+    with torch.no_grad(), dec.statefulness(b_s):
+        dec(torch.randint(4, 50, (b_s, 1), device=DEV), enc, emask)
+        for cur in (1, beam):
+            sel = torch.randint(0, cur, (b_s, beam), generator=g).to(DEV)
+            twin = copy.deepcopy(dec)
+            twin.apply_to_states(reference_expand(sel, cur))
+            dec.reorder_states(sel, b_s, cur, beam)
+            for a, b in zip(dec.states(), twin.states()):
+                assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+            e2 = enc.repeat_interleave(beam, 0) if cur == 1 else e2
+            m2 = emask.repeat_interleave(beam, 0) if cur == 1 else m2
+            dec(torch.randint(4, 50, (b_s * beam, 1), device=DEV), e2, m2)  # the caches keep decoding afterwards

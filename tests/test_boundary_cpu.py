@@ -328,3 +328,42 @@ def test_segment_helpers():
     c = b + 1
     d = torch.randn(3, requires_grad=True).cos()
     assert _reaches(c.grad_fn, b.grad_fn) and not _reaches(b.grad_fn, c.grad_fn) and not _reaches(c.grad_fn, d.grad_fn)
+
+
+def test_reorder_states_cpu_path_equals_apply_to_states():
+    """Module.reorder_states on CPU state buffers takes the reference's per-buffer torch.gather
+    (beam_search.py:19-34) and must equal apply_to_states with that closure (the fused launch is GPU-only)."""
+    import copy
+    import torch
+    from openvivqa_amd.modules.containers import Module
+
+    class Leaf(Module):
+        def __init__(self):
+            super().__init__()
+            self.register_state("running_keys", torch.zeros((0, 8)))
+            self.register_state("running_seq", torch.zeros((1,)).long())
+
+    class Net(Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Leaf(), Leaf()
+    b_s, cur, beam = 2, 3, 3
+    net = Net()
+    net.enable_statefulness(b_s * cur)
+    g = torch.Generator().manual_seed(0)
+    for leaf in (net.a, net.b):
+        leaf.running_keys = torch.randn(b_s * cur, 5, 8, generator=g)
+        leaf.running_seq = torch.randint(0, 9, (b_s * cur, 1), generator=g)
+    sel = torch.randint(0, cur, (b_s, beam), generator=g)
+    twin = copy.deepcopy(net)
+
+    def fn(s):
+        shape = [int(x) for x in s.shape]
+        bm = sel
+        for _ in shape[1:]:
+            bm = bm.unsqueeze(-1)
+        return torch.gather(s.view(*([b_s, cur] + shape[1:])), 1, bm.expand(*([b_s, beam] + shape[1:]))).view(*([-1] + shape[1:]))
+    twin.apply_to_states(fn)
+    net.reorder_states(sel, b_s, cur, beam)
+    for x, y in zip(net.states(), twin.states()):
+        assert torch.equal(x, y)
