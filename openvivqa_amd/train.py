@@ -109,6 +109,7 @@ class GradAllReducer:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pending = False
+        self.timing = None  # list of (ready event, done event, elements) per released segment when instrumented
 
     def bounds(self, numel: int, lo: int = 0):
         return [(s, min(s + self.bucket, lo + numel)) for s in range(lo, lo + numel, self.bucket)]
@@ -138,12 +139,17 @@ class GradAllReducer:
         if self.stream is None:
             self._reduce(grad, ranges)
             return
+        timed = self.timing is not None
         if after is None:
-            after = torch.cuda.Event()
+            after = torch.cuda.Event(enable_timing=timed)
             after.record(torch.cuda.current_stream(self.device))
         self.stream.wait_event(after)
         with torch.cuda.stream(self.stream):
             self._reduce(grad, ranges)
+            if timed:  # (gradients final on the compute stream, segment reduced on the communication stream)
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(self.stream)
+                self.timing.append((after, done, sum(hi - lo for lo, hi in ranges)))
         self._pending = True
 
     def finish(self, grad: torch.Tensor) -> torch.Tensor:
@@ -524,6 +530,34 @@ class TrainStep:
         self.optim.step(g, grad_scale=1.0 / self.reducer.world)
         ops.increment_step(self.drop_step)
         return self.loss
+
+    def timed_comm_step(self, *inputs: torch.Tensor) -> dict:
+        """One extra step with HIP events around every gradient segment's exchange: per segment the bytes, the time
+        from "gradients final" to "reduced" on the communication stream, and how much of it the rest of backward did
+        NOT cover (the exposed part the optimiser waits for).  Diagnostic for the N > 1 runs the driver makes."""
+        if not self.reducer.active or self.reducer.stream is None:
+            return {}
+        self.reducer.timing = []
+        end = torch.cuda.Event(enable_timing=True)
+        try:
+            self.step(*inputs)
+            # step() has queued Adam behind reducer.finish(): the compute stream's position right after the LAST
+            # backward phase is the last segment's `ready` event
+            end.record(torch.cuda.current_stream(self.arena.device))
+            torch.cuda.synchronize()
+            recs = self.reducer.timing
+        finally:
+            self.reducer.timing = None
+        if not recs:
+            return {}
+        last_ready = recs[-1][0]
+        elt = 2 if self.reducer.comm_dtype == torch.bfloat16 else 4
+        segs = []
+        for ready, done, n in recs:
+            segs.append({"mbytes_on_wire": round(n * elt / 1e6, 2), "exchange_ms": round(ready.elapsed_time(done), 4),
+                         "exposed_ms": round(max(0.0, last_ready.elapsed_time(done)), 4)})
+        return {"segments": segs, "exposed_ms_total": round(max(s["exposed_ms"] for s in segs), 4),
+                "world": self.reducer.world, "comm_dtype": str(self.reducer.comm_dtype).replace("torch.", "")}
 
     @property
     def graph(self):  # single-graph view kept for callers that replay the captured fwd+bwd themselves

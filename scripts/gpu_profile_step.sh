@@ -1,0 +1,73 @@
+#!/bin/bash
+# Profiles of the captured training step for profiles/ (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats            -> kernel_stats.csv (per-kernel time; the figure roofline.avg_launch_us must agree with)
+#   2. separate --pmc passes FETCH_SIZE / WRITE_SIZE -> traffic.json   (MI355X_MICROARCH.md: FETCH x2 on gfx950, KB units)
+#   3. separate --pmc passes of SQ counter sets     -> pmc_summary.json (MFMA busy, waits, LDS conflicts per kernel)
+# Never compile from a profiled run: build first, then forbid building.
+set -o pipefail
+TAG=${1:-r02}
+python -m openvivqa_amd.build > /dev/null 2>&1 || { echo "library build failed"; exit 1; }
+export OVQA_NO_BUILD=1 PYTHONDONTWRITEBYTECODE=1
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-roofline --repeats 1"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 10 --warmup 2 > $OUT/trace.log 2>&1; echo "trace exit $?"
+find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+find $OUT/trace -name "*kernel_trace.csv" | head -1 | xargs -I{} sh -c 'gzip -c {} > '$OUT'/kernel_trace.csv.gz'
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- $B --steps 3 --warmup 1 > $OUT/$c.log 2>&1; echo "$c exit $?"
+done
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/sq$i -- $B --steps 3 --warmup 1 > $OUT/sq$i.log 2>&1; echo "sq set $i exit $?"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, json, sys
+out = sys.argv[1]
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "")
+# ---- traffic
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{out}/{c}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                acc[short(r["Kernel_Name"])][c].append(float(r["Counter_Value"]))
+traffic = {}
+for k, v in acc.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        f, w = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> x2; both are in KB
+        traffic[k] = {"launches": len(v["FETCH_SIZE"]), "fetch_kb_avg": f, "write_kb_avg": w,
+                      "hbm_bytes_per_launch": (2 * f + w) * 1024}
+json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
+# ---- SQ counters per kernel (averages per launch) + durations from the kernel trace of the same pass
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(out + "/sq*")):
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {}
+for k, v in pmc.items():
+    row = {c: sum(x) / len(x) for c, x in v.items()}
+    row["launches_sampled"] = max(len(x) for x in v.values())
+    gui = row.get("GRBM_GUI_ACTIVE")
+    if gui and "SQ_VALU_MFMA_BUSY_CYCLES" in row:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs = 1024 matrix pipes
+        row["mfma_busy_frac"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui / 8.0)
+    if "SQ_WAVE_CYCLES" in row and row["SQ_WAVE_CYCLES"] > 0:
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in row:
+                row[c.lower() + "_frac_of_wave_cycles"] = row[c] / row["SQ_WAVE_CYCLES"]
+    summary[k] = row
+json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1)
+top = sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]
+for k, v in top:
+    s = summary.get(k, {})
+    print(f'{k[:78]:78s} n={v["launches"]:4d} hbm={v["hbm_bytes_per_launch"]/1e6:7.1f}MB mfma_busy={s.get("mfma_busy_frac", float("nan")):.3f} '
+          f'wait={s.get("sq_wait_any_frac_of_wave_cycles", float("nan")):.2f} ldsconf={s.get("SQ_LDS_BANK_CONFLICT", float("nan")):.0f}')
+PY
+head -14 $OUT/kernel_stats.csv | cut -c1-160

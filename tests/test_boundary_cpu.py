@@ -259,27 +259,30 @@ def test_grad_allreduce_gloo_world2(comm_bf16):
     assert torch.equal(res[0], res[1])  # every rank ends with identical gradients
 
 
-@pytest.mark.parametrize("overlap_mb,comm_bf16,kind", [(0.0, False, "mcan"), (0.02, False, "mcan"), (0.02, True, "mcan"),
-                                                       (0.02, False, "crossmodality")])
-def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind):
-    """Two ranks x TrainStep on a small MCAN stack (kernel wrappers mocked, gloo): with the gradient exchange
-    released segment by segment during a phased backward (overlap_mb > 0) both ranks end with identical weights,
-    equal to a single process that averages the two ranks' gradients itself."""
+@pytest.mark.parametrize("overlap_mb,comm_bf16,kind,world", [
+    (0.0, False, "mcan", 2), (0.02, False, "mcan", 2), (0.02, True, "mcan", 2), (0.02, False, "crossmodality", 2),
+    (0.02, False, "mcan", 8)])  # 8 ranks: the node size the driver scales to
+def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind, world):
+    """N ranks x TrainStep on a small MCAN stack (kernel wrappers mocked, gloo): with the gradient exchange
+    released segment by segment during a phased backward (overlap_mb > 0) all ranks end with identical weights,
+    equal to a single process that averages the ranks' gradients itself; the segment plan is identical on every
+    rank (TrainStep._check_plan_identical runs inside)."""
     import tempfile
     import torch.multiprocessing as mp
     import dp_helpers as H
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     rdv = os.path.join(tempfile.mkdtemp(prefix="ovqa_rdv_"), "store")
-    procs = [ctx.Process(target=H.dp_worker, args=(r, 2, rdv, overlap_mb, comm_bf16, q, kind)) for r in range(2)]
+    procs = [ctx.Process(target=H.dp_worker, args=(r, world, rdv, overlap_mb, comm_bf16, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    res = {r: (torch.from_numpy(w), seg) for r, w, seg in (q.get(timeout=300) for _ in range(2))}
+    res = {r: (torch.from_numpy(w), seg) for r, w, seg in (q.get(timeout=300) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert torch.equal(res[0][0], res[1][0])
-    assert res[0][1] == res[1][1]
+    for r in range(1, world):
+        assert torch.equal(res[0][0], res[r][0])
+        assert res[0][1] == res[r][1]
     segs = res[0][1]
     if overlap_mb > 0:
         assert len(segs) >= 3, segs  # several segments were released before the end of backward
@@ -296,11 +299,11 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind):
         ts._discover_foreign()
         for _ in range(2):
             g = torch.zeros_like(ts.arena.grad)
-            for r in range(2):
+            for r in range(world):
                 ts.static_inputs = [t.clone() for t in H.batch(r)]
                 ts._fwd_bwd()
                 g += ts.arena.grad
-            ts.optim.step(g, grad_scale=0.5)
+            ts.optim.step(g, grad_scale=1.0 / world)
         ref = ts.arena.master.clone()
         keep = torch.ones_like(ref, dtype=torch.bool)
         for n, prm in model.named_parameters():  # analytically zero gradient: Adam turns rounding noise into
