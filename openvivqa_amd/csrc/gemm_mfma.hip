@@ -379,115 +379,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
   gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC>(g, tc * BC, tr * BT, epi, smem);
 }
 
-// ---- one big tile per CU ------------------------------------------------------------------------------------------
-// The products of this model have few output tiles per CU and a short reduction (K = 512 mostly), and what bounds a
-// tile's main loop is the CU's L2 -> LDS load path (~50 GB/s per CU), i.e. the bytes (rows_c + rows_r) * K * 2 a
-// workgroup pulls in.  A 128x128 tiling of 6400 x 2048 makes 800 tiles: 3.1 rounds of 256 KiB per CU.  Here the
-// output is cut into AT MOST one tile per CU, as large as the accumulators allow (16*CU rows of the c operand x
-// 16*RU rows of the r operand, e.g. 208 x 256 -> 31 x 8 = 248 workgroups, 232 KiB per CU in all): 2.2x fewer bytes
-// through the load path for the same MFMA work.  8 waves as WC x WR; both operands k-contiguous (forward, and dX from
-// the transposed weight copy); direct-to-LDS staging in 1 KiB pieces (8 rows x 128 B, source-swizzled) dealt
-// round-robin to the waves; 16-byte epilogue accesses through the permuted P row order (perm32).
-template <typename Epi, int CU, int RU, int WC, int WR, int NBUF>
-__device__ __forceinline__ void gemm_tile_big(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
-  static_assert(WC * WR == 8, "8 waves");
-  static_assert(RU % WR == 0 && (RU / WR) % 2 == 0, "even number of r units per wave (the wide epilogue pairs them)");
-  static_assert(Epi::kWide, "wide epilogues only");
-  constexpr int NI = (CU + WC - 1) / WC;  // c units per wave (the last wave rows may own fewer)
-  constexpr int NJ = RU / WR;
-  constexpr int PCH = 2 * RU, QCH = 2 * CU;  // 1 KiB pieces per K tile
-  constexpr int NCH = PCH + QCH;
-  constexpr int PER = (NCH + 7) / 8;  // LDS-DMA instructions per wave per K tile
-  constexpr int STAGE = NCH * 1024;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave / WR, wr = wave % WR;
-  const int ci0 = wc * NI;
-  const int ni = (CU - ci0) < NI ? (CU - ci0) : NI;  // wave-uniform, >= 1 by construction of the candidates
-
-  f32x4 acc[NJ][NI];
-#pragma unroll
-  for (int j = 0; j < NJ; j++)
-#pragma unroll
-    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = g.K / BK;
-  auto issue = [&](int kt) {
-    char* buf = smem + (kt % NBUF) * STAGE;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < PER; i++) {
-      int ci = wave + 8 * i;
-      ci = ci < NCH ? ci : NCH - 1;  // padding instruction: re-loads the last piece (same bytes, same place)
-      const bf16* src;
-      const int pos = lane & 7;
-      if (ci < PCH) {
-        const int row = ci * 8 + (lane >> 3);
-        int grow = r0 + perm32(row);
-        grow = grow < g.R ? grow : g.R - 1;
-        src = g.P + (int64_t)grow * g.ldp + k0 + ((pos ^ (row & 7)) << 3);
-      } else {
-        const int row = (ci - PCH) * 8 + (lane >> 3);
-        int grow = c0 + row;
-        grow = grow < g.C ? grow : g.C - 1;
-        src = g.Q + (int64_t)grow * g.ldq + k0 + ((pos ^ (row & 7)) << 3);
-      }
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + ci * 1024), 16, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int p = 0; p < NBUF - 1; p++)
-    if (p < nkt) issue(p);
-
-  for (int kt = 0; kt < nkt; kt++) {
-    if (NBUF == 2 || kt + NBUF - 2 >= nkt) wait_vmcnt<0>();
-    else wait_vmcnt<PER * (NBUF - 2)>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
-    const char* Ps = smem + (kt % NBUF) * STAGE;
-    const char* Qs = Ps + PCH * 1024;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf16x8 pf[NJ], qf[NI];
-#pragma unroll
-      for (int j = 0; j < NJ; j++) pf[j] = frag<false>(Ps, (wr * NJ + j) * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < NI; i++)
-        if (i < ni) qf[i] = frag<false>(Qs, (ci0 + i) * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < NI; i++)
-        if (i < ni) {
-#pragma unroll
-          for (int j = 0; j < NJ; j++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
-        }
-    }
-  }
-  epi.init();
-#pragma unroll
-  for (int i = 0; i < NI; i++) {
-    if (i >= ni) continue;
-    const int c = c0 + (ci0 + i) * 16 + (lane & 15);
-    if (c >= g.C) continue;
-#pragma unroll
-    for (int jp = 0; jp < NJ / 2; jp++) {
-      const int r = r0 + (wr * NJ + 2 * jp) * 16 + (lane >> 4) * 8;
-      if (r < g.R) epi.wide(c, r, acc[2 * jp][i], acc[2 * jp + 1][i]);
-    }
-  }
-}
-
-template <typename Epi, int CU, int RU, int WC, int WR, int NBUF>
-__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmArgs g, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nwg = g.tiles_r * g.tiles_c;
-  int bid = blockIdx.x;
-  {  // XCD-aware remap: the r tiles of a c panel (same activations) run on one XCD
-    const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
-  const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_big<Epi, CU, RU, WC, WR, NBUF>(g, tc * 16 * CU, tr * 16 * RU, epi, smem);
-}
-
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
@@ -769,16 +660,6 @@ inline int tiny_nbuf() {
   return v;
 }
 
-inline bool big_tiles_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_BIG");
-    v = e ? atoi(e) : 0;  // MEASURED (MI355X): L2-warm microbenchmark -2 us on the >= 600-tile products, but +0.19 ms
-                          // per MCAN step: one workgroup per CU has nothing to overlap its cold first K tiles with
-  }
-  return v != 0;
-}
-
 inline int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -810,37 +691,6 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
            hipStream_t st, const char* what, bool wide_ok = true) {
   GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
              (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
-  if constexpr (!PK && !QK && Epi::kWide) {
-    if (K % BK == 0 && wide_ok && R % 32 == 0 && big_tiles_enabled()) {
-      // candidates (c units, r units, wave grid): the one with at most 256 tiles that pulls the fewest bytes per CU
-      int best = -1;
-      int64_t best_cost = 0;
-      static const int cand[][2] = {{13, 16}, {13, 12}, {7, 8}};
-      for (int t = 0; t < 3; t++) {
-        const int cu = cand[t][0], ru = cand[t][1];
-        if (R % (16 * ru) != 0) continue;
-        const int64_t tiles = ((C + 16 * cu - 1) / (16 * cu)) * (R / (16 * ru));
-        if (tiles > 256 || tiles < 160) continue;  // one round of workgroups, most CUs busy
-        const int64_t cost = 16 * (cu + ru);
-        if (best < 0 || cost < best_cost) { best = t; best_cost = cost; }
-      }
-#define OVQA_BIG(CUV, RUV, WCV, WRV)                                                                              \
-  {                                                                                                               \
-    g.tiles_r = (int)(R / (16 * RUV));                                                                            \
-    g.tiles_c = (int)((C + 16 * CUV - 1) / (16 * CUV));                                                           \
-    const size_t lds = (size_t)2 * (2 * RUV + 2 * CUV) * 1024;                                                    \
-    int rc = set_max_lds(gemm_bf16_big_kernel<Epi, CUV, RUV, WCV, WRV, 2>, lds);                                  \
-    if (rc != OVQA_OK) return rc;                                                                                 \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<Epi, CUV, RUV, WCV, WRV, 2>), dim3(g.tiles_r* g.tiles_c), dim3(512), \
-                       lds, st, g, epi);                                                                          \
-    return ovqa_check_launch(what);                                                                               \
-  }
-      if (best == 0) OVQA_BIG(13, 16, 2, 4)
-      if (best == 1) OVQA_BIG(13, 12, 4, 2)
-      if (best == 2) OVQA_BIG(7, 8, 2, 4)
-#undef OVQA_BIG
-    }
-  }
   const int variant = (K % BK == 0 && (PK || !Epi::kWide || wide_ok)) ? gemm_variant() : 0;
   // few 128x128 tiles (the M = 1280 question stack): halve the c tile -> twice the workgroups
   const bool small_c = !QK && variant >= 10 && g.tiles_r * g.tiles_c <= small_tile_threshold();

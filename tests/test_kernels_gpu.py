@@ -47,7 +47,7 @@ def gelu_grad(x):
 
 LIN_SHAPES = [(37, 50, 29), (64, 64, 16), (256, 128, 64), (300, 256, 128), (6400, 512, 512), (1280, 1536, 512),
               (128, 512, 2048),
-              # one-big-tile-per-CU kernels: 208x256, 208x192 and 112x128 tiles, ragged last row panel included
+              # the BASELINE products (and ragged row counts of the same widths)
               (6400, 2048, 512), (6400, 1536, 512), (6400, 512, 2048), (6001, 2048, 512), (5555, 512, 512)]
 
 
