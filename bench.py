@@ -44,10 +44,13 @@ def parse():
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
                          "single-rank group")
-    ap.add_argument("--workload", default="stack", choices=["stack", "model"],
+    ap.add_argument("--workload", default="stack", choices=["stack", "model", "m4c_decode"],
                     help="stack = BASELINE's metric (the two encoder stacks, default); model = SECONDARY diagnostic: "
                          "the whole MCAN model (FeatureEmbedding + LSTM text embedding + stacks + pooling head + "
-                         "classifier + NLLLoss) on synthetic region features / token ids (SURVEY 8d)")
+                         "classifier + NLLLoss) on synthetic region features / token ids (SURVEY 8d); m4c_decode = "
+                         "SECONDARY diagnostic for BASELINE configs[3]: M4C's multimodal transformer (hidden 768, 4 layers x "
+                         "8 heads, 20 question + 100 region + 50 OCR + 12 decoding positions) run through the 12-pass "
+                         "greedy decoding loop with the classifier || OcrPtrNet head, evaluation mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the CPU leg at the best thread count")
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
@@ -354,6 +357,53 @@ def cpu_baseline(cfg, steps, thread_list):
             "cpus_available": avail}
 
 
+def m4c_decode_bench(args, device, world, rank, dist, B, seed):
+    """SECONDARY diagnostic (not the headline metric): BASELINE configs[3], `configs/mmf_m4c.yaml:92-95` -- samples/s of
+    M4C's evaluation path, max_iter = 12 passes of the multimodal transformer per batch (mmf_m4c.py:236-256; the early
+    exit is disabled by an unreachable eos index so that every batch costs the same), random weights, synthetic
+    embeddings of the reference's shapes.  One "step" = one full greedy decode of a batch."""
+    from types import SimpleNamespace
+    from openvivqa_amd.modules.mmt import MMT, M4CDecodingHead
+    cfg = SimpleNamespace(hidden_size=768, num_hidden_layers=4, num_attention_heads=8, intermediate_size=3072,
+                          layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(seed)
+    mmt, head = MMT(cfg).to(device).eval(), M4CDecodingHead(768, 5000).to(device).eval()
+    g = torch.Generator().manual_seed(seed + rank)
+    txt, obj, ocr = (torch.randn(B, n, 768, generator=g).to(device) for n in (20, 100, 50))
+    z = lambda n: torch.zeros(B, 1, 1, n, device=device)
+    run = lambda: head.greedy_decode(mmt, txt, z(20), obj, z(100), ocr, z(50), 12, 1, -1)
+    for _ in range(max(1, args.warmup)):
+        run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, _, passes = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SECONDARY: M4C greedy decode samples/sec (12 MMT passes per sample), hidden 768, S=182",
+            "value": round(world * B * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "secondary, BASELINE configs[3]: MMT 4 layers x 8 heads of 96, intermediate 3072, "
+                       f"20 txt + 100 obj + 50 ocr + 12 dec positions, classifier(5000) || OcrPtrNet(768), B={B}/GPU, "
+                       f"{passes} passes per decode, eager launches", "global_batch": world * B,
+                       "parallelism": f"dp{world}"},
+            "ms_per_mmt_pass": round(dt / args.steps / passes * 1e3, 3)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def ensure_library(local_rank):
     """The C-ABI library is a build artefact.  Decide about it BEFORE anything touches the GPU or the process group
     (hipcc must never run in a process that initialised HIP, and never under a profiler): local rank 0 compiles a
@@ -430,6 +480,8 @@ def main():
     A.set_compute_dtype(dtype)
     A.manual_seed(b.SEED + rank)
     torch.manual_seed(b.SEED)  # identical initial weights on every rank
+    if args.workload == "m4c_decode":
+        return m4c_decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
     model = MCANEncoderStack(cfg.MODEL).to(device).train()
     D = cfg.MODEL.D_MODEL
     v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,

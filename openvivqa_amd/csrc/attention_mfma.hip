@@ -1,4 +1,5 @@
-// MFMA attention core for gfx950 (bf16 storage, fp32 softmax), d_k = d_v = 64, n_k <= 256.
+// MFMA attention core for gfx950 (bf16 storage, fp32 softmax), d_k = d_v in {64, 96, 128}, n_k <= 256 (192 for the
+// larger heads).
 //
 // Whole K and V of one (batch, head) stay resident in LDS (sequences are <= 237, so a
 // single-tile kernel without online-softmax rescaling is the right shape).  Scores are computed
@@ -25,8 +26,21 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ int xs(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
-// byte offset of 16-byte chunk `ch` (0..7) of row `row` in a [rows][64 bf16] image
-__device__ __forceinline__ int img_off(int row, int ch) { return row * 128 + ((ch ^ xs(row)) << 4); }
+// Head size D (64, 96 or 128 features): an image row holds D bf16 in a pitch of 128 B (D = 64) or 256 B (D = 96, 128: one
+// full 64-bank row per image row; the 96-feature image leaves its last 4 chunk slots unused).  With the 256-B pitch the
+// XOR pattern takes the row's parity as a fourth bit: the 16 rows of a ds_read_b128 lane group then land on 16 distinct
+// 16-byte slots, and the 4 rows x 4 chunks x 2 halves of a transposing read cover the bank row exactly once -- both
+// read kinds stay conflict free, as with the 128-B pitch (where parity selects the half of the bank row instead).
+template <int D> struct Img {
+  static constexpr int PITCH = D <= 64 ? 128 : 256;
+  static constexpr int CH = D / 8;   // 16-byte chunks of a row
+  static constexpr int KS = D / 16;  // k steps of a 32x32x16 product over the features
+  static constexpr int DT = D / 32;  // 32-feature output tiles
+  static __device__ __forceinline__ int sw(int row) { return D <= 64 ? xs(row) : (xs(row) | ((row & 1) << 3)); }
+  // byte offset of 16-byte chunk `ch` of row `row`
+  static __device__ __forceinline__ int off(int row, int ch) { return row * PITCH + ((ch ^ sw(row)) << 4); }
+};
+__device__ __forceinline__ int img_off(int row, int ch) { return Img<64>::off(row, ch); }
 
 // One [rows_pad][64] bf16 LDS image to fill from `rows` rows of global memory (row stride ld), zero padded.
 struct ImgDesc {
@@ -39,11 +53,12 @@ struct ImgDesc {
 // Cooperative staging of N images.  All 16-byte loads of a pass (up to 4 per image per thread) are issued
 // before the first LDS store: the staging phase is pure latency (a (b,h) problem is only 10-60 KB), so the
 // number of loads in flight is what matters.
-template <int N>
+template <int N, int D = 64>
 __device__ __forceinline__ void load_images(const ImgDesc (&d)[N], int tid) {
+  constexpr int CH = Img<D>::CH;
   int maxtot = 0;
 #pragma unroll
-  for (int n = 0; n < N; n++) maxtot = max(maxtot, d[n].rows_pad * 8);
+  for (int n = 0; n < N; n++) maxtot = max(maxtot, d[n].rows_pad * CH);
   for (int e0 = tid; e0 < maxtot; e0 += 4 * 256) {
     uint4 v[N][4];
 #pragma unroll
@@ -51,9 +66,9 @@ __device__ __forceinline__ void load_images(const ImgDesc (&d)[N], int tid) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int e = e0 + u * 256;
-        const int row = e >> 3, ch = e & 7;
+        const int row = e / CH, ch = e % CH;
         v[n][u] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < d[n].rows_pad * 8 && row < d[n].rows)
+        if (e < d[n].rows_pad * CH && row < d[n].rows)
           v[n][u] = *reinterpret_cast<const uint4*>(d[n].src + (int64_t)row * d[n].ld + ch * 8);
       }
 #pragma unroll
@@ -61,7 +76,7 @@ __device__ __forceinline__ void load_images(const ImgDesc (&d)[N], int tid) {
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int e = e0 + u * 256;
-        if (e < d[n].rows_pad * 8) *reinterpret_cast<uint4*>(d[n].img + img_off(e >> 3, e & 7)) = v[n][u];
+        if (e < d[n].rows_pad * CH) *reinterpret_cast<uint4*>(d[n].img + Img<D>::off(e / CH, e % CH)) = v[n][u];
       }
   }
 }
@@ -73,17 +88,19 @@ __device__ __forceinline__ void load_mask_row(float* dst, const float* mask, int
 }
 
 // k-contiguous 32-row operand fragment (A or B of 32x32x16): lane -> row base+(lane&31), k = 16*ks + 8*(lane>>5) + j
+template <int D = 64>
 __device__ __forceinline__ bf16x8 frag_rows(const char* img, int base, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(img + img_off(base + (lane & 31), 2 * ks + (lane >> 5)));
+  return *reinterpret_cast<const bf16x8*>(img + Img<D>::off(base + (lane & 31), 2 * ks + (lane >> 5)));
 }
 // transposed operand fragment from a [k rows][64] image: lane -> column cbase+(lane&31),
 // element j <-> k row  kbase + 8*(j>>2) + 4*(lane>>5) + (j&3)   (the order an accumulator tile has)
+template <int D = 64>
 __device__ __forceinline__ bf16x8 frag_tr(const char* img, int kbase, int cbase, int lane) {
   const int row = kbase + 4 * (lane >> 5) + ((lane >> 2) & 3);
   const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int ch = col >> 3, sub = (col & 7) * 2;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off(row, ch) + sub));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + img_off(row + 8, ch) + sub));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + Img<D>::off(row, ch) + sub));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + Img<D>::off(row + 8, ch) + sub));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -96,13 +113,14 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // grid.x = ceil(B*H / G), grid.y = ceil(nq / (32*W)) ; W = query tiles per problem in this workgroup
 // ROWMASK: the mask is one fp32 row per (b,h) (key padding; staged in LDS, -inf beyond n_k) -- the common case,
 // compiled without the per-element bound checks / global mask reads; WANT_ATT: also write the probabilities.
-template <int NKT, bool ROWMASK, bool WANT_ATT>
+template <int NKT, bool ROWMASK, bool WANT_ATT, int D = 64>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, int W, int G) {
+  constexpr int PITCH = Img<D>::PITCH, KS = Img<D>::KS, DT = Img<D>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = 32 * W;                         // query rows staged per problem
-  const int prob_bytes = (q_rows + 2 * NKT * 32) * 128 + NKT * 32 * 4;  // Q | K | V | mask row
+  const int prob_bytes = (q_rows + 2 * NKT * 32) * PITCH + NKT * 32 * 4;  // Q | K | V | mask row
   const int slot = wave / W, tq = wave % W;
   const int q_blk0 = blockIdx.y * q_rows;
 
@@ -114,12 +132,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
     char* base = smem + g * prob_bytes;
     const int qr = min(q_rows, nq - q_blk0);
     const ImgDesc d[3] = {
-        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows},
-        {base + q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, NKT * 32},
-        {base + (q_rows + NKT * 32) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, NKT * 32}};
-    load_images<3>(d, tid);
+        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * D, a.ldq, qr, q_rows},
+        {base + q_rows * PITCH, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * D, a.ldk, nk, NKT * 32},
+        {base + (q_rows + NKT * 32) * PITCH, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * D, a.ldv, nk, NKT * 32}};
+    load_images<3, D>(d, tid);
     if (ROWMASK)
-      load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * 128),
+      load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * PITCH),
                     a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, NKT * 32, tid);
   }
   __syncthreads();
@@ -130,22 +148,22 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   const int q0 = q_blk0 + tq * 32;
   if (q0 >= nq) return;
   const char* Qs = smem + slot * prob_bytes;
-  const char* Ks = Qs + q_rows * 128;
-  const char* Vs = Ks + NKT * 32 * 128;
-  const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * 128);
+  const char* Ks = Qs + q_rows * PITCH;
+  const char* Vs = Ks + NKT * 32 * PITCH;
+  const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * PITCH);
 
   // ---- S^T = K Q^T  (rows = keys, columns = this wave's 32 queries)
-  bf16x8 qf[4];
+  bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
+  for (int ks = 0; ks < KS; ks++) qf[ks] = frag_rows<D>(Qs, tq * 32, ks, lane);
   f32x16 st[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; t++) {
 #pragma unroll
     for (int r = 0; r < 16; r++) st[t][r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++)
-      st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, t * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++)
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Ks, t * 32, ks, lane), qf[ks], st[t], 0, 0, 0);
   }
 
   // ---- softmax over keys (in-lane registers + the partner half-wave)
@@ -203,9 +221,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
   }
 
   // ---- O^T = V^T P^T : P^T accumulator registers are the B operand (k = key), V^T via transposing reads
-  f32x16 ot[2];
+  f32x16 ot[DT];
 #pragma unroll
-  for (int d = 0; d < 2; d++)
+  for (int d = 0; d < DT; d++)
 #pragma unroll
     for (int r = 0; r < 16; r++) ot[d][r] = 0.f;
 #pragma unroll
@@ -216,13 +234,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
 #pragma unroll
       for (int j = 0; j < 8; j++) pb[j] = (bf16)st[t][8 * s + j];
 #pragma unroll
-      for (int d = 0; d < 2; d++)
-        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vs, t * 32 + 16 * s, d * 32, lane), pb, ot[d], 0, 0, 0);
+      for (int d = 0; d < DT; d++)
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Vs, t * 32 + 16 * s, d * 32, lane), pb, ot[d], 0, 0, 0);
     }
   if (qok) {
-    bf16* orow = (bf16*)a.o + ((int64_t)b * nq + q) * a.ldo + h * 64;
+    bf16* orow = (bf16*)a.o + ((int64_t)b * nq + q) * a.ldo + h * D;
 #pragma unroll
-    for (int d = 0; d < 2; d++)
+    for (int d = 0; d < DT; d++)
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         bf16x4 o4;
@@ -237,13 +255,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
 // Kernel A: one wave = 32 queries (columns).  delta_q = dO_q . O_q ;  for every key tile:
 //   S^T = K Q^T, dP^T = V dO^T, P^T = exp(S^T*scale + mask - lse_q), dS^T = P^T (dP^T - delta_q),
 //   dQ^T += K^T dS^T   (K^T through transposing reads, dS^T straight from the accumulator registers).
-template <bool ROWMASK>
+template <bool ROWMASK, int D = 64>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nkt) {
+  constexpr int PITCH = Img<D>::PITCH, KS = Img<D>::KS, DT = Img<D>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = 32 * W, k_rows = nkt * 32;
-  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128 + k_rows * 4;  // Q | dO | K | V | mask row
+  const int prob_bytes = (2 * q_rows + 2 * k_rows) * PITCH + k_rows * 4;  // Q | dO | K | V | mask row
   const int slot = wave / W, tq = wave % W;
   const int q_blk0 = blockIdx.y * q_rows;
 
@@ -254,13 +273,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
     char* base = smem + g * prob_bytes;
     const int qr = min(q_rows, nq - q_blk0);
     const ImgDesc d[4] = {
-        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * 64, a.ldq, qr, q_rows},
-        {base + q_rows * 128, (const bf16*)a.d_o + ((int64_t)b * nq + q_blk0) * a.lddo + h * 64, a.lddo, qr, q_rows},
-        {base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
-        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
-    load_images<4>(d, tid);
+        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * D, a.ldq, qr, q_rows},
+        {base + q_rows * PITCH, (const bf16*)a.d_o + ((int64_t)b * nq + q_blk0) * a.lddo + h * D, a.lddo, qr, q_rows},
+        {base + 2 * q_rows * PITCH, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * D, a.ldk, nk, k_rows},
+        {base + (2 * q_rows + k_rows) * PITCH, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * D, a.ldv, nk, k_rows}};
+    load_images<4, D>(d, tid);
     if (a.msq == 0)
-      load_mask_row(reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * 128),
+      load_mask_row(reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * PITCH),
                     a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
   }
   __syncthreads();
@@ -271,22 +290,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   const int q0 = q_blk0 + tq * 32;
   if (q0 >= nq) return;
   const char* Qs = smem + slot * prob_bytes;
-  const char* Gs = Qs + q_rows * 128;
-  const char* Ks = Gs + q_rows * 128;
-  const char* Vs = Ks + k_rows * 128;
-  const float* mlds = reinterpret_cast<const float*>(Vs + k_rows * 128);
+  const char* Gs = Qs + q_rows * PITCH;
+  const char* Ks = Gs + q_rows * PITCH;
+  const char* Vs = Ks + k_rows * PITCH;
+  const float* mlds = reinterpret_cast<const float*>(Vs + k_rows * PITCH);
   constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
 
   const int q = q0 + (lane & 31);
   const bool qok = q < nq;
   const int qc = qok ? q : nq - 1;
-  // delta = dO . O over this lane's half of the 64 features, combined with the partner half-wave
+  // delta = dO . O over this lane's half of the D features, combined with the partner half-wave
   float delta = 0.f;
   {
-    const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * 64 + 32 * (lane >> 5);
-    const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * 64 + 32 * (lane >> 5);
+    const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * D + (D / 2) * (lane >> 5);
+    const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * D + (D / 2) * (lane >> 5);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < D / 16; c++) {
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
       const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
       const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
@@ -299,15 +318,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   if (qok && lane < 32) a.delta[((int64_t)b * a.H + h) * nq + q] = delta;
   const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
 
-  bf16x8 qf[4], gf[4];
+  bf16x8 qf[KS], gf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    qf[ks] = frag_rows(Qs, tq * 32, ks, lane);
-    gf[ks] = frag_rows(Gs, tq * 32, ks, lane);
+  for (int ks = 0; ks < KS; ks++) {
+    qf[ks] = frag_rows<D>(Qs, tq * 32, ks, lane);
+    gf[ks] = frag_rows<D>(Gs, tq * 32, ks, lane);
   }
-  f32x16 dqt[2];
+  f32x16 dqt[DT];
 #pragma unroll
-  for (int d = 0; d < 2; d++)
+  for (int d = 0; d < DT; d++)
 #pragma unroll
     for (int r = 0; r < 16; r++) dqt[d][r] = 0.f;
 
@@ -316,9 +335,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
 #pragma unroll
     for (int r = 0; r < 16; r++) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, t * 32, ks, lane), gf[ks], dp, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Ks, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Vs, t * 32, ks, lane), gf[ks], dp, 0, 0, 0);
     }
     float ds[16];
 #pragma unroll
@@ -339,14 +358,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
 #pragma unroll
       for (int j = 0; j < 8; j++) db[j] = (bf16)ds[8 * s + j];
 #pragma unroll
-      for (int d = 0; d < 2; d++)
-        dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, t * 32 + 16 * s, d * 32, lane), db, dqt[d], 0, 0, 0);
+      for (int d = 0; d < DT; d++)
+        dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Ks, t * 32 + 16 * s, d * 32, lane), db, dqt[d], 0, 0, 0);
     }
   }
   if (qok) {
-    bf16* drow = (bf16*)a.dq + ((int64_t)b * nq + q) * a.lddq + h * 64;
+    bf16* drow = (bf16*)a.dq + ((int64_t)b * nq + q) * a.lddq + h * D;
 #pragma unroll
-    for (int d = 0; d < 2; d++)
+    for (int d = 0; d < DT; d++)
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         bf16x4 o4;
@@ -360,13 +379,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
 // Kernel B: one wave = 32 keys (columns).  For every query tile (rows):
 //   S = Q K^T, dP = dO V^T, P = exp(S*scale + mask - lse_row), dS = P (dP - delta_row),
 //   dV^T += dO^T P ,  dK^T += Q^T dS    (dO^T / Q^T through transposing reads).
-template <bool ROWMASK>
+template <bool ROWMASK, int D = 64>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G, int nqt) {
+  constexpr int PITCH = Img<D>::PITCH, KS = Img<D>::KS, DT = Img<D>::DT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int k_rows = 32 * W, q_rows = nqt * 32;
-  const int prob_bytes = (2 * q_rows + 2 * k_rows) * 128 + 2 * q_rows * 4;  // Q | dO | K | V | lse | delta
+  const int prob_bytes = (2 * q_rows + 2 * k_rows) * PITCH + 2 * q_rows * 4;  // Q | dO | K | V | lse | delta
   const int slot = wave / W, tk = wave % W;
   const int k_blk0 = blockIdx.y * k_rows;
 
@@ -377,13 +397,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
     char* base = smem + g * prob_bytes;
     const int kr = min(k_rows, nk - k_blk0);
     const ImgDesc d[4] = {
-        {base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
-        {base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
-        {base + 2 * q_rows * 128, (const bf16*)a.k + ((int64_t)b * nk + k_blk0) * a.ldk + h * 64, a.ldk, kr, k_rows},
-        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + ((int64_t)b * nk + k_blk0) * a.ldv + h * 64, a.ldv, kr,
+        {base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * D, a.ldq, nq, q_rows},
+        {base + q_rows * PITCH, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * D, a.lddo, nq, q_rows},
+        {base + 2 * q_rows * PITCH, (const bf16*)a.k + ((int64_t)b * nk + k_blk0) * a.ldk + h * D, a.ldk, kr, k_rows},
+        {base + (2 * q_rows + k_rows) * PITCH, (const bf16*)a.v + ((int64_t)b * nk + k_blk0) * a.ldv + h * D, a.ldv, kr,
          k_rows}};
-    load_images<4>(d, tid);
-    float* ls = reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * 128);
+    load_images<4, D>(d, tid);
+    float* ls = reinterpret_cast<float*>(base + (2 * q_rows + 2 * k_rows) * PITCH);
     for (int i = tid; i < q_rows; i += 256) {
       ls[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
       ls[q_rows + i] = i < nq ? a.delta[((int64_t)b * a.H + h) * nq + i] : 0.f;
@@ -397,10 +417,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
   const int k0 = k_blk0 + tk * 32;
   if (k0 >= nk) return;
   const char* Qs = smem + slot * prob_bytes;
-  const char* Gs = Qs + q_rows * 128;
-  const char* Ks = Gs + q_rows * 128;
-  const char* Vs = Ks + k_rows * 128;
-  const float* ls = reinterpret_cast<const float*>(Vs + k_rows * 128);
+  const char* Gs = Qs + q_rows * PITCH;
+  const char* Ks = Gs + q_rows * PITCH;
+  const char* Vs = Ks + k_rows * PITCH;
+  const float* ls = reinterpret_cast<const float*>(Vs + k_rows * PITCH);
 
   const int key = k0 + (lane & 31);
   const bool kok = key < nk;
@@ -408,15 +428,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
   constexpr bool row_mask = ROWMASK;  // key-padding mask: one value per key column, i.e. per lane
   const float mconst = (row_mask && mcol) ? mcol[0] : 0.f;
 
-  bf16x8 kf[4], vf[4];
+  bf16x8 kf[KS], vf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    kf[ks] = frag_rows(Ks, tk * 32, ks, lane);
-    vf[ks] = frag_rows(Vs, tk * 32, ks, lane);
+  for (int ks = 0; ks < KS; ks++) {
+    kf[ks] = frag_rows<D>(Ks, tk * 32, ks, lane);
+    vf[ks] = frag_rows<D>(Vs, tk * 32, ks, lane);
   }
-  f32x16 dvt[2], dkt[2];
+  f32x16 dvt[DT], dkt[DT];
 #pragma unroll
-  for (int d = 0; d < 2; d++)
+  for (int d = 0; d < DT; d++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
 
@@ -425,9 +445,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 #pragma unroll
     for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) {
+      s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
     }
     float p[16], ds[16];
 #pragma unroll
@@ -447,17 +467,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 #pragma unroll
       for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s + j]; db[j] = (bf16)ds[8 * s + j]; }
 #pragma unroll
-      for (int d = 0; d < 2; d++) {
-        dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, t * 32 + 16 * s, d * 32, lane), pb, dvt[d], 0, 0, 0);
-        dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, t * 32 + 16 * s, d * 32, lane), db, dkt[d], 0, 0, 0);
+      for (int d = 0; d < DT; d++) {
+        dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Gs, t * 32 + 16 * s, d * 32, lane), pb, dvt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Qs, t * 32 + 16 * s, d * 32, lane), db, dkt[d], 0, 0, 0);
       }
     }
   }
   if (kok) {
-    bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
-    bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+    bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * D;
+    bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * D;
 #pragma unroll
-    for (int d = 0; d < 2; d++)
+    for (int d = 0; d < DT; d++)
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         bf16x4 k4, v4;
@@ -943,30 +963,88 @@ inline int pack_factor(int W, size_t prob_bytes) {
   return G < 1 ? 1 : G;
 }
 
-template <int NKT, bool ROWMASK, bool WANT_ATT>
-int launch_fwd_t(const ovqa::AttnArgs& a, hipStream_t st) {
-  int W = (a.nq + 31) / 32;
+// query tiles per problem and workgroup: as many as the queries need (1, 2 or 4), fewer if the images do not fit
+inline int fit_tiles(int n, size_t fixed_bytes, size_t bytes_per_tile) {
+  int W = (n + 31) / 32;
   if (W > 4) W = 4;
   if (W == 3) W = 4;
-  const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * 128 + NKT * 32 * 4;
+  while (W > 1 && fixed_bytes + (size_t)W * bytes_per_tile > 150 * 1024) W >>= 1;
+  return W;
+}
+
+template <int NKT, bool ROWMASK, bool WANT_ATT, int D>
+int launch_fwd_t(const ovqa::AttnArgs& a, hipStream_t st) {
+  constexpr int PITCH = Img<D>::PITCH;
+  const int W = fit_tiles(a.nq, (size_t)2 * NKT * 32 * PITCH + NKT * 32 * 4, (size_t)32 * PITCH);
+  const size_t prob = (size_t)(32 * W + 2 * NKT * 32) * PITCH + NKT * 32 * 4;
   const int G = pack_factor(W, prob);
   const size_t lds = (size_t)G * prob;
-  int rc = ensure_lds(attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT>, lds, "attention_fwd(mfma)");
+  int rc = ensure_lds(attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT, D>, lds, "attention_fwd(mfma)");
   if (rc != OVQA_OK) return rc;
   const int64_t nprob = (int64_t)a.B * a.H;
   dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT>), grid, dim3(256), lds, st, a, W, G);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT, D>), grid, dim3(256), lds, st, a, W, G);
   return ovqa_check_launch("attention_fwd(mfma)");
 }
 
-template <int NKT>
+template <int NKT, int D>
 int launch_fwd(const ovqa::AttnArgs& a, hipStream_t st) {
   const bool rowmask = a.msq == 0, att = a.att != nullptr;
-  if (rowmask) return att ? launch_fwd_t<NKT, true, true>(a, st) : launch_fwd_t<NKT, true, false>(a, st);
-  return att ? launch_fwd_t<NKT, false, true>(a, st) : launch_fwd_t<NKT, false, false>(a, st);
+  if (rowmask) return att ? launch_fwd_t<NKT, true, true, D>(a, st) : launch_fwd_t<NKT, true, false, D>(a, st);
+  return att ? launch_fwd_t<NKT, false, true, D>(a, st) : launch_fwd_t<NKT, false, false, D>(a, st);
+}
+
+template <int D>
+int launch_fwd_d(const ovqa::AttnArgs& a, hipStream_t st) {
+  if (a.nk <= 32) return launch_fwd<1, D>(a, st);
+  if (a.nk <= 64) return launch_fwd<2, D>(a, st);
+  if (a.nk <= 128) return launch_fwd<4, D>(a, st);
+  if (a.nk <= 192) return launch_fwd<6, D>(a, st);
+  if constexpr (D == 64) return launch_fwd<8, D>(a, st);
+  ovqa_set_error("attention_fwd(mfma): n_k = %d > 192 with heads of %d features", a.nk, D);
+  return OVQA_ERR_UNSUPPORTED;
+}
+
+// two-kernel backward (dQ, then dK/dV) for any supported head size
+template <int D>
+int launch_bwd_two(const ovqa::AttnBwdArgs& a, hipStream_t st) {
+  constexpr int PITCH = Img<D>::PITCH;
+  const int64_t nprob = (int64_t)a.B * a.H;
+  const bool rowmask = a.msq == 0;
+  {  // dQ: waves over query tiles, all keys resident
+    const int nkt = (a.nk + 31) / 32;
+    const int W = fit_tiles(a.nq, (size_t)2 * nkt * 32 * PITCH + nkt * 32 * 4, (size_t)2 * 32 * PITCH);
+    const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * PITCH + nkt * 32 * 4;
+    const int G = pack_factor(W, prob);
+    const size_t lds = (size_t)G * prob;
+    int rc = rowmask ? ensure_lds(attn_bwd_dq_mfma_kernel<true, D>, lds, "attention_bwd(mfma,dq)")
+                     : ensure_lds(attn_bwd_dq_mfma_kernel<false, D>, lds, "attention_bwd(mfma,dq)");
+    if (rc != OVQA_OK) return rc;
+    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
+    if (rowmask) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nkt);
+    else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nkt);
+    rc = ovqa_check_launch("attention_bwd(mfma,dq)");
+    if (rc != OVQA_OK) return rc;
+  }
+  {  // dK/dV: waves over key tiles, all queries resident
+    const int nqt = (a.nq + 31) / 32;
+    const int W = fit_tiles(a.nk, (size_t)2 * nqt * 32 * PITCH + 2 * nqt * 32 * 4, (size_t)2 * 32 * PITCH);
+    const size_t prob = (size_t)(2 * nqt * 32 + 2 * 32 * W) * PITCH + 2 * nqt * 32 * 4;
+    const int G = pack_factor(W, prob);
+    const size_t lds = (size_t)G * prob;
+    int rc = rowmask ? ensure_lds(attn_bwd_dkv_mfma_kernel<true, D>, lds, "attention_bwd(mfma,dkv)")
+                     : ensure_lds(attn_bwd_dkv_mfma_kernel<false, D>, lds, "attention_bwd(mfma,dkv)");
+    if (rc != OVQA_OK) return rc;
+    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));
+    if (rowmask) hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nqt);
+    else hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nqt);
+    return ovqa_check_launch("attention_bwd(mfma,dkv)");
+  }
 }
 
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
+  if (a.dk == 96) return launch_bwd_two<96>(a, st);
+  if (a.dk == 128) return launch_bwd_two<128>(a, st);
   const int64_t nprob = (int64_t)a.B * a.H;
   const bool rowmask = a.msq == 0;
   static int merged = -1;
@@ -1005,39 +1083,7 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel<false>, grid, block, lds, st, a, W, G);
     return ovqa_check_launch("attention_bwd(mfma,merged)");
   }
-  {  // dQ: waves over query tiles, all keys resident
-    int W = (a.nq + 31) / 32;
-    if (W > 4) W = 4;
-    if (W == 3) W = 4;
-    const int nkt = (a.nk + 31) / 32;
-    const size_t prob = (size_t)(2 * 32 * W + 2 * nkt * 32) * 128 + nkt * 32 * 4;
-    const int G = pack_factor(W, prob);
-    const size_t lds = (size_t)G * prob;
-    int rc = rowmask ? ensure_lds(attn_bwd_dq_mfma_kernel<true>, lds, "attention_bwd(mfma,dq)")
-                     : ensure_lds(attn_bwd_dq_mfma_kernel<false>, lds, "attention_bwd(mfma,dq)");
-    if (rc != OVQA_OK) return rc;
-    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-    if (rowmask) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, dim3(256), lds, st, a, W, G, nkt);
-    else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, dim3(256), lds, st, a, W, G, nkt);
-    rc = ovqa_check_launch("attention_bwd(mfma,dq)");
-    if (rc != OVQA_OK) return rc;
-  }
-  {  // dK/dV: waves over key tiles, all queries resident
-    int W = (a.nk + 31) / 32;
-    if (W > 4) W = 4;
-    if (W == 3) W = 4;
-    const int nqt = (a.nq + 31) / 32;
-    const size_t prob = (size_t)(2 * nqt * 32 + 2 * 32 * W) * 128 + 2 * nqt * 32 * 4;
-    const int G = pack_factor(W, prob);
-    const size_t lds = (size_t)G * prob;
-    int rc = rowmask ? ensure_lds(attn_bwd_dkv_mfma_kernel<true>, lds, "attention_bwd(mfma,dkv)")
-                     : ensure_lds(attn_bwd_dkv_mfma_kernel<false>, lds, "attention_bwd(mfma,dkv)");
-    if (rc != OVQA_OK) return rc;
-    dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));
-    if (rowmask) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, dim3(256), lds, st, a, W, G, nqt);
-    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, dim3(256), lds, st, a, W, G, nqt);
-    return ovqa_check_launch("attention_bwd(mfma,dkv)");
-  }
+  return launch_bwd_two<64>(a, st);
 }
 
 }  // namespace
@@ -1048,8 +1094,10 @@ bool mfma_attention_bwd_supported(const AttnBwdArgs& a) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   auto al8 = [](const void* p) { return ((uintptr_t)p & 7) == 0; };
   // gradients of the returned attention weights / log-sum-exp and dropout on the probabilities: VALU kernels
-  return a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && a.dk == 64 && a.dv == 64 && a.nk >= 1 &&
-         a.nk <= 256 && a.nq >= 1 && a.nq <= 256 &&
+  const bool d_ok = a.dk == a.dv && (a.dk == 64 || a.dk == 96 || a.dk == 128);
+  const int n_max = a.dk == 64 ? 256 : 192;  // what stays LDS-resident next to two 32-row tiles of the other side
+  return a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && d_ok && a.nk >= 1 &&
+         a.nk <= n_max && a.nq >= 1 && a.nq <= n_max &&
          a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.lddo % 8 == 0 && a.ldo % 4 == 0 && a.lddq % 4 == 0 &&
          a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && al(a.d_o) && al8(a.o) && al8(a.dq) &&
          al8(a.dk_) && al8(a.dv_) && a.lse && a.delta;
@@ -1059,16 +1107,16 @@ int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st) { return launch_bwd
 
 bool mfma_attention_supported(const AttnArgs& a) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  return a.drop.p <= 0.f && a.dk == 64 && a.dv == 64 && a.nk >= 1 && a.nk <= 256 && a.nq >= 1 && a.ldq % 8 == 0 &&
+  const bool d_ok = a.dk == a.dv && (a.dk == 64 || a.dk == 96 || a.dk == 128);
+  return a.drop.p <= 0.f && d_ok && a.nk >= 1 && a.nk <= (a.dk == 64 ? 256 : 192) && a.nq >= 1 && a.ldq % 8 == 0 &&
          a.ldk % 8 == 0 &&
          a.ldv % 8 == 0 && a.ldo % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && (((uintptr_t)a.o & 7) == 0);
 }
 
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st) {
-  if (a.nk <= 32) return launch_fwd<1>(a, st);
-  if (a.nk <= 64) return launch_fwd<2>(a, st);
-  if (a.nk <= 128) return launch_fwd<4>(a, st);
-  return launch_fwd<8>(a, st);
+  if (a.dk == 96) return launch_fwd_d<96>(a, st);
+  if (a.dk == 128) return launch_fwd_d<128>(a, st);
+  return launch_fwd_d<64>(a, st);
 }
 
 }  // namespace ovqa

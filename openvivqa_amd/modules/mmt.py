@@ -6,7 +6,7 @@ same constructor argument (a BertConfig-like object), same ``state_dict`` keys
 (``layer.{i}.attention.self.query.weight`` ...), so HF / reference checkpoints load.  A layer is exactly the two
 fused blocks of the hot path -- MHA block (QKV GEMM, attention with an additive (B,1,S,S) prefix-LM mask, output
 GEMM + dropout + residual, LayerNorm eps 1e-12) and FFN block (GEMM+GELU, GEMM + dropout + residual, LayerNorm).
-Heads of 96 features (768/8) run on the LDS-resident VALU attention kernel (the MFMA kernel tiles d = 64).
+Heads of 96 features (768/8) run on the MFMA attention kernels (256-byte LDS image rows; two-kernel backward).
 
 Dropout on the attention PROBABILITIES (attention_probs_dropout_prob, training only) runs inside the VALU attention
 kernels (ovqa_attention_fwd/bwd ``att_drop``); evaluation / decoding (BASELINE config 4) has none.

@@ -130,6 +130,12 @@ def test_dispatch_hook_reports_kernel_family():
     assert _lib.last_dispatch() == "simple"
     o.linear_fwd(rnd(37, 29, dtype=BF16), rnd(50, 29, dtype=BF16, seed=1), None)  # K % 8 != 0
     assert _lib.last_dispatch() == "simple"
+    for d in (96, 128):  # M4C's heads of 96 features, and 128
+        q, k = rnd(4, 182, 8 * d, dtype=BF16, seed=2), rnd(4, 182, 8 * d, dtype=BF16, seed=3)
+        out, lse, _ = o.attention_fwd(q, k, k, None, 8)
+        assert _lib.last_dispatch() == "mfma"
+        o.attention_bwd(rnd(4, 182, 8 * d, dtype=BF16, seed=4), q, k, k, out, lse, None, 8)
+        assert _lib.last_dispatch() == "mfma"
     for nq, nk in ((100, 100), (100, 20), (20, 20)):
         q = rnd(64, nq, 1536, dtype=BF16, seed=2)
         kv = rnd(64, nk, 1024, dtype=BF16, seed=3)
@@ -263,6 +269,9 @@ def test_layernorm_bwd_dropout_branch(dtype):
 
 ATT_SHAPES = [(2, 4, 5, 7, 8), (3, 8, 100, 100, 64), (2, 8, 100, 20, 64), (2, 8, 20, 20, 64), (2, 8, 20, 100, 64),
               (2, 2, 1, 7, 16), (1, 8, 237, 237, 64), (2, 8, 182, 182, 96),
+              # heads of 96 / 128 features on the MFMA kernels (256-byte image rows): M4C's 182 positions, short and
+              # ragged key counts, more queries than one workgroup's tiles
+              (2, 8, 12, 50, 96), (3, 4, 100, 100, 128), (2, 4, 150, 192, 96), (2, 4, 64, 128, 128), (2, 8, 33, 1, 96), (1, 8, 160, 64, 64),
               # merged small-n_k backward: 2 and 3(->4) query tiles, ragged packing (9 problems, 4 per workgroup)
               (3, 8, 50, 32, 64), (2, 8, 70, 13, 64), (5, 8, 128, 20, 64), (2, 8, 33, 1, 64), (3, 3, 20, 20, 64)]
 
