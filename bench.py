@@ -181,26 +181,27 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
 
 
 def instep_probe(ts, dom_hint=None):
-    """The GEMM kernel families INSIDE a real step: one eager forward+loss+backward of the captured workload with every
-    launch of a family bracketed by HIP events on the stream the kernels run on (torch's current stream, where the
-    C-ABI entry points launch).  A long gate kernel goes first, so that all ~240 launches and event records are
-    queued before the GPU starts the first one: the intervals contain kernel time, not host launch latency.
-    Operands are whatever the previous kernel of the step left behind (cold L2), unlike roofline_probe's replay of a
-    family on reused buffers.  profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same step: its
-    per-family average must agree with the figure returned here."""
-    from openvivqa_amd import ops
+    """The GEMM kernel families INSIDE a real step: one eager forward+loss+backward of the captured workload with the
+    library's launch timing armed (ovqa_launch_timing_begin/_end): every launch of the bf16 GEMM kernels carries its
+    own start / stop HIP events (hipExtLaunchKernel), which take the dispatch packet's begin / end timestamps on the
+    stream the kernel runs on -- the kernel's execution time as rocprofv3 --kernel-trace reports it, with no
+    event-record packets in between to calibrate away.  A long gate kernel goes first, so that all ~240 launches of
+    the step are queued before the GPU starts the first one (back to back, as in the graph replay).  Operands are
+    whatever the previous kernel of the step left behind (cold L2), unlike roofline_probe's replay of a family on
+    reused buffers.  profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same step: its per-family
+    average must agree with the figure returned here."""
+    import ctypes as C
+    from openvivqa_amd import _lib, ops
+    lib = _lib.load()
     recs = []
-    stream = torch.cuda.current_stream()
 
-    def bracket(fam_of, fn):
+    def tagged(fam_of, fn):
         def wrapped(*a, **kw):
-            fam, flops = fam_of(*a, **kw)
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record(stream)
+            n0 = lib.ovqa_launch_timing_count()
             out = fn(*a, **kw)
-            e1.record(stream)
-            e2.record(stream)  # empty bracket e1 -> e2: what a pair of event records costs by itself
-            recs.append((fam, flops, e0, e1, e2))
+            n1 = lib.ovqa_launch_timing_count()
+            if n1 == n0 + 1:  # exactly one timed GEMM launch (a VALU fallback records none)
+                recs.append((n0,) + fam_of(*a, **kw))
             return out
         return wrapped
 
@@ -218,25 +219,27 @@ def instep_probe(ts, dom_hint=None):
         return "dx", 2.0 * rows(dy) * wt.shape[0] * wt.shape[1]
 
     saved = (ops.linear_fwd, ops.linear_fwd_res32, ops.linear_bwd_data_wt)
-    ops.linear_fwd = bracket(fam_fwd, saved[0])
-    ops.linear_fwd_res32 = bracket(fam_res32, saved[1])
-    ops.linear_bwd_data_wt = bracket(fam_dx, saved[2])
+    ops.linear_fwd = tagged(fam_fwd, saved[0])
+    ops.linear_fwd_res32 = tagged(fam_res32, saved[1])
+    ops.linear_bwd_data_wt = tagged(fam_dx, saved[2])
+    cap = 4096
+    us = (C.c_float * cap)()
+    torch.cuda.synchronize()
+    _lib.check(lib.ovqa_launch_timing_begin(cap), "launch_timing_begin")
     try:
-        torch.cuda.synchronize()
         torch.cuda._sleep(200_000_000)  # gate (~0.1 s): the host queues the whole step behind it
         ts._fwd_bwd()
-        torch.cuda.synchronize()
     finally:
         ops.linear_fwd, ops.linear_fwd_res32, ops.linear_bwd_data_wt = saved
-    import statistics
-    # an event record is itself a barrier packet on the stream: the empty brackets measure that cost, and it is
-    # subtracted from every interval (profiles/README.md: the corrected figures match rocprofv3's averages)
-    overhead_ms = statistics.median(e1.elapsed_time(e2) for _, _, _, e1, e2 in recs)
-    fams = {"_event_pair_overhead_us": round(overhead_ms * 1e3, 2)}
-    for fam, flops, e0, e1, _ in recs:
+        n = lib.ovqa_launch_timing_end(us, cap)
+    if n < 0:
+        _lib.check(n, "launch_timing_end")
+    torch.cuda.synchronize()
+    fams = {}
+    for idx, fam, flops in recs:
         f = fams.setdefault(fam, {"launches": 0, "time_s": 0.0, "flops": 0.0})
         f["launches"] += 1
-        f["time_s"] += max(0.0, e0.elapsed_time(e1) - overhead_ms) * 1e-3
+        f["time_s"] += us[idx] * 1e-6
         f["flops"] += flops
     return fams
 
@@ -616,7 +619,6 @@ def main():
             warm = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
                                   cfg.MODEL.SELF_ENCODER.LAYERS)
             fams = instep_probe(ts)
-            ev_overhead = fams.pop("_event_pair_overhead_us")
             dom = max(fams, key=lambda k: fams[k]["time_s"])
             f = fams[dom]
             achieved = f["flops"] / f["time_s"] / 1e12
@@ -626,10 +628,11 @@ def main():
                 "kernel": KERNEL_OF_FAMILY[dom] + " ...>", "launches_per_step": f["launches"],
                 "avg_launch_us": round(f["time_s"] / f["launches"] * 1e6, 2),
                 "algorithmic_flops_per_launch": round(f["flops"] / f["launches"]),
-                "method": "in-step: HIP events around every launch of the family inside one eager step of the real "
-                          "workload (gate kernel first; cold operands), minus the cost of an empty event bracket "
-                          f"({ev_overhead} us, measured in the same pass); profiles/r02_step_kernel_stats.csv holds the "
-                          "rocprofv3 --kernel-trace --stats averages of the same step",
+                "method": "in-step: every launch of the family inside one eager step of the real workload carries its own "
+                          "start/stop HIP events (hipExtLaunchKernel via ovqa_launch_timing_begin/_end: the dispatch "
+                          "packet's begin/end timestamps on the launch stream; gate kernel first; cold operands); "
+                          "profiles/r02_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
+                          "the same step",
                 "families_in_step": {k: {"launches": v["launches"], "avg_launch_us": round(v["time_s"] / v["launches"] * 1e6, 2),
                                          "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in fams.items()},
                 "families_warm_replay": warm["families"],

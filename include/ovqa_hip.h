@@ -65,6 +65,18 @@ const char* ovqa_last_error(void);
  * single form).  With OVQA_REQUIRE_MFMA=1 in the environment a bf16 call that would fall back returns
  * OVQA_ERR_UNSUPPORTED instead, so a test can assert which kernel it validated. */
 const char* ovqa_last_dispatch(void);
+/* Launch timing (diagnostic, used by bench.py's roofline figure).  Between ovqa_launch_timing_begin(max) and
+ * ovqa_launch_timing_end(), every launch of the bf16 GEMM kernels behind ovqa_linear_fwd / ovqa_linear_fwd_res32 /
+ * ovqa_linear_bwd_data / ovqa_linear_bwd_data_wt made by this PROCESS (any thread: autograd runs backward on its
+ * own) carries a start / stop event pair
+ * (hipExtLaunchKernel): the dispatch packet's own begin / end timestamps, i.e. the kernel's execution time as
+ * rocprofv3 --kernel-trace reports it.  ovqa_launch_timing_count() = launches recorded so far (a caller maps its
+ * calls to records with it); ovqa_launch_timing_end(us, cap) waits for the recorded kernels, writes their durations
+ * in microseconds in launch order, returns their number (or a negative status) and disarms.  Not for use under
+ * stream capture; launches beyond `max` are not timed. */
+int ovqa_launch_timing_begin(int max_launches);
+int ovqa_launch_timing_count(void);
+int ovqa_launch_timing_end(float* us, int cap);
 /* Scratch bytes the caller must provide to the entry points that take `ws`. */
 int64_t ovqa_workspace_bytes(void);
 
@@ -243,6 +255,22 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
                        void* o, int64_t ldo, float* lse, void* att,
                        int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
                        float scale, const ovqa_dropout* att_drop, void* stream);
+
+/* Self-attention forward with the Q/K/V projections inside: MultiHeadAttention.forward with queries is keys is
+ * values (attentions.py:316-326 -> :49-57; the MCAN SA blocks, encoders.py:46-49, and the M4C MMT layers):
+ *     qkv[B*n, 3*H*d] = x[B*n, d_model] @ w^T + bias     (w = fc_q | fc_k | fc_v weight rows, packed [3*H*d, d_model];
+ *                                                         qkv is kept: the backward pass reads it)
+ *     o, lse          = attention(q = qkv[:, 0:H*d], k = qkv[:, H*d:2*H*d], v = qkv[:, 2*H*d:], mask)
+ * with nq = nk = n, dk = dv = d and a key mask (msq = 0) or none.  For bf16, d = 64, n <= 128 and d_model a multiple
+ * of 64 this is ONE kernel -- a workgroup projects the rows of a few samples for one head with MFMA, keeps the projected
+ * tiles in LDS and runs the attention on them; the projections are written to HBM once and never re-read in forward.
+ * Any other shape / dtype runs the two separate entry points (ovqa_linear_fwd + ovqa_attention_fwd): same results
+ * either way up to bf16 rounding of identical fp32 sums in a different order.  ovqa_last_dispatch() = "mfma-fused".
+ * ------------------------------------------------------------------------- */
+int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias,
+                           void* qkv, int64_t ldqkv, const float* mask, int64_t msb, int64_t msh,
+                           void* o, int64_t ldo, float* lse,
+                           int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale, void* stream);
 
 /* Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
  * the caller (rowsum(P*dP)); dq/dk/dv use the same [b,n,h*d+c] addressing.

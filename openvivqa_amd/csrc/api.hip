@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include "kernels.h"
 
@@ -50,6 +52,33 @@ static bool force_simple() {
   return v == 1;
 }
 
+// A/B switch: run self-attention as the separate projection GEMM + attention kernels (read per call: tests flip it)
+static bool no_fused_qkv() {
+  const char* e = getenv("OVQA_NO_FUSED_QKV");
+  return e && e[0] == '1';
+}
+
+// launch timing state: process-wide (autograd runs backward on its own thread), serialised by a mutex
+struct LaunchTimer {
+  hipEvent_t* ev = nullptr;  // 2 * cap events: start, stop per launch
+  int cap = 0, limit = 0, n = 0;  // events allocated, launches to record this time, launches recorded
+  bool on = false;
+};
+static LaunchTimer g_timer;
+static std::mutex g_timer_mu;
+static std::atomic<bool> g_timer_on{false};
+
+bool ovqa_timer_next(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_timer_on.load(std::memory_order_acquire)) return false;
+  std::lock_guard<std::mutex> lock(g_timer_mu);
+  LaunchTimer& t = g_timer;
+  if (!t.on || t.n >= t.limit) return false;
+  *start = t.ev[2 * t.n];
+  *stop = t.ev[2 * t.n + 1];
+  t.n++;
+  return true;
+}
+
 static inline bool dtype_ok(int d) { return d == OVQA_F32 || d == OVQA_BF16; }
 
 extern "C" {
@@ -57,6 +86,52 @@ extern "C" {
 int ovqa_abi_version(void) { return OVQA_ABI_VERSION; }
 const char* ovqa_last_error(void) { return g_err; }
 const char* ovqa_last_dispatch(void) { return g_dispatch; }
+
+int ovqa_launch_timing_begin(int max_launches) {
+  std::lock_guard<std::mutex> lock(g_timer_mu);
+  LaunchTimer& t = g_timer;
+  OVQA_REQUIRE(max_launches > 0 && max_launches <= 65536, OVQA_ERR_BAD_ARG, "launch_timing_begin: bad capacity");
+  OVQA_REQUIRE(!t.on, OVQA_ERR_BAD_ARG, "launch_timing_begin: already armed");
+  if (t.cap < max_launches) {
+    for (int i = 0; i < 2 * t.cap; i++) (void)hipEventDestroy(t.ev[i]);
+    free(t.ev);
+    t.ev = (hipEvent_t*)calloc((size_t)2 * max_launches, sizeof(hipEvent_t));
+    OVQA_REQUIRE(t.ev, OVQA_ERR_BAD_ARG, "launch_timing_begin: out of memory");
+    t.cap = 0;
+    for (int i = 0; i < 2 * max_launches; i++) {
+      hipError_t e = hipEventCreate(&t.ev[i]);
+      OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "launch_timing_begin: hipEventCreate: %s", hipGetErrorString(e));
+    }
+    t.cap = max_launches;
+  }
+  t.n = 0;
+  t.limit = max_launches;
+  t.on = true;
+  g_timer_on.store(true, std::memory_order_release);
+  return OVQA_OK;
+}
+
+int ovqa_launch_timing_count(void) {
+  std::lock_guard<std::mutex> lock(g_timer_mu);
+  return g_timer.n;
+}
+
+int ovqa_launch_timing_end(float* us, int cap) {
+  std::lock_guard<std::mutex> lock(g_timer_mu);
+  LaunchTimer& t = g_timer;
+  OVQA_REQUIRE(t.on, OVQA_ERR_BAD_ARG, "launch_timing_end: not armed");
+  t.on = false;
+  g_timer_on.store(false, std::memory_order_release);
+  OVQA_REQUIRE(us && cap >= t.n, OVQA_ERR_BAD_ARG, "launch_timing_end: output holds %d of %d launches", cap, t.n);
+  for (int i = 0; i < t.n; i++) {
+    hipError_t e = hipEventSynchronize(t.ev[2 * i + 1]);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
+    OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "launch_timing_end: launch %d: %s", i, hipGetErrorString(e));
+    us[i] = ms * 1e3f;
+  }
+  return t.n;
+}
 int64_t ovqa_workspace_bytes(void) { return ovqa::kWorkspaceBytes; }
 
 int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
@@ -245,6 +320,32 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
   }
   OVQA_FALLBACK("attention_fwd");
   return ovqa::simple_attention_fwd(dtype, a, as_stream(stream));
+}
+
+int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
+                           int64_t ldqkv, const float* mask, int64_t msb, int64_t msh, void* o, int64_t ldo, float* lse,
+                           int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_qkv_fwd: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && H > 0 && n >= 0 && d > 0 && d_model > 0, OVQA_ERR_BAD_ARG, "attention_qkv_fwd: bad sizes");
+  if (B == 0 || n == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && w && qkv && o, OVQA_ERR_BAD_ARG, "attention_qkv_fwd: null pointer");
+  OVQA_REQUIRE(ldx >= d_model && ldqkv >= 3 * H * d && ldo >= H * d, OVQA_ERR_BAD_ARG,
+               "attention_qkv_fwd: row stride smaller than the row");
+  OVQA_REQUIRE(B * H <= 0x7fffffff && B * n <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_qkv_fwd: batch too large");
+  const size_t es = dtype == OVQA_BF16 ? 2 : 4;
+  const char* qp = (const char*)qkv;
+  ovqa::AttnArgs a{qp, qp + (size_t)(H * d) * es, qp + (size_t)(2 * H * d) * es, ldqkv, ldqkv, ldqkv, mask, msb, msh, 0,
+                   o, ldo, lse, nullptr, (int)B, (int)H, (int)n, (int)n, (int)d, (int)d, scale, make_drop_args(nullptr)};
+  if (dtype == OVQA_BF16 && !force_simple() && !no_fused_qkv() &&
+      ovqa::mfma_attention_qkv_supported(a, d_model, ldx, ldqkv, x, w, qkv)) {
+    g_dispatch = "mfma-fused";
+    return ovqa::mfma_attention_qkv_fwd(a, x, ldx, w, bias, qkv, ldqkv, d_model, as_stream(stream));
+  }
+  int rc = ovqa_linear_fwd(dtype, OVQA_EPI_BIAS, x, ldx, w, bias, nullptr, 0, qkv, ldqkv, nullptr, B * n, 3 * H * d, d_model,
+                           nullptr, stream);
+  if (rc != OVQA_OK) return rc;
+  return ovqa_attention_fwd(dtype, a.q, ldqkv, a.k, ldqkv, a.v, ldqkv, mask, msb, msh, 0, o, ldo, lse, nullptr, B, H, n, n,
+                            d, d, scale, nullptr, stream);
 }
 
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,

@@ -113,49 +113,18 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // grid.x = ceil(B*H / G), grid.y = ceil(nq / (32*W)) ; W = query tiles per problem in this workgroup
 // ROWMASK: the mask is one fp32 row per (b,h) (key padding; staged in LDS, -inf beyond n_k) -- the common case,
 // compiled without the per-element bound checks / global mask reads; WANT_ATT: also write the probabilities.
-template <int NKT, bool ROWMASK, bool WANT_ATT, int D = 64>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, int W, int G) {
-  constexpr int PITCH = Img<D>::PITCH, KS = Img<D>::KS, DT = Img<D>::DT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One wave: 32 queries (q0 .. q0+31 of problem (b, h), staged at rows qrow0.. of the Q image) against all keys of the
+// problem's K / V images; writes o, lse (and the probabilities).  Shared by the plain forward kernel and by the fused
+// projection + attention kernel.
+template <int NKT, bool ROWMASK, bool WANT_ATT, int D>
+__device__ __forceinline__ void attn_fwd_core(const ovqa::AttnArgs& a, int b, int h, int q0, int qrow0, const char* Qs,
+                                              const char* Ks, const char* Vs, const float* mlds, int lane) {
+  constexpr int KS = Img<D>::KS, DT = Img<D>::DT;
   const int nk = a.nk, nq = a.nq;
-  const int q_rows = 32 * W;                         // query rows staged per problem
-  const int prob_bytes = (q_rows + 2 * NKT * 32) * PITCH + NKT * 32 * 4;  // Q | K | V | mask row
-  const int slot = wave / W, tq = wave % W;
-  const int q_blk0 = blockIdx.y * q_rows;
-
-  // ---- stage Q / K / V of the G problems of this workgroup (all threads)
-  for (int g = 0; g < G; g++) {
-    const int64_t pid = (int64_t)blockIdx.x * G + g;
-    if (pid >= (int64_t)a.B * a.H) break;
-    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
-    char* base = smem + g * prob_bytes;
-    const int qr = min(q_rows, nq - q_blk0);
-    const ImgDesc d[3] = {
-        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * D, a.ldq, qr, q_rows},
-        {base + q_rows * PITCH, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * D, a.ldk, nk, NKT * 32},
-        {base + (q_rows + NKT * 32) * PITCH, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * D, a.ldv, nk, NKT * 32}};
-    load_images<3, D>(d, tid);
-    if (ROWMASK)
-      load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * PITCH),
-                    a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, NKT * 32, tid);
-  }
-  __syncthreads();
-
-  const int64_t pid = (int64_t)blockIdx.x * G + slot;
-  if (slot >= G || pid >= (int64_t)a.B * a.H) return;
-  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
-  const int q0 = q_blk0 + tq * 32;
-  if (q0 >= nq) return;
-  const char* Qs = smem + slot * prob_bytes;
-  const char* Ks = Qs + q_rows * PITCH;
-  const char* Vs = Ks + NKT * 32 * PITCH;
-  const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * PITCH);
-
   // ---- S^T = K Q^T  (rows = keys, columns = this wave's 32 queries)
   bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ks++) qf[ks] = frag_rows<D>(Qs, tq * 32, ks, lane);
+  for (int ks = 0; ks < KS; ks++) qf[ks] = frag_rows<D>(Qs, qrow0, ks, lane);
   f32x16 st[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; t++) {
@@ -249,6 +218,184 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, in
         *reinterpret_cast<bf16x4*>(orow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
       }
   }
+}
+
+template <int NKT, bool ROWMASK, bool WANT_ATT, int D = 64>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(ovqa::AttnArgs a, int W, int G) {
+  constexpr int PITCH = Img<D>::PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  const int q_rows = 32 * W;                         // query rows staged per problem
+  const int prob_bytes = (q_rows + 2 * NKT * 32) * PITCH + NKT * 32 * 4;  // Q | K | V | mask row
+  const int slot = wave / W, tq = wave % W;
+  const int q_blk0 = blockIdx.y * q_rows;
+
+  // ---- stage Q / K / V of the G problems of this workgroup (all threads)
+  for (int g = 0; g < G; g++) {
+    const int64_t pid = (int64_t)blockIdx.x * G + g;
+    if (pid >= (int64_t)a.B * a.H) break;
+    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+    char* base = smem + g * prob_bytes;
+    const int qr = min(q_rows, nq - q_blk0);
+    const ImgDesc d[3] = {
+        {base, (const bf16*)a.q + ((int64_t)b * nq + q_blk0) * a.ldq + h * D, a.ldq, qr, q_rows},
+        {base + q_rows * PITCH, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * D, a.ldk, nk, NKT * 32},
+        {base + (q_rows + NKT * 32) * PITCH, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * D, a.ldv, nk, NKT * 32}};
+    load_images<3, D>(d, tid);
+    if (ROWMASK)
+      load_mask_row(reinterpret_cast<float*>(base + (q_rows + 2 * NKT * 32) * PITCH),
+                    a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, NKT * 32, tid);
+  }
+  __syncthreads();
+
+  const int64_t pid = (int64_t)blockIdx.x * G + slot;
+  if (slot >= G || pid >= (int64_t)a.B * a.H) return;
+  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  const int q0 = q_blk0 + tq * 32;
+  if (q0 >= nq) return;
+  const char* Qs = smem + slot * prob_bytes;
+  const char* Ks = Qs + q_rows * PITCH;
+  const char* Vs = Ks + NKT * 32 * PITCH;
+  const float* mlds = reinterpret_cast<const float*>(Vs + NKT * 32 * PITCH);
+  attn_fwd_core<NKT, ROWMASK, WANT_ATT, D>(a, b, h, q0, tq * 32, Qs, Ks, Vs, mlds, lane);
+}
+
+// ------------------------------------------------------------------------- fused Q/K/V projection + attention
+// Self-attention forward with the projections inside (hard part 1): a workgroup owns S samples of
+// ONE head -- x rows [S * RP][512] against the head's 192 weight rows (64 of fc_q, fc_k, fc_v each) -- computes
+// Q | K | V = x W_h^T + b with the GEMM main loop of gemm_mfma.hip (v_mfma_f32_16x16x32_bf16, direct-to-LDS ring of two
+// K tiles, XOR-swizzled [rows][64] images, weight rows staged in the permuted order that gives a lane 8 consecutive
+// output features), stores the bf16 projections BOTH to HBM (backward needs them) and into the LDS images the
+// attention core reads, and runs that core on them: the projected Q, K, V are never re-read from HBM, the separate
+// QKV GEMM launch is gone, and per x row panel the head's weights are streamed once for S samples.
+//   RP = rows per sample, padded (32, 64 or 128; rows beyond n re-read row n-1: finite, masked / not stored),
+//   M = S * RP = 128 or 256 GEMM rows per workgroup, 8 waves as 4 (rows) x 2 (features): NI = M / 64 row units x 6
+//   feature units of 16 per wave.  Attention: wave w takes query tile w % (RP/32) of sample w / (RP/32).
+__device__ __forceinline__ int kc_off(int row, int chunk) { return (row * 8 + (chunk ^ (row & 7))) * 16; }
+__device__ __forceinline__ int perm32(int t) { return (t & ~31) | ((t & 12) << 1) | (((t >> 4) & 1) << 2) | (t & 3); }
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+struct QkvAttnArgs {
+  const bf16* x; int64_t ldx;       // [B * n, Dm]
+  const bf16* w;                    // packed [3 * H * 64, Dm]: fc_q | fc_k | fc_v rows
+  const float* bias;                // [3 * H * 64] or nullptr
+  bf16* qkv; int64_t ldqkv;         // [B * n, 3 * H * 64] out
+  ovqa::AttnArgs att;               // o, ldo, lse, mask (row mask or none), B, H, nq = nk = n, scale
+  int Dm;
+};
+
+template <int RP, int S, bool ROWMASK>
+__global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
+  constexpr int M = RP * S, NI = M / 64, NJ = 6, NKT = RP / 32, TQ = RP / 32;
+  constexpr int WCH = 24, XCH = M / 8;               // 1 KiB staging pieces (8 rows x 128 B) of the W / x tiles
+  constexpr int PER = (WCH + XCH) / 8;               // per wave and K tile
+  constexpr int STAGE = (WCH + XCH) * 1024;
+  static_assert((WCH + XCH) % 8 == 0, "pieces divide over 8 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ovqa::AttnArgs& a = g.att;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wr = wave & 1;
+  const int h = blockIdx.y, b0 = blockIdx.x * S, n = a.nq, HD = a.H * 64;
+
+  f32x4 acc[NJ][NI];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt & 1) * STAGE;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int ci = wave * PER + i;
+      const int pos = lane & 7;
+      const bf16* src;
+      if (ci < WCH) {  // weight rows of this head: tile row t -> kind t/64 (q, k, v), feature t%64, permuted within 32
+        const int row = ci * 8 + (lane >> 3);
+        const int t = perm32(row);
+        src = g.w + (int64_t)((t >> 6) * HD + h * 64 + (t & 63)) * g.Dm + k0 + ((pos ^ (row & 7)) << 3);
+      } else {         // x rows: sample (row / RP), position clamped to the sample's last row
+        const int row = (ci - WCH) * 8 + (lane >> 3);
+        int bs = b0 + row / RP;
+        bs = bs < a.B ? bs : a.B - 1;
+        int r = row % RP;
+        r = r < n ? r : n - 1;
+        src = g.x + ((int64_t)bs * n + r) * g.ldx + k0 + ((pos ^ (row & 7)) << 3);
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + ci * 1024), 16, 0, 0);
+    }
+  };
+  const int nkt = g.Dm / 64;
+  issue(0);
+  for (int kt = 0; kt < nkt; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue(kt + 1);
+    const char* Ws = smem + (kt & 1) * STAGE;
+    const char* Xs = Ws + WCH * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 pf[NJ], qf[NI];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + kc_off(wr * 96 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + kc_off(wc * (NI * 16) + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with the staging buffers: they become the Q | K | V images
+
+  // ---- epilogue: + bias -> bf16 -> HBM (rows < n) and the LDS images [sample][kind][RP rows][64]
+  float* mrow_s = reinterpret_cast<float*>(smem + S * 3 * RP * 128);  // [S][RP] mask rows behind the images
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int row = wc * (NI * 16) + i * 16 + (lane & 15);
+    const int sm = row / RP, r = row % RP;
+    const int bs = b0 + sm;
+#pragma unroll
+    for (int jp = 0; jp < NJ / 2; jp++) {
+      const int f = wr * 96 + jp * 32 + (lane >> 4) * 8;  // 8 consecutive features of one of q / k / v
+      const int kind = f >> 6, col = f & 63;
+      const int gcol = kind * HD + h * 64 + col;
+      float u[8] = {acc[2 * jp][i][0], acc[2 * jp][i][1], acc[2 * jp][i][2], acc[2 * jp][i][3],
+                    acc[2 * jp + 1][i][0], acc[2 * jp + 1][i][1], acc[2 * jp + 1][i][2], acc[2 * jp + 1][i][3]};
+      if (g.bias) {
+        const float4 c0 = *reinterpret_cast<const float4*>(g.bias + gcol), c1 = *reinterpret_cast<const float4*>(g.bias + gcol + 4);
+        u[0] += c0.x; u[1] += c0.y; u[2] += c0.z; u[3] += c0.w; u[4] += c1.x; u[5] += c1.y; u[6] += c1.z; u[7] += c1.w;
+      }
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o8[e] = (bf16)u[e];
+      *reinterpret_cast<bf16x8*>(smem + ((sm * 3 + kind) * RP) * 128 + Img<64>::off(r, col >> 3)) = o8;
+      if (bs < a.B && r < n) *reinterpret_cast<bf16x8*>(g.qkv + ((int64_t)bs * n + r) * g.ldqkv + gcol) = o8;
+    }
+  }
+  if (ROWMASK) {
+    for (int e = tid; e < S * RP; e += 512) {
+      const int sm = e / RP, j = e % RP;
+      int bs = b0 + sm;
+      bs = bs < a.B ? bs : a.B - 1;
+      const float* mr = a.mask ? a.mask + (int64_t)bs * a.msb + (int64_t)h * a.msh : nullptr;
+      mrow_s[e] = j < n ? (mr ? mr[j] : 0.f) : -INFINITY;
+    }
+  }
+  __syncthreads();
+
+  // ---- attention on the images: one wave per (sample, 32-query tile)
+  const int sm = wave / TQ, tq = wave % TQ;
+  if (sm >= S || b0 + sm >= a.B || tq * 32 >= n) return;
+  const char* Qs = smem + (sm * 3 + 0) * RP * 128;
+  const char* Ks = smem + (sm * 3 + 1) * RP * 128;
+  const char* Vs = smem + (sm * 3 + 2) * RP * 128;
+  attn_fwd_core<NKT, ROWMASK, false, 64>(a, b0 + sm, h, tq * 32, tq * 32, Qs, Ks, Vs, mrow_s + sm * RP, lane);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -1111,6 +1258,35 @@ bool mfma_attention_supported(const AttnArgs& a) {
   return a.drop.p <= 0.f && d_ok && a.nk >= 1 && a.nk <= (a.dk == 64 ? 256 : 192) && a.nq >= 1 && a.ldq % 8 == 0 &&
          a.ldk % 8 == 0 &&
          a.ldv % 8 == 0 && a.ldo % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && (((uintptr_t)a.o & 7) == 0);
+}
+
+bool mfma_attention_qkv_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldqkv, const void* x, const void* w,
+                                  const void* qkv) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return a.dk == 64 && a.dv == 64 && a.nq == a.nk && a.nq >= 1 && a.nq <= 128 && Dm % 64 == 0 && Dm >= 64 && ldx % 8 == 0 &&
+         ldqkv % 8 == 0 && a.ldo % 4 == 0 && a.msq == 0 && a.att == nullptr && a.drop.p <= 0.f && al(x) && al(w) &&
+         al(qkv) && (((uintptr_t)a.o & 7) == 0);
+}
+
+int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
+                           int64_t ldqkv, int64_t Dm, hipStream_t st) {
+  QkvAttnArgs g{(const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)qkv, ldqkv, a, (int)Dm};
+  // the key mask row (zeros when there is no mask, -inf beyond n) always lives in LDS: ROWMASK = true
+#define OVQA_QKV(RPV, SV)                                                                                          \
+  {                                                                                                                \
+    constexpr int Mv = RPV * SV;                                                                                   \
+    const size_t stage = (size_t)(24 + Mv / 8) * 1024, images = (size_t)SV * 3 * RPV * 128 + (size_t)SV * RPV * 4;  \
+    const size_t lds = 2 * stage > images ? 2 * stage : images;                                                    \
+    const dim3 grid((unsigned)((a.B + SV - 1) / SV), (unsigned)a.H);                                               \
+    int rc = ensure_lds(attn_qkv_fwd_mfma_kernel<RPV, SV, true>, lds, "attention_qkv_fwd");                        \
+    if (rc != OVQA_OK) return rc;                                                                                  \
+    hipLaunchKernelGGL((attn_qkv_fwd_mfma_kernel<RPV, SV, true>), grid, dim3(512), lds, st, g);                    \
+  }
+  if (a.nq <= 32) OVQA_QKV(32, 4)
+  else if (a.nq <= 64) OVQA_QKV(64, 4)
+  else OVQA_QKV(128, 2)
+#undef OVQA_QKV
+  return ovqa_check_launch("attention_qkv_fwd(mfma)");
 }
 
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st) {

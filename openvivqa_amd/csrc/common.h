@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/ovqa_hip.h"
@@ -32,6 +33,20 @@ static inline int ovqa_check_launch(const char* what) {
   }
   return OVQA_OK;
 }
+
+// ---- launch timing (diagnostic; ovqa_launch_timing_begin / _end) -------------------------------------------
+// While armed, the instrumented launches go through hipExtLaunchKernelGGL with a start / stop event pair: the events
+// take the dispatch packet's own begin / end timestamps -- the kernel's execution time as rocprofv3 --kernel-trace
+// reports it, free of the cost of separate event-record packets around the launch.
+bool ovqa_timer_next(hipEvent_t* start, hipEvent_t* stop);
+#define OVQA_LAUNCH_TIMED(kernel, grid, block, lds, st, ...)                              \
+  do {                                                                                    \
+    hipEvent_t t0_ = nullptr, t1_ = nullptr;                                              \
+    if (ovqa_timer_next(&t0_, &t1_))                                                      \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t0_, t1_, 0, __VA_ARGS__);      \
+    else                                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                      \
+  } while (0)
 
 // ---- scalar conversion -----------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -702,7 +702,7 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     const size_t lds = (size_t)NBUF * (TILE_BYTES + BCV * BK * 2);                                                 \
     int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>, lds);                                  \
     if (rc != OVQA_OK) return rc;                                                                                  \
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>), grid, dim3(NW * 64), lds, st, g, epi); \
+    OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>), grid, dim3(NW * 64), lds, st, g, epi);  \
   }
   if constexpr (!QK) {
     if (tiny_c) {
@@ -728,7 +728,7 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     case 12: OVQA_GLDS(2, 8, 128) break;
     case 13: OVQA_GLDS(3, 8, 128) break;
     default:
-      hipLaunchKernelGGL((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
+      OVQA_LAUNCH_TIMED((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
   }
 #undef OVQA_GLDS
   return ovqa_check_launch(what);

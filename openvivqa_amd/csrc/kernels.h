@@ -59,6 +59,10 @@ int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);
 // ---- attention_mfma.hip (bf16, d=64, nk<=256) --------------------------------------
 bool mfma_attention_supported(const AttnArgs& a);
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st);
+bool mfma_attention_qkv_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldqkv, const void* x, const void* w,
+                                  const void* qkv);
+int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
+                           int64_t ldqkv, int64_t Dm, hipStream_t st);
 bool mfma_attention_bwd_supported(const AttnBwdArgs& a);
 int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st);
 

@@ -282,6 +282,24 @@ def _project_qkv(st, queries, keys, values):
     return q, k, v, "general", (q, k, v)
 
 
+def _project_and_attend(st, queries, keys, values, mask, save_lse=True):
+    """Projections + attention core of a MultiHeadAttention call -> (o, lse, mode, saved projection buffers).
+    Self-attention with a key mask (or none) and no probability dropout goes through ``ovqa_attention_qkv_fwd``:
+    one kernel for the packed projection and the attention where the shape allows, the two separate kernels
+    (inside the library) otherwise."""
+    a, arena = st["att"], st["arena"]
+    if (st.get("pre_kv") is None and queries is keys and keys is values and st.get("att_drop") is None
+            and (mask is None or mask.shape[2] == 1) and a.fc_q.weight.shape[0] == a.fc_v.weight.shape[0]):
+        wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
+        qkv, o, lse = ops.attention_qkv_fwd(queries, arena.packed([wq, wk, wv]),
+                                            arena.packed([a.fc_q.bias, a.fc_k.bias, a.fc_v.bias], "master"), mask, a.h,
+                                            save_lse=save_lse)
+        return o, lse, "self", (qkv,)
+    q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
+    o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"))
+    return o, lse, mode, bufs
+
+
 class _MHABlock(Function):
     """LN(queries + dropout(fc_o(attention(fc_q(queries), fc_k(keys), fc_v(values)))))."""
 
@@ -289,8 +307,7 @@ class _MHABlock(Function):
     def forward(ctx, queries, keys, values, mask, st, *params):
         arena, a, ln = st["arena"], st["att"], st["ln"]
         queries, keys, values = _canon(queries, keys, values, st["same"])
-        q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
-        o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, att_drop=st.get("att_drop"))
+        o, lse, mode, bufs = _project_and_attend(st, queries, keys, values, mask)
         drop = st["drop"]
         if queries.dtype == torch.bfloat16:  # fp32 residual stream: fp32 pre-LN sum, bf16 operand out
             pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
@@ -382,8 +399,7 @@ def mha_block(queries, keys, values, mask, st, projected_kv=None):
         return _attach(_MHABlock.apply(queries, keys, values, mask, st, *st["params"]), st)
     arena, a, ln = st["arena"], st["att"], st["ln"]
     queries, keys, values = _canon(queries, keys, values, st["same"])
-    q, k, v, _, _ = _project_qkv(st, queries, keys, values)
-    o, _, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=False, att_drop=st.get("att_drop"))
+    o, _, _, _ = _project_and_attend(st, queries, keys, values, mask, save_lse=False)
     if bf16:
         pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
                                    drop=st["drop"])

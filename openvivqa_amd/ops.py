@@ -522,6 +522,28 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, a
     return o, lse, att
 
 
+def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True):
+    """Self-attention forward with the packed projections inside (``ovqa_attention_qkv_fwd``): x [B,n,d_model],
+    w [3*H*d, d_model] (fc_q | fc_k | fc_v rows), bias fp32 [3*H*d] -> (qkv [B,n,3*H*d], o [B,n,H*d], lse).
+    ``mask``: key mask (b|1, h|1, 1, n) or None."""
+    _dev(x)
+    lib = _lib.load()
+    B, n, Dm = x.shape
+    d = w.shape[0] // (3 * H)
+    assert w.shape[0] == 3 * H * d and w.shape[1] == Dm and w.is_contiguous() and w.dtype == x.dtype
+    ldx, _ = _rows(x)
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    qkv = torch.empty(B, n, 3 * H * d, dtype=x.dtype, device=x.device)
+    o = torch.empty(B, n, H * d, dtype=x.dtype, device=x.device)
+    lse = torch.empty(B, H, n, dtype=torch.float32, device=x.device) if save_lse else None
+    mask, sb, sh, sq = _mask_strides(mask, B, H, n, n)
+    assert sq == 0, "attention_qkv_fwd takes a key mask (one row per (b, h))"
+    _lib.check(lib.ovqa_attention_qkv_fwd(_dt(x), _p(x), ldx, _p(w), _p(bias), _p(qkv), 3 * H * d, _p(mask), sb, sh,
+                                          _p(o), H * d, _p(lse), B, H, n, Dm, d, float(scale), _stream()),
+               "attention_qkv_fwd")
+    return qkv, o, lse
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None):
     _dev(q)

@@ -182,6 +182,13 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, a
     return o, torch.logsumexp(s, -1), (p.to(q.dtype) if need_att else None)
 
 
+def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True):
+    qkv = linear_fwd(x, w, bias)
+    n3 = qkv.shape[-1] // 3
+    o, lse, _ = attention_fwd(qkv[..., :n3], qkv[..., n3:2 * n3], qkv[..., 2 * n3:], mask, H, scale, save_lse=save_lse)
+    return qkv, o, lse
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None):
     assert att_drop is None or att_drop.p == 0

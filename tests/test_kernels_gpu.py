@@ -525,6 +525,88 @@ def test_errors_are_loud():
         o.layernorm_fwd(rnd(4, 12), torch.ones(12, device=DEV), torch.zeros(12, device=DEV))  # D % 8 != 0
 
 
+def test_launch_timing_hook():
+    """ovqa_launch_timing_begin/_end: per-launch kernel durations of the bf16 GEMM kernels (bench.py's roofline figure
+    is built on them).  Counts only MFMA GEMM launches, in order, also from another thread; durations are sane."""
+    import ctypes as C
+    import threading
+    from openvivqa_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    x, w, b = rnd(6400, 512, dtype=BF16), rnd(512, 512, dtype=BF16, scale=0.05), rnd(512)
+    o.linear_fwd(x, w, b)  # warm
+    torch.cuda.synchronize()
+    assert lib.ovqa_launch_timing_begin(8) == 0
+    assert lib.ovqa_launch_timing_begin(8) != 0          # already armed
+    o.linear_fwd(x, w, b)
+    o.linear_fwd(x.float(), w.float(), b)                # fp32: VALU kernel, not recorded
+    assert lib.ovqa_launch_timing_count() == 1
+    t = threading.Thread(target=lambda: o.linear_bwd_data(x, w))   # autograd runs backward on its own thread
+    t.start()
+    t.join()
+    assert lib.ovqa_launch_timing_count() == 2
+    us = (C.c_float * 8)()
+    assert lib.ovqa_launch_timing_end(us, 1) < 0          # output too small; disarms
+    assert lib.ovqa_launch_timing_begin(2) == 0
+    for _ in range(3):
+        o.linear_fwd(x, w, b)                             # the third launch is beyond the capacity: not timed
+    n = lib.ovqa_launch_timing_end(us, 8)
+    assert n == 2
+    assert all(2.0 < us[i] < 500.0 for i in range(n)), list(us)[:n]   # 3.4 GFLOP: ~10 us on an MI355X
+    assert lib.ovqa_launch_timing_end(us, 8) < 0          # not armed
+
+
+QKV_SHAPES = [
+    # B, n, H, d_model, masked   (d = 64: the fused kernel; anything else: the library's two-kernel route)
+    (64, 100, 8, 512, True),    # MCAN vision SA (BASELINE configs[1]): 128-row panels, 2 samples / workgroup
+    (64, 20, 8, 512, True),     # MCAN text SA: 32-row panels, 4 samples / workgroup
+    (7, 49, 8, 512, True),      # 64-row panels, ragged last workgroup (7 = 4 + 3 samples)
+    (3, 128, 4, 256, False),    # full panel, no mask, odd batch
+    (5, 1, 8, 512, False),      # a single position
+    (2, 33, 12, 768, True),     # BERT-base geometry (M4C MMT): d_model = 768, 12 heads
+    (2, 150, 8, 512, True),     # n > 128: separate kernels
+    (2, 20, 4, 384, False),     # d = 96: separate kernels
+]
+
+
+@pytest.mark.parametrize("B,n,H,Dm,masked", QKV_SHAPES)
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_attention_qkv_fwd(B, n, H, Dm, masked, dtype):
+    """Fused projection + attention (ovqa_attention_qkv_fwd) against fp64 math AND against the separate
+    ovqa_linear_fwd + ovqa_attention_fwd route on the same inputs; the stored projections must equal the
+    separate GEMM's output (backward reads them)."""
+    o = ops()
+    d = (Dm // H) if Dm != 384 else 96
+    x = rnd(B, n, Dm, dtype=dtype, seed=1)
+    w = rnd(3 * H * d, Dm, dtype=dtype, scale=Dm ** -0.5, seed=2)
+    b = rnd(3 * H * d, scale=0.1, seed=3)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, 1, 1, n, device=DEV)
+        for i in range(B):
+            mask[i, ..., n - (i % max(1, n // 2)):] = -1e5 if i % 3 else float("-inf")
+        mask[0] = 0
+        if n > 4 and dtype == BF16:  # (fp32: score + (-1e5) rounds to 2^-7, which the fp64 reference does not do)
+            mask[B - 1, ..., :] = -1e5  # a fully padded sample: uniform attention (models/utils.py:44-73 semantics)
+    qkv, out, lse = o.attention_qkv_fwd(x, w, b, mask, H)
+    from openvivqa_amd import _lib
+    disp = _lib.last_dispatch()
+    assert (disp == "mfma-fused") == (dtype == BF16 and d == 64 and n <= 128), (disp, d, n)
+    qkv_ref = (x.double() @ w.double().t() + b.double())
+    assert nerr(qkv, qkv_ref) < tol(dtype)
+    hd = H * d
+    q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
+    ref, _, lse_ref = att_ref(q, k, v, mask, H)   # attention of the STORED projections
+    ok = torch.isfinite(lse_ref)
+    assert nerr(out, ref) < tol(dtype)
+    assert nerr(torch.where(ok, lse, 0), torch.where(ok, lse_ref.to(lse.dtype), 0)) < tol(dtype)
+    # the two-kernel route on the same inputs
+    qkv2 = o.linear_fwd(x, w, b)
+    out2, lse2, _ = o.attention_fwd(qkv2[..., :hd], qkv2[..., hd:2 * hd], qkv2[..., 2 * hd:], mask, H)
+    assert nerr(qkv, qkv2) < (1e-6 if dtype == F32 else 8e-3)  # same fp32 sums, at most a bf16 rounding flip
+    assert nerr(out, out2) < tol(dtype)
+
+
 def test_empty_and_limit_shapes():
     """Edge cases: empty batches go through every entry point (no launch, right shapes); the MFMA attention's
     limits (n_k = 256 resident keys, then the LDS-resident VALU kernel takes over at 257) and LayerNorm's widest
