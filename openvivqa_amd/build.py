@@ -43,7 +43,8 @@ def needs_build() -> bool:
 
 
 def _compile(hipcc, src, obj):
-    cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+    extra = os.environ.get("OVQA_EXTRA_HIPCC_FLAGS", "").split()  # development builds (e.g. -DOVQA_PHASE_PROBE)
+    cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return src, r.returncode, r.stdout + r.stderr
 

@@ -17,6 +17,24 @@
 #include "common.h"
 #include "kernels.h"
 
+// Phase probe (development only, -DOVQA_PHASE_PROBE): wall-clock timestamps (100 MHz) of one thread of two workgroups
+// at marked points of a kernel, read back by ovqa_debug_probe().
+#ifdef OVQA_PHASE_PROBE
+__device__ unsigned long long g_probe[2][16];
+#define OVQA_PROBE_T(i, t)                                                               \
+  do {                                                                                   \
+    if (threadIdx.x == (t) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))          \
+      g_probe[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64();                              \
+  } while (0)
+#define OVQA_PROBE(i) OVQA_PROBE_T(i, 0)
+extern "C" int ovqa_debug_probe(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe));
+}
+#else
+#define OVQA_PROBE(i) do {} while (0)
+#define OVQA_PROBE_T(i, t) do {} while (0)
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -289,10 +307,15 @@ struct QkvAttnArgs {
 template <int RP, int S, bool ROWMASK>
 __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
   constexpr int M = RP * S, NI = M / 64, NJ = 6, NKT = RP / 32, TQ = RP / 32;
-  constexpr int WCH = 24, XCH = M / 8;               // 1 KiB staging pieces (8 rows x 128 B) of the W / x tiles
-  constexpr int PER = (WCH + XCH) / 8;               // per wave and K tile
-  constexpr int STAGE = (WCH + XCH) * 1024;
-  static_assert((WCH + XCH) % 8 == 0, "pieces divide over 8 waves");
+  // K steps of 32 in a ring of 4: a stage is [192 weight rows | M x rows] x 64 B = 20-28 KiB, three stages in flight.
+  // (The workgroup is alone on its CU -- the images need 48-96 KiB --, so nothing else covers the L2 -> LDS latency:
+  // with two 56-KiB stages of 64 a K step took 1.7 us, the whole loop 13.6 of the kernel's 21 us.)
+  constexpr int NBUF = 4, BKF = 32;
+  constexpr int WCH = 12, XCH = M / 16;              // 1 KiB staging pieces (16 rows x 64 B) of the W / x tiles
+  constexpr int PCS = WCH + XCH;                     // 28 (M = 256) or 20 (M = 128) pieces per stage
+  constexpr int PER = (PCS + 7) / 8;                 // per wave: PER pieces, the last one only for waves < PCS - 8 * (PER - 1)
+  constexpr int FULL = PCS - 8 * (PER - 1);          // waves with PER pieces
+  constexpr int STAGE = PCS * 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ovqa::AttnArgs& a = g.att;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -305,53 +328,79 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
 #pragma unroll
     for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int kt) {
-    char* buf = smem + (kt & 1) * STAGE;
-    const int k0 = kt * 64;
+  // [rows][32] bf16 image, 64 B per row: 16-byte slot of chunk ch in row r = ch ^ ((r >> 2) & 3) -- the 16 rows x 1
+  // chunk of a ds_read_b128 lane group then cover 256 B of distinct banks.  A staging piece is 16 rows = 1 KiB; lane l
+  // of the loading wave fills slot l & 3 of row l >> 2, i.e. fetches global chunk (l & 3) ^ ((row >> 2) & 3).
+  auto off32 = [](int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); };
+  const bf16* src[PER];  // this lane's source row (+ chunk) of each of its pieces, K offset 0
 #pragma unroll
-    for (int i = 0; i < PER; i++) {
-      const int ci = wave * PER + i;
-      const int pos = lane & 7;
-      const bf16* src;
-      if (ci < WCH) {  // weight rows of this head: tile row t -> kind t/64 (q, k, v), feature t%64, permuted within 32
-        const int row = ci * 8 + (lane >> 3);
-        const int t = perm32(row);
-        src = g.w + (int64_t)((t >> 6) * HD + h * 64 + (t & 63)) * g.Dm + k0 + ((pos ^ (row & 7)) << 3);
-      } else {         // x rows: sample (row / RP), position clamped to the sample's last row
-        const int row = (ci - WCH) * 8 + (lane >> 3);
-        int bs = b0 + row / RP;
-        bs = bs < a.B ? bs : a.B - 1;
-        int r = row % RP;
-        r = r < n ? r : n - 1;
-        src = g.x + ((int64_t)bs * n + r) * g.ldx + k0 + ((pos ^ (row & 7)) << 3);
-      }
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(buf + ci * 1024), 16, 0, 0);
-    }
-  };
-  const int nkt = g.Dm / 64;
-  issue(0);
-  for (int kt = 0; kt < nkt; kt++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) issue(kt + 1);
-    const char* Ws = smem + (kt & 1) * STAGE;
-    const char* Xs = Ws + WCH * 1024;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf16x8 pf[NJ], qf[NI];
-#pragma unroll
-      for (int j = 0; j < NJ; j++)
-        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + kc_off(wr * 96 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
-#pragma unroll
-      for (int i = 0; i < NI; i++)
-        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + kc_off(wc * (NI * 16) + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
-#pragma unroll
-      for (int j = 0; j < NJ; j++)
-#pragma unroll
-        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+  for (int i = 0; i < PER; i++) {
+    const int ci = wave + 8 * i;
+    const int prow = lane >> 2;
+    if (ci < WCH) {  // weight rows of this head: tile row t -> kind t/64 (q, k, v), feature t%64, permuted within 32
+      const int row = ci * 16 + prow;
+      const int t = perm32(row);
+      src[i] = g.w + (int64_t)((t >> 6) * HD + h * 64 + (t & 63)) * g.Dm + (((lane & 3) ^ ((row >> 2) & 3)) << 3);
+    } else {         // x rows: sample (row / RP), position clamped to the sample's last row
+      const int row = (ci - WCH) * 16 + prow;
+      int bs = b0 + row / RP;
+      bs = bs < a.B ? bs : a.B - 1;
+      int r = row % RP;
+      r = r < n ? r : n - 1;
+      src[i] = g.x + ((int64_t)bs * n + r) * g.ldx + (((lane & 3) ^ ((row >> 2) & 3)) << 3);
     }
   }
+  // the epilogue's bias values (8 consecutive features per (jp) of this lane), requested before the K loop
+  float4 bias_r[NJ / 2][2];
+#pragma unroll
+  for (int jp = 0; jp < NJ / 2; jp++) {
+    const int f = wr * 96 + jp * 32 + (lane >> 4) * 8;
+    const int gcol = (f >> 6) * HD + h * 64 + (f & 63);
+    bias_r[jp][0] = g.bias ? *reinterpret_cast<const float4*>(g.bias + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias_r[jp][1] = g.bias ? *reinterpret_cast<const float4*>(g.bias + gcol + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool full = wave < FULL;  // wave-uniform
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt % NBUF) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      if (i == PER - 1 && !full) break;
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+  };
+  const int nkt = g.Dm / BKF;
+  OVQA_PROBE(0);
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nkt) issue(p);
+  for (int kt = 0; kt < nkt; kt++) {
+    // stage kt has landed once at most the loads of the two younger stages are outstanding (in-order return)
+    if (kt + NBUF - 2 >= nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (full) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NBUF - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PER - 1) * (NBUF - 2)) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
+    const char* Ws = smem + (kt % NBUF) * STAGE;
+    const char* Xs = Ws + WCH * 1024;
+    bf16x8 pf[NJ], qf[NI];
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 96 + j * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+      qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * (NI * 16) + i * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+  }
+  OVQA_PROBE(1);
   __syncthreads();  // every wave is done with the staging buffers: they become the Q | K | V images
+  OVQA_PROBE(2);
 
   // ---- epilogue: + bias -> bf16 -> HBM (rows < n) and the LDS images [sample][kind][RP rows][64]
   float* mrow_s = reinterpret_cast<float*>(smem + S * 3 * RP * 128);  // [S][RP] mask rows behind the images
@@ -360,22 +409,20 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
     const int row = wc * (NI * 16) + i * 16 + (lane & 15);
     const int sm = row / RP, r = row % RP;
     const int bs = b0 + sm;
+    bf16* grow = g.qkv + ((int64_t)(bs < a.B ? bs : 0) * n + (r < n ? r : 0)) * g.ldqkv + h * 64;
+    const bool live = bs < a.B && r < n;
 #pragma unroll
     for (int jp = 0; jp < NJ / 2; jp++) {
       const int f = wr * 96 + jp * 32 + (lane >> 4) * 8;  // 8 consecutive features of one of q / k / v
       const int kind = f >> 6, col = f & 63;
-      const int gcol = kind * HD + h * 64 + col;
-      float u[8] = {acc[2 * jp][i][0], acc[2 * jp][i][1], acc[2 * jp][i][2], acc[2 * jp][i][3],
-                    acc[2 * jp + 1][i][0], acc[2 * jp + 1][i][1], acc[2 * jp + 1][i][2], acc[2 * jp + 1][i][3]};
-      if (g.bias) {
-        const float4 c0 = *reinterpret_cast<const float4*>(g.bias + gcol), c1 = *reinterpret_cast<const float4*>(g.bias + gcol + 4);
-        u[0] += c0.x; u[1] += c0.y; u[2] += c0.z; u[3] += c0.w; u[4] += c1.x; u[5] += c1.y; u[6] += c1.z; u[7] += c1.w;
-      }
+      const float4 c0 = bias_r[jp][0], c1 = bias_r[jp][1];
       bf16x8 o8;
-#pragma unroll
-      for (int e = 0; e < 8; e++) o8[e] = (bf16)u[e];
+      o8[0] = (bf16)(acc[2 * jp][i][0] + c0.x); o8[1] = (bf16)(acc[2 * jp][i][1] + c0.y);
+      o8[2] = (bf16)(acc[2 * jp][i][2] + c0.z); o8[3] = (bf16)(acc[2 * jp][i][3] + c0.w);
+      o8[4] = (bf16)(acc[2 * jp + 1][i][0] + c1.x); o8[5] = (bf16)(acc[2 * jp + 1][i][1] + c1.y);
+      o8[6] = (bf16)(acc[2 * jp + 1][i][2] + c1.z); o8[7] = (bf16)(acc[2 * jp + 1][i][3] + c1.w);
       *reinterpret_cast<bf16x8*>(smem + ((sm * 3 + kind) * RP) * 128 + Img<64>::off(r, col >> 3)) = o8;
-      if (bs < a.B && r < n) *reinterpret_cast<bf16x8*>(g.qkv + ((int64_t)bs * n + r) * g.ldqkv + gcol) = o8;
+      if (live) *reinterpret_cast<bf16x8*>(grow + kind * HD + col) = o8;
     }
   }
   if (ROWMASK) {
@@ -387,7 +434,9 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
       mrow_s[e] = j < n ? (mr ? mr[j] : 0.f) : -INFINITY;
     }
   }
+  OVQA_PROBE(3);
   __syncthreads();
+  OVQA_PROBE(4);
 
   // ---- attention on the images: one wave per (sample, 32-query tile)
   const int sm = wave / TQ, tq = wave % TQ;
@@ -396,6 +445,7 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
   const char* Ks = smem + (sm * 3 + 1) * RP * 128;
   const char* Vs = smem + (sm * 3 + 2) * RP * 128;
   attn_fwd_core<NKT, ROWMASK, false, 64>(a, b0 + sm, h, tq * 32, tq * 32, Qs, Ks, Vs, mrow_s + sm * RP, lane);
+  OVQA_PROBE(5);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -647,97 +697,131 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 // single tile per problem the two orientations are split over two waves, see `both` below):
 //   transposed orientation (lane = query):  S^T, dP^T -> dS^T -> dQ^T += K^T dS^T            (as kernel A)
 //   direct orientation     (lane = key):    S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS  (as kernel B)
-// The dK/dV partials of the <= 4 query tiles of a problem are summed in LDS, one wave after the other between
-// workgroup barriers (LDS fp32 atomics were measured 4x slower: ~100 cycles per ds_add_f32 wave-instruction).
-template <bool ROWMASK>
-__global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a, int W, int G) {
+// W (query tiles per problem: 1, 2 or 4) is a template parameter: G = 4 / W problems are packed per workgroup, and all
+// staging index arithmetic folds to shifts.  These kernels are latency chains (launch -> loads -> ~20 MFMAs -> stores),
+// so instruction count matters like nowhere else: a wave64 VALU instruction is 4 cycles, 600 instructions are 1 us.
+template <bool ROWMASK, int W>
+__global__ __launch_bounds__(W == 1 ? 512 : 256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a) {
+  constexpr int NT = W == 1 ? 512 : 256, G = 4 / W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
-  const int q_rows = 32 * W, k_rows = 32;
-  const int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
-  const int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | dV^T,dK^T
+  constexpr int q_rows = 32 * W, k_rows = 32;
+  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
+  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | P,dS
   // 512 threads (W == 1: the 20 x 20 question attention): waves 0-3 take the dQ role, waves 4-7 the dK/dV role of
   // the same 4 packed problems -- half the dependent chain per wave.  256 threads (W >= 2): every wave does both
   // (with 4 query tiles per problem the doubled wave count only adds VALU contention: 14.8 vs 18.3 us).
-  const bool both = blockDim.x == 256;
+  constexpr bool both = NT == 256;
   const int role = wave >> 2, w4 = wave & 3;
   const int slot = w4 / W, tq = w4 % W;
+  OVQA_PROBE(0);
 
-  for (int g = 0; g < G; g++) {
-    const int64_t pid = (int64_t)blockIdx.x * G + g;
-    if (pid >= (int64_t)a.B * a.H) break;
-    const int b = (int)(pid / a.H), h = (int)(pid % a.H);
-    char* base = smem + g * prob_bytes;
-    const ImgDesc d[4] = {
-        {base, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
-        {base + q_rows * 128, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
-        {base + 2 * q_rows * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
-        {base + (2 * q_rows + k_rows) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
-    if (both) {
-      load_images<4>(d, tid);
-    } else if (tid < 256) {
-      const ImgDesc d0[2] = {d[0], d[1]};
-      load_images<2>(d0, tid);
-    } else {
-      const ImgDesc d1[2] = {d[2], d[3]};
-      load_images<2>(d1, tid - 256);
+  // ---- staging: ONE round of global loads for everything the workgroup needs (all loads of all G problems are
+  // issued before the first LDS store).  Q / dO: W 16-byte chunks per thread and problem, K / V: one.  The thread that
+  // owns a dO chunk also fetches the matching chunk of O: delta = dO . O falls out of the staging (8 consecutive lanes
+  // hold a row) instead of a second pass over dO and O behind the first one; mask row and log-sum-exp ride along.
+  // W == 1: threads 0-255 stage Q and K, threads 256-511 dO (+ O) and V.
+  {
+    const int pid0 = (int)blockIdx.x * G, nprob = a.B * a.H;
+    const bool ld_q = both || tid < 256, ld_d = both || tid >= 256;  // wave-uniform
+    const int t = tid & 255;
+    const int ch = t & 7;
+    float mval = 0.f;  // mask row entries: thread -> (problem tid / 32, key tid % 32)
+    const bool mtask = a.msq == 0 && tid < G * k_rows && pid0 + tid / k_rows < nprob;
+    if (mtask) {
+      const int pid = pid0 + tid / k_rows;
+      const int key = tid % k_rows;
+      const int mb = pid / a.H, mh = pid - mb * a.H;
+      mval = key < nk ? (a.mask ? a.mask[(int64_t)mb * a.msb + (int64_t)mh * a.msh + key] * LOG2E : 0.f) : -INFINITY;
     }
-    float* mrow_s = reinterpret_cast<float*>(base + img_bytes);
-    if (a.msq == 0 && tid < 256)
-      load_mask_row(mrow_s, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
-    // lse and delta = dO . O per query row: 4 lanes per row, 16 features each
-    float* lse_g = mrow_s + k_rows;
-    float* del_g = lse_g + q_rows;
-    for (int e = tid; e < q_rows * 4; e += (int)blockDim.x) {
-      const int i = e >> 2, part = e & 3;
-      float dl = 0.f;
-      if (i < nq) {
-        const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + i) * a.lddo + h * 64 + 16 * part;
-        const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + i) * a.ldo + h * 64 + 16 * part;
+    uint4 vq[G][W], vd[G][W], vo[G][W], vk[G], vv[G];
+    float lse_r[G][W];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
-          const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
-          const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
+    for (int g = 0; g < G; g++) {
+      const int pid = pid0 + g;  // uniform
+      const bool ok = pid < nprob;
+      const int b = ok ? pid / a.H : 0, h = ok ? pid - (pid / a.H) * a.H : 0;
+      const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
+      const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
+      const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
+      const float* lb = a.lse + ((int64_t)b * a.H + h) * nq;
 #pragma unroll
-          for (int t = 0; t < 4; t++) dl += (float)g8[t] * (float)oa[t] + (float)g8[4 + t] * (float)ob[t];
+      for (int i = 0; i < W; i++) {
+        const int row = (t >> 3) + 32 * i;
+        const bool v = ok && row < nq;
+        vq[g][i] = zero4; vd[g][i] = zero4; vo[g][i] = zero4; lse_r[g][i] = INFINITY;  // p = 0 beyond nq
+        if (ld_q && v) vq[g][i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
+        if (ld_d && v) {
+          vd[g][i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
+          vo[g][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+          if (ch == 0) lse_r[g][i] = lb[row] * LOG2E;
         }
       }
-      dl += __shfl_xor(dl, 1, 64);
-      dl += __shfl_xor(dl, 2, 64);
-      if (part == 0) {
-        del_g[i] = dl;
-        lse_g[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
-        if (i < nq) a.delta[((int64_t)b * a.H + h) * nq + i] = dl;
-      }
+      const int krow = t >> 3;
+      const bool kv = ok && krow < nk;
+      vk[g] = zero4; vv[g] = zero4;
+      if (ld_q && kv) vk[g] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + krow) * a.ldk + h * 64 + ch * 8);
+      if (ld_d && kv) vv[g] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + krow) * a.ldv + h * 64 + ch * 8);
     }
+    OVQA_PROBE(1);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      char* base = smem + g * prob_bytes;
+      float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
+      const int pid = pid0 + g;
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        const int row = (t >> 3) + 32 * i;
+        if (ld_q) *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[g][i];
+        if (ld_d) {
+          *reinterpret_cast<uint4*>(base + q_rows * 128 + img_off(row, ch)) = vd[g][i];
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[g][i]);
+          const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[g][i]);
+          float dl = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) dl += (float)g8[e] * (float)o8[e];
+          dl += __shfl_xor(dl, 1, 64);
+          dl += __shfl_xor(dl, 2, 64);
+          dl += __shfl_xor(dl, 4, 64);
+          if (ch == 0) {
+            lse_g[row] = lse_r[g][i];
+            lse_g[q_rows + row] = dl;
+            if (row < nq && pid < nprob) a.delta[(int64_t)pid * nq + row] = dl;
+          }
+        }
+      }
+      const int krow = t >> 3;
+      if (ld_q) *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(krow, ch)) = vk[g];
+      if (ld_d) *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(krow, ch)) = vv[g];
+    }
+    if (mtask) reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] = mval;
   }
+  OVQA_PROBE(2);
   __syncthreads();
+  OVQA_PROBE(3);
 
-  const int64_t pid = (int64_t)blockIdx.x * G + slot;
-  const bool active = slot < G && pid < (int64_t)a.B * a.H && tq * 32 < nq;
-  const int b = active ? (int)(pid / a.H) : 0, h = active ? (int)(pid % a.H) : 0;
-  const char* Qs = smem + (active ? slot : 0) * prob_bytes;
+  const int pidw = (int)blockIdx.x * G + slot;
+  const bool prob_ok = slot < G && pidw < a.B * a.H;
+  const bool active = prob_ok && tq * 32 < nq;  // this wave's query tile exists
+  const int b = prob_ok ? pidw / a.H : 0, h = prob_ok ? pidw - (pidw / a.H) * a.H : 0;
+  const char* Qs = smem + (prob_ok ? slot : 0) * prob_bytes;
   const char* Gs = Qs + q_rows * 128;
   const char* Ks = Gs + q_rows * 128;
   const char* Vs = Ks + k_rows * 128;
   float* mlds = reinterpret_cast<float*>(const_cast<char*>(Vs) + k_rows * 128);
   float* lse_s = mlds + k_rows;
   float* del_s = lse_s + q_rows;
-  float* red = del_s + q_rows;
+  char* xch = reinterpret_cast<char*>(del_s + q_rows);  // [tile][P | dS][lane][16 bf16]: 4 KiB per query tile
   constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
-  f32x16 dvt[2], dkt[2];
-#pragma unroll
-  for (int d = 0; d < 2; d++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
 
   if (active) {
     const int q = tq * 32 + (lane & 31);
     const bool qok = q < nq;
     const int qc = qok ? q : nq - 1;
-    const float lse = lse_s[qc], delta = del_s[qc];
+    const float lse2 = lse_s[qc], delta = del_s[qc];  // (mask row and lse are staged in log2 units)
+    const float scale2 = a.scale * LOG2E;
     const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
 
     bf16x8 qf[4], gf[4], kf[4], vf[4];
@@ -760,16 +844,25 @@ __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
       }
       float ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = acc_row(r, lane);
-        float p;
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int key0 = 8 * g4 + 4 * (lane >> 5);  // acc_row(4 * g4 + e, lane) = key0 + e
+        float mm[4];
         if (row_mask) {
-          p = exp2_fast((st[r] * a.scale + mlds[key] - lse) * LOG2E);  // -inf beyond nk -> 0
-        } else {
-          p = 0.f;
-          if (key < nk) p = exp2_fast((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+          const float4 m4 = *reinterpret_cast<const float4*>(mlds + key0);
+          mm[0] = m4.x - lse2; mm[1] = m4.y - lse2; mm[2] = m4.z - lse2; mm[3] = m4.w - lse2;
         }
-        ds[r] = p * (dp[r] - delta);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g4 + e;
+          float p;
+          if (row_mask) {
+            p = exp2_fast(st[r] * scale2 + mm[e]);  // -inf beyond nk -> 0
+          } else {
+            p = 0.f;
+            if (key0 + e < nk) p = exp2_fast(st[r] * scale2 + ((mrow ? mrow[key0 + e] : 0.f) * LOG2E - lse2));
+          }
+          ds[r] = p * (dp[r] - delta);
+        }
       }
       f32x16 dqt[2];
 #pragma unroll
@@ -798,12 +891,13 @@ __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
           }
       }
     }
-    // ---- direct orientation: this query tile's share of dK^T / dV^T (role 1)
+    OVQA_PROBE(4);
+    // ---- direct orientation (role 1): P and dS of this query tile, rows = queries, lane = key
     if (both || role == 1) {
       const int key = lane & 31;
       const bool kok = key < nk;
       const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
-      const float mconst = row_mask ? mlds[key] : 0.f;  // -inf beyond nk
+      const float mconst = row_mask ? mlds[key] : 0.f;  // log2 units; -inf beyond nk
       f32x16 s_, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
@@ -812,71 +906,106 @@ __global__ __launch_bounds__(512) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwd
         s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s_, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[ks], vf[ks], dp, 0, 0, 0);
       }
-      float p[16], ds[16];
+      bf16x8 pb[2], db[2];  // the B operands (k = query) of dV^T += dO^T P and dK^T += Q^T dS
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int ql = tq * 32 + acc_row(r, lane);
-        float pv = 0.f;
-        if (ql < nq && kok) {
-          const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)ql * a.msq] : 0.f);
-          pv = exp2_fast((s_[r] * a.scale + mv - lse_s[ql]) * LOG2E);
-        }
-        p[r] = pv;
-        ds[r] = pv * (dp[r] - del_s[ql]);
-      }
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int q0 = tq * 32 + 8 * g4 + 4 * (lane >> 5);  // acc_row(4 * g4 + e, lane) = q0 - tq * 32 + e
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);  // +inf beyond nq: p = 0
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + q0);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 pb, db;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s2 + j]; db[j] = (bf16)ds[8 * s2 + j]; }
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, tq * 32 + 16 * s2, d * 32, lane), pb, dvt[d], 0, 0, 0);
-          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, tq * 32 + 16 * s2, d * 32, lane), db, dkt[d], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // sum over the query tiles of each problem: tile `ph` adds its share in phase `ph` (tile 0 stores)
-  for (int ph = 0; ph < W; ph++) {
-    if (active && (both || role == 1) && tq == ph) {
-#pragma unroll
-      for (int d = 0; d < 2; d++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float* pv = red + ((0 * 2 + d) * 16 + r) * 64 + lane;
-          float* pk = red + ((1 * 2 + d) * 16 + r) * 64 + lane;
-          if (ph == 0) {
-            *pv = dvt[d][r];
-            *pk = dkt[d][r];
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g4 + e;
+          float pv;
+          if (row_mask) {
+            pv = exp2_fast(s_[r] * scale2 + (mconst - ll[e]));
           } else {
-            *pv += dvt[d][r];
-            *pk += dkt[d][r];
+            pv = 0.f;
+            if (q0 + e < nq && kok)
+              pv = exp2_fast(s_[r] * scale2 + ((mcol ? mcol[(int64_t)(q0 + e) * a.msq] : 0.f) * LOG2E - ll[e]));
           }
+          pb[r >> 3][r & 7] = (bf16)pv;
+          db[r >> 3][r & 7] = (bf16)(pv * (dp[r] - dd[e]));
         }
+      }
+      if constexpr (both) {
+        // several query tiles per problem: hand P / dS to the waves that own the output accumulators (below)
+        bf16x8* px = reinterpret_cast<bf16x8*>(xch + ((tq * 2 + 0) * 64 + lane) * 32);
+        bf16x8* dx = reinterpret_cast<bf16x8*>(xch + ((tq * 2 + 1) * 64 + lane) * 32);
+        px[0] = pb[0]; px[1] = pb[1];
+        dx[0] = db[0]; dx[1] = db[1];
+      } else {
+        // one query tile: this wave has the complete dK^T / dV^T
+        f32x16 dvt[2], dkt[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) { dvt[d][r] = 0.f; dkt[d][r] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+          for (int d = 0; d < 2; d++) {
+            dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, 16 * s2, d * 32, lane), pb[s2], dvt[d], 0, 0, 0);
+            dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, 16 * s2, d * 32, lane), db[s2], dkt[d], 0, 0, 0);
+          }
+        OVQA_PROBE(5);
+        if (kok) {
+          bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
+          bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+#pragma unroll
+          for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+              bf16x4 k4, v4;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                v4[e] = (bf16)dvt[d][4 * g4 + e];
+                k4[e] = (bf16)(dkt[d][4 * g4 + e] * a.scale);
+              }
+              *reinterpret_cast<bf16x4*>(dkrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = k4;
+              *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
+            }
+        }
+      }
     }
+  }
+  if constexpr (both) {
+    // dK^T / dV^T: four [32 keys x 32 features] accumulators per problem (dV features 0-31, 32-63, dK likewise), dealt
+    // over the problem's W waves; each sums over ALL query tiles with the P / dS operands the tiles' waves left in LDS
+    // -- one barrier and 4 KiB per tile instead of a W-phase fp32 reduction of the accumulators.
+    OVQA_PROBE(5);
     __syncthreads();
-  }
-  if (active && (both || role == 1) && tq == 0) {
-    const int key = lane & 31;
-    if (key < nk) {
-      bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
-      bf16* dvrow = (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv + h * 64;
+    OVQA_PROBE(6);
+    if (prob_ok) {
+      const int key = lane & 31;
+      for (int acc = tq; acc < 4; acc += W) {
+        const bool is_k = acc >= 2;
+        const int d = acc & 1;
+        const char* Xs = is_k ? Qs : Gs;
+        f32x16 out;
 #pragma unroll
-      for (int d = 0; d < 2; d++)
+        for (int r = 0; r < 16; r++) out[r] = 0.f;
+        for (int t = 0; t < W && t * 32 < nq; t++) {
+          const bf16x8* src = reinterpret_cast<const bf16x8*>(xch + ((t * 2 + (is_k ? 1 : 0)) * 64 + lane) * 32);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-          bf16x4 k4, v4;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            v4[e] = (bf16)red[((0 * 2 + d) * 16 + 4 * g4 + e) * 64 + lane];
-            k4[e] = (bf16)(red[((1 * 2 + d) * 16 + 4 * g4 + e) * 64 + lane] * a.scale);
-          }
-          *reinterpret_cast<bf16x4*>(dkrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = k4;
-          *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
+          for (int s2 = 0; s2 < 2; s2++)
+            out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Xs, t * 32 + 16 * s2, d * 32, lane), src[s2], out, 0, 0, 0);
         }
+        if (key < nk) {
+          bf16* row = (is_k ? (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk : (bf16*)a.dv_ + ((int64_t)b * nk + key) * a.lddv) + h * 64;
+          const float sc = is_k ? a.scale : 1.f;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; g4++) {
+            bf16x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o4[e] = (bf16)(out[4 * g4 + e] * sc);
+            *reinterpret_cast<bf16x4*>(row + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+          }
+        }
+      }
     }
   }
+  OVQA_PROBE(7);
 }
 
 
@@ -894,67 +1023,92 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = nqt * 32, k_rows = nkt * 32;
-  const int64_t pid = blockIdx.x;
-  const int b = (int)(pid / a.H), h = (int)(pid % a.H);
+  const int pid = (int)blockIdx.x;
+  const int b = pid / a.H, h = pid - b * a.H;
   char* Qs = smem;
   char* Gs = Qs + q_rows * 128;
   char* Ks = Gs + q_rows * 128;
   char* Vs = Ks + k_rows * 128;
-  float* mlds = reinterpret_cast<float*>(Vs + k_rows * 128);  // key-padding mask row (-inf beyond nk)
+  // fp32 rows behind the images, all in log2 units so that a probability is one fma + one exp2:
+  //   mlds[key] = mask * log2(e) (-inf beyond nk),  lse_s[q] = lse * log2(e) (+inf beyond nq: p = 0 without a branch)
+  float* mlds = reinterpret_cast<float*>(Vs + k_rows * 128);
   float* lse_s = mlds + k_rows;
   float* del_s = lse_s + q_rows;
+  OVQA_PROBE(0);
+  // ---- staging: one round of global loads (all issued before the first LDS store): a thread owns chunk `ch` of rows
+  // r0 and r0 + 64 of each of Q, dO, K, V -- and of O, so that delta = dO . O falls out of the staging (8 consecutive
+  // lanes hold a row) instead of a second, dependent pass over dO and O.
   {
-    const ImgDesc d[4] = {
-        {Qs, (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64, a.ldq, nq, q_rows},
-        {Gs, (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64, a.lddo, nq, q_rows},
-        {Ks, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, k_rows},
-        {Vs, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, k_rows}};
-    // load_images strides by 4 * 256 threads: run it as two half-workgroups over two images each
-    if (tid < 256) {
-      const ImgDesc d0[2] = {d[0], d[1]};
-      load_images<2>(d0, tid);
-    } else {
-      const ImgDesc d1[2] = {d[2], d[3]};
-      load_images<2>(d1, tid - 256);
-    }
-    if (a.msq == 0 && tid < 256)
-      load_mask_row(mlds, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, k_rows, tid);
-    // lse and delta = dO . O per query row: 4 lanes per row, 16 features each
-    for (int e = tid; e < q_rows * 4; e += 512) {
-      const int i = e >> 2, part = e & 3;
-      float dl = 0.f;
-      if (i < nq) {
-        const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + i) * a.lddo + h * 64 + 16 * part;
-        const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + i) * a.ldo + h * 64 + 16 * part;
+    const int ch = tid & 7, r0 = tid >> 3;
+    const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
+    const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
+    const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
+    const bf16* kb = (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64 + ch * 8;
+    const bf16* vb = (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64 + ch * 8;
+    const float* lb = a.lse + (int64_t)pid * nq;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 vq[2], vd[2], vo[2], vk[2], vv[2];
+    float lse_r[2];
+    float mval = -INFINITY;
+    if (a.msq == 0 && tid < nk) mval = a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)h * a.msh + tid] * LOG2E : 0.f;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
-          const bf16x4 oa = *reinterpret_cast<const bf16x4*>(orow + 8 * c);
-          const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
-#pragma unroll
-          for (int t = 0; t < 4; t++) dl += (float)g8[t] * (float)oa[t] + (float)g8[4 + t] * (float)ob[t];
-        }
+    for (int i = 0; i < 2; i++) {
+      const int row = r0 + 64 * i;
+      vq[i] = zero4; vd[i] = zero4; vo[i] = zero4; vk[i] = zero4; vv[i] = zero4;
+      lse_r[i] = INFINITY;
+      if (row < nq) {
+        vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
+        vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
+        vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+        if (ch == 0) lse_r[i] = lb[row] * LOG2E;
       }
+      if (row < nk) {
+        vk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk);
+        vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * a.ldv);
+      }
+    }
+    OVQA_PROBE(1);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = r0 + 64 * i;
+      const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[i]);
+      const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
+      float dl = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) dl += (float)g8[e] * (float)o8[e];
       dl += __shfl_xor(dl, 1, 64);
       dl += __shfl_xor(dl, 2, 64);
-      if (part == 0) {
-        del_s[i] = dl;
-        lse_s[i] = i < nq ? a.lse[((int64_t)b * a.H + h) * nq + i] : 0.f;
-        if (i < nq) a.delta[((int64_t)b * a.H + h) * nq + i] = dl;
+      dl += __shfl_xor(dl, 4, 64);
+      if (row < q_rows) {
+        *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = vq[i];
+        *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
+        if (ch == 0) {
+          lse_s[row] = lse_r[i];
+          del_s[row] = dl;
+          if (row < nq) a.delta[(int64_t)pid * nq + row] = dl;
+        }
+      }
+      if (row < k_rows) {
+        *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = vk[i];
+        *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vv[i];
       }
     }
+    if (a.msq == 0 && tid < k_rows) mlds[tid] = mval;
   }
+  OVQA_PROBE(2);
   __syncthreads();
+  OVQA_PROBE(3);
   constexpr bool row_mask = ROWMASK;  // compile-time: the common key-padding form carries no per-element checks
+  const float scale2 = a.scale * LOG2E;
 
   if (wave < 4) {
-    // ------------------------------------------------ role A: dQ of query tile tq
+    // ------------------------------------------------ role A: dQ of query tile tq (lane = query)
     const int tq = wave;
     if (tq * 32 >= nq) return;
     const int q = tq * 32 + (lane & 31);
     const bool qok = q < nq;
     const int qc = qok ? q : nq - 1;
-    const float lse = lse_s[qc], delta = del_s[qc];
+    const float lse2 = lse_s[qc], delta = del_s[qc];
     const float* mrow = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (int64_t)qc * a.msq : nullptr;
     bf16x8 qf[4], gf[4];
 #pragma unroll
@@ -979,16 +1133,25 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
       }
       float ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = t * 32 + acc_row(r, lane);
-        float p;
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int key0 = t * 32 + 8 * g4 + 4 * (lane >> 5);  // acc_row(4 * g4 + e, lane) = key0 + e
+        float mm[4];
         if (row_mask) {
-          p = exp2_fast((st[r] * a.scale + mlds[key] - lse) * LOG2E);
-        } else {
-          p = 0.f;
-          if (key < nk) p = exp2_fast((st[r] * a.scale + (mrow ? mrow[key] : 0.f) - lse) * LOG2E);
+          const float4 m4 = *reinterpret_cast<const float4*>(mlds + key0);
+          mm[0] = m4.x - lse2; mm[1] = m4.y - lse2; mm[2] = m4.z - lse2; mm[3] = m4.w - lse2;
         }
-        ds[r] = p * (dp[r] - delta);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g4 + e;
+          float p;
+          if (row_mask) {
+            p = exp2_fast(st[r] * scale2 + mm[e]);  // -inf beyond nk -> 0
+          } else {
+            p = 0.f;
+            if (key0 + e < nk) p = exp2_fast(st[r] * scale2 + ((mrow ? mrow[key0 + e] : 0.f) * LOG2E - lse2));
+          }
+          ds[r] = p * (dp[r] - delta);
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
@@ -1012,14 +1175,15 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
           *reinterpret_cast<bf16x4*>(drow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
         }
     }
+    OVQA_PROBE(4);
   } else {
-    // ------------------------------------------------ role B: dK / dV of key tile tk
+    // ------------------------------------------------ role B: dK / dV of key tile tk (lane = key)
     const int tk = wave - 4;
     if (tk * 32 >= nk) return;
     const int key = tk * 32 + (lane & 31);
     const bool kok = key < nk;
     const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
-    const float mconst = row_mask ? mlds[key] : 0.f;
+    const float mconst = row_mask ? mlds[key] : 0.f;  // log2 units; -inf beyond nk
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
@@ -1041,29 +1205,35 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
         s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
-      float p[16], ds[16];
+      bf16x8 pb[2], db[2];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int qi = t * 32 + acc_row(r, lane);
-        float pv = 0.f;
-        if (qi < nq && kok) {
-          const float mv = row_mask ? mconst : (mcol ? mcol[(int64_t)qi * a.msq] : 0.f);
-          pv = exp2_fast((s_[r] * a.scale + mv - lse_s[qi]) * LOG2E);
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int q0 = t * 32 + 8 * g4 + 4 * (lane >> 5);  // acc_row(4 * g4 + e, lane) = q0 + e
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0);  // +inf beyond nq: p = 0
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + q0);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 4 * g4 + e;
+          float pv;
+          if (row_mask) {
+            pv = exp2_fast(s_[r] * scale2 + (mconst - ll[e]));
+          } else {
+            pv = 0.f;
+            if (q0 + e < nq && kok)
+              pv = exp2_fast(s_[r] * scale2 + ((mcol ? mcol[(int64_t)(q0 + e) * a.msq] : 0.f) * LOG2E - ll[e]));
+          }
+          pb[r >> 3][r & 7] = (bf16)pv;
+          db[r >> 3][r & 7] = (bf16)(pv * (dp[r] - dd[e]));
         }
-        p[r] = pv;
-        ds[r] = pv * (dp[r] - del_s[qi]);
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 pb, db;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { pb[j] = (bf16)p[8 * s2 + j]; db[j] = (bf16)ds[8 * s2 + j]; }
+      for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int d = 0; d < 2; d++) {
-          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, t * 32 + 16 * s2, d * 32, lane), pb, dvt[d], 0, 0, 0);
-          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, t * 32 + 16 * s2, d * 32, lane), db, dkt[d], 0, 0, 0);
+          dvt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Gs, t * 32 + 16 * s2, d * 32, lane), pb[s2], dvt[d], 0, 0, 0);
+          dkt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, t * 32 + 16 * s2, d * 32, lane), db[s2], dkt[d], 0, 0, 0);
         }
-      }
     }
     if (kok) {
       bf16* dkrow = (bf16*)a.dk_ + ((int64_t)b * nk + key) * a.lddk + h * 64;
@@ -1082,6 +1252,7 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
           *reinterpret_cast<bf16x4*>(dvrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = v4;
         }
     }
+    OVQA_PROBE_T(5, 256);
   }
 }
 
@@ -1219,15 +1390,24 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
     int W = (a.nq + 31) / 32;
     if (W == 3) W = 4;
+    const int G = 4 / W;  // problems per workgroup (compile-time in the kernel)
     const size_t prob = (size_t)(2 * 32 * W + 2 * 32) * 128 + 32 * 4 + 2 * 32 * W * 4 + 4096 * 4;
-    const int G = pack_factor(W, prob);
     const size_t lds = (size_t)G * prob;
-    int rc = rowmask ? ensure_lds(attn_bwd_smallk_mfma_kernel<true>, lds, "attention_bwd(mfma,merged)")
-                     : ensure_lds(attn_bwd_smallk_mfma_kernel<false>, lds, "attention_bwd(mfma,merged)");
-    if (rc != OVQA_OK) return rc;
-    const dim3 grid((unsigned)((nprob + G - 1) / G)), block(W == 1 ? 512 : 256);
-    if (rowmask) hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel<true>, grid, block, lds, st, a, W, G);
-    else hipLaunchKernelGGL(attn_bwd_smallk_mfma_kernel<false>, grid, block, lds, st, a, W, G);
+    const dim3 grid((unsigned)((nprob + G - 1) / G));
+#define OVQA_SMALLK(RM, WV)                                                                                  \
+  {                                                                                                          \
+    int rc = ensure_lds(attn_bwd_smallk_mfma_kernel<RM, WV>, lds, "attention_bwd(mfma,merged)");             \
+    if (rc != OVQA_OK) return rc;                                                                            \
+    hipLaunchKernelGGL((attn_bwd_smallk_mfma_kernel<RM, WV>), grid, dim3(WV == 1 ? 512 : 256), lds, st, a);  \
+  }
+    if (W == 1) {
+      if (rowmask) OVQA_SMALLK(true, 1) else OVQA_SMALLK(false, 1)
+    } else if (W == 2) {
+      if (rowmask) OVQA_SMALLK(true, 2) else OVQA_SMALLK(false, 2)
+    } else {
+      if (rowmask) OVQA_SMALLK(true, 4) else OVQA_SMALLK(false, 4)
+    }
+#undef OVQA_SMALLK
     return ovqa_check_launch("attention_bwd(mfma,merged)");
   }
   return launch_bwd_two<64>(a, st);
@@ -1263,7 +1443,7 @@ bool mfma_attention_supported(const AttnArgs& a) {
 bool mfma_attention_qkv_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldqkv, const void* x, const void* w,
                                   const void* qkv) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  return a.dk == 64 && a.dv == 64 && a.nq == a.nk && a.nq >= 1 && a.nq <= 128 && Dm % 64 == 0 && Dm >= 64 && ldx % 8 == 0 &&
+  return a.dk == 64 && a.dv == 64 && a.nq == a.nk && a.nq >= 1 && a.nq <= 128 && Dm % 32 == 0 && Dm >= 32 && ldx % 8 == 0 &&
          ldqkv % 8 == 0 && a.ldo % 4 == 0 && a.msq == 0 && a.att == nullptr && a.drop.p <= 0.f && al(x) && al(w) &&
          al(qkv) && (((uintptr_t)a.o & 7) == 0);
 }
@@ -1275,8 +1455,8 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
 #define OVQA_QKV(RPV, SV)                                                                                          \
   {                                                                                                                \
     constexpr int Mv = RPV * SV;                                                                                   \
-    const size_t stage = (size_t)(24 + Mv / 8) * 1024, images = (size_t)SV * 3 * RPV * 128 + (size_t)SV * RPV * 4;  \
-    const size_t lds = 2 * stage > images ? 2 * stage : images;                                                    \
+    const size_t stage = (size_t)(12 + Mv / 16) * 1024, images = (size_t)SV * 3 * RPV * 128 + (size_t)SV * RPV * 4; \
+    const size_t lds = 4 * stage > images ? 4 * stage : images;                                                    \
     const dim3 grid((unsigned)((a.B + SV - 1) / SV), (unsigned)a.H);                                               \
     int rc = ensure_lds(attn_qkv_fwd_mfma_kernel<RPV, SV, true>, lds, "attention_qkv_fwd");                        \
     if (rc != OVQA_OK) return rc;                                                                                  \

@@ -1,0 +1,90 @@
+"""Development probe: where the time goes INSIDE the small attention backward kernels.
+
+Builds the library with -DOVQA_PHASE_PROBE (wall-clock timestamps of thread 0 of two workgroups at marked points),
+runs the MCAN question self-attention (20 x 20) and guided attention (100 x 20) backward shapes, prints the phase
+deltas in microseconds (100 MHz counter: 10 ns resolution).  Run on the GPU box:  python scripts/phase_probe.py
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["OVQA_EXTRA_HIPCC_FLAGS"] = "-DOVQA_PHASE_PROBE"
+from openvivqa_amd import build as B  # noqa: E402
+
+B.build(force=True, verbose=False)
+import torch  # noqa: E402
+
+from openvivqa_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["start", "loads issued", "staged", "barrier", "dQ done", "dK/dV mfma", "reduced", "end"]
+
+
+def run(nq, nk, label, flush=False):
+    Bn, H, D = 64, 8, 512
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(Bn, nq, 3 * D, device="cuda", generator=g).bfloat16()
+    kv = torch.randn(Bn, nk, 2 * D, device="cuda", generator=g).bfloat16()
+    q = qkv[..., :D]
+    k, v = (qkv[..., D:2 * D], qkv[..., 2 * D:]) if nq == nk else (kv[..., :D], kv[..., D:])
+    mask = torch.zeros(Bn, 1, 1, nk, device="cuda")
+    mask[:, :, :, nk - 3:] = -1e5
+    o, lse, _ = ops.attention_fwd(q, k, v, mask, H)
+    d_o = torch.randn_like(o)
+    junk = torch.empty(512 * 1024 * 1024 // 4, device="cuda")
+    for it in range(4):
+        if flush:
+            junk.fill_(1.0)  # push the operands out of L2 / MALL
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention_bwd(d_o, q, k, v, o, lse, mask, H)
+        e1.record()
+        torch.cuda.synchronize()
+    out = (C.c_ulonglong * 32)()
+    assert lib.ovqa_debug_probe(out) == 0
+    for wg in range(2):
+        ts = [out[wg * 16 + i] for i in range(len(names))]
+        t0 = ts[0]
+        print(f"{label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
+              "  ".join(f"{n} {((t - t0) / 100.0):.2f}" for n, t in zip(names, ts) if t >= t0) +
+              f"   [events {e0.elapsed_time(e1) * 1e3:.1f} us]")
+
+
+for flush in (False, True):
+    run(20, 20, "text 20x20", flush)
+    run(100, 20, "guided 100x20", flush)
+def run_fused(n, label, flush=False):
+    Bn, H, D = 64, 8, 512
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(Bn, n, D, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(3 * D, D, device="cuda", generator=g) * D ** -0.5).bfloat16()
+    bias = torch.zeros(3 * D, device="cuda")
+    mask = torch.zeros(Bn, 1, 1, n, device="cuda")
+    mask[:, :, :, n - 3:] = -1e5
+    junk = torch.empty(512 * 1024 * 1024 // 4, device="cuda")
+    for it in range(4):
+        if flush:
+            junk.fill_(1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention_qkv_fwd(x, w, bias, mask, H)
+        e1.record()
+        torch.cuda.synchronize()
+    out = (C.c_ulonglong * 32)()
+    assert lib.ovqa_debug_probe(out) == 0
+    nm = ["start", "K loop", "barrier", "epilogue", "barrier", "attention"]
+    for wg in range(2):
+        ts = [out[wg * 16 + i] for i in range(len(nm))]
+        print(f"{label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
+              "  ".join(f"{a} {((t - ts[0]) / 100.0):.2f}" for a, t in zip(nm, ts)) + f"   [events {e0.elapsed_time(e1) * 1e3:.1f} us]")
+
+
+for flush in (False, True):
+    run_fused(100, "fused fwd 100", flush)
+    run_fused(20, "fused fwd 20", flush)
+names = ["start", "images", "delta", "barrier", "dQ waves end", "dK/dV waves end"]
+for flush in (False, True):
+    run(100, 100, "image 100x100", flush)
