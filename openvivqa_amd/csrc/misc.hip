@@ -144,12 +144,27 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __
 
 template <typename T>
 __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, const T* __restrict__ tgt,
-                                                      T* __restrict__ dx, float* __restrict__ loss, int64_t n) {
+                                                      T* __restrict__ dx, float* __restrict__ loss, int64_t n, int vec) {
   __shared__ float red[4];
   const float inv_n = 1.f / (float)n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  constexpr int V = 16 / (int)sizeof(T);  // elements per 16-byte access
+  const int64_t nv = vec ? n / V : 0;     // (vec: x, tgt, dx are 16-byte aligned)
+  for (int64_t i = t0; i < nv; i += stride) {
+    alignas(16) T xv[V], tv[V], gv[V];
+    *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + i * V);
+    if (tgt) *reinterpret_cast<uint4*>(tv) = *reinterpret_cast<const uint4*>(tgt + i * V);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float v = to_f32<T>(xv[e]) - (tgt ? to_f32<T>(tv[e]) : 0.f);
+      s += v * v;
+      gv[e] = from_f32<T>(2.f * v * inv_n);
+    }
+    if (dx) *reinterpret_cast<uint4*>(dx + i * V) = *reinterpret_cast<const uint4*>(gv);
+  }
+  for (int64_t i = nv * V + t0; i < n; i += stride) {  // tail (or everything, unaligned)
     const float v = to_f32<T>(x[i]) - (tgt ? to_f32<T>(tgt[i]) : 0.f);
     s += v * v;
     if (dx) dx[i] = from_f32<T>(2.f * v * inv_n);
@@ -261,13 +276,17 @@ int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, floa
       return OVQA_ERR_LAUNCH;
     }
   }
-  dim3 grid(blocks_for(n) > 512 ? 512 : blocks_for(n)), block(256);
+  const int vec = (((uintptr_t)x | (uintptr_t)target | (uintptr_t)dx) & 15) == 0;
+  const int64_t per = dtype == OVQA_F32 ? 4 : 8;  // elements per thread and pass
+  int blocks = blocks_for((n + per - 1) / per);
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), block(256);
   if (dtype == OVQA_F32)
     hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)target, (float*)dx,
-                       loss, n);
+                       loss, n, vec);
   else
     hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (const bf16*)target, (bf16*)dx, loss,
-                       n);
+                       n, vec);
   return ovqa_check_launch("sq_loss");
 }
 

@@ -74,12 +74,28 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
 
     def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
-        a = self.arena
+        self.begin_step()
+        self.apply(grad, grad_scale)
+        self.end_step()
+
+    # The three parts of ``step``, for callers that update the arena piecewise (TrainStep with several gradient
+    # segments: the update of a segment whose exchange is complete runs while the next segment is still on the wire).
+    def begin_step(self) -> None:
         ops.increment_step(self.step_t)
-        ops.adam_step(a.master, a.grad if grad is None else grad, self.exp_avg, self.exp_avg_sq, a.shadow, self.lr,
-                      self.step_t, lr_scale=self.lr_scale, betas=self.betas, eps=self.eps,
-                      weight_decay=self.weight_decay, grad_scale=grad_scale)
-        a.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
+
+    def apply(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0, ranges=None) -> None:
+        """Adam update of ``[lo, hi)`` for every range (default: the whole arena), one launch per range."""
+        a = self.arena
+        g = a.grad if grad is None else grad
+        for lo, hi in ([(0, a.numel)] if ranges is None else ranges):
+            if hi <= lo:
+                continue
+            ops.adam_step(a.master[lo:hi], g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                          None if a.shadow is None else a.shadow[lo:hi], self.lr, self.step_t, lr_scale=self.lr_scale,
+                          betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
+
+    def end_step(self) -> None:
+        self.arena.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
         self.host_step += 1
         if self.lr_lambda is not None:  # scheduler.step(): value used by the NEXT optimiser step
             self.lr_scale.fill_(self.lr_lambda(self.host_step))
@@ -109,6 +125,7 @@ class GradAllReducer:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pending = False
+        self._done = []     # one event per released segment (communication stream), in release order
         self.timing = None  # list of (ready event, done event, elements) per released segment when instrumented
 
     def bounds(self, numel: int, lo: int = 0):
@@ -146,11 +163,21 @@ class GradAllReducer:
         self.stream.wait_event(after)
         with torch.cuda.stream(self.stream):
             self._reduce(grad, ranges)
+            done = torch.cuda.Event(enable_timing=timed)
+            done.record(self.stream)
+            self._done.append(done)
             if timed:  # (gradients final on the compute stream, segment reduced on the communication stream)
-                done = torch.cuda.Event(enable_timing=True)
-                done.record(self.stream)
                 self.timing.append((after, done, sum(hi - lo for lo, hi in ranges)))
         self._pending = True
+
+    def wait_segment(self, i: int, grad: torch.Tensor) -> torch.Tensor:
+        """Make the current stream wait for the i-th segment released since the last ``finish`` ONLY (later segments
+        may still be on the wire); returns the buffer that holds that segment's summed gradients."""
+        if self.stream is not None and i < len(self._done):
+            torch.cuda.current_stream(self.device).wait_event(self._done[i])
+        if self.active and self.staging is not None and grad.is_cuda:
+            return self.staging
+        return grad
 
     def finish(self, grad: torch.Tensor) -> torch.Tensor:
         """Make the current stream wait for every segment started with ``reduce_ranges``; returns the buffer that
@@ -159,6 +186,7 @@ class GradAllReducer:
         if self._pending:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
             self._pending = False
+        self._done = []
         if self.active and self.staging is not None and grad.is_cuda:
             return self.staging
         return grad
@@ -526,8 +554,17 @@ class TrainStep:
                 self._release(k)
         else:
             self._fwd_bwd(on_phase=self._release)
-        g = self.reducer.finish(self.arena.grad)
-        self.optim.step(g, grad_scale=1.0 / self.reducer.world)
+        scale = 1.0 / self.reducer.world
+        if self.reducer.active and len(self.segments) > 1:
+            # segment by segment: the update of a segment that has arrived overlaps the exchange of the later ones
+            # (only the LAST segment's exchange is exposed, and the earlier segments' share of Adam now hides part of it)
+            self.optim.begin_step()
+            for k, seg in enumerate(self.segments):
+                self.optim.apply(self.reducer.wait_segment(k, self.arena.grad), scale, ranges=seg)
+            self.reducer.finish(self.arena.grad)
+            self.optim.end_step()
+        else:
+            self.optim.step(self.reducer.finish(self.arena.grad), grad_scale=scale)
         ops.increment_step(self.drop_step)
         return self.loss
 

@@ -505,6 +505,12 @@ def test_sq_loss_and_cast():
         dx = o.sq_loss_fwd_bwd(x, loss, target=t)
         d = x.double() - t.double()
         assert abs(loss.item() - d.pow(2).mean().item()) < 1e-4 and nerr(dx, 2 * d / x.numel()) < tol(dtype)
+        # ragged length (16-byte passes + scalar tail) and an unaligned slice (scalar path throughout)
+        big = rnd(70001 + 1, dtype=dtype, seed=5)
+        for xs in (big[:70001], big[1:]):
+            dx = o.sq_loss_fwd_bwd(xs, loss)
+            assert abs(loss.item() - xs.double().pow(2).mean().item()) < 1e-4
+            assert nerr(dx * xs.numel(), 2 * xs.double()) < tol(dtype)
     a = rnd(1000)
     b = torch.empty(1000, dtype=BF16, device=DEV)
     assert torch.equal(o.cast(a, b), a.to(BF16))
