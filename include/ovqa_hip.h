@@ -262,7 +262,7 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
  *                                                         qkv is kept: the backward pass reads it)
  *     o, lse          = attention(q = qkv[:, 0:H*d], k = qkv[:, H*d:2*H*d], v = qkv[:, 2*H*d:], mask)
  * with nq = nk = n, dk = dv = d and a key mask (msq = 0) or none.  For bf16, d = 64, n <= 128 and d_model a multiple
- * of 64 this is ONE kernel -- a workgroup projects the rows of a few samples for one head with MFMA, keeps the projected
+ * of 32 this is ONE kernel -- a workgroup projects the rows of a few samples for one head with MFMA, keeps the projected
  * tiles in LDS and runs the attention on them; the projections are written to HBM once and never re-read in forward.
  * Any other shape / dtype runs the two separate entry points (ovqa_linear_fwd + ovqa_attention_fwd): same results
  * either way up to bf16 rounding of identical fp32 sums in a different order.  ovqa_last_dispatch() = "mfma-fused".
