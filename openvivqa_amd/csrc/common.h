@@ -143,28 +143,29 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
   return cdf + u * pdf;
 }
 
-// Branch-free erf for the bf16 epilogues (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, far below bf16
-// resolution): GELU stays the exact-erf FORM of the reference (F.gelu default), not the tanh approximation.
-// Returns erf(u / sqrt(2)) and e = exp(-u*u/2) (shared with the Gaussian pdf of the GELU derivative).
-__device__ __forceinline__ float erf_sqrt2_fast(float u, float& e) {
-  const float x = fabsf(u) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));  // raw v_rcp_f32 (1 ulp): not the IEEE division sequence
-  e = __expf(-x * x);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.f - p * t * e;
-  return copysignf(r, u);
+// GELU of the bf16 MFMA epilogues.  The FORM stays the reference's exact-erf GELU, u * Phi(u) (F.gelu default), not the
+// tanh approximation; Phi, the normal CDF 0.5 (1 + erf(u / sqrt 2)), is evaluated as 0.5 + u Q(u^2) with Q a degree-7
+// minimax polynomial on |u| <= 4 (|error| <= 2.2e-5 there; u and u^2 are clamped beyond: <= 5.2e-5) -- 11 VALU
+// instructions and no transcendental, against ~14 + v_rcp + v_exp (4 cycles x 4 each) for the Abramowitz-Stegun
+// 7.1.26 form used before: the GELU epilogues are VALU-bound (a wave64 VALU instruction is 4 cycles, a transcendental
+// 16), and the outputs are rounded to bf16 (2^-9) anyway.  The fp32 mode uses erff (gelu_f above).
+__device__ __forceinline__ float norm_cdf_fast(float u) {
+  const float t = fminf(u * u, 16.f);
+  float q = -1.5807682306e-09f;
+  q = fmaf(q, t, 1.2171011739e-07f);
+  q = fmaf(q, t, -4.1008447793e-06f);
+  q = fmaf(q, t, 8.0667156048e-05f);
+  q = fmaf(q, t, -1.0482029970e-03f);
+  q = fmaf(q, t, 9.6648700100e-03f);
+  q = fmaf(q, t, -6.6175373779e-02f);
+  q = fmaf(q, t, 3.9884750779e-01f);
+  return fmaf(__builtin_amdgcn_fmed3f(u, -4.f, 4.f), q, 0.5f);
 }
-__device__ __forceinline__ float gelu_fast(float u) {
-  float e;
-  return 0.5f * u * (1.f + erf_sqrt2_fast(u, e));
-}
+__device__ __forceinline__ float gelu_fast(float u) { return u * norm_cdf_fast(u); }
+// d/du [u Phi(u)] = Phi(u) + u phi(u), phi = exp(-u^2 / 2) / sqrt(2 pi)
 __device__ __forceinline__ float gelu_grad_fast(float u) {
-  float e;
-  const float cdf = 0.5f * (1.f + erf_sqrt2_fast(u, e));
-  return fmaf(u * 0.39894228040143267794f, e, cdf);
+  const float e = __builtin_amdgcn_exp2f(u * u * -0.72134752044448170368f);  // exp(-u^2 / 2)
+  return fmaf(u * 0.39894228040143267794f, e, norm_cdf_fast(u));
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

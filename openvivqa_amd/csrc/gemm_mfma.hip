@@ -501,8 +501,9 @@ struct MEpiBiasRes32 {
       const float4 b0 = *reinterpret_cast<const float4*>(beta + n), b1 = *reinterpret_cast<const float4*>(beta + n + 4);
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float nmr = -mu * rs;  // (r - mu) * rs * g + b as two fmas per element
 #pragma unroll
-      for (int t = 0; t < 8; t++) r[t] = (r[t] - mu) * rs * g[t] + b[t];
+      for (int t = 0; t < 8; t++) r[t] = fmaf(fmaf(r[t], rs, nmr), g[t], b[t]);
     }
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
     float dm[8];
@@ -521,8 +522,9 @@ struct MEpiBiasRes32 {
       const float mu = mean[m], rs = rstd[m];
       const float4 g0 = *reinterpret_cast<const float4*>(gamma + n), b0 = *reinterpret_cast<const float4*>(beta + n);
       const float g[4] = {g0.x, g0.y, g0.z, g0.w}, b[4] = {b0.x, b0.y, b0.z, b0.w};
+      const float nmr = -mu * rs;
 #pragma unroll
-      for (int t = 0; t < 4; t++) r[t] = (r[t] - mu) * rs * g[t] + b[t];
+      for (int t = 0; t < 4; t++) r[t] = fmaf(fmaf(r[t], rs, nmr), g[t], b[t]);
     }
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
     const float u[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
