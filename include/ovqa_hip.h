@@ -326,6 +326,8 @@ int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_av
 
 /* step counter++ (device side, inside the graph) */
 int ovqa_increment_step(uint32_t* step_ptr, void* stream);
+/* two counters in one launch (the optimiser's step and the dropout step of a training loop); `b` may be NULL */
+int ovqa_increment_steps(uint32_t* a, uint32_t* b, void* stream);
 
 /* fp32 -> bf16 / bf16 -> fp32 flat casts (shadow refresh after load_state_dict). */
 int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -92,6 +92,7 @@ SIGNATURES = {
                           c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_adam_step": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
     "ovqa_increment_step": [c_vp, c_vp],
+    "ovqa_increment_steps": [c_vp, c_vp, c_vp],
     "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],
     "ovqa_gelu_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, _DP, c_vp],
     "ovqa_row_padding_mask": [c_int, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],

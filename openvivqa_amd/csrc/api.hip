@@ -405,7 +405,12 @@ int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_av
 
 int ovqa_increment_step(uint32_t* step_ptr, void* stream) {
   OVQA_REQUIRE(step_ptr, OVQA_ERR_BAD_ARG, "increment_step: null pointer");
-  return ovqa::increment_step(step_ptr, as_stream(stream));
+  return ovqa::increment_step(step_ptr, nullptr, as_stream(stream));
+}
+
+int ovqa_increment_steps(uint32_t* a, uint32_t* b, void* stream) {
+  OVQA_REQUIRE(a && a != b, OVQA_ERR_BAD_ARG, "increment_steps: first counter is NULL or the two are the same");
+  return ovqa::increment_step(a, b, as_stream(stream));
 }
 
 int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {

@@ -70,7 +70,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- dropout: stateless counter hash ---------------------------------------
 // keep(idx) is a pure function of (seed, site, step, idx); forward and backward
-// regenerate it.  One 32-bit hash (fmix32 of murmur3 over pair * golden ^ key) serves the element PAIR
+// regenerate it.  One 32-bit hash (fmix32 of murmur3 over pair ^ key) serves the element PAIR
 // {2j, 2j+1}: each element compares its own 16 bits with a 16-bit threshold (p is resolved to 2^-16).  The fused
 // epilogues own 8 consecutive elements per lane, i.e. 4 hashes instead of 8: the epilogues are VALU-bound and the
 // 32-bit integer multiplies of the hash were a third of their instruction stream.
@@ -109,7 +109,10 @@ __device__ __forceinline__ DropState drop_init(const DropArgs& a) {
   return s;
 }
 __device__ __forceinline__ uint32_t drop_pair_hash(const DropState& s, uint32_t pair) {
-  return ovqa_fmix32(pair * 0x9E3779B1u ^ s.key);
+  // murmur3's finalizer is a full-avalanche bijection: the counter needs no multiply of its own in front of it (a
+  // 32-bit integer multiply is quarter rate: 16 cycles per wave instruction; lag / cross-key / uniformity statistics
+  // of the masks are indistinguishable from the pre-multiplied form, scripts/README.md)
+  return ovqa_fmix32(pair ^ s.key);
 }
 __device__ __forceinline__ bool drop_keep(const DropState& s, uint32_t idx) {
   const uint32_t h = drop_pair_hash(s, idx >> 1);

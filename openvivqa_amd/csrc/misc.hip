@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-__global__ void increment_kernel(uint32_t* s) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *s = *s + 1u;
+__global__ void increment_kernel(uint32_t* s, uint32_t* s2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *s = *s + 1u;
+    if (s2) *s2 = *s2 + 1u;
+  }
 }
 
 template <typename TS, typename TD>
@@ -202,8 +205,8 @@ int adam_step(float* param, const void* grad, int grad_dtype, float* m, float* v
   return ovqa_check_launch("adam_step");
 }
 
-int increment_step(uint32_t* step_ptr, hipStream_t st) {
-  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, st, step_ptr);
+int increment_step(uint32_t* step_ptr, uint32_t* second, hipStream_t st) {
+  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, st, step_ptr, second);
   return ovqa_check_launch("increment_step");
 }
 

@@ -607,9 +607,13 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None,
                                   float(weight_decay), float(grad_scale), _p(step), _stream()), "adam_step")
 
 
-def increment_step(step):
+def increment_step(step, also=None):
+    """step += 1 (and ``also`` += 1 in the same launch)."""
     _dev(step)
-    _lib.check(_lib.load().ovqa_increment_step(_p(step), _stream()), "increment_step")
+    if also is None:
+        _lib.check(_lib.load().ovqa_increment_step(_p(step), _stream()), "increment_step")
+    else:
+        _lib.check(_lib.load().ovqa_increment_steps(_p(step), _p(also), _stream()), "increment_steps")
 
 
 def cast(src, dst):

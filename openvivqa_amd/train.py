@@ -49,17 +49,19 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(arena.master)
         self.exp_avg_sq = torch.zeros_like(arena.master)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)  # number of optimiser steps taken
-        self.lr_scale = torch.ones(1, dtype=torch.float32, device=dev)
+        # LambdaLR factor of the NEXT optimiser step: a host float folded into the kernel's `lr` argument (Adam is
+        # launched eagerly every step, so the schedule costs no launch of its own)
+        self.lr_scale = 1.0
         self.lr_lambda = lr_lambda
         self.host_step = 0
         if lr_lambda is not None:
-            self.lr_scale.fill_(lr_lambda(0))
+            self.lr_scale = float(lr_lambda(0))
 
     def state_dict(self) -> dict:
         """Moments by parameter name-free arena offset (flat fp32), step counters and the LR scale: what
         tasks/base_task.py:97-112 stores as ``optimizer`` / ``scheduler`` so that a run can resume."""
         return {"exp_avg": self.exp_avg.detach().cpu().clone(), "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(),
-                "step": int(self.step_t.item()), "host_step": self.host_step, "lr_scale": float(self.lr_scale.item()),
+                "step": int(self.step_t.item()), "host_step": self.host_step, "lr_scale": float(self.lr_scale),
                 "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                 "numel": self.arena.numel}
 
@@ -70,18 +72,20 @@ class FlatAdam:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_t.fill_(int(sd["step"]))
         self.host_step = int(sd["host_step"])
-        self.lr_scale.fill_(float(sd["lr_scale"]))
+        self.lr_scale = float(sd["lr_scale"])
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
 
-    def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
-        self.begin_step()
+    def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+             also: Optional[torch.Tensor] = None) -> None:
+        self.begin_step(also)
         self.apply(grad, grad_scale)
         self.end_step()
 
     # The three parts of ``step``, for callers that update the arena piecewise (TrainStep with several gradient
     # segments: the update of a segment whose exchange is complete runs while the next segment is still on the wire).
-    def begin_step(self) -> None:
-        ops.increment_step(self.step_t)
+    def begin_step(self, also: Optional[torch.Tensor] = None) -> None:
+        """step_t += 1; ``also`` (another device counter, e.g. the dropout step of the loop) rides in the same launch."""
+        ops.increment_step(self.step_t, also)
 
     def apply(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0, ranges=None) -> None:
         """Adam update of ``[lo, hi)`` for every range (default: the whole arena), one launch per range."""
@@ -91,14 +95,14 @@ class FlatAdam:
             if hi <= lo:
                 continue
             ops.adam_step(a.master[lo:hi], g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                          None if a.shadow is None else a.shadow[lo:hi], self.lr, self.step_t, lr_scale=self.lr_scale,
+                          None if a.shadow is None else a.shadow[lo:hi], self.lr * self.lr_scale, self.step_t,
                           betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
 
     def end_step(self) -> None:
         self.arena.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
         self.host_step += 1
         if self.lr_lambda is not None:  # scheduler.step(): value used by the NEXT optimiser step
-            self.lr_scale.fill_(self.lr_lambda(self.host_step))
+            self.lr_scale = float(self.lr_lambda(self.host_step))
 
 
 class GradAllReducer:
@@ -558,14 +562,13 @@ class TrainStep:
         if self.reducer.active and len(self.segments) > 1:
             # segment by segment: the update of a segment that has arrived overlaps the exchange of the later ones
             # (only the LAST segment's exchange is exposed, and the earlier segments' share of Adam now hides part of it)
-            self.optim.begin_step()
+            self.optim.begin_step(also=self.drop_step)  # (the dropout step is next read by the NEXT forward)
             for k, seg in enumerate(self.segments):
                 self.optim.apply(self.reducer.wait_segment(k, self.arena.grad), scale, ranges=seg)
             self.reducer.finish(self.arena.grad)
             self.optim.end_step()
         else:
-            self.optim.step(self.reducer.finish(self.arena.grad), grad_scale=scale)
-        ops.increment_step(self.drop_step)
+            self.optim.step(self.reducer.finish(self.arena.grad), grad_scale=scale, also=self.drop_step)
         return self.loss
 
     def timed_comm_step(self, *inputs: torch.Tensor) -> dict:

@@ -240,8 +240,10 @@ def cast(src, dst):
     return dst
 
 
-def increment_step(step):
+def increment_step(step, also=None):
     step.add_(1)
+    if also is not None:
+        also.add_(1)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None, betas=(0.9, 0.98), eps=1e-8,
