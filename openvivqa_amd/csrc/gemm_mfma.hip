@@ -257,17 +257,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // BC = rows of the c (Q) operand per tile: 128, or 64 for problems with few tiles (more workgroups, fewer
 // bytes per K-step and CU: the per-CU L2->LDS path, not the matrix pipe, bounds these kernels).
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128>
+// BR = rows of the r (P) operand per tile: 128, or 64 with 4 waves and BC = 32 (the M = 1280 products: twice the
+// workgroups again).
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128>
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
-  static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR), "unsupported tile");
+  static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || (BC == 32 && NW == 4 && !Q_KMAJOR),
+                "unsupported tile");
+  static_assert(BR == 128 || (BR == 64 && NW == 4 && BC == 32 && !P_KMAJOR), "unsupported tile");
   constexpr int WC = NW == 8 ? (BC >= 64 ? 4 : BC / 16) : 2;  // wave grid: WC along c x WR along r
   constexpr int WR = NW / WC;
   constexpr int NI = BC / (16 * WC);   // 16-wide c sub-tiles per wave
-  constexpr int NJ = 128 / (16 * WR);  // 16-wide r sub-tiles per wave
+  constexpr int NJ = BR / (16 * WR);   // 16-wide r sub-tiles per wave
+  constexpr int PCH = BR / 8;          // 1 KiB chunks of the P tile
   constexpr int QCH = BC / 8;          // 1 KiB chunks of the Q tile
   constexpr int QPER = (QCH + NW - 1) / NW;
-  constexpr int STAGE = TILE_BYTES + BC * BK * 2;  // bytes of one ring stage (P tile + Q tile)
-  constexpr int LOADS = 16 / NW + QPER;  // LDS-DMA instructions per (loading) wave per K tile
+  constexpr int PT_BYTES = BR * BK * 2;
+  constexpr int STAGE = PT_BYTES + BC * BK * 2;  // bytes of one ring stage (P tile + Q tile)
+  constexpr int LOADS = PCH / NW + QPER;  // LDS-DMA instructions per (loading) wave per K tile
   constexpr bool WIDE = !P_KMAJOR && Epi::kWide;  // 8 consecutive r per lane (see perm32)
   static_assert(!WIDE || NJ % 2 == 0, "wide epilogue pairs the r sub-tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -290,11 +296,11 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   const int nkt = g.K / BK;
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
-    stage_glds<P_KMAJOR, NW, 16, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
+    stage_glds<P_KMAJOR, NW, PCH, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
     if constexpr (QCH >= NW) {
-      stage_glds<Q_KMAJOR, NW, QCH>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+      stage_glds<Q_KMAJOR, NW, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
     } else {  // fewer Q chunks than waves (BC = 32): the first QCH waves load one chunk each
-      if (wave < QCH) stage_glds<Q_KMAJOR, QCH, QCH>(buf + TILE_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+      if (wave < QCH) stage_glds<Q_KMAJOR, QCH, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
     }
   };
 #pragma unroll
@@ -310,12 +316,12 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
       wait_vmcnt<LOADS * (NBUF - 2)>();
     } else {  // waves >= QCH issue no Q loads: their count per stage is smaller (wave-uniform branch)
       if (wave < QCH) wait_vmcnt<LOADS * (NBUF - 2)>();
-      else wait_vmcnt<(16 / NW) * (NBUF - 2)>();
+      else wait_vmcnt<(PCH / NW) * (NBUF - 2)>();
     }
     __builtin_amdgcn_s_barrier();
     if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
     const char* Ps = smem + (kt % NBUF) * STAGE;
-    const char* Qs = Ps + TILE_BYTES;
+    const char* Qs = Ps + PT_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       bf16x8 pf[NJ], qf[NI];
@@ -366,7 +372,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   }
 }
 
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128>
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = g.tiles_r * g.tiles_c;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC>(g, tc * BC, tr * BT, epi, smem);
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR>(g, tc * BC, tr * BR, epi, smem);
 }
 
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
@@ -645,6 +651,16 @@ inline int tiny_tile_threshold() {
 // tile must be covered by more than one tile in flight).  MEASURED in the MCAN step (operands cold: produced by
 // the previous kernel on other XCDs): (small, tiny) = (2,2) 4.905 ms, (3,3) 4.766, (3,4) 4.721, (4,4) 5.132
 // (BC = 64 with 4 stages leaves one workgroup per CU); an L2-warm microbenchmark prefers 2.
+// the 128 x 32 tier as 64 x 32 tiles with 4 waves (A/B switch; on)
+inline int micro_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_MICRO_TILES");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 inline int small_nbuf() {
   static int v = -1;
   if (v < 0) {
@@ -705,6 +721,20 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>, lds);                                  \
     if (rc != OVQA_OK) return rc;                                                                                  \
     OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>), grid, dim3(NW * 64), lds, st, g, epi);  \
+  }
+  if constexpr (!QK && !PK) {
+    // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of the 128 x 32
+    // tier (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step
+    // 3.53 -> 3.49 ms; a ring of 3 / 6 and the same idea for the 128 x 64 tier (64 x 64 tiles) measured slower.
+    if (tiny_c && micro_tiles()) {
+      g.tiles_r = (int)((R + 63) / 64);
+      const dim3 grid2(g.tiles_r * g.tiles_c);
+      const size_t lds = (size_t)4 * (64 * BK * 2 + 32 * BK * 2);
+      int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>, lds);
+      if (rc != OVQA_OK) return rc;
+      OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>), grid2, dim3(256), lds, st, g, epi);
+      return ovqa_check_launch(what);
+    }
   }
   if constexpr (!QK) {
     if (tiny_c) {
