@@ -703,9 +703,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 // W (query tiles per problem: 1, 2 or 4) is a template parameter: G = 4 / W problems are packed per workgroup, and all
 // staging index arithmetic folds to shifts.  These kernels are latency chains (launch -> loads -> ~20 MFMAs -> stores),
 // so instruction count matters like nowhere else: a wave64 VALU instruction is 4 cycles, 600 instructions are 1 us.
-template <bool ROWMASK, int W>
-__global__ __launch_bounds__(W == 1 ? 512 : 256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a) {
-  constexpr int NT = W == 1 ? 512 : 256, G = 4 / W;
+template <bool ROWMASK, int W, int G = 4 / W>
+__global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a) {
+  static_assert(W * G == 4 || (W == 1 && G == 2), "problems per workgroup: 4 / W, or 2 single-tile problems");
+  constexpr int NT = W == 1 ? 128 * G : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
@@ -715,8 +716,10 @@ __global__ __launch_bounds__(W == 1 ? 512 : 256) void attn_bwd_smallk_mfma_kerne
   // 512 threads (W == 1: the 20 x 20 question attention): waves 0-3 take the dQ role, waves 4-7 the dK/dV role of
   // the same 4 packed problems -- half the dependent chain per wave.  256 threads (W >= 2): every wave does both
   // (with 4 query tiles per problem the doubled wave count only adds VALU contention: 14.8 vs 18.3 us).
-  constexpr bool both = NT == 256;
-  const int role = wave >> 2, w4 = wave & 3;
+  // (W == 1, G == 2: the same role split with 2 + 2 waves -- 256 instead of 128 workgroups for 64 samples x 8 heads)
+  constexpr bool both = W > 1;
+  constexpr bool stage_all = NT == 256;  // every thread stages a chunk of every image
+  const int role = W == 1 ? wave / G : 0, w4 = W == 1 ? wave % G : wave & 3;
   const int slot = w4 / W, tq = w4 % W;
   OVQA_PROBE(0);
 
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(W == 1 ? 512 : 256) void attn_bwd_smallk_mfma_kerne
   // W == 1: threads 0-255 stage Q and K, threads 256-511 dO (+ O) and V.
   {
     const int pid0 = (int)blockIdx.x * G, nprob = a.B * a.H;
-    const bool ld_q = both || tid < 256, ld_d = both || tid >= 256;  // wave-uniform
+    const bool ld_q = stage_all || tid < 256, ld_d = stage_all || tid >= 256;  // wave-uniform
     const int t = tid & 255;
     const int ch = t & 7;
     float mval = 0.f;  // mask row entries: thread -> (problem tid / 32, key tid % 32)
@@ -1393,22 +1396,26 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
     int W = (a.nq + 31) / 32;
     if (W == 3) W = 4;
-    const int G = 4 / W;  // problems per workgroup (compile-time in the kernel)
+    // problems per workgroup (compile-time in the kernel): 4 / W; single-tile problems 2 at a time when 4 at a time
+    // would leave CUs without a workgroup
+    const int G = (W == 1 && (nprob + 3) / 4 < 256) ? 2 : 4 / W;
     const size_t prob = (size_t)(2 * 32 * W + 2 * 32) * 128 + 32 * 4 + 2 * 32 * W * 4 + 4096 * 4;
     const size_t lds = (size_t)G * prob;
     const dim3 grid((unsigned)((nprob + G - 1) / G));
-#define OVQA_SMALLK(RM, WV)                                                                                  \
-  {                                                                                                          \
-    int rc = ensure_lds(attn_bwd_smallk_mfma_kernel<RM, WV>, lds, "attention_bwd(mfma,merged)");             \
-    if (rc != OVQA_OK) return rc;                                                                            \
-    hipLaunchKernelGGL((attn_bwd_smallk_mfma_kernel<RM, WV>), grid, dim3(WV == 1 ? 512 : 256), lds, st, a);  \
+#define OVQA_SMALLK(RM, WV, GV)                                                                                       \
+  {                                                                                                                   \
+    int rc = ensure_lds(attn_bwd_smallk_mfma_kernel<RM, WV, GV>, lds, "attention_bwd(mfma,merged)");                  \
+    if (rc != OVQA_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((attn_bwd_smallk_mfma_kernel<RM, WV, GV>), grid, dim3(WV == 1 ? 128 * GV : 256), lds, st, a);  \
   }
-    if (W == 1) {
-      if (rowmask) OVQA_SMALLK(true, 1) else OVQA_SMALLK(false, 1)
+    if (W == 1 && G == 2) {
+      if (rowmask) OVQA_SMALLK(true, 1, 2) else OVQA_SMALLK(false, 1, 2)
+    } else if (W == 1) {
+      if (rowmask) OVQA_SMALLK(true, 1, 4) else OVQA_SMALLK(false, 1, 4)
     } else if (W == 2) {
-      if (rowmask) OVQA_SMALLK(true, 2) else OVQA_SMALLK(false, 2)
+      if (rowmask) OVQA_SMALLK(true, 2, 2) else OVQA_SMALLK(false, 2, 2)
     } else {
-      if (rowmask) OVQA_SMALLK(true, 4) else OVQA_SMALLK(false, 4)
+      if (rowmask) OVQA_SMALLK(true, 4, 1) else OVQA_SMALLK(false, 4, 1)
     }
 #undef OVQA_SMALLK
     return ovqa_check_launch("attention_bwd(mfma,merged)");
