@@ -252,6 +252,20 @@ class WgradQueue:
         self._used_side = False
         self.defer_uploads = False  # capture mode of a harness: tables are uploaded ONCE after the capture
         self._deferred = []         # (pinned host, device, nbytes) of tables a captured launch reads
+        self._producers = set()     # streams (other than the flushing one) whose kernels wrote queued operands
+
+    def _note_producer(self, t):
+        if t.is_cuda:
+            self._producers.add(torch.cuda.current_stream(t.device))
+
+    def _join_producers(self):
+        """Backward ops run on the stream their forward ran on; a block that ran on a side stream queues operands the
+        deferred launches (current stream) must not read early."""
+        for st in self._producers:
+            cur = torch.cuda.current_stream(st.device)
+            if st != cur:
+                cur.wait_stream(st)
+        self._producers.clear()
 
     def _side_stream(self, dev):
         st = self._side.get(dev)
@@ -270,6 +284,7 @@ class WgradQueue:
             self.finish()
         flags = int(bool(accumulate)) | (int(bool(accumulate_db)) << 1)
         N, K = dy.shape[-1], x.shape[-1]
+        self._note_producer(dy)
         self.items.append((dy, x, dw, lddy, ldx, M, N, K, flags, db))
         self.ntiles += ((N + self.TILE - 1) // self.TILE) * ((K + self.TILE - 1) // self.TILE)
         if self.ntiles >= self.FLUSH_TILES:
@@ -277,6 +292,7 @@ class WgradQueue:
 
     def add_reduce(self, partial, blocks, D, out0, out1):
         assert out0.dtype == torch.float32 and out1.dtype == torch.float32 and partial.dtype == torch.float32
+        self._note_producer(partial)
         self.reduces.append((partial, blocks, D, out0, out1))
 
     def _flush_reduces(self):
@@ -379,6 +395,7 @@ class WgradQueue:
 
     def finish(self):
         """End of the backward pass: launch the remainder and make the main stream wait for the side stream."""
+        self._join_producers()
         self._flush_reduces()
         self.flush()
         if self._used_side:
