@@ -32,6 +32,22 @@
 #include "common.h"
 #include "kernels.h"
 
+// Phase probe (development only, -DOVQA_PHASE_PROBE; see attention_mfma.hip): wall-clock stamps of thread 0 of the first
+// and the middle workgroup at marked points of gemm_tile_glds, read back by ovqa_debug_probe_gemm().
+#ifdef OVQA_PHASE_PROBE
+__device__ unsigned long long g_probe_gemm[2][16];
+#define OVQA_GPROBE(i)                                                                   \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))            \
+      g_probe_gemm[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64();                         \
+  } while (0)
+extern "C" int ovqa_debug_probe_gemm(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_gemm), sizeof(g_probe_gemm));
+}
+#else
+#define OVQA_GPROBE(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BT = 128, BK = 64;
@@ -294,6 +310,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
 
   const int nkt = g.K / BK;
+  OVQA_GPROBE(0);
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
     stage_glds<P_KMAJOR, NW, PCH, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
@@ -306,8 +323,10 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
 #pragma unroll
   for (int p = 0; p < NBUF - 1; p++)
     if (p < nkt) issue(p);
+  OVQA_GPROBE(1);
 
   for (int kt = 0; kt < nkt; kt++) {
+    if (kt == 1) OVQA_GPROBE(2);
     // tile kt has landed (all but the youngest NBUF-2 tiles' loads are done), and -- after the barrier --
     // every wave has finished reading the buffer that the next issue overwrites
     if (NBUF == 2 || kt + NBUF - 2 >= nkt) {
@@ -342,6 +361,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
       }
     }
   }
+  OVQA_GPROBE(3);
   if constexpr (COLSUM) {
     if (do_colsum && lane < 16) {
 #pragma unroll
@@ -370,6 +390,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
       }
     }
   }
+  OVQA_GPROBE(4);
 }
 
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128>

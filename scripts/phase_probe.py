@@ -82,6 +82,33 @@ def run_fused(n, label, flush=False):
               "  ".join(f"{a} {((t - ts[0]) / 100.0):.2f}" for a, t in zip(nm, ts)) + f"   [events {e0.elapsed_time(e1) * 1e3:.1f} us]")
 
 
+def run_gemm(M, N, K, label, flush=False, kind="dx"):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    wt = (torch.randn(K, N, device="cuda", generator=g) * N ** -0.5).bfloat16()
+    add = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    junk = torch.empty(512 * 1024 * 1024 // 4, device="cuda")
+    for it in range(4):
+        if flush:
+            junk.fill_(1.0)
+        torch.cuda.synchronize()
+        ops.linear_bwd_data_wt(dy, wt, addend=add)
+        torch.cuda.synchronize()
+    out = (C.c_ulonglong * 32)()
+    assert lib.ovqa_debug_probe_gemm(out) == 0
+    nm = ["start", "prologue issued", "first K tile done", "K loop done", "epilogue done"]
+    for wg in range(2):
+        ts = [out[wg * 16 + i] for i in range(len(nm))]
+        print(f"{label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
+              "  ".join(f"{a} {((t - ts[0]) / 100.0):.2f}" for a, t in zip(nm, ts)))
+
+
+for flush in (False, True):
+    run_gemm(6400, 512, 512, "dX 6400x512<-512", flush)
+    run_gemm(6400, 1536, 512, "dX 6400x512<-1536", flush)
+    run_gemm(6400, 2048, 512, "dX 6400x512<-2048", flush)
+    run_gemm(6400, 512, 2048, "dX 6400x2048<-512", flush)
+    run_gemm(1280, 512, 512, "dX 1280x512<-512", flush)
 for flush in (False, True):
     run_fused(100, "fused fwd 100", flush)
     run_fused(20, "fused fwd 20", flush)
