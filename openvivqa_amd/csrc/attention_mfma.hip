@@ -303,15 +303,17 @@ struct QkvAttnArgs {
   int Dm;
 };
 
-template <int RP, int S, bool ROWMASK>
+// BKF = K step (32 or 64), NBUF = ring depth.  The direct-to-LDS stream is faster with 128-byte row segments (BKF = 64)
+// and with two workgroups per CU (scripts/lds_stream_probe.py: 105 GB/s per CU against 64-71), which is what the
+// 128-row single-sample form <128, 1, 64, 2> buys (80 KiB of LDS: two workgroups per CU, the attention of one under the
+// projection of the other) at the price of streaming the head's weights once per sample instead of once per pair.
+template <int RP, int S, bool ROWMASK, int BKF = 32, int NBUF = 4>
 __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
   constexpr int M = RP * S, NI = M / 64, NJ = 6, NKT = RP / 32, TQ = RP / 32;
-  // K steps of 32 in a ring of 4: a stage is [192 weight rows | M x rows] x 64 B = 20-28 KiB, three stages in flight.
-  // (The workgroup is alone on its CU -- the images need 48-96 KiB --, so nothing else covers the L2 -> LDS latency:
-  // with two 56-KiB stages of 64 a K step took 1.7 us, the whole loop 13.6 of the kernel's 21 us.)
-  constexpr int NBUF = 4, BKF = 32;
-  constexpr int WCH = 12, XCH = M / 16;              // 1 KiB staging pieces (16 rows x 64 B) of the W / x tiles
-  constexpr int PCS = WCH + XCH;                     // 28 (M = 256) or 20 (M = 128) pieces per stage
+  constexpr int PROWS = 1024 / (BKF * 2);            // rows of a 1 KiB staging piece: 16 (64-B rows) or 8 (128-B rows)
+  constexpr int CHR = BKF / 8;                       // 16-byte chunks per row: 4 or 8
+  constexpr int WCH = 192 / PROWS, XCH = M / PROWS;  // pieces of the W / x tiles
+  constexpr int PCS = WCH + XCH;                     // pieces per stage
   constexpr int PER = (PCS + 7) / 8;                 // per wave: PER pieces, the last one only for waves < PCS - 8 * (PER - 1)
   constexpr int FULL = PCS - 8 * (PER - 1);          // waves with PER pieces
   constexpr int STAGE = PCS * 1024;
@@ -333,24 +335,25 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
   // the next, and this g puts their 16 slots on 16 distinct 16-byte bank columns (the plain (r >> 2) & 3 is 2-way
   // conflicting: 1.5 M conflict cycles per launch).  A staging piece is 16 rows = 1 KiB; lane l of the loading wave
   // fills slot l & 3 of row l >> 2, i.e. fetches global chunk (l & 3) ^ g.
-  auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };
-  auto off32 = [&](int row, int ch) { return row * 64 + ((ch ^ swz(row)) << 4); };
+  // (128-byte rows, BKF = 64: the GEMM kernels' slot = chunk ^ (row & 7))
+  auto swz = [](int row) { return BKF == 32 ? (0x78 >> (2 * ((row >> 2) & 3))) & 3 : (row & 7); };
+  auto off32 = [&](int row, int ch) { return row * (BKF * 2) + ((ch ^ swz(row)) << 4); };
   const bf16* src[PER];  // this lane's source row (+ chunk) of each of its pieces, K offset 0
 #pragma unroll
   for (int i = 0; i < PER; i++) {
     const int ci = wave + 8 * i;
-    const int prow = lane >> 2;
+    const int prow = lane / CHR, pch = lane % CHR;
     if (ci < WCH) {  // weight rows of this head: tile row t -> kind t/64 (q, k, v), feature t%64, permuted within 32
-      const int row = ci * 16 + prow;
+      const int row = ci * PROWS + prow;
       const int t = perm32(row);
-      src[i] = g.w + (int64_t)((t >> 6) * HD + h * 64 + (t & 63)) * g.Dm + (((lane & 3) ^ swz(row)) << 3);
+      src[i] = g.w + (int64_t)((t >> 6) * HD + h * 64 + (t & 63)) * g.Dm + ((pch ^ swz(row)) << 3);
     } else {         // x rows: sample (row / RP), position clamped to the sample's last row
-      const int row = (ci - WCH) * 16 + prow;
+      const int row = (ci - WCH) * PROWS + prow;
       int bs = b0 + row / RP;
       bs = bs < a.B ? bs : a.B - 1;
       int r = row % RP;
       r = r < n ? r : n - 1;
-      src[i] = g.x + ((int64_t)bs * n + r) * g.ldx + (((lane & 3) ^ swz(row)) << 3);
+      src[i] = g.x + ((int64_t)bs * n + r) * g.ldx + ((pch ^ swz(row)) << 3);
     }
   }
   // the epilogue's bias values (8 consecutive features per (jp) of this lane), requested before the K loop
@@ -389,17 +392,20 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
     if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
     const char* Ws = smem + (kt % NBUF) * STAGE;
     const char* Xs = Ws + WCH * 1024;
-    bf16x8 pf[NJ], qf[NI];
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
-      pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 96 + j * 16 + (lane & 15), lane >> 4));
+    for (int ks = 0; ks < BKF / 32; ks++) {
+      bf16x8 pf[NJ], qf[NI];
 #pragma unroll
-    for (int i = 0; i < NI; i++)
-      qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * (NI * 16) + i * 16 + (lane & 15), lane >> 4));
+      for (int j = 0; j < NJ; j++)
+        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 96 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
+      for (int i = 0; i < NI; i++)
+        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * (NI * 16) + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
 #pragma unroll
-      for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    }
   }
   OVQA_PROBE(1);
   __syncthreads();  // every wave is done with the staging buffers: they become the Q | K | V images
@@ -1462,22 +1468,32 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
                            int64_t ldqkv, int64_t Dm, hipStream_t st) {
   QkvAttnArgs g{(const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)qkv, ldqkv, a, (int)Dm};
   // the key mask row (zeros when there is no mask, -inf beyond n) always lives in LDS: ROWMASK = true
-#define OVQA_QKV(RPV, SV)                                                                                          \
+#define OVQA_QKV(RPV, SV, BKV, NBV)                                                                                \
   {                                                                                                                \
     constexpr int Mv = RPV * SV;                                                                                   \
-    const size_t stage = (size_t)(12 + Mv / 16) * 1024, images = (size_t)SV * 3 * RPV * 128 + (size_t)SV * RPV * 4; \
-    const size_t lds = 4 * stage > images ? 4 * stage : images;                                                    \
+    const size_t stage = (size_t)(192 + Mv) * BKV * 2, images = (size_t)SV * 3 * RPV * 128 + (size_t)SV * RPV * 4; \
+    const size_t lds = NBV * stage > images ? NBV * stage : images;                                                \
     const dim3 grid((unsigned)((a.B + SV - 1) / SV), (unsigned)a.H);                                               \
-    int rc = ensure_lds(attn_qkv_fwd_mfma_kernel<RPV, SV, true>, lds, "attention_qkv_fwd");                        \
+    int rc = ensure_lds(attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>, lds, "attention_qkv_fwd");              \
     if (rc != OVQA_OK) return rc;                                                                                  \
-    hipLaunchKernelGGL((attn_qkv_fwd_mfma_kernel<RPV, SV, true>), grid, dim3(512), lds, st, g);                    \
+    hipLaunchKernelGGL((attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>), grid, dim3(512), lds, st, g);          \
   }
+  static int form = -1;
+  if (form < 0) {
+    const char* e = getenv("OVQA_QKV_FORM");  // A/B switch for the long-sequence form
+    form = e ? atoi(e) : 1;
+  }
+  const bool k64 = Dm % 64 == 0;
   // short sequences: 4 samples per workgroup, or 2 when 4 would leave CUs without a workgroup (64 samples x 8 heads:
-  // 128 -> 256 workgroups, 3.455 -> 3.442 ms per MCAN step)
-  if (a.nq <= 32 && (int64_t)((a.B + 3) / 4) * a.H < 256) OVQA_QKV(32, 2)
-  else if (a.nq <= 32) OVQA_QKV(32, 4)
-  else if (a.nq <= 64) OVQA_QKV(64, 4)
-  else OVQA_QKV(128, 2)
+  // 128 -> 256 workgroups, 3.455 -> 3.442 ms per MCAN step; K steps of 64 made no difference here)
+  if (a.nq <= 32 && (int64_t)((a.B + 3) / 4) * a.H < 256) OVQA_QKV(32, 2, 32, 4)
+  else if (a.nq <= 32) OVQA_QKV(32, 4, 32, 4)
+  else if (a.nq <= 64) OVQA_QKV(64, 4, 32, 4)
+  // 65-128 positions (100 regions): one sample per workgroup, K steps of 64, two workgroups per CU: 3.408 -> 3.382 ms
+  // per MCAN step (two samples per workgroup with K steps of 64: 3.390)
+  else if (form == 1 && k64) OVQA_QKV(128, 1, 64, 2)
+  else if (form == 2 && k64) OVQA_QKV(128, 2, 64, 2)
+  else OVQA_QKV(128, 2, 32, 4)
 #undef OVQA_QKV
   return ovqa_check_launch("attention_qkv_fwd(mfma)");
 }
