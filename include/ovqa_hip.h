@@ -324,6 +324,25 @@ int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_av
                    float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, const uint32_t* step_ptr, void* stream);
 
+/* The same Adam step with the transposed bf16 weight copy written in the same pass.  `tiles` (DEVICE array, n_tiles
+ * entries) lists the 64 x 64 tiles of every weight matrix (or adjacency group of matrices) of the arena; one workgroup
+ * updates param / exp_avg / exp_avg_sq of a tile, writes the bf16 shadow (row-major, same offsets as param) AND the
+ * tile's transpose into `shadow_t` ([cols, rows] at the matrix' offset: what ovqa_linear_bwd_data_wt reads) -- the
+ * separate ovqa_grouped_transpose pass over the shadow (2 x 2 B per parameter of HBM traffic and a launch) goes away.
+ * Elements of [flat_lo, flat_hi) (the 1-D parameters behind the matrices) are updated like ovqa_adam_step does.
+ * rows, cols multiples of 8; offsets, flat_lo, flat_hi multiples of 4. */
+typedef struct ovqa_adam_tile {
+  int64_t off;            /* element offset of the matrix in the arena */
+  int32_t rows, cols;     /* of the matrix (row-major [rows, cols]) */
+  int32_t r0, c0;         /* origin of this tile */
+  int32_t reserved[2];
+} ovqa_adam_tile;
+int ovqa_adam_step_tiled(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
+                         void* shadow_bf16, void* shadow_t_bf16, const ovqa_adam_tile* tiles, int32_t n_tiles,
+                         int64_t flat_lo, int64_t flat_hi, float lr, const float* lr_scale_ptr,
+                         float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, const uint32_t* step_ptr, void* stream);
+
 /* step counter++ (device side, inside the graph) */
 int ovqa_increment_step(uint32_t* step_ptr, void* stream);
 /* two counters in one launch (the optimiser's step and the dropout step of a training loop); `b` may be NULL */

@@ -32,6 +32,12 @@ class TransposeProblem(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class AdamTile(C.Structure):
+    """ovqa_adam_tile (include/ovqa_hip.h)."""
+    _fields_ = [("off", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("r0", C.c_int32), ("c0", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
 class ReduceProblem(C.Structure):
     """ovqa_reduce_problem (include/ovqa_hip.h)."""
     _fields_ = [("partial", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
@@ -91,6 +97,8 @@ SIGNATURES = {
     "ovqa_batched_gemm": [c_int, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                           c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_adam_step": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
+    "ovqa_adam_step_tiled": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_f32, c_vp, c_f32, c_f32,
+                             c_f32, c_f32, c_f32, c_vp, c_vp],
     "ovqa_increment_step": [c_vp, c_vp],
     "ovqa_increment_steps": [c_vp, c_vp, c_vp],
     "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],

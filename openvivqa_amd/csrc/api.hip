@@ -403,6 +403,24 @@ int ovqa_adam_step(float* param, const void* grad, int grad_dtype, float* exp_av
                          weight_decay, grad_scale, step_ptr, as_stream(stream));
 }
 
+int ovqa_adam_step_tiled(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
+                         void* shadow_bf16, void* shadow_t_bf16, const ovqa_adam_tile* tiles, int32_t n_tiles,
+                         int64_t flat_lo, int64_t flat_hi, float lr, const float* lr_scale_ptr, float beta1, float beta2,
+                         float eps, float weight_decay, float grad_scale, const uint32_t* step_ptr, void* stream) {
+  OVQA_REQUIRE(dtype_ok(grad_dtype) && n_tiles >= 0 && flat_lo >= 0 && flat_hi >= flat_lo, OVQA_ERR_BAD_ARG,
+               "adam_step_tiled: bad argument");
+  OVQA_REQUIRE(param && grad && exp_avg && exp_avg_sq && (n_tiles == 0 || tiles), OVQA_ERR_BAD_ARG,
+               "adam_step_tiled: null pointer");
+  OVQA_REQUIRE(flat_lo % 4 == 0 && flat_hi % 4 == 0, OVQA_ERR_BAD_ARG, "adam_step_tiled: flat range must be 4-aligned");
+  OVQA_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 8 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
+                   ((uintptr_t)exp_avg_sq % 16 == 0) && ((uintptr_t)shadow_bf16 % 8 == 0) &&
+                   ((uintptr_t)shadow_t_bf16 % 16 == 0),
+               OVQA_ERR_BAD_ARG, "adam_step_tiled: arena pointers must be 16-byte aligned");
+  return ovqa::adam_step_tiled(param, grad, grad_dtype, exp_avg, exp_avg_sq, shadow_bf16, shadow_t_bf16, tiles, n_tiles,
+                               flat_lo, flat_hi, lr, lr_scale_ptr, beta1, beta2, eps, weight_decay, grad_scale, step_ptr,
+                               as_stream(stream));
+}
+
 int ovqa_increment_step(uint32_t* step_ptr, void* stream) {
   OVQA_REQUIRE(step_ptr, OVQA_ERR_BAD_ARG, "increment_step: null pointer");
   return ovqa::increment_step(step_ptr, nullptr, as_stream(stream));

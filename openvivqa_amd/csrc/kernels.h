@@ -80,6 +80,10 @@ int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_bloc
 int adam_step(float* param, const void* grad, int grad_dtype, float* m, float* v, void* shadow, int64_t n, float lr,
               const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
               const uint32_t* step_ptr, hipStream_t st);
+int adam_step_tiled(float* param, const void* grad, int grad_dtype, float* m, float* v, void* shadow, void* shadow_t,
+                    const ovqa_adam_tile* tiles, int n_tiles, int64_t flat_lo, int64_t flat_hi, float lr,
+                    const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
+                    const uint32_t* step_ptr, hipStream_t st);
 int increment_step(uint32_t* step_ptr, uint32_t* second, hipStream_t st);
 int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st);
 int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st);

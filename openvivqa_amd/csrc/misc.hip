@@ -67,6 +67,86 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Adam over 64 x 64 tiles of the weight matrices, writing the bf16 shadow and its transpose (through LDS) in the same
+// pass; trailing workgroups (blockIdx >= n_tiles) update the flat range of 1-D parameters.
+template <typename TG>
+__global__ __launch_bounds__(256) void adam_tiled_kernel(float* __restrict__ p, const TG* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         bf16* __restrict__ shadow, bf16* __restrict__ shadow_t,
+                                                         const ovqa_adam_tile* __restrict__ tiles, int n_tiles,
+                                                         int64_t flat_lo, int64_t flat_hi, float lr,
+                                                         const float* __restrict__ lr_scale_ptr, float b1, float b2,
+                                                         float eps, float wd, float grad_scale,
+                                                         const uint32_t* __restrict__ step_ptr) {
+  __shared__ bf16 tile[64][64 + 8];
+  const float t = (float)(step_ptr ? *step_ptr : 1u);
+  const float lr_eff = lr * (lr_scale_ptr ? *lr_scale_ptr : 1.f);
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2 = 1.f - powf(b2, t);
+  const float step_size = lr_eff / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  typedef __attribute__((ext_vector_type(4))) TG g4_t;
+  auto update4 = [&](int64_t i4, bf16x4& s) {  // elements 4 * i4 .. 4 * i4 + 3 of the arena
+    float4 pp = reinterpret_cast<float4*>(p)[i4];
+    const g4_t g4 = reinterpret_cast<const g4_t*>(g)[i4];
+    float4 mm = reinterpret_cast<float4*>(m)[i4];
+    float4 vv = reinterpret_cast<float4*>(v)[i4];
+    float* pa = &pp.x;
+    float* ma = &mm.x;
+    float* va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float gk = to_f32<TG>(g4[k]) * grad_scale + wd * pa[k];
+      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
+      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
+      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
+      pa[k] -= step_size * ma[k] / denom;
+      s[k] = (bf16)pa[k];
+    }
+    reinterpret_cast<float4*>(p)[i4] = pp;
+    reinterpret_cast<float4*>(m)[i4] = mm;
+    reinterpret_cast<float4*>(v)[i4] = vv;
+    if (shadow) reinterpret_cast<bf16x4*>(shadow)[i4] = s;
+  };
+  if ((int)blockIdx.x >= n_tiles) {  // flat range
+    const int64_t nb = (int64_t)gridDim.x - n_tiles;
+    const int64_t stride = nb * blockDim.x;
+    for (int64_t i4 = (flat_lo >> 2) + ((int64_t)blockIdx.x - n_tiles) * blockDim.x + threadIdx.x; i4 < (flat_hi >> 2);
+         i4 += stride) {
+      bf16x4 s;
+      update4(i4, s);
+    }
+    return;
+  }
+  const ovqa_adam_tile tl = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  // thread -> rows tid / 16 + 16 * i (i = 0..3), columns (tid % 16) * 4 .. + 3: 16 lanes cover a 256-byte row segment
+  const int c = (tid & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int r = (tid >> 4) + 16 * i;
+    bf16x4 s;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = (bf16)0.f;
+    if (tl.r0 + r < tl.rows && tl.c0 + c < tl.cols)
+      update4((tl.off + (int64_t)(tl.r0 + r) * tl.cols + tl.c0 + c) >> 2, s);
+    *reinterpret_cast<bf16x4*>(&tile[r][c]) = s;
+  }
+  __syncthreads();
+  if (shadow_t == nullptr) return;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int cc = tid / 8 + 32 * pass, ch = tid % 8;  // output row = source column
+    const int gc = tl.c0 + cc, gr = tl.r0 + ch * 8;
+    if (gc < tl.cols && gr < tl.rows) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = tile[ch * 8 + e][cc];
+      *reinterpret_cast<bf16x8*>(shadow_t + tl.off + (int64_t)gc * tl.rows + gr) = o;
+    }
+  }
+}
+
 __global__ void increment_kernel(uint32_t* s, uint32_t* s2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     *s = *s + 1u;
@@ -203,6 +283,26 @@ int adam_step(float* param, const void* grad, int grad_dtype, float* m, float* v
     hipLaunchKernelGGL(adam_kernel<float>, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, (const float*)grad, m,
                        v, (bf16*)shadow, n, lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
   return ovqa_check_launch("adam_step");
+}
+
+int adam_step_tiled(float* param, const void* grad, int grad_dtype, float* m, float* v, void* shadow, void* shadow_t,
+                    const ovqa_adam_tile* tiles, int n_tiles, int64_t flat_lo, int64_t flat_hi, float lr,
+                    const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
+                    const uint32_t* step_ptr, hipStream_t st) {
+  const int64_t flat4 = (flat_hi - flat_lo) >> 2;
+  int flat_blocks = flat4 > 0 ? (int)((flat4 + 255) / 256) : 0;
+  if (flat_blocks > 64) flat_blocks = 64;
+  if (n_tiles + flat_blocks == 0) return OVQA_OK;
+  const dim3 grid((unsigned)(n_tiles + flat_blocks));
+  if (grad_dtype == OVQA_BF16)
+    hipLaunchKernelGGL(adam_tiled_kernel<bf16>, grid, dim3(256), 0, st, param, (const bf16*)grad, m, v, (bf16*)shadow,
+                       (bf16*)shadow_t, tiles, n_tiles, flat_lo, flat_hi, lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale,
+                       step_ptr);
+  else
+    hipLaunchKernelGGL(adam_tiled_kernel<float>, grid, dim3(256), 0, st, param, (const float*)grad, m, v, (bf16*)shadow,
+                       (bf16*)shadow_t, tiles, n_tiles, flat_lo, flat_hi, lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale,
+                       step_ptr);
+  return ovqa_check_launch("adam_step_tiled");
 }
 
 int increment_step(uint32_t* step_ptr, uint32_t* second, hipStream_t st) {

@@ -624,6 +624,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None,
                                   float(weight_decay), float(grad_scale), _p(step), _stream()), "adam_step")
 
 
+def adam_step_tiled(param, grad, exp_avg, exp_avg_sq, shadow, shadow_t, tiles, n_tiles, flat_lo, flat_hi, lr, step,
+                    lr_scale=None, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """Adam over the whole arena with the transposed bf16 shadow written in the same pass (``tiles``: device table of
+    ovqa_adam_tile from ParamArena.adam_tiles())."""
+    _dev(param)
+    lib = _lib.load()
+    assert grad.numel() == param.numel()
+    _lib.check(lib.ovqa_adam_step_tiled(_p(param), _p(grad), _dt(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), _p(shadow_t),
+                                        _p(tiles), int(n_tiles), int(flat_lo), int(flat_hi), float(lr), _p(lr_scale),
+                                        float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                        float(grad_scale), _p(step), _stream()), "adam_step_tiled")
+
+
 def increment_step(step, also=None):
     """step += 1 (and ``also`` += 1 in the same launch)."""
     _dev(step)

@@ -211,6 +211,65 @@ class ParamArena:
             self._tr_table = (raw.to(self.device), len(self._groups2d), tiles)
         ops.grouped_transpose(*self._tr_table)
 
+    def adam_tiles(self):
+        """(device table of ovqa_adam_tile, number of tiles, flat_lo, flat_hi) for ops.adam_step_tiled, or None when the
+        arena does not have the shape that kernel assumes: every element in front of the 1-D tail belongs to a matrix
+        group (up to alignment padding) whose rows and columns are multiples of 8."""
+        if self.shadow_t is None:
+            return None
+        if getattr(self, "_adam_tiles", None) is None:
+            self._adam_tiles = False
+            end = 0
+            ok = True
+            for off, rows, cols in sorted(self._groups2d):
+                ok = ok and off == (end + ALIGN - 1) // ALIGN * ALIGN and rows % 8 == 0 and cols % 8 == 0
+                end = off + rows * cols
+            ok = ok and (end + ALIGN - 1) // ALIGN * ALIGN == self.small_lo
+            if ok:
+                import numpy as np
+                from . import _lib
+                entries = []
+                for off, rows, cols in sorted(self._groups2d):
+                    for r0 in range(0, rows, 64):
+                        for c0 in range(0, cols, 64):
+                            entries.append(_lib.AdamTile(off, rows, cols, r0, c0))
+                arr = (_lib.AdamTile * len(entries))(*entries)
+                raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+                self._adam_tiles = (raw.to(self.device), len(entries), self.small_lo, self.numel)
+                # per matrix group: (offset, end, first tile, number of tiles) -- for updates of a sub-range of the arena
+                self._adam_groups, t0 = [], 0
+                for off, rows, cols in sorted(self._groups2d):
+                    nt = ((rows + 63) // 64) * ((cols + 63) // 64)
+                    self._adam_groups.append((off, off + rows * cols, t0, nt))
+                    t0 += nt
+        return self._adam_tiles or None
+
+    def adam_tiles_in(self, lo: int, hi: int):
+        """The part of ``adam_tiles()`` inside the arena range [lo, hi): (table view, number of tiles, flat_lo, flat_hi),
+        or None when a matrix group straddles the range's bounds (or there is no table)."""
+        full = self.adam_tiles()
+        if full is None:
+            return None
+        table, _, small_lo, numel = full
+        inside = [g for g in self._adam_groups if g[0] < hi and g[1] > lo]
+        if any(g[0] < lo or g[1] > hi for g in inside):
+            return None
+        import ctypes
+        from . import _lib
+        sz = ctypes.sizeof(_lib.AdamTile)
+        if inside:
+            t0, t1 = inside[0][2], inside[-1][2] + inside[-1][3]
+            if t1 - t0 != sum(g[3] for g in inside):
+                return None
+        else:
+            t0 = t1 = 0
+        flat_lo, flat_hi = max(lo, small_lo), min(hi, numel)
+        if flat_hi <= flat_lo:
+            flat_lo = flat_hi = 0
+        if flat_lo % 4 or flat_hi % 4:
+            return None
+        return table[t0 * sz:t1 * sz] if t1 > t0 else table[:0], t1 - t0, flat_lo, flat_hi
+
     def transposed(self, ps: Sequence[nn.Parameter]):
         """[cols, sum(rows)] bf16 view (row stride = rows of the whole adjacency group) of the transposed copy of
         the adjacent matrices ``ps``, or None when there is none (fp32 mode, CPU, parameters of different groups)."""

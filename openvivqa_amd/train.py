@@ -52,6 +52,7 @@ class FlatAdam:
         # LambdaLR factor of the NEXT optimiser step: a host float folded into the kernel's `lr` argument (Adam is
         # launched eagerly every step, so the schedule costs no launch of its own)
         self.lr_scale = 1.0
+        self._transposed_stale = False  # a flat (un-tiled) update happened in this step: see end_step
         self.lr_lambda = lr_lambda
         self.host_step = 0
         if lr_lambda is not None:
@@ -86,20 +87,33 @@ class FlatAdam:
     def begin_step(self, also: Optional[torch.Tensor] = None) -> None:
         """step_t += 1; ``also`` (another device counter, e.g. the dropout step of the loop) rides in the same launch."""
         ops.increment_step(self.step_t, also)
+        self._transposed_stale = False
 
     def apply(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0, ranges=None) -> None:
         """Adam update of ``[lo, hi)`` for every range (default: the whole arena), one launch per range."""
         a = self.arena
         g = a.grad if grad is None else grad
+        tiled_ok = hasattr(a, "adam_tiles_in") and os.environ.get("OVQA_ADAM_TILED", "1") != "0"
         for lo, hi in ([(0, a.numel)] if ranges is None else ranges):
             if hi <= lo:
                 continue
+            tiles = a.adam_tiles_in(lo, hi) if tiled_ok else None
+            if tiles is not None:
+                # one pass: update + bf16 shadow + its transpose (no separate transpose launch in end_step)
+                table, n_tiles, flat_lo, flat_hi = tiles
+                ops.adam_step_tiled(a.master, g, self.exp_avg, self.exp_avg_sq, a.shadow, a.shadow_t, table, n_tiles,
+                                    flat_lo, flat_hi, self.lr * self.lr_scale, self.step_t, betas=self.betas,
+                                    eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
+                continue
+            self._transposed_stale = True  # a flat update: the transposed copy needs the separate pass
             ops.adam_step(a.master[lo:hi], g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                           None if a.shadow is None else a.shadow[lo:hi], self.lr * self.lr_scale, self.step_t,
                           betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
 
     def end_step(self) -> None:
-        self.arena.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
+        if self._transposed_stale:
+            self.arena.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
+        self._transposed_stale = False
         self.host_step += 1
         if self.lr_lambda is not None:  # scheduler.step(): value used by the NEXT optimiser step
             self.lr_scale = float(self.lr_lambda(self.host_step))

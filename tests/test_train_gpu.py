@@ -256,3 +256,43 @@ def test_crossmodality_train_step_with_comm(single_rank_group):
         assert len(moved) > 20
         results.append((ts.arena.grad.clone(), float(ts.loss)))
     assert _rel(results[1][0], results[0][0]) <= 1e-5 and abs(results[1][1] - results[0][1]) <= 1e-5 * abs(results[0][1])
+
+
+def test_tiled_adam_equals_flat_adam_plus_transpose(monkeypatch):
+    """ovqa_adam_step_tiled (update + bf16 shadow + its transpose in one pass over 64 x 64 tiles) against the flat
+    ovqa_adam_step followed by ovqa_grouped_transpose on the SAME state and gradients: the same arithmetic per element,
+    so masters and moments agree to 2 ulp and the bf16 copies up to rare rounding flips (two kernels: the compiler
+    contracts multiply-adds differently); fp32 and bf16 gradient buffers (the latter is
+    what a bf16 all-reduce leaves), two consecutive updates each."""
+    model, ts, batch = _make(1, use_graph=False)
+    ts.step(*batch)  # a real step: non-trivial moments and gradients
+    a, opt = ts.arena, ts.optim
+    assert a.adam_tiles() is not None
+    state = [t.clone() for t in (a.master, opt.exp_avg, opt.exp_avg_sq, a.shadow, a.shadow_t, opt.step_t)]
+    grads = {"fp32": a.grad.clone(), "bf16": a.grad.to(torch.bfloat16)}
+    for kind, g in grads.items():
+        results = {}
+        for tiled in ("1", "0"):
+            monkeypatch.setenv("OVQA_ADAM_TILED", tiled)
+            for dst, src in zip((a.master, opt.exp_avg, opt.exp_avg_sq, a.shadow, a.shadow_t, opt.step_t), state):
+                dst.copy_(src)
+            opt.step(g, grad_scale=0.5)
+            opt.step(g, grad_scale=0.25)
+            torch.cuda.synchronize()
+            results[tiled] = [t.clone() for t in (a.master, opt.exp_avg, opt.exp_avg_sq, a.shadow, a.shadow_t)]
+        for name, x, y in zip(("master", "exp_avg", "exp_avg_sq", "shadow", "shadow_t"), results["1"], results["0"]):
+            # the same formulas, but two kernels: the compiler may contract a*b+c differently -> allow 2 ulp of fp32
+            # on the fp32 state and, for the bf16 copies, a rounding flip on a vanishing fraction of the elements
+            xd, yd = x.double(), y.double()
+            if x.dtype == torch.float32:
+                # (a weight is p - update: its error is an ulp of the larger of the two, not of the result)
+                err = ((xd - yd).abs() / yd.abs().clamp_min(1e-3 if name == "master" else 1e-12)).max().item()
+                assert err < 3e-5 if name == "master" else err < 3e-7, (kind, name, err, (xd - yd).abs().max().item())
+            else:
+                flips = (x != y).float().mean().item()
+                assert flips < 1e-3 and ((xd - yd).abs() <= yd.abs() * 2 ** -7 + 1e-30).all(), (kind, name, flips)
+        assert not torch.equal(results["1"][0], state[0])
+        # and the transposed copy IS the transpose of the shadow
+        for off, rows, cols in a._groups2d:
+            assert torch.equal(results["1"][4][off:off + rows * cols].view(cols, rows),
+                               results["1"][3][off:off + rows * cols].view(rows, cols).t())
