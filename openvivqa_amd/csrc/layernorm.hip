@@ -109,15 +109,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
 // Each wave walks rows (row = wave_global, += total_waves); per-lane column
 // partials of dgamma/dbeta stay in registers, are combined across the block's
 // 4 waves through LDS and written to ws[block][2][D]; ln_bwd_reduce sums them.
-template <typename TDY, typename TX, typename TDX, int CHUNKS>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
+// NWAVES = waves per workgroup: 8 for long inputs (half as many [2][D] partial rows for the deferred reduce to read: it
+// streams them all, ~90 MB per MCAN step with 4), 4 otherwise.
+template <typename TDY, typename TX, typename TDX, int CHUNKS, int NWAVES = 4>
+__global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, TDX* __restrict__ dx,
                                                      TDY* __restrict__ dx_dropped, float* __restrict__ partial,
                                                      int M, int D, DropArgs da) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3 waves][2][D]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [NWAVES - 1][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int total_waves = gridDim.x * 4;
+  const int total_waves = gridDim.x * NWAVES;
   const DropState ds = drop_init(da);
   float dg[CHUNKS][VEC], db[CHUNKS][VEC], g[CHUNKS][VEC];
 #pragma unroll
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     for (int i = 0; i < VEC; i++) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
     if (col < D) load8<float>(gamma + col, g[c]);
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += total_waves) {
+  for (int row = blockIdx.x * NWAVES + wave; row < M; row += total_waves) {
     const float mu = mean[row], rs = rstd[row];
     float xh[CHUNKS][VEC], d[CHUNKS][VEC];
     float s1 = 0.f, s2 = 0.f;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     for (int c = 0; c < CHUNKS; c++) {
       const int col = (c * 64 + lane) * VEC;
       if (col < D) {
-        for (int w = 0; w < 3; w++) {
+        for (int w = 0; w < NWAVES - 1; w++) {
           float a[VEC], b[VEC];
           load8<float>(smem + (int64_t)w * 2 * D + col, a);
           load8<float>(smem + (int64_t)w * 2 * D + D + col, b);
@@ -276,14 +278,18 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
                  void* dx_dropped, float* dgamma, float* dbeta, int64_t M, int64_t D, int accumulate,
                  const DropArgs& da, void* ws, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
-  int nblocks = (int)((M + 3) / 4);
-  if (nblocks > 1024) nblocks = 1024;
+  const int nblocks = ovqa::layernorm_bwd_blocks(M);
+  const bool wide = ovqa::layernorm_bwd_waves(M) == 8;
   OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
   float* partial = (float*)ws;
-  const size_t smem = (size_t)3 * 2 * D * sizeof(float);
-#define LN_BWD(C)                                                                                            \
-  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C>), dim3(nblocks), dim3(256), smem, st, (const TDY*)dy,   \
-                     (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
+  const size_t smem = (size_t)(wide ? 7 : 3) * 2 * D * sizeof(float);
+#define LN_BWD(C)                                                                                                  \
+  if (wide)                                                                                                        \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, 8>), dim3(nblocks), dim3(512), smem, st, (const TDY*)dy,    \
+                       (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da);  \
+  else                                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, 4>), dim3(nblocks), dim3(256), smem, st, (const TDY*)dy,    \
+                       (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
   switch (chunks) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -329,9 +335,12 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
   return OVQA_ERR_UNSUPPORTED;
 }
 
+int layernorm_bwd_waves(int64_t M) { return M >= 4096 ? 8 : 4; }
 int layernorm_bwd_blocks(int64_t M) {
-  int64_t nb = (M + 3) / 4;
-  return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+  const int nw = layernorm_bwd_waves(M);
+  const int64_t cap = nw == 8 ? 512 : 1024;
+  int64_t nb = (M + nw - 1) / nw;
+  return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }
 
 int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_blocks, int max_D, hipStream_t st) {
