@@ -5,11 +5,17 @@ Tolerances (written here, per the north star): OVQA_F32 paths <= 1e-3 (in fact
 max|a-b| / max(1, max|b|), inputs/outputs being bf16-rounded.
 """
 import math
+import os
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# A/B switches of the library (scripts/gpu_alt_paths.sh runs this suite under them): assertions about WHICH kernel
+# family ran hold for the default paths only
+FORCED_SIMPLE = os.environ.get("OVQA_FORCE_SIMPLE", "0") == "1"
+NO_FUSED_QKV = os.environ.get("OVQA_NO_FUSED_QKV", "0") == "1"
 
 DEV = "cuda"
 F32, BF16 = torch.float32, torch.bfloat16
@@ -93,7 +99,7 @@ def test_linear_fwd_res32(M, N, K, lazy):
     assert pre.dtype == F32 and nerr(pre, rres + u) < 2e-3
     if K % 8 == 0 and N % 8 == 0:
         from openvivqa_amd import _lib
-        assert _lib.last_dispatch() == "mfma"
+        assert FORCED_SIMPLE or _lib.last_dispatch() == "mfma"
     d = o.DropSpec(p=0.3, seed=9, site=11, step=torch.tensor([3], dtype=torch.int32, device=DEV))
     keep = o.dropout_keep_mask(d, M * N, DEV).view(M, N).double() / 0.7
     assert nerr(o.linear_fwd_res32(x, w, b, res, drop=d), rres + u * keep) < 2e-3
@@ -119,6 +125,7 @@ def test_layernorm_bwd_fp32_input_bf16_gradient():
     assert nerr(dxd, dx.double() * keep / 0.75) < 1e-2
 
 
+@pytest.mark.skipif(FORCED_SIMPLE, reason="OVQA_FORCE_SIMPLE=1 routes everything to the VALU kernels")
 def test_dispatch_hook_reports_kernel_family():
     """ovqa_last_dispatch(): BASELINE shapes run the MFMA kernels, fp32 / ragged shapes the VALU ones."""
     from openvivqa_amd import _lib
@@ -448,12 +455,12 @@ def test_grouped_transpose_and_dx_from_transposed_weights():
         add = rnd(M, 512, dtype=BF16, seed=5)
         a = o.linear_bwd_data(dy, w, addend=add)
         b = o.linear_bwd_data_wt(dy, wt, addend=add)
-        assert nerr(b, a) < 4e-3  # identical on the MFMA path; one bf16 ulp when OVQA_FORCE_SIMPLE reroutes `a`
+        assert nerr(b, a) < 6e-3  # identical on the MFMA path; one bf16 ulp (0.125 at ~25) when OVQA_FORCE_SIMPLE reroutes `a`
         # column block: the middle 512 weight rows only (a strided [512, 512] view of wt)
         a = o.linear_bwd_data(dy[:, 512:1024].contiguous(), w[512:1024])
         blk = wt[:, 512:1024]
         b = o.linear_bwd_data_wt(dy[:, 512:1024], blk)
-        assert nerr(b, a) < 4e-3  # identical on the MFMA path; one bf16 ulp when OVQA_FORCE_SIMPLE reroutes `a`
+        assert nerr(b, a) < 6e-3  # identical on the MFMA path; one bf16 ulp (0.125 at ~25) when OVQA_FORCE_SIMPLE reroutes `a`
         # FFN seam: dy [M, 512] x W2 [512, 2048] with dropout * gelu'(u)
         w2 = rnd(512, 2048, dtype=BF16, seed=6)
         w2t = w2.t().contiguous()
@@ -462,7 +469,7 @@ def test_grouped_transpose_and_dx_from_transposed_weights():
         drop = DropSpec(p=0.1, seed=123, site=4, step=step)
         a = o.linear_bwd_data(dyo, w2, preact=u, drop=drop)
         b = o.linear_bwd_data_wt(dyo, w2t, preact=u, drop=drop)
-        assert nerr(b, a) < 4e-3  # identical on the MFMA path; one bf16 ulp when OVQA_FORCE_SIMPLE reroutes `a`
+        assert nerr(b, a) < 6e-3  # identical on the MFMA path; one bf16 ulp (0.125 at ~25) when OVQA_FORCE_SIMPLE reroutes `a`
 
 
 def test_layernorm_bwd_deferred_grouped_reduce():
@@ -531,6 +538,7 @@ def test_errors_are_loud():
         o.layernorm_fwd(rnd(4, 12), torch.ones(12, device=DEV), torch.zeros(12, device=DEV))  # D % 8 != 0
 
 
+@pytest.mark.skipif(FORCED_SIMPLE, reason="the timed launches are those of the MFMA GEMM kernels")
 def test_launch_timing_hook():
     """ovqa_launch_timing_begin/_end: per-launch kernel durations of the bf16 GEMM kernels (bench.py's roofline figure
     is built on them).  Counts only MFMA GEMM launches, in order, also from another thread; durations are sane."""
@@ -597,7 +605,8 @@ def test_attention_qkv_fwd(B, n, H, Dm, masked, dtype):
     qkv, out, lse = o.attention_qkv_fwd(x, w, b, mask, H)
     from openvivqa_amd import _lib
     disp = _lib.last_dispatch()
-    assert (disp == "mfma-fused") == (dtype == BF16 and d == 64 and n <= 128), (disp, d, n)
+    if not (FORCED_SIMPLE or NO_FUSED_QKV):
+        assert (disp == "mfma-fused") == (dtype == BF16 and d == 64 and n <= 128), (disp, d, n)
     qkv_ref = (x.double() @ w.double().t() + b.double())
     assert nerr(qkv, qkv_ref) < tol(dtype)
     hd = H * d
