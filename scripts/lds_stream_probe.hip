@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // MODE 0: a piece (1 KiB, one wave instruction) is contiguous.  MODE 1: a piece is 8 rows x 128 B, rows `row_stride`
 // bytes apart (a K-contiguous GEMM operand tile, BK = 64).  MODE 2: 16 rows x 64 B (BK = 32).
-template <int NW, int NBUF, int PPW, int MODE, bool BARRIER, bool CONSUME>
+template <int NW, int NBUF, int PPW, int MODE, bool BARRIER, bool CONSUME, int RD = 1>
 __global__ __launch_bounds__(NW * 64) void stream_kernel(const char* __restrict__ src, long long wg_stride, int nsteps,
                                                          int row_stride, int lds_pad, float* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,22 +45,25 @@ __global__ __launch_bounds__(NW * 64) void stream_kernel(const char* __restrict_
     if (s + NBUF - 1 < nsteps) issue(s + NBUF - 1);
     if (CONSUME) {  // every wave reads the whole stage's worth per lane share: STAGE / (NW * 64) bytes per lane
       const char* buf = smem + (s % NBUF) * STAGE;
+      // RD x the stage's bytes per workgroup in ds_read_b128 (a 128 x 64 GEMM tile reads ~4x what it stages)
 #pragma unroll
-      for (int r = 0; r < PPW; r++) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(buf + ((wave * PPW + r) * 64 + lane) * 16);
-        acc += v;
-      }
+      for (int rep = 0; rep < RD; rep++)
+#pragma unroll
+        for (int r = 0; r < PPW; r++) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(buf + ((((wave + rep) % NW) * PPW + r) * 64 + lane) * 16);
+          acc += v;
+        }
     }
   }
   if (CONSUME && acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[tid] = acc[0];
   (void)lds_pad;
 }
 
-template <int NW, int NBUF, int PPW, int MODE, bool BARRIER, bool CONSUME>
+template <int NW, int NBUF, int PPW, int MODE, bool BARRIER, bool CONSUME, int RD = 1>
 static int run(const char* src, long long wg_stride, int nsteps, int row_stride, int lds_pad, int blocks, int reps,
                float* sink, float* ms_out) {
   const size_t lds = (size_t)NBUF * NW * PPW * 1024 + lds_pad;
-  auto k = stream_kernel<NW, NBUF, PPW, MODE, BARRIER, CONSUME>;
+  auto k = stream_kernel<NW, NBUF, PPW, MODE, BARRIER, CONSUME, RD>;
   if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -94,6 +97,12 @@ extern "C" int lsp_run(int variant, const char* src, long long wg_stride, int ns
     case 8: return run<8, 3, 3, 2, true, true>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
     case 9: return run<8, 6, 3, 1, false, false>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
     case 10: return run<8, 3, 6, 1, true, true>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 11: return run<16, 3, 3, 1, true, true>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 12: return run<16, 2, 3, 1, true, true>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 13: return run<16, 3, 2, 1, true, true>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 14: return run<8, 3, 3, 1, true, true, 2>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 15: return run<8, 3, 3, 1, true, true, 4>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
+    case 16: return run<8, 3, 3, 1, true, true, 8>(src, wg_stride, nsteps, row_stride, lds_pad, blocks, reps, sink, ms_out);
     default: return -3;
   }
 }

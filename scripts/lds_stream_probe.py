@@ -24,6 +24,12 @@ VARIANTS = {
     8: "16 rows x 64 B pieces (BK = 32)",
     9: "8 rows x 128 B, ring 6, no barrier, no reads (pure stream)",
     10: "8 rows x 128 B, 48 KiB stages (6 pieces per wave)",
+    11: "8 rows x 128 B, 16 waves x 3 pieces (48 KiB stages), ring 3",
+    12: "8 rows x 128 B, 16 waves x 3 pieces (48 KiB stages), ring 2",
+    13: "8 rows x 128 B, 16 waves x 2 pieces (32 KiB stages), ring 3",
+    14: "GEMM form, fragment reads = 2 x the staged bytes",
+    15: "GEMM form, fragment reads = 4 x the staged bytes (what a 128 x 64 tile reads)",
+    16: "GEMM form, fragment reads = 8 x the staged bytes",
 }
 
 
@@ -40,12 +46,12 @@ def main():
     sink = torch.zeros(1024, dtype=torch.float32, device="cuda")
     out = {}
     nsteps = 64
-    for blocks, lds_pad, occ in ((256, 70 * 1024, "1 WG/CU"), (512, 0, "2 WG/CU")):
+    for blocks, lds_pad, occ in ((256, 70 * 1024, "1 WG/CU"), (256, 0, "256 WGs, no LDS pad"), (512, 0, "2 WG/CU")):
         for res, wg_stride in (("shared 2 MiB source (L2-resident)", 0), ("own 1.5 MiB per workgroup (MALL / HBM)", 1536 * 1024)):
             for v, name in VARIANTS.items():
                 for row_stride in ((1024, 4096) if v in (1, 8) else (1024,)):
-                    ppw = {7: 6, 10: 6}.get(v, 3)
-                    nw = 4 if v == 7 else 8
+                    ppw = {7: 6, 10: 6, 13: 2}.get(v, 3)
+                    nw = 4 if v == 7 else (16 if 11 <= v <= 13 else 8)
                     stage = nw * ppw * 1024
                     ms = C.c_float(0)
                     rc = lib.lsp_run(v, buf.data_ptr(), wg_stride, nsteps, row_stride, lds_pad, blocks, 20,
