@@ -57,15 +57,30 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
 
 // ---- wave reductions (64-wide) --------------------------------------------
+// All-lane sum / max through DPP row operations (quad swaps, half-row and row mirrors, then the gfx9 row broadcasts
+// 15 / 31 with row masks) and one v_readlane of lane 63: six ~8-cycle VALU operations instead of six dependent
+// ds_bpermute round trips (__shfl_xor) -- the one-wave-per-row LayerNorm kernels are chains of two such reductions.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v, float identity) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xF>(v, 0.f);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF>(v, 0.f);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF>(v, 0.f);  // row_half_mirror
+  v += dpp_move<0x140, 0xF>(v, 0.f);  // row_mirror: every lane holds its 16-lane row's sum
+  v += dpp_move<0x142, 0xA>(v, 0.f);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xC>(v, 0.f);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- dropout: stateless counter hash ---------------------------------------
