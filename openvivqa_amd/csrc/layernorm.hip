@@ -39,6 +39,19 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[VEC]) {
   *reinterpret_cast<bf16x8*>(p) = a;
 }
 
+// Workgroup -> row block, XCD-consistent with the GEMM kernels: workgroups are dealt to the 8 XCDs round-robin, and the
+// GEMMs' block remap gives XCD x the x-th contiguous eighth of the activation rows (gemm_mfma.hip); the same
+// bijection here makes a LayerNorm workgroup read rows the SAME XCD's GEMM tiles just wrote (its L2 still holds
+// them) and write rows the same XCD's next GEMM tiles will read, instead of rows interleaved over all XCDs.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nwg) {
+#ifdef OVQA_LN_NO_REMAP
+  return bid;
+#else
+  const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+#endif
+}
+
 // ---------------------------------------------------------------- forward
 template <typename TIN, typename TOUT, int CHUNKS>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
@@ -47,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      int D, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const TIN* xr = x + (int64_t)row * D;
   float v[CHUNKS][VEC];
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------- backward
-// Each wave walks rows (row = wave_global, += total_waves); per-lane column
+// Each workgroup walks a contiguous block of rows (its waves interleaved); per-lane column
 // partials of dgamma/dbeta stay in registers, are combined across the block's
 // 4 waves through LDS and written to ws[block][2][D]; ln_bwd_reduce sums them.
 // NWAVES = waves per workgroup: 8 for long inputs (half as many [2][D] partial rows for the deferred reduce to read: it
@@ -119,7 +132,6 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
                                                      int M, int D, DropArgs da) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NWAVES - 1][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int total_waves = gridDim.x * NWAVES;
   const DropState ds = drop_init(da);
   float dg[CHUNKS][VEC], db[CHUNKS][VEC], g[CHUNKS][VEC];
 #pragma unroll
@@ -129,7 +141,12 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
     for (int i = 0; i < VEC; i++) { dg[c][i] = 0.f; db[c][i] = 0.f; g[c][i] = 0.f; }
     if (col < D) load8<float>(gamma + col, g[c]);
   }
-  for (int row = blockIdx.x * NWAVES + wave; row < M; row += total_waves) {
+  // a workgroup owns a contiguous block of rows (its waves interleave inside it), the blocks dealt XCD-consistently:
+  // XCD x ends up with rows [x M / 8, (x + 1) M / 8), the GEMM kernels' split
+  const int wgp = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int row_lo = (int)((int64_t)wgp * M / (int)gridDim.x);
+  const int row_hi = (int)((int64_t)(wgp + 1) * M / (int)gridDim.x);
+  for (int row = row_lo + wave; row < row_hi; row += NWAVES) {
     const float mu = mean[row], rs = rstd[row];
     float xh[CHUNKS][VEC], d[CHUNKS][VEC];
     float s1 = 0.f, s2 = 0.f;
