@@ -48,6 +48,21 @@ bool ovqa_timer_next(hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                      \
   } while (0)
 
+// ---- XCD-consistent ownership of activation rows -------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin by block id, each XCD has its own L2, and a kernel's output is still in
+// the producing XCD's L2 when the next kernel starts.  The GEMM kernels' block remap gives XCD x the x-th contiguous
+// eighth of the activation rows (gemm_mfma.hip); the LayerNorm kernels use the same bijection for their row blocks, so a
+// row is normalised by the XCD whose GEMM tiles wrote it and read by that XCD's next GEMM tiles (3.372 -> 3.359 ms per
+// step; dealing the attention kernels' (sample, head) problems the same way measured no difference).
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nwg) {
+#ifdef OVQA_NO_XCD_REMAP
+  return bid;
+#else
+  const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+#endif
+}
+
 // ---- scalar conversion -----------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

@@ -39,19 +39,6 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[VEC]) {
   *reinterpret_cast<bf16x8*>(p) = a;
 }
 
-// Workgroup -> row block, XCD-consistent with the GEMM kernels: workgroups are dealt to the 8 XCDs round-robin, and the
-// GEMMs' block remap gives XCD x the x-th contiguous eighth of the activation rows (gemm_mfma.hip); the same
-// bijection here makes a LayerNorm workgroup read rows the SAME XCD's GEMM tiles just wrote (its L2 still holds
-// them) and write rows the same XCD's next GEMM tiles will read, instead of rows interleaved over all XCDs.
-__device__ __forceinline__ int xcd_contiguous_block(int bid, int nwg) {
-#ifdef OVQA_LN_NO_REMAP
-  return bid;
-#else
-  const int q = nwg / 8, rem = nwg % 8, xcd = bid % 8, idx = bid / 8;
-  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-#endif
-}
-
 // ---------------------------------------------------------------- forward
 template <typename TIN, typename TOUT, int CHUNKS>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
