@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
                     help="thread counts the CPU leg sweeps (one B=16 step each) before timing at the best")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test (no GPU): start the ranks exactly as a real run would, bring up a gloo "
+                         "process group, count the ranks with an all-reduce and print the JSON skeleton with `n_gpus` = "
+                         "the group's world size and `value` null")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of --steps steps: the first is the contract's measurement (`value`), the rest "
                          "give median / min / max in extra keys")
@@ -428,11 +432,68 @@ def ensure_library(local_rank):
         time.sleep(1.0)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only the launcher.
+    It builds the library, checks that the node has N devices (`torch.cuda.device_count()` does not initialise HIP) and
+    starts N FRESH rank processes through torch.distributed.run -- it never touches the GPU itself and never execs --
+    then relays their output (rank 0's single JSON line on stdout) and exits with the children's code."""
+    import subprocess
+    ensure_library(0)
+    rehearse = os.environ.get("OVQA_REHEARSE_BACKEND", "nccl") != "nccl"
+    ndev = torch.cuda.device_count()
+    if not args.dry_launch and not rehearse and ndev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {ndev} GPU(s); refusing to run fewer ranks "
+                         "than asked for (one process per GPU; OVQA_REHEARSE_BACKEND=gloo shares one GPU for rehearsals)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OVQA_NO_BUILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_launch(args, world, rank):
+    """--dry-launch: what a rank does before any GPU work, on gloo -- proves that `--gpus N` became N ranks."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        counted, pg_world = int(t.item()), dist.get_world_size()
+    else:
+        counted = pg_world = 1
+    if rank == 0:
+        print(json.dumps({"metric": "VQA samples/sec fwd+bwd, MCAN d=512 L=6, B=64, 100 regions x 20 tokens",
+                          "value": None, "unit": "samples/s", "n_gpus": pg_world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_launch": True, "world_size": pg_world, "ranks_counted": counted,
+                          "device_count": torch.cuda.device_count(),
+                          "config": {"parallelism": f"dp{pg_world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different "
+                         "number of ranks than the command line asks for")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     ensure_library(local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback for the product path)")
@@ -587,6 +648,8 @@ def main():
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "world_size": dist.get_world_size() if (dist is not None and world > 1) else 1,
+            "device_count": torch.cuda.device_count(),
             "config": {"workload": "configs[1]: MCAN encoder stack (Encoder + GuidedAttentionEncoder) d=512 L=6 H=8 "
                        "dff=2048, 64 samples/GPU x (100 regions + 20 tokens), padded lengths, dropout 0.1, "
                        "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",

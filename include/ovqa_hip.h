@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 2
+#define OVQA_ABI_VERSION 3
 
 typedef enum {
   OVQA_OK = 0,
@@ -217,7 +217,7 @@ int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, i
 
 /* Deferred dgamma/dbeta: ovqa_layernorm_bwd called with dgamma == dbeta == NULL computes dx only and leaves
  * its row-slab partials in `ws` as fp32 [blocks][2][D] (dgamma partials, then dbeta partials), where
- * blocks = ovqa_layernorm_bwd_blocks(M).  ovqa_grouped_partial_reduce then sums the partials of MANY LayerNorms
+ * blocks = ovqa_layernorm_bwd_blocks(M, D).  ovqa_grouped_partial_reduce then sums the partials of MANY LayerNorms
  * in one launch (each ~5 us dependent launch saved matters: the MCAN step has 32 of them):
  *   out0[D] (+)= sum_b partial[b][0][:],  out1[D] (+)= sum_b partial[b][1][:]   (fp32 atomics across row groups:
  *   outputs must hold zeros or the value to accumulate into).  `problems` is a DEVICE array. */
@@ -228,7 +228,7 @@ typedef struct ovqa_reduce_problem {
   int32_t blocks;
   int32_t D;
 } ovqa_reduce_problem;
-int ovqa_layernorm_bwd_blocks(int64_t M);
+int ovqa_layernorm_bwd_blocks(int64_t M, int64_t D);
 int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_problems, int32_t max_blocks,
                                 int32_t max_D, void* stream);
 

@@ -289,7 +289,7 @@ int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, i
                              accumulate, da, ws, as_stream(stream));
 }
 
-int ovqa_layernorm_bwd_blocks(int64_t M) { return ovqa::layernorm_bwd_blocks(M); }
+int ovqa_layernorm_bwd_blocks(int64_t M, int64_t D) { return ovqa::layernorm_bwd_blocks(M, D); }
 
 int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_problems, int32_t max_blocks,
                                 int32_t max_D, void* stream) {

@@ -73,8 +73,8 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
 int layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, int x_dtype, const float* gamma,
                   const float* mean, const float* rstd, void* dx, void* dx_dropped, float* dgamma, float* dbeta,
                   int64_t M, int64_t D, int accumulate, const DropArgs& da, void* ws, hipStream_t st);
-int layernorm_bwd_blocks(int64_t M);
-int layernorm_bwd_waves(int64_t M);
+int layernorm_bwd_blocks(int64_t M, int64_t D);
+int layernorm_bwd_waves(int64_t M, int64_t D);
 int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_blocks, int max_D, hipStream_t st);
 
 // ---- misc.hip ------------------------------------------------------------------

@@ -282,8 +282,8 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
                  void* dx_dropped, float* dgamma, float* dbeta, int64_t M, int64_t D, int accumulate,
                  const DropArgs& da, void* ws, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
-  const int nblocks = ovqa::layernorm_bwd_blocks(M);
-  const bool wide = ovqa::layernorm_bwd_waves(M) == 8;
+  const int nblocks = ovqa::layernorm_bwd_blocks(M, D);
+  const bool wide = ovqa::layernorm_bwd_waves(M, D) == 8;
   OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
   float* partial = (float*)ws;
   const size_t smem = (size_t)(wide ? 7 : 3) * 2 * D * sizeof(float);
@@ -339,9 +339,11 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
   return OVQA_ERR_UNSUPPORTED;
 }
 
-int layernorm_bwd_waves(int64_t M) { return M >= 4096 ? 8 : 4; }
-int layernorm_bwd_blocks(int64_t M) {
-  const int nw = layernorm_bwd_waves(M);
+// 8 waves per workgroup for the long activations, while its 7 * 2 * D floats of dynamic LDS stay inside the 64 KiB a
+// launch gets without hipFuncSetAttribute (D <= 1168); wider rows keep the 4-wave form (3 * 2 * D floats: 48 KiB at 2048)
+int layernorm_bwd_waves(int64_t M, int64_t D) { return (M >= 4096 && 7 * 2 * D * 4 <= 64 * 1024) ? 8 : 4; }
+int layernorm_bwd_blocks(int64_t M, int64_t D) {
+  const int nw = layernorm_bwd_waves(M, D);
   const int64_t cap = nw == 8 ? 512 : 1024;
   int64_t nb = (M + nw - 1) / nw;
   return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));

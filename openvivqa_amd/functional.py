@@ -104,8 +104,26 @@ def _ln_bwd(arena, dy, x, gamma, beta, mean, rstd, drop=None, dx_dtype=None):
 # twin (prologue) or an ops.LnRef from which the next block's epilogue recomputes it (block outputs: the fp32 values
 # are never written to HBM).  The attribute is plumbing, not an autograd edge: the gradient of both uses flows through
 # the bf16 tensor, exactly as before.  A tensor without the attribute falls back to its own values cast to fp32.
-def residual_of(x):
+def attach_residual(y, res):
+    """Attach ``res`` (fp32 twin or ops.LnRef) to the bf16 tensor ``y`` together with y's identity at this moment
+    (version counter, storage address, shape): an IN-PLACE change of y afterwards (masked_fill_, mul_ by a padding mask,
+    a slice assignment by the caller of a drop-in module) bumps the version and invalidates the twin."""
+    y._ovqa_res = res
+    y._ovqa_res_tag = (y._version, y.data_ptr(), tuple(y.shape))
+    return y
+
+
+def _twin(x):
     res = getattr(x, "_ovqa_res", None)
+    if res is None:
+        return None
+    if getattr(x, "_ovqa_res_tag", None) != (x._version, x.data_ptr(), tuple(x.shape)):
+        return None  # x was modified in place since the twin was attached: the fp32 values are stale
+    return res
+
+
+def residual_of(x):
+    res = _twin(x)
     if res is None:
         return x.float()
     return res
@@ -118,22 +136,22 @@ def to_compute(x, dtype):
         return x
     y = x.to(dtype)
     if dtype == torch.bfloat16 and x.dtype == torch.float32:
-        y._ovqa_res = x.detach().contiguous()
+        attach_residual(y, x.detach().contiguous())
     return y
 
 
 def _attach(y, st):
     res = st.pop("_res_out", None)
     if res is not None:
-        y._ovqa_res = res
+        attach_residual(y, res)
     return y
 
 
 def carry_residual(dst, src):
     """Hand ``src``'s fp32 twin to ``dst`` (a detached / re-rooted alias of the same values)."""
-    res = getattr(src, "_ovqa_res", None)
+    res = _twin(src)
     if res is not None:
-        dst._ovqa_res = res
+        attach_residual(dst, res)
     return dst
 
 
@@ -152,7 +170,7 @@ class _WithValue(Function):
 
 def finalize(out, dtype):
     """Stack output in the caller's dtype: an fp32 caller of the bf16 mode gets the unrounded fp32 stream."""
-    res = getattr(out, "_ovqa_res", None)
+    res = _twin(out)
     if dtype == torch.float32 and out.dtype != torch.float32 and res is not None:
         y32 = res.materialize() if isinstance(res, ops.LnRef) else res
         return _WithValue.apply(out, y32) if out.requires_grad else y32

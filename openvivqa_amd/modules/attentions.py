@@ -308,7 +308,7 @@ class MultiHeadAttention(Module):
                                        Fn.residual_of(queries))
             gamma, beta = arena.master_of(ln.weight), arena.master_of(ln.bias)
             out, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=q.dtype)
-            out._ovqa_res = ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps)
+            Fn.attach_residual(out, ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps))
         else:
             pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
                                  residual=queries.contiguous())

@@ -279,8 +279,10 @@ class WgradQueue:
         ldx, Mx = _rows(x)
         assert M == Mx and dw.dtype == torch.float32 and dw.is_contiguous()
         assert db is None or (db.dtype == torch.float32 and db.numel() == dy.shape[-1])
-        if any(it[2].data_ptr() == dw.data_ptr() for it in self.items + [i for grp in self.inflight for i in grp]):
-            # the same weight used twice in one backward pass: its two contributions must be ordered
+        if self._overlaps_queued(dw) or (db is not None and self._overlaps_queued(db)):
+            # the same weight (or an overlapping packed group: [fc_q|fc_k|fc_v] of a module's self-attention use and
+            # [fc_k|fc_v] of its cross-attention use have different base pointers) written twice in one backward
+            # pass: the two contributions must be ordered, not binned into one grouped launch
             self.finish()
         flags = int(bool(accumulate)) | (int(bool(accumulate_db)) << 1)
         N, K = dy.shape[-1], x.shape[-1]
@@ -289,6 +291,20 @@ class WgradQueue:
         self.ntiles += ((N + self.TILE - 1) // self.TILE) * ((K + self.TILE - 1) // self.TILE)
         if self.ntiles >= self.FLUSH_TILES:
             self.flush()
+
+    @staticmethod
+    def _span(t):
+        return t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+
+    def _overlaps_queued(self, t):
+        lo, hi = self._span(t)
+        for it in self.items + [i for grp in self.inflight for i in grp]:
+            for other in (it[2], it[9]):
+                if other is not None:
+                    olo, ohi = self._span(other)
+                    if lo < ohi and olo < hi:
+                        return True
+        return False
 
     def add_reduce(self, partial, blocks, D, out0, out1):
         assert out0.dtype == torch.float32 and out1.dtype == torch.float32 and partial.dtype == torch.float32
@@ -488,7 +504,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=N
     has_drop = drop is not None and drop.p > 0.0
     dxd = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if has_drop else None
     if defer is not None and M > 0:
-        blocks = lib.ovqa_layernorm_bwd_blocks(M)
+        blocks = lib.ovqa_layernorm_bwd_blocks(M, D)
         ws = torch.empty(blocks * 2 * D, dtype=torch.float32, device=x.device)
         gout, bout = None, None
     else:

@@ -148,6 +148,13 @@ class ParamArena:
         self._versions = None
         self.refresh_shadow()
 
+    def layout(self, names: Optional[Dict[int, str]] = None) -> list:
+        """Signature of the flat layout: ``[key, shape, offset]`` per parameter in arena order, key = the parameter's
+        name when ``names`` (id(param) -> name) is given, else its position.  A checkpoint of flat moments is only
+        meaningful for the layout it was written with (FlatAdam.load_state_dict compares)."""
+        return [[names.get(id(p), str(i)) if names else str(i), list(p.shape), int(self.offsets[id(p)])]
+                for i, p in enumerate(self.params)]
+
     # -- views -------------------------------------------------------------
     def _slice(self, buf, p):
         o = self.offsets[id(p)]
@@ -322,7 +329,9 @@ class ParamArena:
 
     def attach_grads(self) -> None:
         for p in self.params:
-            p.grad = self.grad_of(p)
+            v = self.grad_of(p)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def grad_views(self, ps: Sequence[nn.Parameter]):
         """(packed fp32 grad view over ``ps``, accumulate flag) for a backward pass,

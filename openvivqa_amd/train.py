@@ -58,23 +58,90 @@ class FlatAdam:
         if lr_lambda is not None:
             self.lr_scale = float(lr_lambda(0))
 
-    def state_dict(self) -> dict:
-        """Moments by parameter name-free arena offset (flat fp32), step counters and the LR scale: what
-        tasks/base_task.py:97-112 stores as ``optimizer`` / ``scheduler`` so that a run can resume."""
+    def state_dict(self, names=None) -> dict:
+        """Flat fp32 moments in arena order, step counters and the LR scale: what tasks/base_task.py:97-112 stores as
+        ``optimizer`` / ``scheduler`` so that a run can resume.  ``layout`` (ParamArena.layout: name or position,
+        shape and offset of every parameter) says which weights the flat moments belong to."""
         return {"exp_avg": self.exp_avg.detach().cpu().clone(), "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(),
                 "step": int(self.step_t.item()), "host_step": self.host_step, "lr_scale": float(self.lr_scale),
                 "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
-                "numel": self.arena.numel}
+                "numel": self.arena.numel, "layout": self.arena.layout(names)}
 
-    def load_state_dict(self, sd: dict) -> None:
+    def load_state_dict(self, sd: dict, names=None, params=None) -> None:
+        """Accepts this class's own format, or -- given ``params``, the parameters in the order the torch optimiser
+        was built with (``model.parameters()``: tasks/base_task.py:46) -- the ``state_dict()`` of a ``torch.optim.Adam``,
+        i.e. the reference's ``checkpoint['optimizer']``."""
+        if "param_groups" in sd:
+            if params is None:
+                raise RuntimeError("FlatAdam.load_state_dict: a torch.optim.Adam state needs the parameter order "
+                                   "(params=list(model.parameters()))")
+            return self._load_torch_adam(sd, list(params))
         if sd["numel"] != self.arena.numel:
             raise RuntimeError("FlatAdam.load_state_dict: arena layout differs from the checkpoint's")
+        theirs = sd.get("layout")
+        if theirs is not None:
+            mine = self.arena.layout(names if all(not k.isdigit() for k, _, _ in theirs) else None)
+            theirs = [[k, list(shp), int(off)] for k, shp, off in theirs]
+            if names is None:  # positions only: compare shapes and offsets
+                mine, theirs = [m[1:] for m in mine], [t[1:] for t in theirs]
+            if mine != theirs:
+                bad = next((a, b) for a, b in zip(mine + [None], theirs + [None]) if a != b)
+                raise RuntimeError("FlatAdam.load_state_dict: the checkpoint's moments were written for another "
+                                   f"parameter layout (first difference: here {bad[0]}, checkpoint {bad[1]})")
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_t.fill_(int(sd["step"]))
         self.host_step = int(sd["host_step"])
         self.lr_scale = float(sd["lr_scale"])
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+
+    def _load_torch_adam(self, sd: dict, params) -> None:
+        a = self.arena
+        index = {}
+        for g in sd["param_groups"]:
+            for k in g["params"]:
+                index[k] = len(index)
+        if len(index) != len(params):
+            raise RuntimeError(f"FlatAdam.load_state_dict: the torch Adam state covers {len(index)} parameters, "
+                               f"the model has {len(params)}")
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for k, st in sd["state"].items():
+            p = params[index[k]]
+            if id(p) not in a.offsets:
+                raise RuntimeError("FlatAdam.load_state_dict: a parameter of the torch state is not in the arena")
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise RuntimeError(f"FlatAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} != parameter "
+                                   f"shape {tuple(p.shape)} at position {index[k]}")
+            o = a.offsets[id(p)]
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"].item() if torch.is_tensor(st["step"]) else st["step"]))
+        if len(steps) > 1:
+            raise RuntimeError("FlatAdam.load_state_dict: per-parameter step counts differ (FlatAdam keeps one)")
+        g0 = sd["param_groups"][0]
+        self.step_t.fill_(steps.pop() if steps else 0)
+        # LambdaLR keeps the un-scaled rate in `initial_lr`; `lr` is initial_lr * lambda(last_epoch)
+        self.lr = float(g0.get("initial_lr", g0["lr"]))
+        self.betas, self.eps, self.weight_decay = tuple(g0["betas"]), float(g0["eps"]), float(g0["weight_decay"])
+
+    def torch_adam_state_dict(self, params) -> dict:
+        """The same state in ``torch.optim.Adam.state_dict()`` form for ``params`` (the order of ``model.parameters()``):
+        what the reference's ``load_checkpoint`` hands to ``optim.load_state_dict`` (tasks/base_task.py:84-95)."""
+        a, params = self.arena, list(params)
+        state = {}
+        step = float(self.step_t.item())
+        if step > 0:
+            for i, p in enumerate(params):
+                o = a.offsets[id(p)]
+                state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+        group = {"lr": self.lr * self.lr_scale, "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "initial_lr": self.lr, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
 
     def step(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
              also: Optional[torch.Tensor] = None) -> None:
@@ -393,6 +460,9 @@ class TrainStep:
     def _fwd_bwd(self, on_phase=None):
         """Eager pass over all phases; ``on_phase(k)`` is called after phase k (0-based, backward order)."""
         first, later = self._phase_fns()
+        # autograd accumulates foreign parameters' gradients into ``p.grad``: that must be the arena view (a caller's
+        # ``optimizer.zero_grad(set_to_none=True)`` between steps would silently detach it)
+        self.arena.attach_grads()
         first()
         if on_phase:
             on_phase(0)
@@ -548,13 +618,27 @@ class TrainStep:
         if self.static_inputs is None:
             self._capture(inputs)
 
+    def _param_names(self):
+        return {id(p): n for n, p in self.model.named_parameters()}
+
     def state_dict(self) -> dict:
-        """Optimiser + dropout-counter state (the model's own ``state_dict`` holds the fp32 master weights)."""
-        return {"optim": self.optim.state_dict(), "drop_step": int(self.drop_step.item())}
+        """Optimiser + dropout-counter state (the model's own ``state_dict`` holds the fp32 master weights).  The
+        optimiser part names every parameter, so a checkpoint cannot be loaded onto a differently ordered model."""
+        return {"optim": self.optim.state_dict(self._param_names()), "drop_step": int(self.drop_step.item())}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.optim.load_state_dict(sd["optim"])
-        self.drop_step.fill_(int(sd["drop_step"]))
+        """``sd`` = what ``state_dict`` returned, or a reference checkpoint's ``optimizer`` entry (the ``state_dict()``
+        of ``torch.optim.Adam(model.parameters(), ...)``, tasks/base_task.py:46,97-112; the LambdaLR position is then
+        taken from the Adam step count: scheduler.step() follows every optim.step(), classification_task.py:133-139)."""
+        if "param_groups" in sd:
+            self.optim.load_state_dict(sd, params=list(self.model.parameters()))
+            self.optim.host_step = int(self.optim.step_t.item())
+            if self.optim.lr_lambda is not None:
+                self.optim.lr_scale = float(self.optim.lr_lambda(self.optim.host_step))
+            self.drop_step.fill_(self.optim.host_step)
+        else:
+            self.optim.load_state_dict(sd["optim"], names=self._param_names())
+            self.drop_step.fill_(int(sd["drop_step"]))
         self.arena.refresh_shadow()
 
     def step(self, *inputs: torch.Tensor) -> torch.Tensor:

@@ -370,3 +370,36 @@ def test_reorder_states_cpu_path_equals_apply_to_states():
     net.reorder_states(sel, b_s, cur, beam)
     for x, y in zip(net.states(), twin.states()):
         assert torch.equal(x, y)
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """The driver's command shape is `python bench.py --gpus N ...` with no launcher around it: the script itself must
+    become N ranks.  --dry-launch runs the launcher and the ranks' rendezvous on gloo, no GPU."""
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["ranks_counted"] == 2
+    assert out["config"]["parallelism"] == "dp2" and out["steps"] == 3 and out["warmup"] == 1
+
+
+def test_bench_refuses_fewer_ranks_than_asked():
+    """`--gpus 2` on a node with fewer than two devices fails loudly instead of printing a dp1 line, and a launcher
+    that set a different WORLD_SIZE than --gpus is refused too."""
+    if torch.cuda.device_count() < 2:
+        r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+    r = _run_bench("--gpus", "2", "--dry-launch", env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
+    r = _run_bench("--dry-launch", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1" in r.stderr

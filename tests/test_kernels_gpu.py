@@ -260,6 +260,22 @@ def test_layernorm_fwd_bwd(in_dtype, out_dtype, D):
     assert nerr(dg, 2 * gd.grad) < 2 * t
 
 
+@pytest.mark.parametrize("M,D", [(4096, 2048), (4100, 1168), (4096, 1176), (5000, 1024)])
+def test_layernorm_bwd_long_activation_wide_rows(M, D):
+    """the 8-wave backward (M >= 4096) asks for 56 * D bytes of dynamic LDS, more than a launch gets by
+    default once D > 1168; such rows keep the 4-wave form.  Both sides of the switch, at sizes that need it."""
+    o = ops()
+    x, dy = rnd(M, D, dtype=BF16, scale=1.5), rnd(M, D, dtype=BF16, seed=4)
+    g, b = (rnd(D, seed=1) * 0.2 + 1.0), rnd(D, seed=2) * 0.1
+    _, mean, rstd = o.layernorm_fwd(x, g, b, 1e-5)
+    xd = x.double().detach().cpu().requires_grad_(True)
+    gd, bd = g.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5).backward(dy.double().cpu())
+    dg, dbt = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx, _ = o.layernorm_bwd(dy, x, g, mean, rstd, dg, dbt)
+    assert nerr(dx, xd.grad) < 1e-2 and nerr(dg, gd.grad) < 1e-2 and nerr(dbt, bd.grad) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_layernorm_bwd_dropout_branch(dtype):
     o = ops()

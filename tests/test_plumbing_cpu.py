@@ -148,9 +148,8 @@ def test_arena_packing_and_state_dict_roundtrip():
     assert not torch.equal(before, a.fc_o.weight.detach()) and arena.owns(list(m.parameters()))
 
 
-def test_train_step_harness_matches_reference_trajectory():
-    """Row T: the product's TrainStep (flat Adam, Noam schedule, reference op order) on the G11
-    fixture reproduces the reference's two-step loss values and post-step weights."""
+def _g11_train_step():
+    """The G11 fixture's model (Encoder L=2 + mean-pool head, NLLLoss) under the product's TrainStep, CPU plumbing."""
     import openvivqa_amd.modules as M
     from openvivqa_amd.config import ConfigNode
     from openvivqa_amd.train import TrainStep, noam_lr_scale
@@ -175,19 +174,101 @@ def test_train_step_harness_matches_reference_trajectory():
     ts = TrainStep(net, lambda x: nll(net(x), y), lr=case.meta["lr"], betas=tuple(case.meta["betas"]),
                    lr_lambda=lambda s: noam_lr_scale(s, 32, case.meta["warmup"]), use_graph=False,
                    compute_dtype=torch.float32)
+
     def capture_cpu(inputs):  # no CUDA streams/graphs on CPU: same steps minus the stream plumbing
         ts.static_inputs = [t.clone() for t in inputs]
         w0 = ts.arena.master.clone()
         ts._discover_foreign()
         assert torch.equal(w0, ts.arena.master)  # discovery runs fwd+bwd only
     ts._capture = capture_cpu
-    losses = [float(ts.step(case.inputs["x"]).item()) for _ in range(2)]
-    _close(torch.tensor(losses), case.out["losses"], 1e-5, "losses")
-    for k, v in enc.state_dict().items():
+    return case, net, ts
+
+
+def _check_g11_final(case, net):
+    for k, v in net.enc.state_dict().items():
         if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             continue
         _close(v, case.out["w2/" + k], 5e-5, "post-step " + k)
-    _close(head.weight, case.out["w2/head.weight"], 5e-5, "head")
+    _close(net.head.weight, case.out["w2/head.weight"], 5e-5, "head")
+
+
+def test_train_step_harness_matches_reference_trajectory():
+    """Row T: the product's TrainStep (flat Adam, Noam schedule, reference op order) on the G11
+    fixture reproduces the reference's two-step loss values and post-step weights."""
+    case, net, ts = _g11_train_step()
+    losses = [float(ts.step(case.inputs["x"]).item()) for _ in range(2)]
+    _close(torch.tensor(losses), case.out["losses"], 1e-5, "losses")
+    _check_g11_final(case, net)
+
+
+def test_train_step_checkpoint_resume_matches_uninterrupted_run():
+    """save after step 1 (model state_dict + TrainStep.state_dict), rebuild everything, load, take step 2:
+    the reference's uninterrupted two-step result (G11) must come out.  The checkpoint names every parameter; a
+    model whose layout differs is refused."""
+    import copy
+    case, net, ts = _g11_train_step()
+    l1 = float(ts.step(case.inputs["x"]).item())
+    ckpt = copy.deepcopy({"state_dict": net.state_dict(), "train": ts.state_dict()})
+    assert [k for k, _, _ in ckpt["train"]["optim"]["layout"]][:1] != ["0"]  # names, not positions
+    case2, net2, ts2 = _g11_train_step()
+    net2.load_state_dict(ckpt["state_dict"])
+    ts2.load_state_dict(ckpt["train"])
+    l2 = float(ts2.step(case.inputs["x"]).item())
+    _close(torch.tensor([l1, l2]), case.out["losses"], 1e-5, "losses across the resume")
+    _check_g11_final(case2, net2)
+    # same total size, different layout: refused
+    bad = copy.deepcopy(ckpt["train"])
+    lay = bad["optim"]["layout"]
+    lay[0], lay[1] = [lay[1][0], lay[0][1], lay[0][2]], [lay[0][0], lay[1][1], lay[1][2]]
+    with pytest.raises(RuntimeError, match="another parameter layout"):
+        ts2.load_state_dict(bad)
+
+
+def test_train_step_loads_and_writes_torch_adam_state():
+    """The reference's checkpoint['optimizer'] is torch.optim.Adam.state_dict() (tasks/base_task.py:46,97-112).  Take
+    step 1 with torch's Adam + LambdaLR on the product's modules (CPU plumbing), hand its state to TrainStep, take
+    step 2 there: G11's two-step result.  And the other direction: TrainStep after step 1 -> torch Adam -> step 2."""
+    from openvivqa_amd.train import noam_lr_scale
+    case, net, ts = _g11_train_step()
+    x, y = case.inputs["x"], case.inputs["y"]
+    nll = torch.nn.NLLLoss(ignore_index=0)
+    lam = lambda s: noam_lr_scale(s, 32, case.meta["warmup"])
+
+    def torch_opt(model):
+        opt = torch.optim.Adam(model.parameters(), lr=case.meta["lr"], betas=tuple(case.meta["betas"]))
+        return opt, torch.optim.lr_scheduler.LambdaLR(opt, lam)
+
+    def torch_step(model, opt, sched):
+        out = model(x)
+        opt.zero_grad()
+        loss = nll(out, y)
+        loss.backward()
+        opt.step()
+        sched.step()
+        return float(loss.item())
+    # torch step 1 -> TrainStep step 2
+    opt, sched = torch_opt(net)
+    l1 = torch_step(net, opt, sched)
+    ts.load_state_dict(opt.state_dict())
+    assert ts.optim.host_step == 1 and int(ts.optim.step_t.item()) == 1 and abs(ts.optim.lr - case.meta["lr"]) < 1e-12
+    l2 = float(ts.step(x).item())
+    _close(torch.tensor([l1, l2]), case.out["losses"], 1e-5, "losses torch->flat")
+    _check_g11_final(case, net)
+    # TrainStep step 1 -> torch step 2
+    case, net, ts = _g11_train_step()
+    ts.step(x)
+    ts.arena.overwrite_grads = False  # hand the model back to autograd's own conventions (TrainStep zeroed / overwrote)
+    for p in net.parameters():
+        p.grad = None
+    opt, sched = torch_opt(net)
+    opt.load_state_dict(ts.optim.torch_adam_state_dict(net.parameters()))
+    sched.last_epoch = 1
+    for g in opt.param_groups:
+        g["lr"] = case.meta["lr"] * lam(1)
+    torch_step(net, opt, sched)
+    _check_g11_final(case, net)
+    with pytest.raises(RuntimeError, match="parameter order"):
+        ts.optim.load_state_dict(opt.state_dict())
 
 
 def test_feature_embedding_plumbing_vs_oracle():
@@ -292,3 +373,57 @@ def test_bf16_mode_residual_stream_plumbing(monkeypatch):
     (vo_r * w).mean().backward()
     (vo * w).mean().backward()
     assert ((v2.grad - v1.grad).norm() / v1.grad.norm()).item() < 2e-2
+
+
+def test_wgrad_queue_orders_overlapping_weight_ranges():
+    """two weight-gradient products whose outputs OVERLAP (packed [fc_q|fc_k|fc_v] group of a shared module's
+    self-attention use and the [fc_k|fc_v] sub-group of its cross-attention use: different base pointers) must not
+    land in one grouped launch -- the queue has to finish() between them.  Host logic only."""
+    from openvivqa_amd.ops import WgradQueue
+    q = WgradQueue()
+    finished = []
+    q.finish = lambda: (finished.append(len(q.items)), q.items.clear())
+    D = 16
+    flat = torch.zeros(3 * D * D + 3 * D)
+    w_qkv, w_kv = flat[:3 * D * D].view(3 * D, D), flat[D * D:3 * D * D].view(2 * D, D)
+    b_qkv, b_kv = flat[3 * D * D:], flat[3 * D * D + D:]
+    other = torch.zeros(D, D)
+    x, dy3, dy2, dy1 = torch.zeros(8, D), torch.zeros(8, 3 * D), torch.zeros(8, 2 * D), torch.zeros(8, D)
+    q.add(dy3, x, w_qkv, False, db=b_qkv)
+    q.add(dy1, x, other, False)
+    assert finished == []
+    q.add(dy2, x, w_kv, True, db=b_kv, accumulate_db=True)  # overlaps rows D..3D of the first product
+    assert finished == [2] and len(q.items) == 1
+    q.add(dy1, x, other, True)  # no longer queued: no second finish
+    assert finished == [2]
+    # bias-only overlap is an overlap too
+    q2 = WgradQueue()
+    fin2 = []
+    q2.finish = lambda: (fin2.append(1), q2.items.clear())
+    q2.add(dy3, x, torch.zeros(3 * D, D), False, db=b_qkv)
+    q2.add(dy2, x, torch.zeros(2 * D, D), False, db=b_kv)
+    assert fin2 == [1]
+
+
+def test_fp32_twin_is_dropped_after_an_in_place_change():
+    """the fp32 residual twin travels as an attribute of the bf16 block output; a caller that changes the
+    output IN PLACE (masked_fill_, mul_, slice assignment) must get its modified values as the next residual, not the
+    stale twin."""
+    import openvivqa_amd.functional as Fn
+    x32 = torch.randn(2, 3, 8)
+    y = Fn.to_compute(x32, torch.bfloat16)
+    assert Fn.residual_of(y) is not None and torch.equal(Fn.residual_of(y), x32)  # the unrounded values
+    alias = Fn.carry_residual(y.detach(), y)
+    assert torch.equal(Fn.residual_of(alias), x32)
+    y.masked_fill_(torch.tensor([[True, False, False], [False, False, True]])[..., None], 0.0)
+    r = Fn.residual_of(y)
+    assert r.dtype == torch.float32 and torch.equal(r, y.float()) and not torch.equal(r, x32)
+    assert torch.equal(Fn.residual_of(alias), alias.float())  # detach() shares the version counter: stale too
+    z = Fn.to_compute(x32, torch.bfloat16)
+    z[0, 1] = 7.0
+    assert torch.equal(Fn.residual_of(z), z.float())
+    w = Fn.to_compute(x32, torch.bfloat16)
+    assert torch.equal(Fn.residual_of(w * 1.0), (w * 1.0).float())  # out-of-place ops never carried the attribute
+    assert torch.equal(Fn.finalize(w, torch.float32), x32)
+    w.mul_(2)
+    assert torch.equal(Fn.finalize(w, torch.float32), w.float())
