@@ -275,13 +275,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // bytes per K-step and CU: the per-CU L2->LDS path, not the matrix pipe, bounds these kernels).
 // BR = rows of the r (P) operand per tile: 128, or 64 with 4 waves and BC = 32 (the M = 1280 products: twice the
 // workgroups again).
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128>
+// KSP = 2 (8 waves): the waves form TWO 2 x 2 grids, one per 32-deep half of every K tile (waves 0-3 take ks = 0, waves 4-7
+// ks = 1): a wave's tile is twice as large (64 x 64 / 64 x 32 instead of 64 x 32 / 64 x 16), so the workgroup reads
+// 64 / 48 KB of fragments per K tile instead of 96 / 80 -- the LDS port (DMA writes + fragment reads, ~450 GB/s per CU)
+// is what the main loop of these kernels runs into -- while 8 waves still cover each other's latencies.  The two partial
+// sums of an output element meet once, after the K loop, through the (then idle) ring buffers: each wave of a pair hands
+// the other one half of its accumulators and finishes the other half.
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128, int KSP = 1>
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
   static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || (BC == 32 && NW == 4 && !Q_KMAJOR),
                 "unsupported tile");
   static_assert(BR == 128 || (BR == 64 && NW == 4 && BC == 32 && !P_KMAJOR), "unsupported tile");
-  constexpr int WC = NW == 8 ? (BC >= 64 ? 4 : BC / 16) : 2;  // wave grid: WC along c x WR along r
-  constexpr int WR = NW / WC;
+  static_assert(KSP == 1 || (KSP == 2 && NW == 8 && BC >= 64 && BR == 128), "k-split form: 8 waves");
+  constexpr int NWT = NW / KSP;  // waves of one tile grid
+  constexpr int WC = NWT == 8 ? (BC >= 64 ? 4 : BC / 16) : 2;  // wave grid: WC along c x WR along r
+  constexpr int WR = NWT / WC;
   constexpr int NI = BC / (16 * WC);   // 16-wide c sub-tiles per wave
   constexpr int NJ = BR / (16 * WR);   // 16-wide r sub-tiles per wave
   constexpr int PCH = BR / 8;          // 1 KiB chunks of the P tile
@@ -293,7 +301,8 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   constexpr bool WIDE = !P_KMAJOR && Epi::kWide;  // 8 consecutive r per lane (see perm32)
   static_assert(!WIDE || NJ % 2 == 0, "wide epilogue pairs the r sub-tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave / WR, wr = wave % WR;
+  const int wt = KSP == 1 ? wave : (wave & (NWT - 1)), ksel = KSP == 1 ? 0 : wave / NWT;
+  const int wc = wt / WR, wr = wt % WR;
 
   f32x4 acc[NJ][NI];
 #pragma unroll
@@ -342,7 +351,8 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     const char* Ps = smem + (kt % NBUF) * STAGE;
     const char* Qs = Ps + PT_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int kk = 0; kk < 2 / KSP; kk++) {
+      const int ks = KSP == 1 ? kk : ksel;
       bf16x8 pf[NJ], qf[NI];
 #pragma unroll
       for (int j = 0; j < NJ; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * (NJ * 16) + j * 16, ks, lane);
@@ -362,7 +372,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     }
   }
   OVQA_GPROBE(3);
-  if constexpr (COLSUM) {
+  if constexpr (COLSUM && KSP == 1) {
     if (do_colsum && lane < 16) {
 #pragma unroll
       for (int i = 0; i < NI; i++) {
@@ -371,7 +381,70 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
       }
     }
   }
+  if constexpr (COLSUM && KSP == 2) {
+    // the two k-halves of the column sums meet through LDS first (workgroup-uniform condition around the barriers)
+    if (r0 == 0 && epi.wants_colsum()) {
+      __builtin_amdgcn_s_barrier();  // the last K tile's fragments are consumed
+      float* cx = reinterpret_cast<float*>(smem);
+      if (ksel == 1 && wr == 0 && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) cx[(wc * NI + i) * 16 + lane] = cs[i][0];
+      }
+      __syncthreads();
+      if (ksel == 0 && wr == 0 && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          const int c = c0 + wc * (NI * 16) + i * 16 + lane;
+          if (c < g.C) epi.colsum(c, cs[i][0] + cx[(wc * NI + i) * 16 + lane]);
+        }
+      }
+    }  // (the exchange below opens with a barrier: cx is read before it is overwritten)
+  }
   epi.init();
+  if constexpr (KSP == 2) {
+    // the pair (wave, wave ^ NWT) holds the two k-halves of the same 64 x (NI * 16) outputs: wave `ksel` keeps the c
+    // sub-tiles [ksel * NI/2, ..) and sends the others.  Slot of (sending wave, j, ih): 1 KiB, 16 B per lane.
+    static_assert(KSP == 1 || NI % 2 == 0, "k-split pairs split the c sub-tiles");
+    constexpr int NH = NI / 2;
+    static_assert(KSP == 1 || NW * NJ * NH * 1024 <= NBUF * STAGE, "exchange area fits in the ring");
+    __builtin_amdgcn_s_barrier();  // every wave is done with the last K tile's fragments
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int ih = 0; ih < NH; ih++)  // (a select, not a runtime index: the accumulators must stay in registers)
+        xch[((wave * NJ + j) * NH + ih) * 64 + lane] = ksel == 0 ? acc[j][NH + ih] : acc[j][ih];
+    __syncthreads();
+    const int partner = wave ^ NWT;
+    OVQA_GPROBE(5);
+#pragma unroll
+    for (int ih = 0; ih < NH; ih++) {
+      const int c = c0 + wc * (NI * 16) + (ksel * NH + ih) * 16 + (lane & 15);
+      f32x4 sum[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const f32x4 o = xch[((partner * NJ + j) * NH + ih) * 64 + lane];
+        const f32x4 m = ksel == 0 ? acc[j][ih] : acc[j][NH + ih];
+        sum[j] = f32x4{m[0] + o[0], m[1] + o[1], m[2] + o[2], m[3] + o[3]};
+      }
+      if (c >= g.C) continue;
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; jp++) {
+          const int r = r0 + wr * (NJ * 16) + jp * 32 + (lane >> 4) * 8;
+          if (r < g.R) epi.wide(c, r, sum[2 * jp], sum[2 * jp + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          const int r = r0 + wr * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+          if (r < g.R) epi(c, r, sum[j]);
+        }
+      }
+    }
+    OVQA_GPROBE(4);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int c = c0 + wc * (NI * 16) + i * 16 + (lane & 15);
@@ -393,7 +466,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   OVQA_GPROBE(4);
 }
 
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128>
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128, int KSP = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = g.tiles_r * g.tiles_c;
@@ -403,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR>(g, tc * BC, tr * BR, epi, smem);
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR, KSP>(g, tc * BC, tr * BR, epi, smem);
 }
 
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
@@ -632,16 +705,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
 }
 
 // The same grouped dW on the direct-to-LDS 8-wave tile (both operands k-major); needs M % 64 == 0 for every problem
-template <int NBUF>
-__global__ __launch_bounds__(512) void gemm_bf16_grouped_wgrad_glds_kernel(const ovqa_wgrad_problem* __restrict__ probs,
-                                                                           const int4* __restrict__ tiles) {
+template <int NBUF, int KSP = 1>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(const ovqa_wgrad_problem* __restrict__ probs,
+                                                                              const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int4 t = tiles[blockIdx.x];
   if (t.x < 0) return;
   const ovqa_wgrad_problem pr = probs[t.x];
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
-  gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128>(g, t.y * BT, t.z * BT, epi, smem);
+  gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128, KSP>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
@@ -699,6 +772,32 @@ inline int tiny_nbuf() {
   return v;
 }
 
+// k-split wave grids (gemm_tile_glds, KSP = 2): bit 0 = the 64 x 128 tier, bit 1 = the 128 x 128 tier.
+// MEASURED (round 3): the K loop gets 10-13 % shorter, the exchange adds ~0.6 us per workgroup; 8192 x 4096 x 4096
+// 939 -> 1005 TFLOP/s, 6400 x 512 x 2048 24.9 -> 23.2 us, 6400 x 512 x 512 8.7 -> 9.0 us; in the MCAN step nothing
+// (3.35 / 3.37 / 3.34 / 3.36 ms for gemm / dW k-split off-off / on-off / off-on / on-on, two alternations): the main
+// loops sit at the direct-to-LDS stream's own rate (~100 GB/s per CU), not at the LDS read port.  Default: the
+// 128 x 128 tier for reductions >= OVQA_GEMM_KSPLIT_MINK (no product of the MCAN step qualifies); dW: off.
+inline int ksplit() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_KSPLIT");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
+// reductions shorter than this keep the plain wave grid: the exchange after the K loop costs ~0.6 us, the K loop gains
+// ~0.06 us per 64-deep step (scripts/gemm_phase_probe.py: 6400 x 512 <- 512: 5.56 -> 5.72 us per workgroup, <- 2048: 18.5 -> 17.2)
+inline int ksplit_min_k() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_KSPLIT_MINK");
+    v = e ? atoi(e) : 1024;
+  }
+  return v;
+}
+
 inline int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -736,13 +835,15 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
   const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold();
   if (small_c) g.tiles_c = (int)((C + (tiny_c ? 31 : 63)) / (tiny_c ? 32 : 64));
   const dim3 grid(g.tiles_r * g.tiles_c);
-#define OVQA_GLDS(NBUF, NW, BCV)                                                                                   \
+#define OVQA_GLDS_K(NBUF, NW, BCV, KSPV)                                                                            \
   {                                                                                                                \
     const size_t lds = (size_t)NBUF * (TILE_BYTES + BCV * BK * 2);                                                 \
-    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>, lds);                                  \
+    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, 128, KSPV>, lds);                       \
     if (rc != OVQA_OK) return rc;                                                                                  \
-    OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV>), grid, dim3(NW * 64), lds, st, g, epi);  \
+    OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, 128, KSPV>), grid, dim3(NW * 64), lds,    \
+                      st, g, epi);                                                                                 \
   }
+#define OVQA_GLDS(NBUF, NW, BCV) OVQA_GLDS_K(NBUF, NW, BCV, 1)
   if constexpr (!QK && !PK) {
     // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of the 128 x 32
     // tier (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step
@@ -767,11 +868,23 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
       return ovqa_check_launch(what);
     }
     if (small_c) {
+      if constexpr (!PK) {
+        if ((ksplit() & 1) && K >= ksplit_min_k()) {
+          OVQA_GLDS_K(3, 8, 64, 2)
+          return ovqa_check_launch(what);
+        }
+      }
       switch (small_nbuf()) {
         case 3: OVQA_GLDS(3, 8, 64) break;
         case 4: OVQA_GLDS(4, 8, 64) break;
         default: OVQA_GLDS(2, 8, 64)
       }
+      return ovqa_check_launch(what);
+    }
+  }
+  if constexpr (!PK && !QK) {
+    if (variant == 12 && (ksplit() & 2) && K >= ksplit_min_k()) {
+      OVQA_GLDS_K(2, 8, 128, 2)
       return ovqa_check_launch(what);
     }
   }
@@ -784,6 +897,7 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
       OVQA_LAUNCH_TIMED((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
   }
 #undef OVQA_GLDS
+#undef OVQA_GLDS_K
   return ovqa_check_launch(what);
 }
 
@@ -977,9 +1091,18 @@ int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles
     const char* e = getenv("OVQA_DW_GLDS");
     allow = e ? atoi(e) : 1;
   }
+  static int dw_ksplit = -1;
+  if (dw_ksplit < 0) {
+    const char* e = getenv("OVQA_DW_KSPLIT");
+    dw_ksplit = e ? atoi(e) : 0;
+  }
   if (direct_to_lds && allow) {
-    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_glds_kernel<2>, dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st,
-                       probs_dev, reinterpret_cast<const int4*>(tiles_dev));
+    if (dw_ksplit)
+      hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_glds_kernel<2, 2>), dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES,
+                         st, probs_dev, reinterpret_cast<const int4*>(tiles_dev));
+    else
+      hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_glds_kernel<2, 1>), dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES,
+                         st, probs_dev, reinterpret_cast<const int4*>(tiles_dev));
     return ovqa_check_launch("grouped_linear_bwd_weight(mfma,glds)");
   }
   hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3((unsigned)n_tiles), dim3(256), 4 * TILE_BYTES, st, probs_dev,

@@ -216,15 +216,21 @@ class OracleMemorySDPA(nn.Module):
         b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
         m_k = math.sqrt(self.d_k) * self.m_k.expand(b, -1, -1)
         m_v = math.sqrt(self.m) * self.m_v.expand(b, -1, -1)
-        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).transpose(1, 2)
-        k = torch.cat([self.fc_k(keys), m_k], 1).view(b, nk + self.m, self.h, self.d_k).transpose(1, 2)
-        v = torch.cat([self.fc_v(values), m_v], 1).view(b, nk + self.m, self.h, self.d_v).transpose(1, 2)
+        q = _r(_lin(self.fc_q, queries)).view(b, nq, self.h, self.d_k).transpose(1, 2)
+        k = torch.cat([_r(_lin(self.fc_k, keys)), _r(m_k)], 1).view(b, nk + self.m, self.h, self.d_k).transpose(1, 2)
+        v = torch.cat([_r(_lin(self.fc_v, values)), _r(m_v)], 1).view(b, nk + self.m, self.h, self.d_v).transpose(1, 2)
         att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.d_k)
         if attention_mask is not None:
             att = torch.cat([att[..., :nk] + attention_mask, att[..., nk:]], dim=-1)
-        att = torch.softmax(att, dim=-1)
-        o = torch.matmul(att, v).transpose(1, 2).reshape(b, nq, self.h * self.d_v)
-        return self.fc_o(o), att
+        if _EMU["on"]:  # as sdpa_core: bf16 numerators into the second product, fp32 row sum
+            e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
+            den = e.sum(dim=-1, keepdim=True)
+            o, att = torch.matmul(_r(e), v) / den, e / den
+        else:
+            att = torch.softmax(att, dim=-1)
+            o = torch.matmul(att, v)
+        o = _r(o.transpose(1, 2).reshape(b, nq, self.h * self.d_v))
+        return _lin(self.fc_o, o), att
 
 
 def box_relational_embedding(f_g, dim_g=64, wave_len=1000, trignometric_embedding=True):
@@ -298,14 +304,25 @@ class OracleAdaptiveSDPA(nn.Module):
 
     def forward(self, queries, keys, values, language_signals, attention_mask=None):
         b, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
-        q = self.fc_q(queries).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)
-        s = self.fc_s(language_signals).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)  # :262
-        k = self.fc_k(keys).view(b, nk, self.h, self.d_k).permute(0, 2, 3, 1)
-        v = self.fc_v(values).view(b, nk, self.h, self.d_v).permute(0, 2, 1, 3)
+        q = _r(_lin(self.fc_q, queries)).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)
+        s = _r(_lin(self.fc_s, language_signals)).view(b, nq, self.h, self.d_k).permute(0, 2, 1, 3)  # :262
+        k = _r(_lin(self.fc_k, keys)).view(b, nk, self.h, self.d_k).permute(0, 2, 3, 1)
+        v = _r(_lin(self.fc_v, values)).view(b, nk, self.h, self.d_v).permute(0, 2, 1, 3)
         attn = torch.matmul(q, k) / math.sqrt(self.d_k)
         if attention_mask is not None:
             attn = attn + attention_mask
         lang = (q * s).sum(-1) / math.sqrt(self.d_k)  # the diagonal of q s^T, :271-272
+        if _EMU["on"]:
+            # the HIP path's closed form (same function): the kernel's output o over the nk keys (bf16 numerators,
+            # stored bf16) merged with the signal column through sigma = sigmoid(lse - lang), in fp32
+            mx = attn.max(dim=-1, keepdim=True).values
+            e = torch.exp(attn - mx)
+            den = e.sum(dim=-1, keepdim=True)
+            o = _r(torch.matmul(_r(e), v) / den)
+            sigma = torch.sigmoid((mx + den.log()).squeeze(-1) - lang).unsqueeze(-1)
+            out = _r((sigma * o + (1 - sigma) * s).permute(0, 2, 1, 3).contiguous().view(b, nq, self.h * self.d_v))
+            comb = torch.cat([e / den * sigma, 1 - sigma], dim=-1)
+            return _lin(self.fc_o, out), [comb[:, :, i:i + 1] for i in range(nq)]
         comb = torch.softmax(torch.cat([attn, lang.unsqueeze(-1)], dim=-1), dim=-1)  # :274-275, row by row
         out = torch.matmul(comb[..., :nk], v) + comb[..., nk:] * s  # :277-281
         out = out.permute(0, 2, 1, 3).contiguous().view(b, nq, self.h * self.d_v)
@@ -649,11 +666,11 @@ class OracleOcrPtrNet(nn.Module):
 
     def forward(self, query_inputs, key_inputs, attention_mask):
         m = attention_mask.squeeze(1)
-        q = self.query(query_inputs)
+        q = _r(_lin(self.query, query_inputs))
         two_d = q.dim() == 2
         if two_d:
             q = q.unsqueeze(1)
-        s = torch.matmul(q, self.key(key_inputs).transpose(-1, -2)) / math.sqrt(self.query_key_size) + m
+        s = torch.matmul(q, _r(_lin(self.key, key_inputs)).transpose(-1, -2)) / math.sqrt(self.query_key_size) + m
         return s.squeeze(1) if two_d else s
 
 
@@ -669,7 +686,8 @@ class OracleDynamicPointerNetwork(nn.Module):
         self.axis = axis
 
     def forward(self, query_inputs, key_inputs, attention_mask):
-        s = torch.matmul(self.query(query_inputs), self.key(key_inputs).transpose(-1, -2)) / math.sqrt(self.d_model)
+        s = torch.matmul(_r(_lin(self.query, query_inputs)),
+                         _r(_lin(self.key, key_inputs)).transpose(-1, -2)) / math.sqrt(self.d_model)
         if self.axis == "key":
             return s.masked_fill(attention_mask.squeeze(1), float("-inf"))
         return s.masked_fill(attention_mask.squeeze(1).squeeze(1).unsqueeze(-1), float("-inf"))
@@ -687,7 +705,7 @@ class OracleFeatureEmbedding(nn.Module):
         self.dropout = nn.Dropout(cfg.DROPOUT)
 
     def forward(self, features):
-        return self.dropout(self.gelu(self.proj(features))), padding_mask(features, 0)
+        return _r(self.dropout(self.gelu(_lin(self.proj, features)))), padding_mask(features, 0)
 
 
 class OracleLSTMTextEmbedding(nn.Module):
@@ -805,17 +823,22 @@ class _BertLayer(nn.Module):
     def forward(self, x, mask):
         a, B, S, H = self.attention, x.shape[0], x.shape[1], self.heads
         d = x.shape[-1] // H
-        q = a.self.query(x).view(B, S, H, d).transpose(1, 2)
-        k = a.self.key(x).view(B, S, H, d).transpose(1, 2)
-        v = a.self.value(x).view(B, S, H, d).transpose(1, 2)
+        q = _r(_lin(a.self.query, x)).view(B, S, H, d).transpose(1, 2)
+        k = _r(_lin(a.self.key, x)).view(B, S, H, d).transpose(1, 2)
+        v = _r(_lin(a.self.value, x)).view(B, S, H, d).transpose(1, 2)
         s = torch.matmul(q, k.transpose(-1, -2)) * d ** -0.5
         if mask is not None:
             s = s + mask
-        p = a.self.dropout(torch.softmax(s, dim=-1))
-        ctx = torch.matmul(p, v).transpose(1, 2).reshape(B, S, H * d)
-        x = a.output.LayerNorm(a.output.dropout(a.output.dense(ctx)) + x)
-        h = torch.nn.functional.gelu(self.intermediate.dense(x))
-        return self.output.LayerNorm(self.output.dropout(self.output.dense(h)) + x)
+        if _EMU["on"] and not (self.training and a.self.dropout.p > 0):
+            e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+            ctx = torch.matmul(_r(e), v) / e.sum(dim=-1, keepdim=True)
+        else:
+            p = a.self.dropout(torch.softmax(s, dim=-1))
+            ctx = torch.matmul(p, v)
+        ctx = _r(ctx.transpose(1, 2).reshape(B, S, H * d))
+        x = a.output.LayerNorm(_gr(a.output.dropout(_lin(a.output.dense, ctx)) + x))
+        h = _r(torch.nn.functional.gelu(_lin(self.intermediate.dense, x)))
+        return self.output.LayerNorm(_gr(self.output.dropout(_lin(self.output.dense, h)) + x))
 
 
 class OracleBertEncoder(nn.Module):

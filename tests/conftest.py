@@ -40,3 +40,14 @@ def _built_library():
         except Exception as exc:  # noqa: BLE001 -- the tests that need it will say so themselves
             print(f"conftest: could not build {B.LIB}: {exc}", file=sys.stderr)
     yield
+
+
+def parity_record(test, what, value, bar):
+    """Measured parity figures: with OVQA_PARITY_REPORT=<file> every compared quantity is appended as a TSV line
+    (test, quantity, measured error, bar), so that the bars written in the tests can be checked against the spread
+    actually measured on the GPU (profiles/README.md quotes the file)."""
+    path = os.environ.get("OVQA_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{test}\t{what}\t{value:.4e}\t{bar:.1e}\n")
+    return value

@@ -46,29 +46,59 @@ def mode(request):
     A.set_compute_dtype(BF16)
 
 
+# Bars of the bf16 mode, gradients: every gradient -- inputs and every parameter, small ones
+# included -- is held against the oracle in bf16-EMULATION mode (oracle.emulate_bf16: rounds values and gradients where
+# the HIP path stores bf16, so that accumulation order and the fast exp / erf are all that is left between the two),
+# relative L2 per tensor.  A parameter whose gradient is analytically zero (fc_k.bias: softmax shift invariance) is
+# pure rounding noise on both sides and is skipped.
+EMU_GRAD_BAR = 1.5e-2
+ZERO_GRAD = ("fc_k.bias", "self.key.bias", "attr_reduce.fc2.bias")
+
+
+def _emu_case(name):
+    """Inputs' and parameters' gradients of golden case ``name`` from the oracle in bf16-emulation mode (CPU)."""
+    import oracle as O
+    with O.emulate_bf16():
+        _, outs, gin, gw, _ = run_case(oracle_namespace(), name)
+    return outs, gin, gw
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_modules_match_reference_golden(name, mode):
+    from conftest import parity_record as rec
     case, outs, gin, gw, _ = run_case(hip_namespace(), name, device=DEV)
+    tag = f"golden[{name},{'fp32' if mode == F32 else 'bf16'}]"
     fwd_tol = 1e-3 if mode == F32 else 1e-2
     for k, ref in case.out.items():
         if k in outs and outs[k] is not None:
-            assert nerr(outs[k], ref) < fwd_tol, f"{name} out/{k}: {nerr(outs[k], ref):.3e}"
-    for k, ref in case.gin.items():
-        e = nerr(gin[k], ref) if mode == F32 else rel_l2(gin[k], ref)
-        assert e < (1e-3 if mode == F32 else 3e-2), f"{name} gin/{k}: {e:.3e}"
-    gmax = max((float(r.double().norm()) for r in case.gw.values()), default=0.0)
-    for k, ref in case.gw.items():
-        assert gw[k] is not None, f"{name}: missing grad for {k}"
-        if k.endswith("fc_k.bias") or k.endswith("self.key.bias") or k.endswith("attr_reduce.fc2.bias"):
-            continue  # analytically zero gradient (softmax shift invariance): pure rounding noise
-        if mode == F32:
-            e = nerr(gw[k], ref)
-        else:  # bf16: relative L2, with gradients below 5 % of the largest one measured against that scale
-            d = (gw[k].detach().double().cpu() - ref.double()).norm().item()
-            e = d / max(float(ref.double().norm()), 0.05 * gmax, 1e-30)
-        assert e < (1e-3 if mode == F32 else 3e-2), f"{name} gw/{k}: {e:.3e}"
+            assert rec(tag, f"out/{k}", nerr(outs[k], ref), fwd_tol) < fwd_tol, f"{name} out/{k}: {nerr(outs[k], ref):.3e}"
     for k in case.meta["grad_none"]:
         assert gw[k] is None or float(gw[k].abs().max()) == 0.0, f"{name}: {k} must not receive a gradient"
+    if mode == F32:  # fp32 mode: the reference's own gradients, normalised max error 1e-3
+        for k, ref in case.gin.items():
+            assert rec(tag, f"gin/{k}", nerr(gin[k], ref), 1e-3) < 1e-3, f"{name} gin/{k}"
+        for k, ref in case.gw.items():
+            assert gw[k] is not None, f"{name}: missing grad for {k}"
+            if not k.endswith(ZERO_GRAD):
+                assert rec(tag, f"gw/{k}", nerr(gw[k], ref), 1e-3) < 1e-3, f"{name} gw/{k}"
+        return
+    # bf16 mode: (1) against the reference's fp32 gradients, relative L2 of ALL parameter gradients taken together
+    # and of each input gradient, 3e-2; (2) every tensor against the bf16-emulating oracle, EMU_GRAD_BAR
+    _, egin, egw = _emu_case(name)
+    for k, ref in case.gin.items():
+        assert rec(tag, f"gin/{k} vs fp32 reference", rel_l2(gin[k], ref), 3e-2) < 3e-2, f"{name} gin/{k}"
+        assert rec(tag, f"gin/{k} vs emulation", rel_l2(gin[k], egin[k]), EMU_GRAD_BAR) < EMU_GRAD_BAR, \
+            f"{name} gin/{k} vs emulation: {rel_l2(gin[k], egin[k]):.3e}"
+    keys = [k for k in case.gw if not k.endswith(ZERO_GRAD)]
+    for k in case.gw:
+        assert gw[k] is not None, f"{name}: missing grad for {k}"
+    if keys:
+        allh = torch.cat([gw[k].detach().double().cpu().flatten() for k in keys])
+        allr = torch.cat([case.gw[k].double().flatten() for k in keys])
+        assert rec(tag, "gw/* together vs fp32 reference", rel_l2(allh, allr), 3e-2) < 3e-2, f"{name} gw"
+    for k in keys:
+        e = rel_l2(gw[k], egw[k])
+        assert rec(tag, f"gw/{k} vs emulation", e, EMU_GRAD_BAR) < EMU_GRAD_BAR, f"{name} gw/{k} vs emulation: {e:.3e}"
 
 
 def test_state_dict_manifest_matches_reference():
