@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 3
+#define OVQA_ABI_VERSION 4
 
 typedef enum {
   OVQA_OK = 0,
@@ -252,7 +252,7 @@ int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_p
 int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, const float* mask,
                        int64_t msb, int64_t msh, int64_t msq,
-                       void* o, int64_t ldo, float* lse, void* att,
+                       void* o, int64_t ldo, float* lse, void* att, void* o_lo,
                        int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
                        float scale, const ovqa_dropout* att_drop, void* stream);
 
@@ -269,10 +269,16 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
  * ------------------------------------------------------------------------- */
 int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias,
                            void* qkv, int64_t ldqkv, const float* mask, int64_t msb, int64_t msh,
-                           void* o, int64_t ldo, float* lse,
+                           void* o, int64_t ldo, float* lse, void* o_lo,
                            int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale, void* stream);
 
-/* Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
+/* o_lo (OVQA_BF16 only; may be NULL in all three calls): the rounding residual of the attention output, bf16, same
+ * layout as o: o_lo = bf16(o_exact - float(o)).  The forward calls write it, ovqa_attention_bwd reads it for
+ * delta_i = dO_i . (o_i + o_lo_i): dS = P (dP - delta) is a cancellation, and with near-uniform attention (a freshly
+ * initialised stack) the bf16 rounding of o alone put errors of 5-8x their own size on the fc_q / fc_k gradients of the
+ * last layers (which are ~3000x smaller than the FFN gradients there); with the residual delta is exact to 2^-17.
+ *
+ * Gradients of the attention core.  `delta` fp32 [B,H,nq] is scratch owned by
  * the caller (rowsum(P*dP)); dq/dk/dv use the same [b,n,h*d+c] addressing.
  * d_att [B,H,nq,nk] (dtype, may be NULL) is the gradient w.r.t. the returned
  * attention weights -- the reference's second return value is differentiable
@@ -282,7 +288,7 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
  * att_drop: the forward call's dropout on the probabilities. */
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo,
                        const void* q, int64_t ldq, const void* k, int64_t ldk,
-                       const void* v, int64_t ldv, const void* o, int64_t ldo,
+                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* o_lo,
                        const void* d_att, const float* lse, const float* mask,
                        int64_t msb, int64_t msh, int64_t msq,
                        void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv,

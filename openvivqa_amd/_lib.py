@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -84,13 +84,13 @@ SIGNATURES = {
     "ovqa_layernorm_bwd_blocks": [c_i64, c_i64],
     "ovqa_grouped_partial_reduce": [c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_attention_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
-                           c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
+                           c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
     "ovqa_launch_timing_begin": [c_int],
     "ovqa_launch_timing_count": [],
     "ovqa_launch_timing_end": [c_vp, c_int],
-    "ovqa_attention_qkv_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp,
+    "ovqa_attention_qkv_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
-    "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+    "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
     "ovqa_pointer_score": [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],

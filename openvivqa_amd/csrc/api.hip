@@ -301,8 +301,8 @@ int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_p
 
 int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        const float* mask, int64_t msb, int64_t msh, int64_t msq, void* o, int64_t ldo, float* lse,
-                       void* att, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv, float scale,
-                       const ovqa_dropout* att_drop, void* stream) {
+                       void* att, void* o_lo, int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
+                       float scale, const ovqa_dropout* att_drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_fwd: bad dtype %d", dtype);
   OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && dk > 0 && dv > 0, OVQA_ERR_BAD_ARG, "attention_fwd: bad sizes");
   if (B == 0 || nq == 0) return OVQA_OK;
@@ -314,6 +314,7 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
                "attention_fwd: dropout on more than 2^32 probabilities");
   ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, msq, o, ldo, lse, att,
                    (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale, make_drop_args(att_drop)};
+  a.o_lo = dtype == OVQA_BF16 ? o_lo : nullptr;
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_supported(a)) {
     g_dispatch = "mfma";
     return ovqa::mfma_attention_fwd(a, as_stream(stream));
@@ -324,7 +325,8 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
 
 int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
                            int64_t ldqkv, const float* mask, int64_t msb, int64_t msh, void* o, int64_t ldo, float* lse,
-                           int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale, void* stream) {
+                           void* o_lo, int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale,
+                           void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_qkv_fwd: bad dtype %d", dtype);
   OVQA_REQUIRE(B >= 0 && H > 0 && n >= 0 && d > 0 && d_model > 0, OVQA_ERR_BAD_ARG, "attention_qkv_fwd: bad sizes");
   if (B == 0 || n == 0) return OVQA_OK;
@@ -336,6 +338,7 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
   const char* qp = (const char*)qkv;
   ovqa::AttnArgs a{qp, qp + (size_t)(H * d) * es, qp + (size_t)(2 * H * d) * es, ldqkv, ldqkv, ldqkv, mask, msb, msh, 0,
                    o, ldo, lse, nullptr, (int)B, (int)H, (int)n, (int)n, (int)d, (int)d, scale, make_drop_args(nullptr)};
+  a.o_lo = dtype == OVQA_BF16 ? o_lo : nullptr;
   if (dtype == OVQA_BF16 && !force_simple() && !no_fused_qkv() &&
       ovqa::mfma_attention_qkv_supported(a, d_model, ldx, ldqkv, x, w, qkv)) {
     g_dispatch = "mfma-fused";
@@ -344,12 +347,13 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
   int rc = ovqa_linear_fwd(dtype, OVQA_EPI_BIAS, x, ldx, w, bias, nullptr, 0, qkv, ldqkv, nullptr, B * n, 3 * H * d, d_model,
                            nullptr, stream);
   if (rc != OVQA_OK) return rc;
-  return ovqa_attention_fwd(dtype, a.q, ldqkv, a.k, ldqkv, a.v, ldqkv, mask, msb, msh, 0, o, ldo, lse, nullptr, B, H, n, n,
-                            d, d, scale, nullptr, stream);
+  return ovqa_attention_fwd(dtype, a.q, ldqkv, a.k, ldqkv, a.v, ldqkv, mask, msb, msh, 0, o, ldo, lse, nullptr, o_lo, B, H,
+                            n, n, d, d, scale, nullptr, stream);
 }
 
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
-                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_att, const float* lse,
+                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* o_lo, const void* d_att,
+                       const float* lse,
                        const float* mask, int64_t msb, int64_t msh, int64_t msq, void* dq, int64_t lddq, void* dk_,
                        int64_t lddk,
                        void* dv_, int64_t lddv, float* delta, const float* d_lse, int64_t B, int64_t H, int64_t nq,
@@ -362,6 +366,7 @@ int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, 
   ovqa::AttnBwdArgs a{d_o, q, k, v, o, d_att, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, msq, dq, dk_, dv_,
                       lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)dk, (int)dv, scale,
                       make_drop_args(att_drop), d_lse};
+  a.o_lo = dtype == OVQA_BF16 ? o_lo : nullptr;
   if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_attention_bwd_supported(a)) {
     g_dispatch = "mfma";
     return ovqa::mfma_attention_bwd(a, as_stream(stream));

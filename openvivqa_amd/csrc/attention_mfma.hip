@@ -127,6 +127,20 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int kbase, int cbase,
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// A probability as two bf16 in one 32-bit register: low half = bf16(p), high half = bf16(p - bf16(p)).
+__device__ __forceinline__ float pack_hi_lo(float p) {
+  const bf16 hb = (bf16)p;
+  const bf16 lb = (bf16)(p - (float)hb);
+  return __uint_as_float((uint32_t)__builtin_bit_cast(unsigned short, hb) |
+                         ((uint32_t)__builtin_bit_cast(unsigned short, lb) << 16));
+}
+__device__ __forceinline__ bf16 packed_hi(float v) {
+  return __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(v) & 0xffffu));
+}
+__device__ __forceinline__ bf16 packed_lo(float v) {
+  return __builtin_bit_cast(bf16, (unsigned short)(__float_as_uint(v) >> 16));
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // grid.x = ceil(B*H / G), grid.y = ceil(nq / (32*W)) ; W = query tiles per problem in this workgroup
 // ROWMASK: the mask is one fp32 row per (b,h) (key padding; staged in LDS, -inf beyond n_k) -- the common case,
@@ -190,8 +204,10 @@ __device__ __forceinline__ void attn_fwd_core(const ovqa::AttnArgs& a, int b, in
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const float p = exp2_fast((st[t][r] - mx) * LOG2E);
-      st[t][r] = p;
       sum += p;
+      // from here on the register holds p as TWO bf16: its bf16 value (low half: the operand of P.V) and the bf16 of
+      // what that rounding dropped (high half: the operand of the o_lo pass) -- 16 bits of p in the same register
+      st[t][r] = pack_hi_lo(p);
     }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.f / sum;
@@ -203,38 +219,65 @@ __device__ __forceinline__ void attn_fwd_core(const ovqa::AttnArgs& a, int b, in
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int key = t * 32 + acc_row(r, lane);
-        if (key < nk) arow[key] = (bf16)(st[t][r] * inv);
+        if (key < nk) arow[key] = (bf16)(((float)packed_hi(st[t][r]) + (float)packed_lo(st[t][r])) * inv);
       }
   }
 
-  // ---- O^T = V^T P^T : P^T accumulator registers are the B operand (k = key), V^T via transposing reads
-  f32x16 ot[DT];
+  // ---- O^T = V^T P^T : P^T accumulator registers are the B operand (k = key), V^T via transposing reads.
+  // One 32-feature slice of the output at a time (16 accumulator registers live instead of 16 * DT: the packed
+  // probabilities must stay live across both passes).
+  // o_lo (training, bf16): what the backward needs for delta = dO . O is O = P V with the UNROUNDED probabilities it
+  // recomputes (dS = P (dP - delta) only cancels when delta = sum_j P_ij dP_ij with that same P): the low halves of the
+  // probabilities go through the matrix cores once more, on top of the rounding residual of o in the same
+  // accumulators; o_lo = bf16 of the total, so that o + o_lo = P V to ~16 bits.
+  bf16* orow = (bf16*)a.o + ((int64_t)b * nq + (qok ? q : 0)) * a.ldo + h * D;
+  bf16* lrow = (bf16*)a.o_lo + ((int64_t)b * nq + (qok ? q : 0)) * a.ldo + h * D;
+  const bool want_lo = a.o_lo != nullptr;  // workgroup-uniform
+#pragma unroll 1  // (a real loop: unrolled, hipcc interleaves the slices and keeps ~40 more registers live)
+  for (int d = 0; d < DT; d++) {
+    f32x16 acc;
 #pragma unroll
-  for (int d = 0; d < DT; d++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r++) ot[d][r] = 0.f;
+    for (int t = 0; t < NKT; t++)
 #pragma unroll
-  for (int t = 0; t < NKT; t++)
+      for (int s = 0; s < 2; s++) {
+        bf16x8 pb;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      bf16x8 pb;
-#pragma unroll
-      for (int j = 0; j < 8; j++) pb[j] = (bf16)st[t][8 * s + j];
-#pragma unroll
-      for (int d = 0; d < DT; d++)
-        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Vs, t * 32 + 16 * s, d * 32, lane), pb, ot[d], 0, 0, 0);
-    }
-  if (qok) {
-    bf16* orow = (bf16*)a.o + ((int64_t)b * nq + q) * a.ldo + h * D;
-#pragma unroll
-    for (int d = 0; d < DT; d++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        bf16x4 o4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o4[e] = (bf16)(ot[d][4 * g4 + e] * inv);
-        *reinterpret_cast<bf16x4*>(orow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+        for (int j = 0; j < 8; j++) pb[j] = packed_hi(st[t][8 * s + j]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Vs, t * 32 + 16 * s, d * 32, lane), pb, acc, 0, 0, 0);
       }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      bf16x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float of = acc[4 * g4 + e] * inv;
+        o4[e] = (bf16)of;
+        acc[4 * g4 + e] = (of - (float)o4[e]) * sum;  // what the rounding took, in the accumulator's units
+      }
+      if (qok) *reinterpret_cast<bf16x4*>(orow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = o4;
+    }
+    if (want_lo) {
+#pragma unroll
+      for (int t = 0; t < NKT; t++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          bf16x8 pl;
+#pragma unroll
+          for (int j = 0; j < 8; j++) pl[j] = packed_lo(st[t][8 * s + j]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(Vs, t * 32 + 16 * s, d * 32, lane), pl, acc, 0, 0, 0);
+        }
+      if (qok) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 l4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) l4[e] = (bf16)(acc[4 * g4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(lrow + d * 32 + 8 * g4 + 4 * (lane >> 5)) = l4;
+        }
+      }
+    }
   }
 }
 
@@ -510,6 +553,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
   {
     const bf16* gr = (const bf16*)a.d_o + ((int64_t)b * nq + qc) * a.lddo + h * D + (D / 2) * (lane >> 5);
     const bf16* orow = (const bf16*)a.o + ((int64_t)b * nq + qc) * a.ldo + h * D + (D / 2) * (lane >> 5);
+    const bf16* lrow = a.o_lo ? (const bf16*)a.o_lo + ((int64_t)b * nq + qc) * a.ldo + h * D + (D / 2) * (lane >> 5) : nullptr;
 #pragma unroll
     for (int c = 0; c < D / 16; c++) {
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gr + 8 * c);
@@ -517,6 +561,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(ovqa::AttnBwdArgs
       const bf16x4 ob = *reinterpret_cast<const bf16x4*>(orow + 8 * c + 4);
 #pragma unroll
       for (int e = 0; e < 4; e++) delta += (float)g8[e] * (float)oa[e] + (float)g8[4 + e] * (float)ob[e];
+      if (lrow) {
+        const bf16x4 la = *reinterpret_cast<const bf16x4*>(lrow + 8 * c);
+        const bf16x4 lb = *reinterpret_cast<const bf16x4*>(lrow + 8 * c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) delta += (float)g8[e] * (float)la[e] + (float)g8[4 + e] * (float)lb[e];
+      }
     }
     delta += __shfl_xor(delta, 32, 64);
   }
@@ -747,7 +797,7 @@ __global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_k
       const int mb = pid / a.H, mh = pid - mb * a.H;
       mval = key < nk ? (a.mask ? a.mask[(int64_t)mb * a.msb + (int64_t)mh * a.msh + key] * LOG2E : 0.f) : -INFINITY;
     }
-    uint4 vq[G][W], vd[G][W], vo[G][W], vk[G], vv[G];
+    uint4 vq[G][W], vd[G][W], vo[G][W], vl[G][W], vk[G], vv[G];
     float lse_r[G][W];
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -758,16 +808,18 @@ __global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_k
       const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
       const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
       const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
+      const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + h * 64 + ch * 8 : nullptr;
       const float* lb = a.lse + ((int64_t)b * a.H + h) * nq;
 #pragma unroll
       for (int i = 0; i < W; i++) {
         const int row = (t >> 3) + 32 * i;
         const bool v = ok && row < nq;
-        vq[g][i] = zero4; vd[g][i] = zero4; vo[g][i] = zero4; lse_r[g][i] = INFINITY;  // p = 0 beyond nq
+        vq[g][i] = zero4; vd[g][i] = zero4; vo[g][i] = zero4; vl[g][i] = zero4; lse_r[g][i] = INFINITY;  // p = 0 beyond nq
         if (ld_q && v) vq[g][i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
         if (ld_d && v) {
           vd[g][i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
           vo[g][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+          if (lob) vl[g][i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
           if (ch == 0) lse_r[g][i] = lb[row] * LOG2E;
         }
       }
@@ -791,9 +843,10 @@ __global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_k
           *reinterpret_cast<uint4*>(base + q_rows * 128 + img_off(row, ch)) = vd[g][i];
           const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[g][i]);
           const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[g][i]);
+          const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[g][i]);
           float dl = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; e++) dl += (float)g8[e] * (float)o8[e];
+          for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
           dl += __shfl_xor(dl, 1, 64);
           dl += __shfl_xor(dl, 2, 64);
           dl += __shfl_xor(dl, 4, 64);
@@ -1055,23 +1108,25 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
     const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
     const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
+    const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + h * 64 + ch * 8 : nullptr;
     const bf16* kb = (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64 + ch * 8;
     const bf16* vb = (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64 + ch * 8;
     const float* lb = a.lse + (int64_t)pid * nq;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 vq[2], vd[2], vo[2], vk[2], vv[2];
+    uint4 vq[2], vd[2], vo[2], vl[2], vk[2], vv[2];
     float lse_r[2];
     float mval = -INFINITY;
     if (a.msq == 0 && tid < nk) mval = a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)h * a.msh + tid] * LOG2E : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
-      vq[i] = zero4; vd[i] = zero4; vo[i] = zero4; vk[i] = zero4; vv[i] = zero4;
+      vq[i] = zero4; vd[i] = zero4; vo[i] = zero4; vl[i] = zero4; vk[i] = zero4; vv[i] = zero4;
       lse_r[i] = INFINITY;
       if (row < nq) {
         vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
         vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
         vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+        if (lob) vl[i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
         if (ch == 0) lse_r[i] = lb[row] * LOG2E;
       }
       if (row < nk) {
@@ -1085,9 +1140,10 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
       const int row = r0 + 64 * i;
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[i]);
       const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
+      const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
       float dl = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; e++) dl += (float)g8[e] * (float)o8[e];
+      for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
       dl += __shfl_xor(dl, 1, 64);
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(ovqa::AttnArgs a) 
       for (int c = lane; c < dv; c += 64) {
         float acc = 0.f;
         for (int j = 0; j < nk; j++) acc = fmaf(sw[j], Vs[(size_t)j * (dv + 1) + c], acc);
-        o[((int64_t)b * nq + i) * a.ldo + h * dv + c] = from_f32<T>(acc * inv);
+        const T ov = from_f32<T>(acc * inv);
+        o[((int64_t)b * nq + i) * a.ldo + h * dv + c] = ov;
+        if (a.o_lo)  // rounding residual for the backward's delta (bf16 mode; see kernels.h)
+          ((T*)a.o_lo)[((int64_t)b * nq + i) * a.ldo + h * dv + c] = from_f32<T>(acc * inv - to_f32<T>(ov));
       }
     }
     __syncthreads();

@@ -39,6 +39,7 @@ struct AttnArgs {
   int B, H, nq, nk, dk, dv;
   float scale;
   DropArgs drop;  // dropout on the attention probabilities (p == 0: off); element index ((b*H+h)*nq+i)*nk+j
+  void* o_lo = nullptr;  // bf16 mode, optional: o_lo = bf16(o_fp32 - float(bf16(o_fp32))), same layout as o (see AttnBwdArgs)
 };
 struct AttnBwdArgs {
   const void *d_o, *q, *k, *v, *o, *d_att;
@@ -52,6 +53,11 @@ struct AttnBwdArgs {
   float scale;
   DropArgs drop;       // as in AttnArgs
   const float* d_lse;  // gradient w.r.t. the returned log-sum-exp [B,H,nq] or nullptr
+  // bf16 mode, optional: the rounding residual of o written by the forward call.  delta_i = dO_i . O_i is the one
+  // place where the bf16 rounding of O is amplified: dS = P (dP - delta) is a cancellation, and for near-uniform
+  // attention (a freshly initialised stack) dQ / dK are 100-3000x smaller than the terms that cancel; with
+  // O = o + o_lo (16 significant bits) the error of delta drops by 2^8 (tests/test_kernels_gpu.py).
+  const void* o_lo = nullptr;
 };
 int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
 int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);

@@ -300,7 +300,7 @@ def _project_qkv(st, queries, keys, values):
     return q, k, v, "general", (q, k, v)
 
 
-def _project_and_attend(st, queries, keys, values, mask, save_lse=True):
+def _project_and_attend(st, queries, keys, values, mask, save_lse=True, lo_out=None):
     """Projections + attention core of a MultiHeadAttention call -> (o, lse, mode, saved projection buffers).
     Self-attention with a key mask (or none) and no probability dropout goes through ``ovqa_attention_qkv_fwd``:
     one kernel for the packed projection and the attention where the shape allows, the two separate kernels
@@ -311,10 +311,10 @@ def _project_and_attend(st, queries, keys, values, mask, save_lse=True):
         wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
         qkv, o, lse = ops.attention_qkv_fwd(queries, arena.packed([wq, wk, wv]),
                                             arena.packed([a.fc_q.bias, a.fc_k.bias, a.fc_v.bias], "master"), mask, a.h,
-                                            save_lse=save_lse)
+                                            save_lse=save_lse, lo_out=lo_out)
         return o, lse, "self", (qkv,)
     q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
-    o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"))
+    o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"), lo_out=lo_out)
     return o, lse, mode, bufs
 
 
@@ -325,7 +325,8 @@ class _MHABlock(Function):
     def forward(ctx, queries, keys, values, mask, st, *params):
         arena, a, ln = st["arena"], st["att"], st["ln"]
         queries, keys, values = _canon(queries, keys, values, st["same"])
-        o, lse, mode, bufs = _project_and_attend(st, queries, keys, values, mask)
+        lo = []  # bf16: the rounding residual of o, for the backward's delta (ops.attention_bwd o_lo)
+        o, lse, mode, bufs = _project_and_attend(st, queries, keys, values, mask, lo_out=lo)
         drop = st["drop"]
         if queries.dtype == torch.bfloat16:  # fp32 residual stream: fp32 pre-LN sum, bf16 operand out
             pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
@@ -337,14 +338,14 @@ class _MHABlock(Function):
             y, mean, rstd = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps)
         ctx.st, ctx.mode = st, mode
         ctx.mask = mask
-        ctx.save_for_backward(queries, keys, values, o, lse, pre, mean, rstd, *bufs)
+        ctx.save_for_backward(queries, keys, values, o, lse, pre, mean, rstd, (lo[0] if lo else None), *bufs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         st, mode = ctx.st, ctx.mode
         arena, a, ln, drop = st["arena"], st["att"], st["ln"], st["drop"]
-        queries, keys, values, o, lse, pre, mean, rstd, *bufs = ctx.saved_tensors
+        queries, keys, values, o, lse, pre, mean, rstd, o_lo, *bufs = ctx.saved_tensors
         dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=drop)
         # fc_o
         _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
@@ -358,7 +359,7 @@ class _MHABlock(Function):
             (qkv,) = bufs
             q, k, v = qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:]
             dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
                               dv=dqkv[..., 2 * nqk:])
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
             dx = _dx(arena, dqkv, [wq, wk, wv], addend=dpre)
@@ -372,7 +373,7 @@ class _MHABlock(Function):
                 shared["dkv"] = torch.empty_like(keys)  # fills its slot, module 0 hands it to autograd
             dkv = shared["dkv"]
             dq = torch.empty_like(q)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., base:base + wk.shape[0]],
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., base:base + wk.shape[0]],
                               dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
             _wgrad(arena, dq, queries, [wq], [bq])
             dx = _dx(arena, dq, [wq], addend=dpre)
@@ -382,14 +383,14 @@ class _MHABlock(Function):
             k, v = kv[..., :nqk], kv[..., nqk:]
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
+            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., :nqk], dv=dkv[..., nqk:])
             _wgrad(arena, dq, queries, [wq], [bq])
             dx = _dx(arena, dq, [wq], addend=dpre)
             _wgrad(arena, dkv, keys, [wk, wv], [bk, bv])
             dkeys = _dx(arena, dkv, [wk, wv]) if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] else None
             return dx, dkeys, None, None, None, *([None] * len(st["params"]))
         q, k, v = bufs
-        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, att_drop=st.get("att_drop"))
+        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"))
         _wgrad(arena, dq, queries, [wq], [bq])
         dx = _dx(arena, dq, [wq], addend=dpre)
         _wgrad(arena, dk, keys, [wk], [bk])
@@ -559,21 +560,22 @@ class _AttentionCore(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, mask, h, need_att):
-        o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att)
+        lo = []
+        o, lse, att = ops.attention_fwd(q, k, v, mask, h, need_att=need_att, lo_out=lo)
         ctx.h, ctx.mask, ctx.need_att = h, mask, need_att
-        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.save_for_backward(q, k, v, o, lse, (lo[0] if lo else None))
         return o, att, lse
 
     @staticmethod
     def backward(ctx, d_o, d_att, d_lse):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, o_lo = ctx.saved_tensors
         if d_o is None:
             d_o = torch.zeros_like(o)
         if d_att is not None:
             d_att = d_att.to(q.dtype).contiguous()
         if d_lse is not None:
             d_lse = d_lse.float().contiguous()
-        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h, d_att=d_att, d_lse=d_lse)
+        dq, dk, dv = ops.attention_bwd(_c(d_o), q, k, v, o, lse, ctx.mask, ctx.h, d_att=d_att, d_lse=d_lse, o_lo=o_lo)
         return dq, dk, dv, None, None, None
 
 
@@ -593,21 +595,22 @@ class _BiasedAttentionCore(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, bias, h):
-        o, lse, att = ops.attention_fwd(q, k, v, bias, h, need_att=True)
+        lo = []
+        o, lse, att = ops.attention_fwd(q, k, v, bias, h, need_att=True, lo_out=lo)
         ctx.h = h
-        ctx.save_for_backward(q, k, v, o, lse, att, bias)
+        ctx.save_for_backward(q, k, v, o, lse, att, bias, (lo[0] if lo else None))
         return o, att
 
     @staticmethod
     def backward(ctx, d_o, d_att):
-        q, k, v, o, lse, att, bias = ctx.saved_tensors
+        q, k, v, o, lse, att, bias, o_lo = ctx.saved_tensors
         h = ctx.h
         if d_o is None:
             d_o = torch.zeros_like(o)
         d_o = _c(d_o)
         if d_att is not None:
             d_att = d_att.to(q.dtype).contiguous()
-        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, bias, h, d_att=d_att)
+        dq, dk, dv = ops.attention_bwd(d_o, q, k, v, o, lse, bias, h, d_att=d_att, o_lo=o_lo)
         dbias = None
         if ctx.needs_input_grad[3]:
             B, nq, nk = q.shape[0], q.shape[1], k.shape[1]

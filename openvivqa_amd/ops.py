@@ -533,7 +533,17 @@ def _mask_strides(mask, B, H, nq, nk):
     return mask, sb, sh, sq
 
 
-def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None):
+def _lo_buffer(lo_out, like):
+    """``lo_out``: a list the caller passes to receive the bf16 rounding residual of the attention output (what
+    attention_bwd takes as ``o_lo``: delta = dO . (o + o_lo)); bf16 only -- fp32 outputs have none."""
+    if lo_out is None or like.dtype != torch.bfloat16:
+        return None
+    lo = torch.empty_like(like)
+    lo_out.append(lo)
+    return lo
+
+
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None, lo_out=None):
     """q [B,nq,H*dk], k [B,nk,H*dk], v [B,nk,H*dv] (row-strided views allowed) -> o [B,nq,H*dv], lse, att.
     ``att_drop`` (DropSpec): dropout on the attention probabilities (BERT-style; VALU kernels)."""
     _dev(q)
@@ -549,13 +559,14 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, a
     lse = torch.empty(B, H, nq, dtype=torch.float32, device=q.device) if save_lse else None
     att = torch.empty(B, H, nq, nk, dtype=q.dtype, device=q.device) if need_att else None
     mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    lo = _lo_buffer(lo_out, o)
     _lib.check(lib.ovqa_attention_fwd(_dt(q), _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(mask), sb, sh, sq, _p(o), H * dv,
-                                      _p(lse), _p(att), B, H, nq, nk, dk, dv, float(scale), _drop(att_drop), _stream()),
-               "attention_fwd")
+                                      _p(lse), _p(att), _p(lo), B, H, nq, nk, dk, dv, float(scale), _drop(att_drop),
+                                      _stream()), "attention_fwd")
     return o, lse, att
 
 
-def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True):
+def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=None):
     """Self-attention forward with the packed projections inside (``ovqa_attention_qkv_fwd``): x [B,n,d_model],
     w [3*H*d, d_model] (fc_q | fc_k | fc_v rows), bias fp32 [3*H*d] -> (qkv [B,n,3*H*d], o [B,n,H*d], lse).
     ``mask``: key mask (b|1, h|1, 1, n) or None."""
@@ -571,14 +582,15 @@ def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True):
     lse = torch.empty(B, H, n, dtype=torch.float32, device=x.device) if save_lse else None
     mask, sb, sh, sq = _mask_strides(mask, B, H, n, n)
     assert sq == 0, "attention_qkv_fwd takes a key mask (one row per (b, h))"
+    lo = _lo_buffer(lo_out, o)
     _lib.check(lib.ovqa_attention_qkv_fwd(_dt(x), _p(x), ldx, _p(w), _p(bias), _p(qkv), 3 * H * d, _p(mask), sb, sh,
-                                          _p(o), H * d, _p(lse), B, H, n, Dm, d, float(scale), _stream()),
+                                          _p(o), H * d, _p(lse), _p(lo), B, H, n, Dm, d, float(scale), _stream()),
                "attention_qkv_fwd")
     return qkv, o, lse
 
 
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
-                  att_drop=None):
+                  att_drop=None, o_lo=None):
     _dev(q)
     lib = _lib.load()
     B, nq = q.shape[0], q.shape[1]
@@ -594,9 +606,11 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
         assert d_att.is_contiguous() and d_att.dtype == q.dtype and d_att.shape == (B, H, nq, nk)
     if d_lse is not None:
         assert d_lse.is_contiguous() and d_lse.dtype == torch.float32 and d_lse.shape == (B, H, nq)
+    if o_lo is not None:
+        assert o_lo.dtype == o.dtype == torch.bfloat16 and o_lo.shape == o.shape and _rows(o_lo)[0] == _rows(o)[0]
     _lib.check(lib.ovqa_attention_bwd(
         _dt(q), _p(d_o), _rows(d_o)[0], _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v), _rows(v)[0], _p(o), _rows(o)[0],
-        _p(d_att), _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
+        _p(o_lo), _p(d_att), _p(lse), _p(mask), sb, sh, sq, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0], _p(dv), _rows(dv)[0], _p(delta),
         _p(d_lse), B, H, nq, nk, dkk, dvv, float(scale), _drop(att_drop), _stream()), "attention_bwd")
     return dq, dk, dv
 

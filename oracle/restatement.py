@@ -159,16 +159,60 @@ def sinusoid_table(max_len: int, d: int, padding_idx: Optional[int] = None) -> t
 # --------------------------------------------------------------------------
 # attention                                  models/modules/attentions.py
 # --------------------------------------------------------------------------
+class _EmuCore(torch.autograd.Function):
+    """The attention core in bf16-emulation mode, backward included: the matrix cores take bf16 operands, so the
+    backward rounds exactly what the HIP kernels feed them -- the probabilities P (for dV) and dS = P (dP - delta)
+    (for dQ, dK) -- and nothing else; delta = rowsum(P dP) = dO . (P V) with the unrounded P (the kernels read that
+    O as o + o_lo, 16 significant bits), sums are fp32.  Plain autograd over fp32 matmuls would keep dS in fp32, which no bf16 MFMA
+    kernel can: with near-uniform attention dQ / dK are cancellations 100-3000x smaller than their terms, and that
+    one rounding is most of their error."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, d_k):
+        s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d_k)
+        if mask is not None:
+            s = s + mask
+        e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+        den = e.sum(dim=-1, keepdim=True)
+        p = e / den
+        o = torch.matmul(e.bfloat16().float(), v) / den  # bf16 numerators into P.V, fp32 row sum
+        ctx.save_for_backward(q, k, v, p, o)
+        ctx.scale = 1.0 / math.sqrt(d_k)
+        return o, p
+
+    @staticmethod
+    def backward(ctx, d_o, d_p):
+        q, k, v, p, o = ctx.saved_tensors
+        dp = torch.matmul(d_o, v.transpose(-1, -2))
+        delta = (p * dp).sum(-1, keepdim=True)  # = dO . (P V) with the unrounded P: what o + o_lo gives the kernels
+        if d_p is not None:  # the returned weights are differentiable too (attentions.py:56,60): VALU kernels, fp32
+            dp = dp + d_p
+            delta = delta + (p * d_p).sum(-1, keepdim=True)
+            ds, pb = p * (dp - delta), p
+        else:
+            ds, pb = (p * (dp - delta)).bfloat16().float(), p.bfloat16().float()
+        dq = torch.matmul(ds, k) * ctx.scale
+        dk = torch.matmul(ds.transpose(-1, -2), q) * ctx.scale
+        dv = torch.matmul(pb.transpose(-1, -2), d_o)
+        return dq, dk, dv, None, None
+
+
 def sdpa_core(q, k, v, mask, d_k):
     """softmax(q k^T / sqrt(d_k) + mask) v on (B,H,n,d) tensors.
     models/modules/attentions.py:53-57.  Returns (out, att)."""
+    if _EMU["on"]:
+        if q.requires_grad or k.requires_grad or v.requires_grad:
+            return _EmuCore.apply(q, k, v, mask, d_k)
+        att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d_k)
+        if mask is not None:
+            att = att + mask
+        # the kernel feeds bf16 exp(s - max) to the second matrix product and divides by the fp32 row sum
+        e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
+        den = e.sum(dim=-1, keepdim=True)
+        return torch.matmul(e.bfloat16().float(), v) / den, e / den
     att = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d_k)
     if mask is not None:
         att = att + mask
-    if _EMU["on"]:  # the kernel feeds bf16 exp(s - max) to the second matrix product and divides by the fp32 row sum
-        e = torch.exp(att - att.max(dim=-1, keepdim=True).values)
-        den = e.sum(dim=-1, keepdim=True)
-        return torch.matmul(_r(e), v) / den, e / den
     att = torch.softmax(att, dim=-1)
     return torch.matmul(att, v), att
 
@@ -648,7 +692,7 @@ class OracleDecoder(_Stateful):
         out = emb + self.pos_emb(seq)
         for layer in self.layers:
             out = layer(out, encoder_features, encoder_features, sam, encoder_attention_mask)
-        return F.log_softmax(self.fc(out), dim=-1)
+        return F.log_softmax(_r(_lin(self.fc, out)), dim=-1)  # (the HIP path's vocabulary GEMM writes bf16 logits)
 
 
 # --------------------------------------------------------------------------
@@ -723,7 +767,7 @@ class OracleLSTMTextEmbedding(nn.Module):
     def forward(self, tokens):
         pad = padding_mask(tokens, self.padding_idx)
         seq = sequential_mask(tokens.shape[-1])
-        x = self.dropout(self.proj(self.embedding(tokens)))
+        x = self.dropout(_r(_lin(self.proj, self.embedding(tokens))))  # (HIP path: bf16 GEMM, bf16 output, fp32 LSTM)
         x, _ = self.lstm(x)
         return x, (pad, seq)
 
@@ -739,7 +783,8 @@ class OracleMLP(nn.Module):
         self.fc2 = nn.Linear(cfg.D_MODEL, 1)
 
     def forward(self, x):
-        return self.fc2(self.dropout(self.relu(self.fc1(x))))
+        # (HIP path: fc1 through the bf16 GEMM with a bf16 output, the D -> 1 product in fp32)
+        return self.fc2(self.dropout(self.relu(_r(_lin(self.fc1, x)))))
 
 
 class OracleMCAN(nn.Module):
@@ -771,8 +816,9 @@ class OracleMCAN(nn.Module):
         av = torch.softmax(self.vision_attr_reduce(v), dim=1)
         at = torch.softmax(self.text_attr_reduce(t), dim=1)
         wv, wt = (v * av).sum(dim=1), (t * at).sum(dim=1)
-        out = self.layer_norm(self.vision_proj(wv) + self.text_proj(wt))
-        return torch.log_softmax(self.classify(out), dim=-1)
+        # (HIP path: the two projections and the classifier are bf16 GEMMs with bf16 outputs; LN on the fp32 sum)
+        out = self.layer_norm(_r(_lin(self.vision_proj, wv)) + _r(_lin(self.text_proj, wt)))
+        return torch.log_softmax(_r(_lin(self.classify, _r(out))), dim=-1)
 
 
 # --------------------------------------------------------------------------

@@ -439,6 +439,38 @@ def g8():
     finish(c)
 
 
+def _reference_class(relpath, name, namespace):
+    """One class of a reference file whose MODULE cannot be imported here (models/m4c.py needs pytorch_transformers):
+    the class statement alone is parsed out of the file with ``ast`` and executed, in memory, in ``namespace`` (the
+    modules its body uses).  Nothing is written anywhere; what is executed is the reference's own class body."""
+    import ast
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == name)
+    ns = dict(namespace)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def g8k():
+    """a17, key-axis variant: the REAL ``DynamicPointerNetwork`` of models/m4c.py:19-33 (boolean mask over the OCR
+    tokens -> -inf columns), same inputs as the query-axis case."""
+    import math
+    cls = _reference_class("models/m4c.py", "DynamicPointerNetwork", dict(torch=torch, nn=torch.nn, np=np, math=math))
+    gen = torch.Generator().manual_seed(16)
+    q3 = torch.randn(2, 4, 24, generator=gen)
+    k = feats(2, 5, 24, gen, pad_rows={1: [3, 4]})
+    torch.manual_seed(803)
+    m = cls(ConfigNode(dict(D_MODEL=24)))
+    kmask = torch.tensor([[False, False, False, False, True], [False, False, False, True, True]])[:, None, None, :]
+    c = Case("G8_dynptr_key_axis")
+    c.meta.update(d_model=24, note="models/m4c.py:19-33 (key-axis fill): the class body executed from the reference "
+                  "file by ast extraction (its module needs pytorch_transformers, absent here)")
+    run_with_grads(c, m, {"q": q3, "k": k, "kmask": kmask},
+                   lambda mod, ins: {"scores": mod(ins["q"], ins["k"], ins["kmask"])}, ["q", "k"])
+    finish(c)
+
+
 # ---------------------------------------------------------------- G9 full size checksum
 def g9():
     torch.manual_seed(901)
@@ -746,7 +778,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g8k=g8k, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

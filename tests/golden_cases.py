@@ -171,6 +171,9 @@ CASES = {
     "G8_dynptr_query_axis": (lambda ns, c: ns.DynamicPointerNetwork(ConfigNode(dict(D_MODEL=c.meta["d_model"])),
                                                                     axis="query"),
                              lambda m, i: {"scores": m(i["q"], i["k"], i["qmask"])}, ["q", "k"]),
+    "G8_dynptr_key_axis": (lambda ns, c: ns.DynamicPointerNetwork(ConfigNode(dict(D_MODEL=c.meta["d_model"])),
+                                                                  axis="key"),
+                           lambda m, i: {"scores": m(i["q"], i["k"], i["kmask"])}, ["q", "k"]),
 }
 
 

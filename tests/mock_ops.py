@@ -165,7 +165,7 @@ def _heads(t, H):
     return t.float().reshape(B, n, H, F // H).transpose(1, 2)
 
 
-def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None):
+def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, att_drop=None, lo_out=None):
     assert att_drop is None or att_drop.p == 0
     qh, kh, vh = _heads(q, H), _heads(k, H), _heads(v, H)
     scale = scale or 1.0 / math.sqrt(qh.shape[-1])
@@ -178,19 +178,23 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, a
         o = (e.bfloat16().float() @ vh) / e.sum(-1, keepdim=True)
     else:
         o = p @ vh
-    o = o.transpose(1, 2).reshape(q.shape[0], q.shape[1], -1).to(q.dtype)
+    o32 = o.transpose(1, 2).reshape(q.shape[0], q.shape[1], -1)
+    o = o32.to(q.dtype)
+    if lo_out is not None and q.dtype == torch.bfloat16:  # o + o_lo = P V with the unrounded probabilities
+        lo_out.append(((p @ vh).transpose(1, 2).reshape(q.shape[0], q.shape[1], -1) - o.float()).to(q.dtype))
     return o, torch.logsumexp(s, -1), (p.to(q.dtype) if need_att else None)
 
 
-def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True):
+def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=None):
     qkv = linear_fwd(x, w, bias)
     n3 = qkv.shape[-1] // 3
-    o, lse, _ = attention_fwd(qkv[..., :n3], qkv[..., n3:2 * n3], qkv[..., 2 * n3:], mask, H, scale, save_lse=save_lse)
+    o, lse, _ = attention_fwd(qkv[..., :n3], qkv[..., n3:2 * n3], qkv[..., 2 * n3:], mask, H, scale, save_lse=save_lse,
+                              lo_out=lo_out)
     return qkv, o, lse
 
 
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
-                  att_drop=None):
+                  att_drop=None, o_lo=None):
     assert att_drop is None or att_drop.p == 0
     qh, kh, vh, gh = _heads(q, H), _heads(k, H), _heads(v, H), _heads(d_o, H)
     scale = scale or 1.0 / math.sqrt(qh.shape[-1])

@@ -36,33 +36,58 @@ def _inputs(B=4, nv=100, nl=20, D=512, seed=0):
     return v, l, O.padding_mask(v, 0), O.padding_mask(l, 0)
 
 
+EMU_GRAD_BAR = 1.5e-2  # bf16 mode, every gradient tensor against the bf16-emulating oracle (relative L2)
+
+
 def _compare(name, mode, oracle_mod, hip_mod, call, inputs, grad_names):
+    """fp32 mode: outputs and every gradient against the fp32 oracle (rel-L2 2e-5 / 2e-4).  bf16 mode: outputs against
+    the fp32 oracle (1e-2) and every gradient -- inputs and each parameter -- against the oracle in bf16-emulation mode
+    (oracle.emulate_bf16), EMU_GRAD_BAR; the gradients' distance from the fp32 oracle is recorded, not asserted (it is
+    the price of bf16 storage, which the emulation shares)."""
+    import oracle as O
+    from conftest import parity_record as rec
     hip_mod.load_state_dict(oracle_mod.state_dict())
     oracle_mod.eval()
     hip_mod = hip_mod.to(DEV).eval()
-    ins_o = {k: (v.clone().requires_grad_(True) if k in grad_names else v) for k, v in inputs.items()}
     ins_h = {k: (v.clone().to(DEV).requires_grad_(True) if k in grad_names else v.to(DEV)) for k, v in inputs.items()}
-    out_o, out_h = call(oracle_mod, ins_o), call(hip_mod, ins_h)
-    if not isinstance(out_o, tuple):
-        out_o, out_h = (out_o,), (out_h,)
+    out_h = call(hip_mod, ins_h)
+    if not isinstance(out_h, tuple):
+        out_h = (out_h,)
     gen = torch.Generator().manual_seed(99)
-    ws = [torch.randn(o.shape, generator=gen) for o in out_o]
-    sum((o * w).sum() for o, w in zip(out_o, ws)).backward()
+    ws = [torch.randn(o.shape, generator=gen) for o in out_h]
     sum((o.float() * w.to(DEV)).sum() for o, w in zip(out_h, ws)).backward()
-    tol_f, tol_g = (2e-5, 2e-4) if mode == F32 else (1e-2, 2e-2)
-    report = []
-    for i, (a, b) in enumerate(zip(out_h, out_o)):
-        report.append((f"out{i}", rel_l2(a, b), tol_f))
+
+    def oracle_pass(emulate):
+        oracle_mod.zero_grad(set_to_none=True)
+        ins_o = {k: (v.clone().requires_grad_(True) if k in grad_names else v) for k, v in inputs.items()}
+        with O.emulate_bf16(emulate):
+            out_o = call(oracle_mod, ins_o)
+            if not isinstance(out_o, tuple):
+                out_o = (out_o,)
+            sum((o * w).sum() for o, w in zip(out_o, ws)).backward()
+        return out_o, {k: ins_o[k].grad for k in grad_names}, \
+            {k: (None if p.grad is None else p.grad.clone()) for k, p in oracle_mod.named_parameters()}
+    out_o, gin_o, gw_o = oracle_pass(False)
+    tag = f"block[{name},{'fp32' if mode == F32 else 'bf16'}]"
+    tol_f = 2e-5 if mode == F32 else 1e-2
+    report = [(f"out{i}", rec(tag, f"out{i} vs fp32 oracle", rel_l2(a, b), tol_f), tol_f)
+              for i, (a, b) in enumerate(zip(out_h, out_o))]
+    if mode == F32:
+        gin_r, gw_r, tol_g, what = gin_o, gw_o, 2e-4, "fp32 oracle"
+    else:
+        for k in grad_names:
+            rec(tag, f"d{k} vs fp32 oracle (recorded)", rel_l2(ins_h[k].grad, gin_o[k]), 0.0)
+        _, gin_r, gw_r = oracle_pass(True)
+        tol_g, what = EMU_GRAD_BAR, "emulation"
     for k in grad_names:
-        report.append((f"d{k}", rel_l2(ins_h[k].grad, ins_o[k].grad), tol_g))
-    go = dict(oracle_mod.named_parameters())
+        report.append((f"d{k}", rec(tag, f"d{k} vs {what}", rel_l2(ins_h[k].grad, gin_r[k]), tol_g), tol_g))
     for k, p in hip_mod.named_parameters():
-        if go[k].grad is None:
+        if gw_r[k] is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0
             continue
         if k.endswith("fc_k.bias") or k.endswith("self.key.bias"):
             continue
-        report.append((f"dW[{k}]", rel_l2(p.grad, go[k].grad), tol_g))
+        report.append((f"dW[{k}]", rec(tag, f"dW[{k}] vs {what}", rel_l2(p.grad, gw_r[k]), tol_g), tol_g))
     bad = [(n, e, t) for n, e, t in report if not e < t]
     assert not bad, f"{name}: " + ", ".join(f"{n}={e:.2e}(>{t:.0e})" for n, e, t in bad)
 
@@ -227,14 +252,29 @@ def test_decoder_config5_shapes(mode):
     eh = enc.clone().to(DEV).requires_grad_(True)
     lh = h(toks.to(DEV), eh, emask.to(DEV))
     (lh * w.to(DEV)).sum().backward()
-    tol_f, tol_g = (1e-4, 5e-4) if mode == F32 else (1e-2, 3e-2)
-    assert rel_l2(lh, lo) < tol_f, rel_l2(lh, lo)
-    assert rel_l2(eh.grad, eo.grad) < tol_g, rel_l2(eh.grad, eo.grad)
+    from conftest import parity_record as rec
+    tag = f"decoder-config5[{'fp32' if mode == F32 else 'bf16'}]"
+    tol_f = 1e-4 if mode == F32 else 1e-2
+    assert rec(tag, "log-probs vs fp32 oracle", rel_l2(lh, lo), tol_f) < tol_f, rel_l2(lh, lo)
+    if mode == F32:
+        tol_g, what = 5e-4, "fp32 oracle"
+    else:  # bf16: every gradient against the bf16-emulating oracle
+        rec(tag, "d enc vs fp32 oracle (recorded)", rel_l2(eh.grad, eo.grad), 0.0)
+        o.zero_grad(set_to_none=True)
+        eo = enc.clone().requires_grad_(True)
+        with O.emulate_bf16():
+            (o(toks, eo, emask) * w).sum().backward()
+        tol_g, what = EMU_GRAD_BAR, "emulation"
+    assert rec(tag, f"d enc vs {what}", rel_l2(eh.grad, eo.grad), tol_g) < tol_g, rel_l2(eh.grad, eo.grad)
     go = dict(o.named_parameters())
     for k, p in h.named_parameters():
         if k.endswith("fc_k.bias") or go[k].grad is None or not p.requires_grad:
             continue
-        assert rel_l2(p.grad, go[k].grad) < (tol_g if mode == F32 else 6e-2), (k, rel_l2(p.grad, go[k].grad))
+        assert rec(tag, f"dW[{k}] vs {what}", rel_l2(p.grad, go[k].grad), tol_g) < tol_g, (k, rel_l2(p.grad, go[k].grad))
+    if mode == BF16:
+        o.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            lo = o(toks, enc, emask)
     # stateful decoding: feed the first 9 (non-padding) tokens one by one
     with torch.no_grad():
         with h.statefulness(4):

@@ -354,6 +354,40 @@ def test_attention_fwd_bwd(dtype, mask_kind, B, H, nq, nk, d):
         assert nerr(dq[-1], qd.grad[-1]) < 3e-2 and nerr(dv[-1], vd.grad[-1]) < 3e-2
 
 
+@pytest.mark.parametrize("B,H,nq,nk", [(4, 8, 100, 100), (4, 8, 100, 20), (6, 8, 20, 20), (2, 8, 237, 237)])
+def test_attention_bwd_delta_uses_the_output_residual(B, H, nq, nk):
+    """delta_i = dO_i . O_i is where the bf16 rounding of O is amplified: dS = P (dP - delta) cancels, and with
+    near-uniform attention (small scores: a freshly initialised stack) dQ / dK are orders of magnitude smaller than the
+    cancelling terms.  The forward kernels write the rounding residual o_lo = bf16(o_exact - o); with it the backward's
+    dQ / dK come within a few percent of fp64 math on the same bf16 inputs, without it they are off by their own size.
+    One case per MFMA backward kernel (role-split, merged small-n_k x2, two-kernel)."""
+    o_ = ops()
+    d = 64
+    q = rnd(B, nq, H * d, dtype=BF16, scale=0.05, seed=1)
+    k = rnd(B, nk, H * d, dtype=BF16, scale=0.05, seed=2)
+    # values nearly equal across the keys (what LayerNorm-ed features through a fresh fc_v look like to dP = dO V^T):
+    # dP is then almost constant along a row, dP - delta cancels to ~2 % of dP
+    v = (rnd(B, 1, H * d, seed=3) + 0.02 * rnd(B, nk, H * d, seed=5)).to(BF16)
+    mask = torch.zeros(B, 1, 1, nk, device=DEV)
+    mask[1, ..., nk - 3:] = -1e5
+    lo = []
+    o, lse, _ = o_.attention_fwd(q, k, v, mask, H, lo_out=lo)
+    assert len(lo) == 1 and lo[0].dtype == BF16 and lo[0].shape == o.shape
+    ro, _, _ = att_ref(q, k, v, mask, H)
+    # o + o_lo carries 16 significant bits of the exact output
+    assert nerr(o.double() + lo[0].double(), ro) < 2e-4 and nerr(o, ro) < 1e-2
+    d_o = rnd(B, nq, H * d, dtype=BF16, seed=4)
+    qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q, k, v))
+    att_ref(qd, kd, vd, mask.cpu(), H)[0].backward(d_o.double().cpu())
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    dq1, dk1, dv1 = o_.attention_bwd(d_o, q, k, v, o, lse, mask, H, o_lo=lo[0])
+    dq0, dk0, dv0 = o_.attention_bwd(d_o, q, k, v, o, lse, mask, H)
+    e1, e0 = (rel(dq1, qd.grad), rel(dk1, kd.grad)), (rel(dq0, qd.grad), rel(dk0, kd.grad))
+    assert rel(dv1, vd.grad) < 1e-2 and rel(dv0, vd.grad) < 1e-2
+    assert e1[0] < 2e-2 and e1[1] < 2e-2, (e1, e0)           # bf16 dS into the matrix cores is what is left
+    assert e1[0] < 0.2 * e0[0] and e1[1] < 0.2 * e0[1], (e1, e0)  # ... and the rounded-O delta was most of the error
+
+
 def test_attention_bwd_with_att_gradient():
     """d_att: gradient w.r.t. the returned attention weights (reference att is differentiable)."""
     o = ops()

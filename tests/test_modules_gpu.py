@@ -52,6 +52,9 @@ def mode(request):
 # relative L2 per tensor.  A parameter whose gradient is analytically zero (fc_k.bias: softmax shift invariance) is
 # pure rounding noise on both sides and is skipped.
 EMU_GRAD_BAR = 1.5e-2
+# 30 chained blocks (MCAN L=6): a 1-ulp bf16 flip early in the stack is amplified by every later rounding, so the
+# gap to the emulation grows with depth (scripts/parity_depth.py); every gradient tensor of the L=6 stacks is held to this
+G9_EMU_BAR = 2.5e-2
 ZERO_GRAD = ("fc_k.bias", "self.key.bias", "attr_reduce.fc2.bias")
 
 
@@ -65,7 +68,7 @@ def _emu_case(name):
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_modules_match_reference_golden(name, mode):
-    from conftest import parity_record as rec
+    from conftest import grad_close, parity_record as rec
     case, outs, gin, gw, _ = run_case(hip_namespace(), name, device=DEV)
     tag = f"golden[{name},{'fp32' if mode == F32 else 'bf16'}]"
     fwd_tol = 1e-3 if mode == F32 else 1e-2
@@ -87,7 +90,8 @@ def test_hip_modules_match_reference_golden(name, mode):
     _, egin, egw = _emu_case(name)
     for k, ref in case.gin.items():
         assert rec(tag, f"gin/{k} vs fp32 reference", rel_l2(gin[k], ref), 3e-2) < 3e-2, f"{name} gin/{k}"
-        assert rec(tag, f"gin/{k} vs emulation", rel_l2(gin[k], egin[k]), EMU_GRAD_BAR) < EMU_GRAD_BAR, \
+        rec(tag, f"gin/{k} vs emulation", rel_l2(gin[k], egin[k]), EMU_GRAD_BAR)
+        assert grad_close(rel_l2(gin[k], egin[k]), rel_l2(egin[k], ref), EMU_GRAD_BAR), \
             f"{name} gin/{k} vs emulation: {rel_l2(gin[k], egin[k]):.3e}"
     keys = [k for k in case.gw if not k.endswith(ZERO_GRAD)]
     for k in case.gw:
@@ -97,8 +101,9 @@ def test_hip_modules_match_reference_golden(name, mode):
         allr = torch.cat([case.gw[k].double().flatten() for k in keys])
         assert rec(tag, "gw/* together vs fp32 reference", rel_l2(allh, allr), 3e-2) < 3e-2, f"{name} gw"
     for k in keys:
-        e = rel_l2(gw[k], egw[k])
-        assert rec(tag, f"gw/{k} vs emulation", e, EMU_GRAD_BAR) < EMU_GRAD_BAR, f"{name} gw/{k} vs emulation: {e:.3e}"
+        e, fmt = rel_l2(gw[k], egw[k]), rel_l2(egw[k], case.gw[k])
+        rec(tag, f"gw/{k} vs emulation", e, EMU_GRAD_BAR)
+        assert grad_close(e, fmt, EMU_GRAD_BAR), f"{name} gw/{k} vs emulation: {e:.3e} (format itself: {fmt:.3e})"
 
 
 def test_state_dict_manifest_matches_reference():
@@ -206,21 +211,50 @@ def test_fullsize_mcan_against_reference_checksum(mode):
         for k, p in mod.named_parameters():
             got[pre + k] = p.grad.norm().item()
     refs = c.out["grad_norms"].tolist()
-    big = max(refs)
     import math
+    from conftest import parity_record as rec
     num = math.sqrt(sum((got[n] - r) ** 2 for n, r in zip(names, refs) if not n.endswith("fc_k.bias")))
     den = math.sqrt(sum(r ** 2 for n, r in zip(names, refs) if not n.endswith("fc_k.bias")))
-    assert num / den < gtol, ("per-parameter grad-norm vector", num / den)
-    for n, ref in zip(names, refs):
-        if n.endswith("fc_k.bias"):
+    tag = f"G9[{'fp32' if mode == F32 else 'bf16'}]"
+    assert rec(tag, "per-parameter grad-norm vector vs reference", num / den, gtol) < gtol
+    if mode == F32:  # every parameter's gradient norm against the real reference's
+        for n, ref in zip(names, refs):
+            if not n.endswith("fc_k.bias"):
+                assert abs(got[n] - ref) <= 2 * gtol * max(ref, 1e-6) + 1e-7, (n, got[n], ref)
+        return
+    # bf16: EVERY parameter gradient, the small ones included (fc_q / fc_k of a freshly initialised stack are ~100x
+    # smaller than the rest: near-uniform softmax, dS = P(dP - delta) is a cancellation), as full tensors against the
+    # oracle in bf16-emulation mode rebuilt from the fixture's seeds (the fixture itself holds only norms and samples)
+    import oracle as O
+    from conftest import grad_close
+    te_o, ve_o = _mcan_pair(oracle_namespace(), 6, c.meta["seed_weights"])
+    te_o.eval(), ve_o.eval()
+
+    def oracle_grads(emulate):
+        te_o.zero_grad(set_to_none=True), ve_o.zero_grad(set_to_none=True)
+        v_r, l_r = v.detach().cpu().clone().requires_grad_(), l.detach().cpu().clone().requires_grad_()
+        with O.emulate_bf16(emulate):
+            lo_r = te_o(l_r, O.padding_mask(l_r.detach(), 0))
+            vo_r = ve_o(v_r, O.padding_mask(v_r.detach(), 0), lo_r, O.padding_mask(l_r.detach(), 0))
+            ((vo_r * wv.cpu()).mean() + (lo_r * wl.cpu()).mean()).backward()
+        g = {"d vision": v_r.grad, "d language": l_r.grad}
+        for pre, m in (("self_encoder.", te_o), ("guided_encoder.", ve_o)):
+            g.update({"gw/" + pre + k: p.grad.clone() for k, p in m.named_parameters()})
+        return g
+    g32, gem = oracle_grads(False), oracle_grads(True)
+    ghip = {"d vision": v.grad, "d language": l.grad}
+    for pre, m in (("self_encoder.", te), ("guided_encoder.", ve)):
+        ghip.update({"gw/" + pre + k: p.grad for k, p in m.named_parameters()})
+    bad = []
+    for k in ghip:
+        if k.endswith("fc_k.bias"):
             continue
-        # fp32: every parameter.  bf16: parameters whose gradient is not itself at the bf16 noise level
-        # (fc_q/fc_k gradients of a freshly initialised stack are ~100x smaller than the others: softmax is
-        # near-uniform, dS = P(dP - delta) is a cancellation); the noise-level ones are covered by the
-        # block-level tests (tests/test_blocks_gpu.py) at a realistic gradient scale.
-        if mode == BF16 and ref < 0.05 * big:
-            continue
-        assert abs(got[n] - ref) <= 2 * gtol * max(ref, 1e-6) + 1e-7, (n, got[n], ref)
+        e, fmt = rel_l2(ghip[k], gem[k]), rel_l2(gem[k], g32[k])
+        rec(tag, f"{k} vs emulation", e, G9_EMU_BAR)
+        rec(tag, f"{k}: emulation vs fp32 oracle (no kernel involved)", fmt, 0.0)
+        if not grad_close(e, fmt, G9_EMU_BAR):
+            bad.append((k, e, fmt))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("B", [64])
@@ -294,6 +328,13 @@ def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers):
         l[i, 8 + i % 12:] = 0
     wv, wl = torch.randn(v.shape, generator=gen), torch.randn(l.shape, generator=gen)
     v_r, l_r = v.clone().requires_grad_(), l.clone().requires_grad_()
+    lo_r = te_o(l_r, O.padding_mask(l, 0))  # fp32 pass first: the storage format's own error per gradient tensor
+    vo_r = ve_o(v_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
+    ((vo_r * wv).mean() + (lo_r * wl).mean()).backward()
+    g32 = {(pre + k): p.grad.clone() for pre, m in (("self_encoder.", te_o), ("guided_encoder.", ve_o))
+           for k, p in m.named_parameters()}
+    te_o.zero_grad(set_to_none=True), ve_o.zero_grad(set_to_none=True)
+    v_r, l_r = v.clone().requires_grad_(), l.clone().requires_grad_()
     with O.emulate_bf16():
         lo_r = te_o(l_r, O.padding_mask(l, 0))
         vo_r = ve_o(v_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
@@ -303,33 +344,38 @@ def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers):
     lo = te(features=ld, padding_mask=lm)
     vo = ve(vision_features=vd, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
     ((vo.float() * wv.to(DEV)).mean() + (lo.float() * wl.to(DEV)).mean()).backward()
+    from conftest import parity_record as rec
     ftol, gtol, wtol = (2e-3, 8e-3, 1.2e-2) if layers == 1 else (6e-3, 2e-2, 2.5e-2)
     assert nerr(lo, lo_r) < ftol and nerr(vo, vo_r) < ftol, (nerr(lo, lo_r), nerr(vo, vo_r))
     assert rel_l2(vd.grad, v_r.grad) < gtol and rel_l2(ld.grad, l_r.grad) < gtol, \
         (rel_l2(vd.grad, v_r.grad), rel_l2(ld.grad, l_r.grad))
-    worst = ("", 0.0)
+    from conftest import grad_close
+    bad = []
     for (pre, hip_m, ref_m) in (("self_encoder.", te, te_o), ("guided_encoder.", ve, ve_o)):
         gref = dict(ref_m.named_parameters())
-        gmax = max(float(p.grad.norm()) for p in gref.values() if p.grad is not None)
         for k, p in hip_m.named_parameters():
-            if k.endswith("fc_k.bias") or float(gref[k].grad.norm()) < 0.05 * gmax:
+            if k.endswith("fc_k.bias"):  # analytically zero
                 continue
-            e = rel_l2(p.grad, gref[k].grad)
-            if e > worst[1]:
-                worst = (pre + k, e)
-    assert worst[1] < wtol, worst
+            e, fmt = rel_l2(p.grad, gref[k].grad), rel_l2(gref[k].grad, g32[pre + k])
+            rec(f"stack-emulation[L={layers}]", f"gw/{pre}{k} vs emulation", e, wtol)
+            if not grad_close(e, fmt, wtol):
+                bad.append((pre + k, e, fmt))
+    assert not bad, bad
 
 
-@pytest.mark.parametrize("arch,layers", [("CrossModalityEncoder", 6), ("CoAttentionEncoder", 4)])
+@pytest.mark.parametrize("arch,layers", [("CrossModalityEncoder", 6), ("CoAttentionEncoder", 4), ("CoAttentionEncoder", 6)])
 def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
     """BASELINE configs[2] (cross_modality_transformer.yaml shape: d=512, L=6, 100 regions x 20 tokens; B=16 here,
-    samples are independent) and its ViLBERT-style sibling: bf16 HIP path vs the fp32 oracle, forward and
-    input/weight gradients (the oracle needs a few seconds at this size).  The co-attention stack chains FOUR
-    EncoderLayers per layer and modality (8 blocks): it runs at L=4 = 32 chained blocks, the depth of MCAN L=6 (30);
-    no shipped config uses it, and at L=6 (48 blocks) bf16 storage of the weights alone reaches 1.1e-2."""
+    samples are independent) and its ViLBERT-style sibling: bf16 HIP path vs the fp32 oracle (outputs, 1e-2) and vs the
+    bf16-emulating oracle (outputs and every gradient).
+    The co-attention stack chains FOUR EncoderLayers per layer and modality (8 blocks): L=4 is 32 chained blocks, the
+    depth of MCAN L=6 (30).  At L=6 (48 blocks; no shipped config uses it) the output is a DOCUMENTED MISS of the 1e-2
+    bar against the fp32 oracle: bf16 storage of weights and activations alone -- the emulating oracle, no kernel
+    involved -- is that far from fp32 there (asserted below), and the HIP path stays within 8e-3 of the emulation."""
     import openvivqa_amd as A
     import openvivqa_amd.utils as U
     import oracle as O
+    from conftest import parity_record as rec
     from openvivqa_amd.config import ConfigNode, attention_config
     A.set_compute_dtype(BF16)
     sa = attention_config()
@@ -351,26 +397,47 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
     vo_r, lo_r = v.clone().requires_grad_(), l.clone().requires_grad_()
     a, b = ref(vo_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
     ((a * wv).mean() + (b * wl).mean()).backward()
+    a, b = a.detach(), b.detach()
+    g32 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    g32.update({"d vision": vo_r.grad, "d language": lo_r.grad})
+    ref.zero_grad(set_to_none=True)
+    vo_r, lo_r = v.clone().requires_grad_(), l.clone().requires_grad_()
+    with O.emulate_bf16():
+        ae, be = ref(vo_r, O.padding_mask(v, 0), lo_r, O.padding_mask(l, 0))
+        ((ae * wv).mean() + (be * wl).mean()).backward()
     vd, ld = v.to(DEV).requires_grad_(), l.to(DEV).requires_grad_()
     ah, bh = hip(vision_features=vd, vision_padding_mask=U.generate_padding_mask(vd.detach(), 0), language_features=ld,
                  language_padding_mask=U.generate_padding_mask(ld.detach(), 0))
     ((ah.float() * wv.to(DEV)).mean() + (bh.float() * wl.to(DEV)).mean()).backward()
-    # L=6 (CoAttention: 24 chained blocks) in bf16
-    assert nerr(ah, a) < 1e-2 and nerr(bh, b) < 1e-2, (nerr(ah, a), nerr(bh, b))
-    assert rel_l2(ah, a) < 1e-2 and rel_l2(bh, b) < 1e-2, (rel_l2(ah, a), rel_l2(bh, b))
-    assert rel_l2(vd.grad, vo_r.grad) < 4e-2 and rel_l2(ld.grad, lo_r.grad) < 4e-2, \
-        (rel_l2(vd.grad, vo_r.grad), rel_l2(ld.grad, lo_r.grad))
+    tag = f"pair[{arch},L={layers}]"
+    e_f = max(rec(tag, "vision out vs fp32 oracle", nerr(ah, a), 1e-2), rec(tag, "language out vs fp32 oracle", nerr(bh, b), 1e-2))
+    e_e = max(rec(tag, "vision out vs emulation", nerr(ah, ae), 8e-3), rec(tag, "language out vs emulation", nerr(bh, be), 8e-3))
+    emu_gap = max(rec(tag, "emulation vs fp32 oracle (no kernel involved), vision", nerr(ae, a), 1e-2),
+                  rec(tag, "emulation vs fp32 oracle (no kernel involved), language", nerr(be, b), 1e-2))
+    assert e_e < 8e-3, (e_e, e_f)
+    if arch == "CoAttentionEncoder" and layers == 6:
+        # documented miss: held to 1.5e-2 against fp32, and the storage format itself must account for the excess
+        assert e_f < 1.5e-2 and (e_f < 1e-2 or emu_gap > 0.6 * e_f), (e_f, emu_gap)
+    else:
+        assert e_f < 1e-2 and rel_l2(ah, a) < 1e-2 and rel_l2(bh, b) < 1e-2, (e_f, rel_l2(ah, a), rel_l2(bh, b))
+    from conftest import grad_close
+    gbar = G9_EMU_BAR  # 24-48 chained blocks
+    bad = []
+    for what, gh, ge in (("d vision", vd.grad, vo_r.grad), ("d language", ld.grad, lo_r.grad)):
+        e, fmt = rec(tag, f"{what} vs emulation", rel_l2(gh, ge), gbar), rel_l2(ge, g32[what])
+        if not grad_close(e, fmt, gbar):
+            bad.append((what, e, fmt))
     gref = dict(ref.named_parameters())
-    gmax = max(float(p.grad.norm()) for p in gref.values() if p.grad is not None)
-    worst = 0.0
     for k, p in hip.named_parameters():
         if gref[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        if k.endswith("fc_k.bias") or float(gref[k].grad.norm()) < 0.05 * gmax:
+        if k.endswith("fc_k.bias"):
             continue
-        worst = max(worst, rel_l2(p.grad, gref[k].grad))
-    assert worst < 5e-2, worst
+        e, fmt = rec(tag, f"gw/{k} vs emulation", rel_l2(p.grad, gref[k].grad), gbar), rel_l2(gref[k].grad, g32[k])
+        if not grad_close(e, fmt, gbar):
+            bad.append((k, e, fmt))
+    assert not bad, bad
 
 
 def test_crossmodality_dead_branch_and_unused_grads(mode):
@@ -514,3 +581,85 @@ def test_geometry_attention_vs_oracle(trig, mode):
     gh = torch.cat([p.grad.flatten() for k, p in hip.named_parameters() if k.startswith("fc_gs")])
     gr = torch.cat([p.grad.flatten() for k, p in ref.named_parameters() if k.startswith("fc_gs")])
     assert rel_l2(gh, gr) < gt, rel_l2(gh, gr)
+
+
+def test_mask_and_position_helpers_bit_exact_on_gpu():
+    """a12 / a13 on the device: the mask helpers, the decoder position table, the encoder
+    sinusoid table and the row-padding-mask kernel against G6 -- outputs of the reference's models/utils.py:32-73 and
+    pos_embeddings.py:58-72 -- bit for bit, with CUDA inputs."""
+    from openvivqa_amd import ops
+    from openvivqa_amd.modules.pos_embeddings import SinusoidPositionalEmbedding
+    from openvivqa_amd.utils import (generate_padding_mask, generate_self_attention_masks, generate_sequential_mask,
+                                     sinusoid_encoding_table)
+    c = load_case("G6_pos_masks")
+    pe = SinusoidPositionalEmbedding(8)(torch.zeros(2, 3, 8, device=DEV))
+    assert pe.is_cuda and pe.shape == (2, 3, 8) and torch.equal(pe[0].cpu(), c.out["sinusoid_3_8"])
+    big = SinusoidPositionalEmbedding(512)(torch.zeros(1, 100, 512, device=DEV))[0]
+    assert torch.equal(big[::33, ::37].cpu(), c.out["sinusoid_100_512"])
+    assert torch.equal(sinusoid_encoding_table(6, 8, 0), c.out["table_6_8_pad0"])
+    assert torch.equal(sinusoid_encoding_table(6, 8), c.out["table_6_8_nopad"])
+    toks, feats = c.inputs["tokens"].to(DEV), c.inputs["feats"].to(DEV)
+    pm = generate_padding_mask(toks, 0)
+    assert pm.is_cuda and pm.dtype == c.out["padmask_tokens"].dtype and torch.equal(pm.cpu(), c.out["padmask_tokens"])
+    pf = generate_padding_mask(feats, 0)
+    assert torch.equal(pf.cpu(), c.out["padmask_feats"])
+    sm = generate_sequential_mask(5, device=DEV)
+    assert sm.is_cuda and torch.equal(sm.cpu(), c.out["seqmask_5"])
+    both = generate_self_attention_masks(pm, sm)
+    assert both.dtype == c.out["selfmask"].dtype and torch.equal(both.cpu(), c.out["selfmask"])
+    # the fused kernel form of generate_padding_mask for feature rows (FeatureEmbedding): same values, fp32 and bf16
+    for dt in (F32, BF16):
+        km = ops.row_padding_mask(feats.to(dt).contiguous(), 0.0)
+        assert km.shape == (2, 1, 1, 4) and torch.equal(km.cpu(), c.out["padmask_feats"].float())
+    # the encoder prologue's fused table add reads the same table: LN(x) + pos == LN(x) + G6's rows
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 8, generator=g).to(DEV)
+    ones, zeros = torch.ones(8, device=DEV), torch.zeros(8, device=DEV)
+    y_pos, _, _ = ops.layernorm_fwd(x, ones, zeros, 1e-5, out_dtype=F32, pos=pe[0].contiguous())
+    y, _, _ = ops.layernorm_fwd(x, ones, zeros, 1e-5, out_dtype=F32)
+    assert torch.equal(y_pos.cpu(), (y + c.out["sinusoid_3_8"].to(DEV)).cpu())
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_train_step_reference_trajectory_on_gpu(graph):
+    """Row T on the device: G11 -- the reference's own two Adam steps (losses and post-step
+    weights of Encoder L=2 + head under NLLLoss, Adam(0.9, 0.98), Noam LambdaLR) -- replayed through TrainStep in fp32
+    mode with the real kernels, eager launches and captured hipGraph."""
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.train import TrainStep, noam_lr_scale
+    from openvivqa_amd.utils import generate_padding_mask
+    A.set_compute_dtype(F32)
+    try:
+        case = load_case("G11_train_two_steps")
+        enc = M.Encoder(ConfigNode(case.meta["cfg"]))
+        head = torch.nn.Linear(32, 5)
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.enc, self.head = enc, head
+
+            def forward(self, x):
+                return torch.log_softmax(self.head(self.enc(x, generate_padding_mask(x, 0)).mean(1)), -1)
+        net = Net()
+        enc.load_state_dict({k: v for k, v in case.w.items() if not k.startswith("head.")})
+        head.load_state_dict({"weight": case.w["head.weight"], "bias": case.w["head.bias"]})
+        net = net.to(DEV).train()
+        y = case.inputs["y"].to(DEV)
+        nll = torch.nn.NLLLoss(ignore_index=0)
+        ts = TrainStep(net, lambda x: nll(net(x), y), lr=case.meta["lr"], betas=tuple(case.meta["betas"]),
+                       lr_lambda=lambda s: noam_lr_scale(s, 32, case.meta["warmup"]), use_graph=graph,
+                       compute_dtype=F32)
+        x = case.inputs["x"].to(DEV)
+        losses = [float(ts.step(x).item()) for _ in range(2)]
+        assert graph == (ts.graphs is not None)
+        assert nerr(torch.tensor(losses), case.out["losses"]) < 1e-4, (losses, case.out["losses"])
+        for k, v in enc.state_dict().items():
+            if k.endswith("fc_k.bias"):
+                continue  # analytically zero gradient: Adam turns its rounding noise into +-lr steps
+            assert nerr(v, case.out["w2/" + k]) < 1e-3, ("post-step " + k, nerr(v, case.out["w2/" + k]))
+        assert nerr(head.weight, case.out["w2/head.weight"]) < 1e-3
+    finally:
+        A.set_compute_dtype(BF16)
