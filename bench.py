@@ -44,13 +44,17 @@ def parse():
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
                          "single-rank group")
-    ap.add_argument("--workload", default="stack", choices=["stack", "model", "m4c_decode"],
+    ap.add_argument("--beam", type=int, default=1, help="--workload decode: beam size (1 = greedy)")
+    ap.add_argument("--workload", default="stack", choices=["stack", "model", "m4c_decode", "decode"],
                     help="stack = BASELINE's metric (the two encoder stacks, default); model = SECONDARY diagnostic: "
                          "the whole MCAN model (FeatureEmbedding + LSTM text embedding + stacks + pooling head + "
                          "classifier + NLLLoss) on synthetic region features / token ids (SURVEY 8d); m4c_decode = "
                          "SECONDARY diagnostic for BASELINE configs[3]: M4C's multimodal transformer (hidden 768, 4 layers x "
                          "8 heads, 20 question + 100 region + 50 OCR + 12 decoding positions) run through the 12-pass "
-                         "greedy decoding loop with the classifier || OcrPtrNet head, evaluation mode")
+                         "greedy decoding loop with the classifier || OcrPtrNet head, evaluation mode; decode = SECONDARY "
+                         "diagnostic for BASELINE configs[4] (configs/vit_mbert_generation.yaml): autoregressive "
+                         "answer decoding, Decoder L=3 over 237 encoder positions (ViT 197 + 40 question tokens), T=20, "
+                         "--beam 1|3, tokens/s and the fraction of HBM peak against the bytes a step must stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the CPU leg at the best thread count")
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
@@ -411,6 +415,85 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
         dist.destroy_process_group()
 
 
+def decode_bench(args, device, world, rank, dist, B, seed):
+    """SECONDARY diagnostic (not the headline metric): BASELINE configs[4], `configs/vit_mbert_generation.yaml:68-98` --
+    the stateful `Decoder` (L=3, d=512, H=8, dff=2048) decoding T=20 tokens per sample over 237 encoder positions with
+    batched beam search (openvivqa_amd.beam = beam_search.py's control flow), evaluation mode, random weights, synthetic
+    encoder features (the ViT / mBERT encoders in front are out of scope).  One "step" = one full decode of a batch.
+    `roofline_decode`: bytes ONE decoding step must stream from HBM -- decoder weights once, the self-attention K/V
+    prefix of every live beam, the projected encoder K/V of every sample (shared by its beams) -- against the measured
+    time per step."""
+    from types import SimpleNamespace
+    import openvivqa_amd as A
+    from openvivqa_amd.beam import BeamSearch
+    from openvivqa_amd.config import ConfigNode, attention_config
+    T, NE, V, L, D = 20, 237, 4000, 3, 512
+
+    class Vocab:
+        max_answer_length, padding_idx, bos_idx, eos_idx = T, 0, 1, 2
+
+        def __len__(self):
+            return V
+    cfg = ConfigNode(dict(
+        ARCHITECTURE="Decoder", D_MODEL=D, LAYERS=L,
+        ATTENTION=dict(SELF_ATTENTION=attention_config(can_be_stateful=True), ENC_ATTENTION=attention_config()),
+        TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=D, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                            WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+    torch.manual_seed(seed)
+    dec = A.build_decoder(cfg, Vocab()).to(device).eval()
+    g = torch.Generator().manual_seed(seed + rank)
+    enc = torch.randn(B, NE, D, generator=g)
+    ne = torch.randint(200, NE + 1, (B,), generator=g)
+    enc[torch.arange(NE)[None, :] >= ne[:, None]] = 0
+    enc = enc.to(device)
+    from openvivqa_amd.utils import generate_padding_mask
+    emask = generate_padding_mask(enc, 0)
+    beam = args.beam
+    from openvivqa_amd.beam import GraphedBeamSearch
+    search = GraphedBeamSearch(dec, B, T, 1, -1, beam)  # eos unreachable: every batch costs the same
+
+    def run():
+        return search(enc, emask, use_graph=not args.no_graph)
+    for _ in range(max(1, args.warmup)):
+        run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        per_step = dt / args.steps / T
+        es = 2 if args.dtype == "bf16" else 4
+        n_w = sum(p.numel() for n, p in dec.named_parameters() if "word_emb" not in n and "pos_emb" not in n)
+        # per decoding step: every weight once; self K/V prefix (mean length T/2) per live beam; encoder K/V per sample
+        bytes_step = n_w * es + L * (B * beam * (T / 2) * 2 * D * es + B * NE * 2 * D * es)
+        print(json.dumps({
+            "metric": "SECONDARY: autoregressive decode tokens/sec (best beam), Decoder L=3 d=512, 237 encoder positions, T=20",
+            "value": round(world * B * T * args.steps / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"secondary, BASELINE configs[4]: Decoder L={L} d={D} H=8 dff=2048, |V|={V}, B={B}/GPU, "
+                                   f"{NE} encoder positions, T={T} decoding steps, beam {beam}, "
+                                   + ("eager launches" if args.no_graph else "whole decode replayed from one hipGraph"),
+                       "global_batch": world * B, "parallelism": f"dp{world}", "beam": beam},
+            "us_per_decoding_step": round(per_step * 1e6, 1),
+            "roofline_decode": {"bound": "hbm", "bytes_per_decoding_step": int(bytes_step), "peak": 8000.0, "unit": "GB/s",
+                                "achieved": round(bytes_step / per_step / 1e9, 1),
+                                "frac": round(bytes_step / per_step / PEAK_HBM, 4)}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def ensure_library(local_rank):
     """The C-ABI library is a build artefact.  Decide about it BEFORE anything touches the GPU or the process group
     (hipcc must never run in a process that initialised HIP, and never under a profiler): local rank 0 compiles a
@@ -546,6 +629,8 @@ def main():
     torch.manual_seed(b.SEED)  # identical initial weights on every rank
     if args.workload == "m4c_decode":
         return m4c_decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
+    if args.workload == "decode":
+        return decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
     model = MCANEncoderStack(cfg.MODEL).to(device).train()
     D = cfg.MODEL.D_MODEL
     v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,

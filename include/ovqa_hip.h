@@ -272,6 +272,17 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
                            void* o, int64_t ldo, float* lse, void* o_lo,
                            int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale, void* stream);
 
+/* Single-query attention of an autoregressive decoding step (replaces attentions.py:314-327 called with ONE new query
+ * per sequence: decoders.py:46-63 under beam_search.py:41-62).  q [R, H*d] (row stride ldq), one query per row;
+ * k / v: in-place caches, query row r reads cache row r / group (the `group` beams of a sample share the projected
+ * encoder K / V; group = 1 for the self-attention caches), key j of that row at `kv_batch_stride * (r / group) +
+ * j * ldk` (elements), `n` live keys (1 <= n <= 1024); mask: additive fp32 [R, ldmask] or NULL; o [R, H*d].
+ * d in {32, 64, 128}; pointers 16-byte aligned, ldq / ldk multiples of 16 bytes.  One wave per (row, head), K and V
+ * streamed once: HBM-bound.  ovqa_last_dispatch() = "decode". */
+int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          int64_t kv_batch_stride, int64_t group, const float* mask, int64_t ldmask,
+                          void* o, int64_t ldo, int64_t R, int64_t H, int64_t n, int64_t d, float scale, void* stream);
+
 /* o_lo (OVQA_BF16 only; may be NULL in all three calls): the rounding residual of the attention output, bf16, same
  * layout as o: o_lo = bf16(o_exact - float(o)).  The forward calls write it, ovqa_attention_bwd reads it for
  * delta_i = dO_i . (o_i + o_lo_i): dS = P (dP - delta) is a cancellation, and with near-uniform attention (a freshly
@@ -378,12 +389,15 @@ int ovqa_row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int6
  *             (one torch.gather with an expanded index tensor per running K/V cache / mask / position buffer).
  *   Every problem is a row-major buffer src [b_s*cur_beam, row_bytes] -> dst [b_s*beam, row_bytes] (any dtype,
  *   out of place):  dst[b*beam + j] = src[b*cur_beam + sel[b*beam + j]],  sel int32 [b_s*beam] in [0, cur_beam).
- *   `problems` and `sel` are DEVICE arrays.
+ *   `sel` is a DEVICE array; `problems` is a HOST array (copied into the launch's kernel arguments, 24 problems per
+ *   launch): nothing is uploaded, so the call can be captured into a hipGraph as it is.
  * ------------------------------------------------------------------------- */
 typedef struct ovqa_gather_problem {
   const void* src;
   void* dst;
-  int64_t row_bytes;
+  int64_t row_bytes;        /* bytes moved per row */
+  int64_t src_stride_bytes; /* distance between consecutive source rows (0 = row_bytes): a live prefix of an in-place */
+  int64_t dst_stride_bytes; /* K / V cache [rows, Lmax, D] is row_bytes = n*D*es at stride Lmax*D*es                  */
 } ovqa_gather_problem;
 int ovqa_grouped_row_gather(const ovqa_gather_problem* problems, int32_t n_problems, const int32_t* sel,
                             int32_t b_s, int32_t cur_beam, int32_t beam, void* stream);

@@ -51,7 +51,8 @@ class LnRef(C.Structure):
 
 class GatherProblem(C.Structure):
     """ovqa_gather_problem (include/ovqa_hip.h)."""
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64)]
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_int64),
+                ("src_stride_bytes", C.c_int64), ("dst_stride_bytes", C.c_int64)]
 
 
 class Dropout(C.Structure):
@@ -90,6 +91,8 @@ SIGNATURES = {
     "ovqa_launch_timing_end": [c_vp, c_int],
     "ovqa_attention_qkv_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_attention_decode": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
+                              c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],

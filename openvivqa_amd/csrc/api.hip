@@ -351,6 +351,24 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
                             n, n, d, d, scale, nullptr, stream);
 }
 
+int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          int64_t kv_batch_stride, int64_t group, const float* mask, int64_t ldmask, void* o, int64_t ldo,
+                          int64_t R, int64_t H, int64_t n, int64_t d, float scale, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_decode: bad dtype %d", dtype);
+  OVQA_REQUIRE(R >= 0 && H > 0 && n >= 1 && d > 0 && group >= 1, OVQA_ERR_BAD_ARG, "attention_decode: bad sizes");
+  if (R == 0) return OVQA_OK;
+  OVQA_REQUIRE(q && k && v && o, OVQA_ERR_BAD_ARG, "attention_decode: null pointer");
+  OVQA_REQUIRE(ldq >= H * d && ldk >= H * d && ldv >= H * d && ldo >= H * d, OVQA_ERR_BAD_ARG,
+               "attention_decode: row stride smaller than H*d");
+  OVQA_REQUIRE(R * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_decode: R*H too large");
+  ovqa::AttnDecodeArgs a{q, k, v, ldq, ldk, ldv, kv_batch_stride, mask, ldmask, o, ldo,
+                         (int)R, (int)H, (int)d, (int)n, (int)group, scale};
+  OVQA_REQUIRE(ovqa::attention_decode_supported(a, dtype == OVQA_BF16 ? 2 : 4), OVQA_ERR_UNSUPPORTED,
+               "attention_decode: d must be 32 / 64 / 128, n <= 1024, 16-byte aligned q / k / v rows");
+  g_dispatch = "decode";
+  return ovqa::attention_decode(dtype, a, as_stream(stream));
+}
+
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, const void* o, int64_t ldo, const void* o_lo, const void* d_att,
                        const float* lse,

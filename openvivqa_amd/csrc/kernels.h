@@ -59,6 +59,20 @@ struct AttnBwdArgs {
   // O = o + o_lo (16 significant bits) the error of delta drops by 2^8 (tests/test_kernels_gpu.py).
   const void* o_lo = nullptr;
 };
+// ---- attention_decode.hip: one query per row against an in-place K/V cache --------------
+struct AttnDecodeArgs {
+  const void *q, *k, *v;   // q [R, H*d] (row stride ldq); k, v: row (r / group) at kv_batch_stride, key j at ldk / ldv
+  int64_t ldq, ldk, ldv, kv_batch_stride;
+  const float* mask;       // additive fp32 [R, ldmask] or nullptr
+  int64_t ldmask;
+  void* o;                 // [R, H*d] (row stride ldo)
+  int64_t ldo;
+  int R, H, d, n, group;
+  float scale;
+};
+bool attention_decode_supported(const AttnDecodeArgs& a, int esize);
+int attention_decode(int dtype, const AttnDecodeArgs& a, hipStream_t st);
+
 int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
 int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);
 

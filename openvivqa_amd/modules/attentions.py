@@ -246,6 +246,7 @@ class MultiHeadAttention(Module):
             self.register_state("running_keys", torch.zeros((0, d_model)))
             self.register_state("running_values", torch.zeros((0, d_model)))
         self._site = rt.new_dropout_site()
+        self._drop_decode_caches()
 
     def forward(self, queries, keys, values, attention_mask, projected_kv=None, **kwargs):
         arena = rt.ensure_arena(self)
@@ -256,9 +257,14 @@ class MultiHeadAttention(Module):
         same_kv = Fn.same_tensor(keys, values)
         same_all = same_kv and Fn.same_tensor(queries, keys)
         queries = Fn.to_compute(queries, T)
+        mask = _as_mask(attention_mask)
+        if (self._is_stateful and not self.can_be_stateful and not torch.is_grad_enabled() and same_kv and not same_all
+                and type(self.attention) is ScaledDotProductAttention and queries.shape[1] == 1 and queries.is_cuda
+                and self.attention.d_k == self.attention.d_v and self.attention.d_k in (32, 64, 128)
+                and keys.shape[1] <= 1024 and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1))):
+            return self._encoder_step(arena, queries, keys, mask)  # (keys as given: the cache is keyed on that tensor)
         keys = queries if same_all else keys.to(T)
         values = keys if same_kv else values.to(T)
-        mask = _as_mask(attention_mask)
         if self.can_be_stateful and self._is_stateful:
             if (type(self.attention) is ScaledDotProductAttention and not torch.is_grad_enabled()
                     and self.attention.h * self.attention.d_k == self.attention.h * self.attention.d_v == keys.shape[-1]):
@@ -286,28 +292,75 @@ class MultiHeadAttention(Module):
             out = i * torch.sigmoid(g)
         return out
 
-    def _stateful_step(self, arena, queries, keys, values, mask):
-        """Autoregressive decode step with a PROJECTED K/V cache.
+    # ------------------------------------------------------------------ autoregressive decoding
+    DECODE_CAPACITY = 32  # keys an in-place cache is first sized for (Decoder sets max_len + 1); doubled when full
 
-        The reference appends the raw d_model inputs to ``running_keys/values`` and re-applies fc_k / fc_v to
-        the whole prefix at every step (attentions.py:320-325: O(T^2) projections per sequence).  Here only
-        the new positions are projected and the projections are what the state buffers hold -- same buffer
-        names, same (B, t, H*d) shape (so beam search's ``apply_to_states`` reorder works unchanged), same
-        outputs."""
+    def enable_statefulness(self, batch_size: int) -> None:
+        super().enable_statefulness(batch_size)
+        self._drop_decode_caches()
+
+    def disable_statefulness(self) -> None:
+        super().disable_statefulness()
+        self._drop_decode_caches()
+
+    def _drop_decode_caches(self):
+        self._kv = None       # self-attention: [k cache, v cache] (R, capacity, H*d) written in place, + spare pair
+        self._kv_spare = None
+        self._enc = None      # encoder attention: (source identity, packed K|V (rows, nk, 2*H*d)) of the encoder features
+        self._beam = None     # (b_s, beam) declared by Module.reorder_states: rows b*beam .. b*beam+beam-1 are one sample
+
+    def _seat_cache(self, like_q):
+        """The in-place K / V caches behind ``running_keys / running_values``.  The state buffers are live-prefix VIEWS
+        of the caches, so the reference's protocol keeps working: ``apply_to_states(fn)`` hands fn the (R, t, H*d)
+        prefix and stores what it returns -- which is then no longer our view and is copied into a cache again here."""
+        rk, rv = self._buffers["running_keys"], self._buffers["running_values"]
+        kv = getattr(self, "_kv", None)
+        n = rk.shape[1] if rk.dim() == 3 else 0
+        R, F = like_q.shape[0], like_q.shape[-1]
+        if (kv is not None and kv[0].dtype == like_q.dtype and kv[0].shape[0] == R and n < kv[0].shape[1]
+                and rk.dim() == 3 and rk.shape[0] == R and rk.data_ptr() == kv[0].data_ptr() and rv.data_ptr() == kv[1].data_ptr()):
+            return kv, n
+        cap = max(int(getattr(self, "decode_capacity", self.DECODE_CAPACITY)), 2 * (n + 1))
+        new = [torch.empty(R, cap, F, dtype=like_q.dtype, device=like_q.device) for _ in range(2)]
+        if n > 0:
+            assert rk.shape[0] == R, "the state buffers' batch dimension must follow the queries'"
+            new[0][:, :n].copy_(rk)
+            new[1][:, :n].copy_(rv)
+        self._kv, self._kv_spare = new, None
+        return new, n
+
+    def _cache_destination(self, name, rows):
+        """reorder_states: where the gathered rows of ``running_keys / running_values`` go -- the live prefix of the
+        SPARE cache buffer (allocated once per decode), so that a beam reorder moves the live keys once and the next
+        step appends in place again.  None when the state is not backed by a cache."""
+        kv = getattr(self, "_kv", None)
+        if kv is None or name not in ("running_keys", "running_values"):
+            return None
+        i = 0 if name == "running_keys" else 1
+        s = self._buffers[name]
+        if s.dim() != 3 or s.data_ptr() != kv[i].data_ptr():
+            return None
+        spare = getattr(self, "_kv_spare", None)
+        if spare is None or spare[0].shape[0] != rows or spare[0].shape[1:] != kv[0].shape[1:] or spare[0].dtype != kv[0].dtype:
+            spare = [torch.empty((rows,) + tuple(kv[0].shape[1:]), dtype=kv[0].dtype, device=kv[0].device) for _ in range(2)]
+            self._kv_spare = spare
+        return spare[i][:, :s.shape[1]]
+
+    def _caches_reordered(self):
+        rk, spare = self._buffers.get("running_keys"), getattr(self, "_kv_spare", None)
+        if spare is not None and rk is not None and rk.dim() == 3 and rk.data_ptr() == spare[0].data_ptr():
+            self._kv, self._kv_spare = spare, self._kv  # the gathered prefix lives in the spare pair: swap roles
+
+    def _finish_step(self, arena, queries, o):
+        """fc_o + residual + LayerNorm (+ AoA) of a decoding step, as the fused block computes them."""
         from .. import ops
         from .._lib import EPI_BIAS_RESIDUAL
         a, ln = self.attention, self.layer_norm
-        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
-        k_new = ops.linear_fwd(keys.contiguous(), arena.compute(a.fc_k.weight), arena.master_of(a.fc_k.bias))
-        v_new = ops.linear_fwd(values.contiguous(), arena.compute(a.fc_v.weight), arena.master_of(a.fc_v.bias))
-        self.running_keys = torch.cat([self.running_keys.to(q.dtype), k_new], 1)
-        self.running_values = torch.cat([self.running_values.to(q.dtype), v_new], 1)
-        o, _, _ = ops.attention_fwd(q, self.running_keys, self.running_values, mask, a.h, save_lse=False)
-        if q.dtype == torch.bfloat16:  # fp32 residual stream, as in the fused block
+        if o.dtype == torch.bfloat16:  # fp32 residual stream, as in the fused block
             pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias),
                                        Fn.residual_of(queries))
             gamma, beta = arena.master_of(ln.weight), arena.master_of(ln.bias)
-            out, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=q.dtype)
+            out, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=o.dtype)
             Fn.attach_residual(out, ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps))
         else:
             pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
@@ -315,3 +368,71 @@ class MultiHeadAttention(Module):
             out, _, _ = ops.layernorm_fwd(pre, arena.master_of(ln.weight), arena.master_of(ln.bias), ln.eps,
                                           save_stats=False)
         return self._aoa(arena, queries, out)
+
+    @staticmethod
+    def _row_mask(mask, R, n):
+        """(R, >= n) fp32 rows of an additive (R | 1, 1, 1, n) mask, or None."""
+        if mask is None:
+            return None
+        m = mask.reshape(mask.shape[0], mask.shape[-1])
+        if m.shape[0] != R:
+            m = m.expand(R, m.shape[1])
+        return m.contiguous()
+
+    def _stateful_step(self, arena, queries, keys, values, mask):
+        """Autoregressive decode step with a PROJECTED, IN-PLACE K/V cache.
+
+        The reference appends the raw d_model inputs to ``running_keys/values`` and re-applies fc_k / fc_v to the whole
+        prefix at every step (attentions.py:320-325: O(T^2) projections per sequence, a torch.cat per buffer and step).
+        Here only the new position is projected, straight into its slot of a pre-allocated (R, capacity, H*d) cache
+        (no concatenation), the state buffers are live-prefix views of the caches -- same names, same (R, t, H*d) shape,
+        so ``apply_to_states`` and ``reorder_states`` work -- and the attention is the single-query kernel
+        (ovqa_attention_decode: one wave per (row, head), K / V streamed once).  Same outputs."""
+        from .. import ops
+        a = self.attention
+        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
+        nq = queries.shape[1]
+        single = (nq == 1 and keys.shape[1] == 1 and q.is_cuda and a.d_k == a.d_v and a.d_k in (32, 64, 128)
+                  and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1)))
+        if not single:  # several new positions at once (teacher-forced prefixes): the general kernel on a grown cache
+            k_new = ops.linear_fwd(keys.contiguous(), arena.compute(a.fc_k.weight), arena.master_of(a.fc_k.bias))
+            v_new = ops.linear_fwd(values.contiguous(), arena.compute(a.fc_v.weight), arena.master_of(a.fc_v.bias))
+            self.running_keys = torch.cat([self.running_keys.to(q.dtype), k_new], 1)
+            self.running_values = torch.cat([self.running_values.to(q.dtype), v_new], 1)
+            self._kv = None
+            o, _, _ = ops.attention_fwd(q, self.running_keys, self.running_values, mask, a.h, save_lse=False)
+            return self._finish_step(arena, queries, o)
+        (kc, vc), n = self._seat_cache(q)
+        ops.linear_fwd(keys.reshape(keys.shape[0], -1), arena.compute(a.fc_k.weight), arena.master_of(a.fc_k.bias),
+                       out=kc[:, n])
+        ops.linear_fwd(values.reshape(values.shape[0], -1), arena.compute(a.fc_v.weight), arena.master_of(a.fc_v.bias),
+                       out=vc[:, n])
+        n += 1
+        self._buffers["running_keys"], self._buffers["running_values"] = kc[:, :n], vc[:, :n]
+        o = ops.attention_decode(q, kc, vc, n, a.h, mask=self._row_mask(mask, q.shape[0], n))
+        return self._finish_step(arena, queries, o)
+
+    def _encoder_step(self, arena, queries, keys, mask):
+        """Decoding step of an attention over the ENCODER positions (the non-stateful enc_attn of a DecoderLayer inside
+        a stateful decoder, decoders.py:21-27): the reference re-applies fc_k / fc_v to all encoder positions at every
+        step and for every beam.  The projections are computed ONCE per sample and decode: cached for the tensor they
+        were computed from, and -- once ``reorder_states`` has declared the beam structure (rows b*beam .. b*beam+beam-1
+        are the beams of sample b, which see the same encoder features: beam_search.py:19-34 gathers copies) -- shared
+        by the beams of a sample through the attention kernel's ``group``."""
+        from .. import ops
+        a = self.attention
+        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
+        R, nk, F = keys.shape[0], keys.shape[1], a.h * a.d_k
+        ident = (keys.data_ptr(), tuple(keys.shape), keys._version)
+        enc, beam, group = getattr(self, "_enc", None), getattr(self, "_beam", None), 1
+        if enc is not None and enc[0] == ident:
+            kv = enc[1]
+        elif (enc is not None and beam is not None and R == beam[0] * beam[1] and enc[1].shape[0] == beam[0]
+              and enc[1].shape[1] == nk):
+            kv, group = enc[1], beam[1]
+        else:
+            kv = ops.linear_fwd(keys.to(q.dtype).contiguous(), arena.packed([a.fc_k.weight, a.fc_v.weight]),
+                                arena.packed([a.fc_k.bias, a.fc_v.bias], "master"))
+            self._enc = (ident, kv)
+        o = ops.attention_decode(q, kv[..., :F], kv[..., F:], nk, a.h, mask=self._row_mask(mask, R, nk), group=group)
+        return self._finish_step(arena, queries, o)

@@ -55,15 +55,25 @@ class Module(nn.Module):
         tensor) per buffer (beam_search.py:19-34).  ``selected_beam`` is (b_s, beam_size).  State tensors that are not
         on the GPU, or whose leading dimension is not b_s * cur_beam_size, take the reference's gather."""
         from .. import ops
+        self._declare_beams(b_s, beam_size)
         slots = [(m, n) for m, n in self._state_slots() if m._buffers[n] is not None]
         fused = [(m, n) for m, n in slots
                  if m._buffers[n].is_cuda and m._buffers[n].dim() >= 1 and m._buffers[n].shape[0] == b_s * cur_beam_size
                  and m._buffers[n].numel() > 0]
         if fused:
-            outs = ops.grouped_row_gather([m._buffers[n].contiguous() for m, n in fused], selected_beam, b_s,
-                                          cur_beam_size, beam_size)
+            srcs, dsts = [], []
+            for m, n in fused:
+                s, d = m._buffers[n], None
+                if hasattr(m, "_cache_destination"):  # live prefix of an in-place K / V cache: gather into the spare one
+                    d = m._cache_destination(n, b_s * beam_size)
+                srcs.append(s if d is not None else s.contiguous())
+                dsts.append(d)
+            outs = ops.grouped_row_gather(srcs, selected_beam, b_s, cur_beam_size, beam_size, outs=dsts)
             for (m, n), o in zip(fused, outs):
                 m._buffers[n] = o
+            for m in {id(m): m for m, _ in fused}.values():
+                if hasattr(m, "_caches_reordered"):
+                    m._caches_reordered()
         done = {(id(m), n) for m, n in fused}
         for m, n in slots:
             if (id(m), n) in done:
@@ -77,11 +87,23 @@ class Module(nn.Module):
                              beam.expand(*([b_s, beam_size] + shape[1:])))
             m._buffers[n] = s.view(*([-1] + shape[1:]))
 
+    def _declare_beams(self, b_s: int, beam_size: int) -> None:
+        """``reorder_states`` knows what ``apply_to_states(fn)`` cannot: rows b*beam .. b*beam+beam-1 are the beams of
+        sample b.  Modules that keep per-SAMPLE decode caches (the projected encoder K / V of an attention) use it."""
+        self._beam = (b_s, beam_size)
+        for child in self._stateful_children():
+            child._declare_beams(b_s, beam_size)
+
     def _fresh(self, name: str, batch_size: Optional[int]):
         default = self._state_defaults[name]
         if default is None:
             return None
-        t = default.clone().detach().to(self._buffers[name].device)
+        cur = self._buffers[name]
+        dev = cur.device if cur is not None else default.device
+        if default.device != dev:  # keep the default where the state lives: no host-to-device copy per decode (a
+            default = default.to(dev)  # pageable upload cannot be captured into a hipGraph)
+            self._state_defaults[name] = default
+        t = default.clone().detach()
         if batch_size is not None:
             t = t.unsqueeze(0).expand([batch_size] + list(t.shape)).contiguous()
         return t

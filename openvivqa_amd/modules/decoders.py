@@ -51,6 +51,8 @@ class Decoder(Module):
         self.pos_emb = nn.Embedding.from_pretrained(
             sinusoid_encoding_table(max_len=self.max_len + 1, d_model=config.D_MODEL, padding_idx=0), freeze=True)
         self.layers = ModuleList([DecoderLayer(config.ATTENTION) for _ in range(config.LAYERS)])
+        for layer in self.layers:  # in-place K / V caches of the decoding steps: sized once for the longest answer
+            layer.self_attn.decode_capacity = self.max_len + 1
         self.fc = nn.Linear(config.D_MODEL, len(vocab), bias=False)
         self.register_state("running_mask_self_attention", torch.zeros((1, 1, 0)).bool())
         self.register_state("running_seq", torch.zeros((1,)).long())

@@ -589,6 +589,32 @@ def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=Non
     return qkv, o, lse
 
 
+def attention_decode(q, k_cache, v_cache, n, H, mask=None, group=1, scale=None, out=None):
+    """One decoding step's attention (``ovqa_attention_decode``): q [R, 1, H*d] or [R, H*d]; k_cache / v_cache
+    [R // group, Lmax, H*d] in-place caches of which the first ``n`` keys are live (the ``group`` beams of a sample
+    share a cache row); mask: additive fp32 [R, >= n] or None.  Returns o with q's shape."""
+    _dev(q)
+    lib = _lib.load()
+    shape = q.shape
+    R, F = shape[0], shape[-1]
+    d = F // H
+    assert q.numel() == R * F and q.stride(-1) == 1 and k_cache.dim() == 3 and v_cache.shape == k_cache.shape
+    assert k_cache.stride(2) == 1 and v_cache.stride(2) == 1 and k_cache.shape[2] == F and 1 <= n <= k_cache.shape[1]
+    assert k_cache.shape[0] * group == R, (tuple(k_cache.shape), group, R)
+    assert k_cache.stride() == v_cache.stride() and k_cache.dtype == q.dtype == v_cache.dtype
+    o = out if out is not None else torch.empty(shape, dtype=q.dtype, device=q.device)
+    ldq = q.stride(0)
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.dim() == 2 and mask.shape[0] == R and mask.shape[1] >= n
+        assert mask.stride(1) == 1
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    _lib.check(lib.ovqa_attention_decode(_dt(q), _p(q), ldq, _p(k_cache), k_cache.stride(1), _p(v_cache),
+                                         v_cache.stride(1), k_cache.stride(0), group, _p(mask),
+                                         0 if mask is None else mask.stride(0), _p(o), o.stride(0), R, H, n, d,
+                                         float(scale), _stream()), "attention_decode")
+    return o
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None, o_lo=None):
     _dev(q)
@@ -704,26 +730,39 @@ def row_padding_mask(x, pad_value=0.0):
     return mask
 
 
-def grouped_row_gather(states, selected_beam, b_s, cur_beam, beam):
+def grouped_row_gather(states, selected_beam, b_s, cur_beam, beam, outs=None):
     """Beam reorder of many state buffers in ONE launch: for every tensor s of ``states`` (leading dimension
-    b_s * cur_beam, contiguous) returns a new tensor with leading dimension b_s * beam whose row b*beam + j is row
-    b*cur_beam + selected_beam[b, j] of s (beam_search.py:19-34)."""
+    b_s * cur_beam) returns a tensor with leading dimension b_s * beam whose row b*beam + j is row
+    b*cur_beam + selected_beam[b, j] of s (beam_search.py:19-34).  A state is contiguous, or a live prefix
+    ``cache[:, :n]`` of an in-place cache (rows contiguous, uniformly strided); ``outs[i]`` (optional) is the
+    destination to fill -- e.g. the prefix of the alternate cache buffer -- instead of a new tensor."""
     import numpy as np
     dev = states[0].device
     _dev(states[0])
     sel = selected_beam.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
     assert sel.numel() == b_s * beam
-    outs, probs = [], (_lib.GatherProblem * len(states))()
+
+    def row_layout(t):  # (bytes per row, row stride in bytes): rows must be dense
+        inner = 1
+        for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+            assert size == 1 or stride == inner, "rows of a gathered state must be dense"
+            inner *= size
+        return inner * t.element_size(), (t.stride(0) if t.shape[0] > 1 else inner) * t.element_size()
+    res, probs = [], (_lib.GatherProblem * len(states))()
     for i, s in enumerate(states):
-        assert s.is_cuda and s.is_contiguous() and s.shape[0] == b_s * cur_beam, (tuple(s.shape), b_s, cur_beam)
-        o = torch.empty((b_s * beam,) + tuple(s.shape[1:]), dtype=s.dtype, device=dev)
-        row_bytes = (s.numel() // max(1, s.shape[0])) * s.element_size()
-        probs[i] = _lib.GatherProblem(_p(s), _p(o), row_bytes)
-        outs.append(o)
-    table = torch.from_numpy(np.frombuffer(bytes(probs), dtype=np.uint8).copy()).to(dev)
-    _lib.check(_lib.load().ovqa_grouped_row_gather(_p(table), len(states), _p(sel), b_s, cur_beam, beam, _stream()),
-               "grouped_row_gather")
-    return outs
+        assert s.is_cuda and s.shape[0] == b_s * cur_beam, (tuple(s.shape), b_s, cur_beam)
+        o = outs[i] if outs is not None and outs[i] is not None else \
+            torch.empty((b_s * beam,) + tuple(s.shape[1:]), dtype=s.dtype, device=dev)
+        assert o.shape == (b_s * beam,) + tuple(s.shape[1:]) and o.dtype == s.dtype
+        row_bytes, sstride = row_layout(s)
+        orow, ostride = row_layout(o)
+        assert orow == row_bytes
+        probs[i] = _lib.GatherProblem(_p(s), _p(o), row_bytes, sstride, ostride)
+        res.append(o)
+    # (the table is a HOST array: it travels in the kernel arguments -- no upload, capturable into a hipGraph)
+    _lib.check(_lib.load().ovqa_grouped_row_gather(C.cast(probs, C.c_void_p), len(states), _p(sel), b_s, cur_beam, beam,
+                                                   _stream()), "grouped_row_gather")
+    return res
 
 
 def dropout_keep_mask(drop: DropSpec, n: int, device) -> torch.Tensor:

@@ -388,6 +388,36 @@ def test_attention_bwd_delta_uses_the_output_residual(B, H, nq, nk):
     assert e1[0] < 0.2 * e0[0] and e1[1] < 0.2 * e0[1], (e1, e0)  # ... and the rounded-O delta was most of the error
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("Bc,group,H,d,Lmax,n", [(4, 1, 8, 64, 20, 1), (4, 1, 8, 64, 20, 13), (5, 3, 8, 64, 237, 237),
+                                                 (3, 2, 4, 32, 40, 33), (2, 1, 8, 128, 300, 257), (64, 3, 8, 64, 237, 200)])
+def test_attention_decode_single_query(dtype, Bc, group, H, d, Lmax, n):
+    """ovqa_attention_decode: one query per row against in-place K / V caches [rows / group, Lmax, H*d] of which n keys
+    are live (rows of a group share a cache row), additive per-row mask; against fp64 softmax attention and against the
+    general attention kernel on the gathered prefix."""
+    o_ = ops()
+    R, F = Bc * group, H * d
+    q = rnd(R, 1, F, dtype=dtype, seed=1)
+    kc, vc = rnd(Bc, Lmax, F, dtype=dtype, seed=2), rnd(Bc, Lmax, F, dtype=dtype, seed=3)
+    mask = torch.zeros(R, Lmax, device=DEV)
+    if n > 4:
+        mask[1, n - 3:] = -1e5
+        mask[R - 1, :2] = -1e5
+    out = o_.attention_decode(q, kc, vc, n, H, mask=mask, group=group)
+    assert out.shape == q.shape and out.dtype == dtype
+    kg, vg = kc[:, :n].repeat_interleave(group, 0), vc[:, :n].repeat_interleave(group, 0)
+    ro, _, _ = att_ref(q, kg, vg, mask[:, None, None, :n], H)
+    assert nerr(out, ro) < tol(dtype), nerr(out, ro)
+    if d == 64:
+        o2, _, _ = o_.attention_fwd(q, kg.contiguous(), vg.contiguous(), mask[:, None, None, :n].contiguous(), H, save_lse=False)
+        assert nerr(out, o2) < tol(dtype)
+    # strided output and no mask
+    buf = torch.zeros(R, 2 * F, dtype=dtype, device=DEV)
+    o_.attention_decode(q.view(R, F), kc, vc, n, H, group=group, out=buf[:, F:])
+    ro2, _, _ = att_ref(q, kg, vg, None, H)
+    assert nerr(buf[:, F:].reshape(R, 1, F), ro2) < tol(dtype) and float(buf[:, :F].abs().max()) == 0.0
+
+
 def test_attention_bwd_with_att_gradient():
     """d_att: gradient w.r.t. the returned attention weights (reference att is differentiable)."""
     o = ops()
