@@ -276,12 +276,17 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
  * per sequence: decoders.py:46-63 under beam_search.py:41-62).  q [R, H*d] (row stride ldq), one query per row;
  * k / v: in-place caches, query row r reads cache row r / group (the `group` beams of a sample share the projected
  * encoder K / V; group = 1 for the self-attention caches), key j of that row at `kv_batch_stride * (r / group) +
- * j * ldk` (elements), `n` live keys (1 <= n <= 1024); mask: additive fp32 [R, ldmask] or NULL; o [R, H*d].
+ * j * ldk` (elements), `n` live keys (1 <= n <= 512); mask: additive fp32 [R, ldmask] or NULL; o [R, H*d].
  * d in {32, 64, 128}; pointers 16-byte aligned, ldq / ldk multiples of 16 bytes.  One wave per (row, head), K and V
  * streamed once: HBM-bound.  ovqa_last_dispatch() = "decode". */
 int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                           int64_t kv_batch_stride, int64_t group, const float* mask, int64_t ldmask,
                           void* o, int64_t ldo, int64_t R, int64_t H, int64_t n, int64_t d, float scale, void* stream);
+
+/* The k best entries of every row of x [R, V] (fp32, row stride ldx), best first, ties by the smaller index:
+ * vals fp32 [R, k], idx int64 [R, k]; 1 <= k <= 8 and k <= V.  Candidate selection of a beam-search step
+ * (beam_search.py:36-39 takes them from a full sort of the cur_beam * |V| candidates). */
+int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream);
 
 /* o_lo (OVQA_BF16 only; may be NULL in all three calls): the rounding residual of the attention output, bf16, same
  * layout as o: o_lo = bf16(o_exact - float(o)).  The forward calls write it, ovqa_attention_bwd reads it for

@@ -93,6 +93,7 @@ SIGNATURES = {
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_attention_decode": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
                               c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_topk_rows": [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],

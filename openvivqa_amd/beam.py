@@ -32,8 +32,13 @@ class BeamSearch:
         multi-block radix path: six launches and a device scan per step)."""
         b_s, cur, V = candidate_logprob.shape
         k = min(self.beam_size, V)
-        v1, i1 = torch.topk(candidate_logprob, k, dim=-1, largest=True, sorted=True)         # (b_s, cur, k)
-        v2, i2 = torch.topk(v1.reshape(b_s, cur * k), self.beam_size, dim=-1, largest=True, sorted=True)
+        if candidate_logprob.is_cuda and candidate_logprob.dtype == torch.float32 and self.beam_size <= 8:
+            from . import ops
+            v1, i1 = ops.topk_rows(candidate_logprob.contiguous(), k)                       # (b_s, cur, k), one launch
+            v2, i2 = ops.topk_rows(v1.reshape(b_s, cur * k), self.beam_size)
+        else:
+            v1, i1 = torch.topk(candidate_logprob, k, dim=-1, largest=True, sorted=True)
+            v2, i2 = torch.topk(v1.reshape(b_s, cur * k), self.beam_size, dim=-1, largest=True, sorted=True)
         beam_of = torch.div(i2, k, rounding_mode="trunc")
         word = torch.gather(i1.reshape(b_s, cur * k), 1, i2)
         return beam_of * V + word, v2
@@ -50,11 +55,16 @@ class BeamSearch:
         return fn
 
     def apply(self, out_size: int = 1):
-        b_s, beam = self.b_s, self.beam_size
+        """beam_search.py:85-118 with the per-step bookkeeping on whole (b_s, beam, T) buffers: the reference keeps the
+        chosen words and their scores as Python lists of (b_s, beam, 1) tensors and re-gathers every element of both
+        lists at every step (2 t tiny launches at step t); one gather per buffer and step gives the same values."""
+        b_s, beam, T = self.b_s, self.beam_size, self.max_len
         seq_mask = torch.ones((b_s, beam, 1), device=self.device)
         seq_logprob = torch.zeros((b_s, 1, 1), device=self.device)
-        log_probs, outputs, selected_words = [], [], None
-        for t in range(self.max_len):
+        outputs = torch.zeros((b_s, beam, T), dtype=torch.long, device=self.device)
+        log_probs = torch.zeros((b_s, beam, T), device=self.device)
+        selected_words = None
+        for t in range(T):
             cur = 1 if t == 0 else beam
             word_logprob = self.step(t, selected_words).view(b_s, cur, -1)
             candidate = seq_logprob + word_logprob
@@ -74,16 +84,16 @@ class BeamSearch:
                 self.module.apply_to_states(self._expand_state(selected_beam, cur))
             seq_logprob = val.unsqueeze(-1)
             seq_mask = torch.gather(seq_mask, 1, selected_beam.unsqueeze(-1))
-            outputs = [torch.gather(o, 1, selected_beam.unsqueeze(-1)) for o in outputs]
-            outputs.append(words.unsqueeze(-1))
-            this = torch.gather(word_logprob, 1, selected_beam.unsqueeze(-1).expand(b_s, beam, word_logprob.shape[-1]))
-            this = torch.gather(this, 2, words.unsqueeze(-1))
-            log_probs = [torch.gather(o, 1, selected_beam.unsqueeze(-1).expand(b_s, beam, 1)) for o in log_probs]
-            log_probs.append(this)
+            this = torch.gather(word_logprob.reshape(b_s, -1), 1, idx)  # word_logprob[b, selected_beam, word]
+            if t > 0:  # histories follow their beams (columns >= t are still zero)
+                sel3 = selected_beam.unsqueeze(-1).expand(b_s, beam, T)
+                outputs, log_probs = torch.gather(outputs, 1, sel3), torch.gather(log_probs, 1, sel3)
+            outputs[:, :, t] = words
+            log_probs[:, :, t] = this
             selected_words = words.view(-1, 1)
         seq_logprob, order = torch.sort(seq_logprob, 1, descending=True)
-        outputs = torch.gather(torch.cat(outputs, -1), 1, order.expand(b_s, beam, self.max_len))
-        log_probs = torch.gather(torch.cat(log_probs, -1), 1, order.expand(b_s, beam, self.max_len))
+        outputs = torch.gather(outputs, 1, order.expand(b_s, beam, T))
+        log_probs = torch.gather(log_probs, 1, order.expand(b_s, beam, T))
         outputs, log_probs = outputs.contiguous()[:, :out_size], log_probs.contiguous()[:, :out_size]
         if out_size == 1:
             outputs, log_probs = outputs.squeeze(1), log_probs.squeeze(1)

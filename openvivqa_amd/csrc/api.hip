@@ -364,9 +364,16 @@ int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, 
   ovqa::AttnDecodeArgs a{q, k, v, ldq, ldk, ldv, kv_batch_stride, mask, ldmask, o, ldo,
                          (int)R, (int)H, (int)d, (int)n, (int)group, scale};
   OVQA_REQUIRE(ovqa::attention_decode_supported(a, dtype == OVQA_BF16 ? 2 : 4), OVQA_ERR_UNSUPPORTED,
-               "attention_decode: d must be 32 / 64 / 128, n <= 1024, 16-byte aligned q / k / v rows");
+               "attention_decode: d must be 32 / 64 / 128, n <= 512, 16-byte aligned q / k / v rows");
   g_dispatch = "decode";
   return ovqa::attention_decode(dtype, a, as_stream(stream));
+}
+
+int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream) {
+  OVQA_REQUIRE(R >= 0 && V >= 1 && k >= 1 && k <= 8 && k <= V && ldx >= V, OVQA_ERR_BAD_ARG, "topk_rows: bad sizes");
+  if (R == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && vals && idx, OVQA_ERR_BAD_ARG, "topk_rows: null pointer");
+  return ovqa::topk_rows(x, ldx, R, V, (int)k, vals, idx, as_stream(stream));
 }
 
 int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,

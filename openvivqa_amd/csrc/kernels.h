@@ -70,6 +70,7 @@ struct AttnDecodeArgs {
   int R, H, d, n, group;
   float scale;
 };
+int topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int k, float* vals, int64_t* idx, hipStream_t st);
 bool attention_decode_supported(const AttnDecodeArgs& a, int esize);
 int attention_decode(int dtype, const AttnDecodeArgs& a, hipStream_t st);
 

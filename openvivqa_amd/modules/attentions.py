@@ -261,7 +261,7 @@ class MultiHeadAttention(Module):
         if (self._is_stateful and not self.can_be_stateful and not torch.is_grad_enabled() and same_kv and not same_all
                 and type(self.attention) is ScaledDotProductAttention and queries.shape[1] == 1 and queries.is_cuda
                 and self.attention.d_k == self.attention.d_v and self.attention.d_k in (32, 64, 128)
-                and keys.shape[1] <= 1024 and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1))):
+                and keys.shape[1] <= 512 and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1))):
             return self._encoder_step(arena, queries, keys, mask)  # (keys as given: the cache is keyed on that tensor)
         keys = queries if same_all else keys.to(T)
         values = keys if same_kv else values.to(T)

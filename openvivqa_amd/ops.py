@@ -615,6 +615,19 @@ def attention_decode(q, k_cache, v_cache, n, H, mask=None, group=1, scale=None, 
     return o
 
 
+def topk_rows(x, k):
+    """(values, indices) of the k <= 8 largest entries of every row of the fp32 tensor x [..., V], best first (ties: the
+    smaller index): what torch.topk(x, k, dim=-1) returns, in one small launch (``ovqa_topk_rows``)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and 1 <= k <= min(8, x.shape[-1])
+    x2 = x.reshape(-1, x.shape[-1])
+    vals = torch.empty(x2.shape[0], k, dtype=torch.float32, device=x.device)
+    idx = torch.empty(x2.shape[0], k, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.load().ovqa_topk_rows(_p(x2), x2.stride(0), x2.shape[0], x2.shape[1], k, _p(vals), _p(idx),
+                                          _stream()), "topk_rows")
+    return vals.view(*x.shape[:-1], k), idx.view(*x.shape[:-1], k)
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None, o_lo=None):
     _dev(q)

@@ -403,3 +403,55 @@ def test_bench_refuses_fewer_ranks_than_asked():
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
     r = _run_bench("--dry-launch", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 1" in r.stderr
+
+
+@pytest.mark.parametrize("beam", [1, 3])
+def test_beam_search_driver_equals_reference_algorithm(beam):
+    """openvivqa_amd.beam.BeamSearch (two-stage top-k selection, whole-buffer history gathers) against a line-by-line
+    restatement of the reference's list-based algorithm (models/modules/beam_search.py:36-118: full sort, per-element
+    history gathers) on a random step function that depends on the previous words; <eos> reachable."""
+    from openvivqa_amd.beam import BeamSearch
+
+    class NoStates:
+        def reorder_states(self, *a):
+            pass
+    torch.manual_seed(beam)
+    b_s, T, V, eos = 5, 9, 13, 2
+    tables = [torch.randn(b_s * (1 if t == 0 else beam), 1, V) * 3 for t in range(T)]
+
+    def step(t, prev):
+        x = tables[t] if prev is None else tables[t] + 0.37 * torch.sin(prev.view(-1, 1, 1).float() + torch.arange(V))
+        return torch.log_softmax(x, -1)
+    out, lp = BeamSearch(NoStates(), step, b_s, T, eos, beam, "cpu").apply(1)
+
+    def reference():
+        seq_mask, seq_logprob = torch.ones((b_s, beam, 1)), torch.zeros((b_s, 1, 1))
+        log_probs, outputs, sw = [], [], None
+        for t in range(T):
+            cur = 1 if t == 0 else beam
+            wl = step(t, sw).view(b_s, cur, -1)
+            cand = seq_logprob + wl
+            if t > 0:
+                mask = (sw.view(b_s, cur) != eos).float().unsqueeze(-1)
+                seq_mask = seq_mask * mask
+                wl = wl * seq_mask.expand_as(wl)
+                old = seq_logprob.expand_as(cand).contiguous()
+                old[:, :, 1:] = -999
+                cand = seq_mask * cand + old * (1 - seq_mask)
+            v, i = torch.sort(cand.view(b_s, -1), -1, descending=True)
+            v, i = v[:, :beam], i[:, :beam]
+            sb = torch.div(i, cand.shape[-1], rounding_mode="trunc")
+            w = i - sb * cand.shape[-1]
+            seq_logprob = v.unsqueeze(-1)
+            seq_mask = torch.gather(seq_mask, 1, sb.unsqueeze(-1))
+            outputs = [torch.gather(o, 1, sb.unsqueeze(-1)) for o in outputs] + [w.unsqueeze(-1)]
+            this = torch.gather(torch.gather(wl, 1, sb.unsqueeze(-1).expand(b_s, beam, wl.shape[-1])), 2, w.unsqueeze(-1))
+            log_probs = [torch.gather(o, 1, sb.unsqueeze(-1).expand(b_s, beam, 1)) for o in log_probs] + [this]
+            sw = w.view(-1, 1)
+        _, order = torch.sort(seq_logprob, 1, descending=True)
+        o = torch.gather(torch.cat(outputs, -1), 1, order.expand(b_s, beam, T))
+        lpr = torch.gather(torch.cat(log_probs, -1), 1, order.expand(b_s, beam, T))
+        return o[:, 0], lpr[:, 0]
+    o2, l2 = reference()
+    assert torch.equal(out, o2) and torch.allclose(lp, l2)
+    assert (out == eos).any()  # the finished-sequence branch was exercised

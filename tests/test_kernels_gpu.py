@@ -418,6 +418,26 @@ def test_attention_decode_single_query(dtype, Bc, group, H, d, Lmax, n):
     assert nerr(buf[:, F:].reshape(R, 1, F), ro2) < tol(dtype) and float(buf[:, :F].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("R,V,k", [(192, 4000, 3), (5, 37, 1), (64, 4000, 8), (3, 9, 4), (7, 130, 5)])
+def test_topk_rows_matches_torch(R, V, k):
+    o_ = ops()
+    x = torch.log_softmax(rnd(R, V, seed=3) * 3, -1)
+    x[0, :] = x[0, 0]          # a row of ties: indices 0..k-1 in order
+    if V > 70:
+        x[1, 5] = x[1, 69] = 9.0   # a tie between two lanes' heads
+    v, i = o_.topk_rows(x, k)
+    tv, ti = torch.topk(x, k, dim=-1, largest=True, sorted=True)
+    assert torch.equal(v, tv)
+    assert torch.equal(torch.gather(x, 1, i), v)  # the indices point at the values
+    assert torch.equal(i[0], torch.arange(k, device=DEV)) and (V <= 70 or i[1, :2].tolist() == [5, 69])
+    rows = torch.ones(R, dtype=torch.bool)
+    rows[:2] = False
+    assert torch.equal(i[rows], ti[rows])  # (no ties elsewhere: random floats)
+    x3 = x.view(1, R, V).expand(2, R, V).contiguous()
+    v3, i3 = o_.topk_rows(x3, k)
+    assert v3.shape == (2, R, k) and torch.equal(v3[1], v) and torch.equal(i3[0], i)
+
+
 def test_attention_bwd_with_att_gradient():
     """d_att: gradient w.r.t. the returned attention weights (reference att is differentiable)."""
     o = ops()
