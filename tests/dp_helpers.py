@@ -81,3 +81,64 @@ def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q, kind="mcan"):
         q.put((rank, ts.arena.master.clone().numpy(), [list(map(list, s)) for s in ts.segments]))
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- real kernels, several ranks on ONE GPU over gloo
+def gpu_stack_step(B, comm_dtype, seed=11, layers=1, lr=1e-4):
+    """A small MCAN stack (d = 512, one layer each, dropout off) under TrainStep with the REAL kernels on cuda:0."""
+    import openvivqa_amd as A
+    from openvivqa_amd import ops
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.mcan_stack import MCANEncoderStack
+    from openvivqa_amd.train import TrainStep
+    dev = torch.device("cuda", 0)
+    A.set_compute_dtype(torch.bfloat16)
+    A.manual_seed(seed)
+    torch.manual_seed(seed)
+    att = dict(ARCHITECTURE="ScaledDotProductAttention", HEAD=8, D_MODEL=512, D_KEY=64, D_VALUE=64, D_FF=2048,
+               USE_AOA=False, CAN_BE_STATEFUL=False, DROPOUT=0.0)
+    cfg = ConfigNode(dict(ARCHITECTURE="MCAN", D_MODEL=512,
+                          SELF_ENCODER=dict(ARCHITECTURE="Encoder", D_MODEL=512, LAYERS=layers, SELF_ATTENTION=att),
+                          GUIDED_ENCODER=dict(ARCHITECTURE="GuidedAttentionEncoder", D_MODEL=512, LAYERS=layers,
+                                              SELF_ATTENTION=att, GUIDED_ATTENTION=att)))
+    model = MCANEncoderStack(cfg).to(dev).train()
+    loss = torch.zeros(1, device=dev)
+    tgt = {}
+
+    def forward_loss(v_, vm_, t_, tm_):
+        vo, lo = model(v_, vm_, t_, tm_)
+        dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss, accumulate=False, target=tgt["v"])
+        dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss, accumulate=True, target=tgt["t"])
+        return (vo, lo), (dvo, dlo)
+    ts = TrainStep(model, forward_loss, lr=lr, betas=(0.9, 0.98), compute_dtype=torch.bfloat16, use_graph=False,
+                   comm_dtype=comm_dtype, overlap_mb=0.0)
+    ts.loss = loss
+    return model, ts, tgt
+
+
+def gpu_rank_batch(rank, B):
+    from openvivqa_amd.mcan_stack import synthetic_batch
+    dev = torch.device("cuda", 0)
+    v, vm, t, tm = synthetic_batch(B, 100, 20, 512, 80, 8, 100 + rank, dev, torch.bfloat16)
+    g = torch.Generator().manual_seed(500 + rank)
+    tv = torch.randn(B, 100, 512, generator=g).to(dev, torch.bfloat16)
+    tt = torch.randn(B, 20, 512, generator=g).to(dev, torch.bfloat16)
+    return (v, vm, t, tm), (tv, tt)
+
+
+def dp_gpu_worker(rank, world, rdv, comm_bf16, steps, q):
+    """One data-parallel rank with the real kernels on cuda:0, gradients exchanged over gloo (RCCL refuses several
+    ranks on one device; the exchange arithmetic -- cast, sum, scale -- is the product's either way)."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + rdv, rank=rank, world_size=world)
+    try:
+        model, ts, tgt = gpu_stack_step(4, torch.bfloat16 if comm_bf16 else torch.float32)
+        batch, (tv, tt) = gpu_rank_batch(rank, 4)
+        tgt["v"], tgt["t"] = tv, tt
+        for _ in range(steps):
+            ts.step(*batch)
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put(ts.arena.master.detach().cpu().numpy())
+    finally:
+        dist.destroy_process_group()
