@@ -48,8 +48,12 @@ def parse():
                     help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
                          "single-rank group")
     ap.add_argument("--beam", type=int, default=1, help="--workload decode: beam size (1 = greedy)")
-    ap.add_argument("--workload", default="stack", choices=["stack", "model", "m4c_decode", "decode"],
-                    help="stack = BASELINE's metric (the two encoder stacks, default); model = SECONDARY diagnostic: "
+    ap.add_argument("--workload", default="stack", choices=["stack", "model", "cross_modality", "m4c_decode", "decode"],
+                    help="stack = BASELINE's metric (the two encoder stacks, default); cross_modality = SECONDARY line for "
+                         "BASELINE configs[2]: the whole CrossModalityTransformer model (configs/cross_modality_bench.yaml "
+                         "= the reference's MODEL node at L=6: FeatureEmbedding 2048->512, UsualEmbedding, 6 "
+                         "CrossModalityEncoder layers, pooling head, classifier, NLLLoss), 64 samples/GPU, data parallel "
+                         "over --gpus ranks; model = SECONDARY diagnostic: "
                          "the whole MCAN model (FeatureEmbedding + LSTM text embedding + stacks + pooling head + "
                          "classifier + NLLLoss) on synthetic region features / token ids (SURVEY 8d); m4c_decode = "
                          "SECONDARY diagnostic for BASELINE configs[3]: M4C's multimodal transformer (hidden 768, 4 layers x "
@@ -109,20 +113,23 @@ KERNEL_OF_FAMILY = {
 }
 
 
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+
+
 def pmc_traffic(kernel_prefix):
-    """Per-launch HBM bytes of a kernel from the committed PMC pass (profiles/r02_traffic.json, produced by
-    scripts/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950, KB -> bytes)."""
-    path = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r02_traffic.json", "r01_traffic.json"))
-                 if os.path.exists(p)), None)
+    """Per-launch HBM bytes of a kernel family from the newest COMMITTED PMC pass (profiles/rNN_traffic.json, produced by
+    scripts/gpu_profile_step.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950, KB -> bytes).  Returns
+    (bytes, file name): the figure is read from the file, not measured by this run -- PMC passes need rocprofv3."""
+    path = next((p for p in (os.path.join(ROOT, "profiles", f) for f in TRAFFIC_FILES) if os.path.exists(p)), None)
     if path is None:
-        return None
+        return None, None
     key = kernel_prefix.replace("(anonymous namespace)::", "")
     tot_bytes, tot_n = 0.0, 0
     for name, v in json.load(open(path)).items():  # a family = all tile-size instantiations of the kernel
         if key in name.replace("(anonymous namespace)::", ""):
             tot_bytes += v["hbm_bytes_per_launch"] * v["launches"]
             tot_n += v["launches"]
-    return round(tot_bytes / tot_n) if tot_n else None
+    return (round(tot_bytes / tot_n) if tot_n else None), "profiles/" + os.path.basename(path)
 
 
 def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
@@ -182,7 +189,7 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
     achieved = r["flops"] / r["time_s"] / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic(KERNEL_OF_FAMILY[dom]),
+        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic(KERNEL_OF_FAMILY[dom])[0],
         "kernel": KERNEL_OF_FAMILY[dom] + " {2|3|4}, 8, {128|64|32}>", "launches_per_step": r["launches"],
         "avg_launch_us": round(r["avg_launch_us"], 2),
         "algorithmic_flops_per_launch": round(r["flops"] / r["launches"]),
@@ -624,6 +631,8 @@ def main():
     from openvivqa_amd.mcan_stack import MCANEncoderStack, synthetic_batch
     from openvivqa_amd.train import TrainStep, noam_lr_scale
 
+    if args.workload == "cross_modality":
+        args.config = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "cross_modality_bench.yaml")
     cfg = A.get_config(args.config)
     b = cfg.BENCH
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -634,16 +643,19 @@ def main():
         return m4c_decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
     if args.workload == "decode":
         return decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
-    model = MCANEncoderStack(cfg.MODEL).to(device).train()
+    whole_model = args.workload in ("model", "cross_modality")
     D = cfg.MODEL.D_MODEL
-    v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,
-                                   b.SEED + rank, device, dtype)
+    model = None if whole_model else MCANEncoderStack(cfg.MODEL).to(device).train()
+    if not whole_model:
+        v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,
+                                       b.SEED + rank, device, dtype)
     loss_buf = torch.zeros(1, device=device)
     # MSE against fixed random targets: mean(out^2) alone is constant for LayerNorm outputs
     # (degenerate gradient), see DESIGN.md section 6.
-    gt = torch.Generator().manual_seed(b.SEED + 7919 * (rank + 1))
-    tgt_v = torch.randn(v.shape, generator=gt).to(device=device, dtype=dtype)
-    tgt_t = torch.randn(t.shape, generator=gt).to(device=device, dtype=dtype)
+    if not whole_model:
+        gt = torch.Generator().manual_seed(b.SEED + 7919 * (rank + 1))
+        tgt_v = torch.randn(v.shape, generator=gt).to(device=device, dtype=dtype)
+        tgt_t = torch.randn(t.shape, generator=gt).to(device=device, dtype=dtype)
 
     def forward_loss(v_, vm_, t_, tm_):
         vo, lo = model(v_, vm_, t_, tm_)
@@ -651,7 +663,7 @@ def main():
         dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
         return (vo, lo), (dvo, dlo)
 
-    if args.workload == "model":
+    if whole_model:
         from types import SimpleNamespace
         from openvivqa_amd.builders import build_model
 
@@ -682,10 +694,10 @@ def main():
                    lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,
                    comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
                    force_comm=args.rehearse_comm)
-    batch = (v, vm, t, tm)
-    if args.workload == "model":
+    if whole_model:
         batch, loss_buf = (v, vm), ts.loss
     else:
+        batch = (v, vm, t, tm)
         ts.loss = loss_buf
 
     ts.prepare(*batch)  # graph capture happens here, never inside the timed region (even with --warmup 0)
@@ -755,11 +767,21 @@ def main():
             "step_tflops": round(value * FLOPS_PER_SAMPLE_FWD_BWD / 1e12, 1),
             "step_frac_of_bf16_peak": round(value * FLOPS_PER_SAMPLE_FWD_BWD / world / PEAK_BF16, 4),
         }
-        if args.workload == "model":  # secondary diagnostic: whole model; no roofline / CPU legs
-            out["metric"] = "SECONDARY: VQA samples/sec fwd+bwd, whole MCAN model (embeddings + stacks + head), L=6, B=64"
-            out["config"]["workload"] = ("secondary (SURVEY 8d model-level): MCAN model via build_model: FeatureEmbedding "
-                                         "1024->512, LSTMTextEmbedding |V|=4000 (torch/MIOpen LSTM), encoder stacks on "
-                                         "the HIP path, attention-pooling head, 353-way classifier, NLLLoss, Adam")
+        if whole_model:  # secondary lines: whole models; no roofline / CPU legs
+            if args.workload == "model":
+                out["metric"] = "SECONDARY: VQA samples/sec fwd+bwd, whole MCAN model (embeddings + stacks + head), L=6, B=64"
+                out["config"]["workload"] = ("secondary (SURVEY 8d model-level): MCAN model via build_model: FeatureEmbedding "
+                                             "1024->512, LSTMTextEmbedding |V|=4000 (torch/MIOpen LSTM), encoder stacks on "
+                                             "the HIP path, attention-pooling head, 353-way classifier, NLLLoss, Adam")
+            else:
+                out["metric"] = ("SECONDARY (BASELINE configs[2]): VQA samples/sec fwd+bwd, CrossModalityTransformer "
+                                 "d=512 L=6, 64 samples/GPU")
+                out["config"]["workload"] = ("secondary, BASELINE configs[2]: CrossModalityTransformer via build_model from "
+                                             "configs/cross_modality_bench.yaml (the reference YAML's MODEL node, L=6): "
+                                             "FeatureEmbedding 2048->512, UsualEmbedding |V|=4000, 6 CrossModalityEncoder "
+                                             "layers (4 attention + 2 feed-forward blocks each), pooling head, 353-way "
+                                             "classifier, NLLLoss on the logits as upstream, Adam + Noam; 100 regions x 20 "
+                                             "tokens, data parallel")
             for k in ("step_tflops", "step_frac_of_bf16_peak"):
                 out.pop(k)
             print(json.dumps(out), flush=True)
@@ -775,16 +797,19 @@ def main():
             dom = max(fams, key=lambda k: fams[k]["time_s"])
             f = fams[dom]
             achieved = f["flops"] / f["time_s"] / 1e12
+            traffic, tfile = pmc_traffic(KERNEL_OF_FAMILY[dom])
+            traffic_src = (f"{tfile}: FETCH_SIZE / WRITE_SIZE PMC passes of this same step under rocprofv3, committed with "
+                           "the round -- read from the file, not collected by this run") if tfile else None
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic(KERNEL_OF_FAMILY[dom]),
+                "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": KERNEL_OF_FAMILY[dom] + " ...>", "launches_per_step": f["launches"],
                 "avg_launch_us": round(f["time_s"] / f["launches"] * 1e6, 2),
                 "algorithmic_flops_per_launch": round(f["flops"] / f["launches"]),
                 "method": "in-step: every launch of the family inside one eager step of the real workload carries its own "
                           "start/stop HIP events (hipExtLaunchKernel via ovqa_launch_timing_begin/_end: the dispatch "
                           "packet's begin/end timestamps on the launch stream; gate kernel first; cold operands); "
-                          "profiles/r02_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
+                          "profiles/r03_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
                           "the same step",
                 "families_in_step": {k: {"launches": v["launches"], "avg_launch_us": round(v["time_s"] / v["launches"] * 1e6, 2),
                                          "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in fams.items()},

@@ -36,13 +36,28 @@
 // and the middle workgroup at marked points of gemm_tile_glds, read back by ovqa_debug_probe_gemm().
 #ifdef OVQA_PHASE_PROBE
 __device__ unsigned long long g_probe_gemm[2][16];
+// per-workgroup timeline of the last launch: {start, K loop done, end, HW_ID | XCC_ID << 32} (scripts/gemm_wg_timeline.py)
+__device__ unsigned long long g_probe_wg[4096][4];
 #define OVQA_GPROBE(i)                                                                   \
   do {                                                                                   \
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))            \
-      g_probe_gemm[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64();                         \
+    if (threadIdx.x == 0) {                                                              \
+      const unsigned long long t_ = wall_clock64();                                      \
+      if (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)                                \
+        g_probe_gemm[blockIdx.x == 0 ? 0 : 1][i] = t_;                                   \
+      if (blockIdx.x < 4096 && ((i) == 0 || (i) == 3 || (i) == 4)) {                     \
+        g_probe_wg[blockIdx.x][(i) == 0 ? 0 : (i) == 3 ? 1 : 2] = t_;                    \
+        if ((i) == 0)                                                                    \
+          g_probe_wg[blockIdx.x][3] =                                                    \
+              (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |            \
+              ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);    \
+      }                                                                                  \
+    }                                                                                    \
   } while (0)
 extern "C" int ovqa_debug_probe_gemm(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_gemm), sizeof(g_probe_gemm));
+}
+extern "C" int ovqa_debug_probe_gemm_wgs(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_wg), sizeof(unsigned long long) * 4 * (size_t)n);
 }
 #else
 #define OVQA_GPROBE(i) do {} while (0)
