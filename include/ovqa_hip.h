@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 4
+#define OVQA_ABI_VERSION 5
 
 typedef enum {
   OVQA_OK = 0,
@@ -287,6 +287,40 @@ int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, 
  * vals fp32 [R, k], idx int64 [R, k]; 1 <= k <= 8 and k <= V.  Candidate selection of a beam-search step
  * (beam_search.py:36-39 takes them from a full sort of the cur_beam * |V| candidates). */
 int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream);
+
+/* ---- the index / elementwise work around one autoregressive decoding step (ABI 5) -------------------------------------
+ * Three launches instead of the ~55 stock elementwise launches a decoding step with beam search spends on it.
+ *
+ * ovqa_decode_embed: the stateful branch of Decoder.forward before the layers (models/modules/decoders.py:46-66) for ONE
+ * new position per row: seq[r] += 1 (running_seq.add_(1)); x[r] = emb[tokens[r]] + pos[seq[r]] (word_emb + pos_emb), written
+ * as fp32 (x32, may be NULL) and / or in out_dtype (x, may be NULL); mask[r * ld_mask + col] = tokens[r] == pad_idx ?
+ * mask_value : 0 -- the new column of running_mask_self_attention (additive, models/utils.py:44-73), mask may be NULL.
+ * emb fp32 [vocab, ld_emb], pos fp32 [n_pos, ld_pos] (indices clamped), D % 4 == 0, tables 16-byte aligned. */
+int ovqa_decode_embed(int out_dtype, const int64_t* tokens, const float* emb, int64_t ld_emb, int64_t vocab,
+                      const float* pos, int64_t ld_pos, int64_t n_pos, int64_t* seq, int64_t pad_idx, float mask_value,
+                      float* mask, int64_t ld_mask, int64_t col, float* x32, void* x, int64_t R, int64_t D, void* stream);
+
+/* ovqa_beam_candidates: for every row r (= sample * cur_beam + beam) of the step's logits [R, V] (dtype; row stride ld):
+ * word_logprob = log_softmax(logits[r]) in fp32 (base_transformer.py:31-44 -> decoders.py:76), the candidate scores of
+ * models/modules/beam_search.py:41-57 -- seq_logprob[r] + word_logprob for a live sequence; a sequence whose previous word
+ * was <eos> (prev_words[r] == eos: seq_mask[r] is set to 0 IN PLACE, beam_search.py:49-51) keeps seq_logprob[r] on word 0
+ * and gets -999 elsewhere -- and the k best of them, best first, ties by the smaller word: vals fp32 [R, k], idx int64
+ * [R, k], wl fp32 [R, k] = word_logprob[idx] * seq_mask[r] (what beam_search.py:66 gathers into the log-prob history).
+ * prev_words == NULL at the first step (nothing is finished).  1 <= k <= 8. */
+int ovqa_beam_candidates(int dtype, const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k,
+                         const float* seq_logprob, float* seq_mask, const int64_t* prev_words, int64_t eos, float* vals,
+                         int64_t* idx, float* wl, void* stream);
+
+/* ovqa_beam_commit: per sample, the `beam` best of its cur * k survivors (beam_search.py:36-39: the first `beam` of the
+ * sorted candidates; ties by the smaller flat index) and the bookkeeping of beam_search.py:58-83: seq_logprob_out /
+ * seq_mask_out [b_s, beam], selected_beam int32 [b_s, beam] (the source beam: the index ovqa_grouped_row_gather takes),
+ * words int64 [b_s, beam] (the next step's tokens), and the histories: out_out / lp_out [b_s, beam, T] = columns < t of
+ * the source beams' rows of out_in / lp_in [b_s, cur, T], column t = the chosen word / its wl.  The histories are
+ * double-buffered (in != out).  beam <= 8, cur * k <= 64, t < T. */
+int ovqa_beam_commit(const float* vals, const int64_t* idx, const float* wl, const float* seq_mask_in,
+                     const int64_t* out_in, const float* lp_in, int64_t* out_out, float* lp_out, float* seq_logprob_out,
+                     float* seq_mask_out, int32_t* selected_beam, int64_t* words, int64_t b_s, int64_t cur, int64_t k,
+                     int64_t beam, int64_t t, int64_t T, void* stream);
 
 /* o_lo (OVQA_BF16 only; may be NULL in all three calls): the rounding residual of the attention output, bf16, same
  * layout as o: o_lo = bf16(o_exact - float(o)).  The forward calls write it, ovqa_attention_bwd reads it for

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -94,6 +94,11 @@ SIGNATURES = {
     "ovqa_attention_decode": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
                               c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_topk_rows": [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "ovqa_decode_embed": [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64,
+                          c_vp, c_vp, c_i64, c_i64, c_vp],
+    "ovqa_beam_candidates": [c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "ovqa_beam_commit": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
+                         c_i64, c_i64, c_vp],
     "ovqa_attention_bwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],

@@ -19,10 +19,13 @@ class BeamSearch:
     ``apply_to_states(_expand_state(selected_beam, cur_beam_size))`` (beam_search.py:19-34,61), for comparison."""
 
     def __init__(self, module, step: Callable, b_s: int, max_len: int, eos_idx: int, beam_size: int, device,
-                 reorder: str = "fused"):
+                 reorder: str = "fused", logits_step: Callable = None):
+        """``logits_step(t, prev_words) -> (b_s * cur_beam, [1,] |V|)`` raw vocabulary logits: when given (and on the
+        GPU, beam <= 8) a step's selection and bookkeeping run as two kernels (``_apply_fused``)."""
         self.module, self.step = module, step
         self.b_s, self.max_len, self.eos_idx, self.beam_size, self.device = b_s, max_len, eos_idx, beam_size, device
         self.reorder = reorder
+        self.logits_step = logits_step
 
     def select(self, candidate_logprob):
         """The `beam` best of the cur_beam * |V| candidates of every sample, best first: (flat index, value), what
@@ -58,6 +61,9 @@ class BeamSearch:
         """beam_search.py:85-118 with the per-step bookkeeping on whole (b_s, beam, T) buffers: the reference keeps the
         chosen words and their scores as Python lists of (b_s, beam, 1) tensors and re-gathers every element of both
         lists at every step (2 t tiny launches at step t); one gather per buffer and step gives the same values."""
+        if (self.logits_step is not None and torch.device(self.device).type == "cuda" and self.beam_size <= 8
+                and self.reorder == "fused"):
+            return self._apply_fused(out_size)
         b_s, beam, T = self.b_s, self.beam_size, self.max_len
         seq_mask = torch.ones((b_s, beam, 1), device=self.device)
         seq_logprob = torch.zeros((b_s, 1, 1), device=self.device)
@@ -99,6 +105,41 @@ class BeamSearch:
             outputs, log_probs = outputs.squeeze(1), log_probs.squeeze(1)
         return outputs, log_probs
 
+    def _apply_fused(self, out_size: int = 1):
+        """The same search with a step's selection and bookkeeping in two launches: ``ovqa_beam_candidates`` (log-softmax
+        of the logits, candidate scores of beam_search.py:41-57, the k best per beam) and ``ovqa_beam_commit`` (the best
+        `beam` per sample, scores / masks / histories of beam_search.py:58-83, the gather index), then ONE grouped gather
+        of every state buffer -- 3 launches where the loop above spends ~45 small torch kernels."""
+        from . import ops
+        b_s, beam, T, dev = self.b_s, self.beam_size, self.max_len, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        hist = [(torch.zeros((b_s, beam, T), dtype=torch.long, device=dev), torch.zeros((b_s, beam, T), **f32))
+                for _ in range(2)]
+        seq_logprob, seq_mask = torch.zeros(b_s, **f32), torch.ones(b_s, **f32)
+        sl = [torch.empty(b_s * beam, **f32) for _ in range(2)]
+        sm = [torch.empty(b_s * beam, **f32) for _ in range(2)]
+        wd = [torch.empty((b_s * beam, 1), dtype=torch.long, device=dev) for _ in range(2)]
+        sel = torch.empty((b_s, beam), dtype=torch.int32, device=dev)
+        words = None
+        for t in range(T):
+            cur, o = (1 if t == 0 else beam), t & 1
+            logits = self.logits_step(t, words)
+            logits = logits.reshape(b_s * cur, logits.shape[-1])
+            k = min(beam, logits.shape[-1])
+            vals, idx, wl = ops.beam_candidates(logits, seq_logprob, seq_mask, None if t == 0 else words.view(-1),
+                                                self.eos_idx, k)
+            ops.beam_commit(vals, idx, wl, seq_mask, hist[1 - o], hist[o], sl[o], sm[o], sel, wd[o], b_s, cur, k, beam, t)
+            self.module.reorder_states(sel, b_s, cur, beam)
+            seq_logprob, seq_mask, words = sl[o], sm[o], wd[o]
+        outputs, log_probs = hist[(T - 1) & 1]
+        seq_logprob, order = torch.sort(seq_logprob.view(b_s, beam, 1), 1, descending=True)
+        outputs = torch.gather(outputs, 1, order.expand(b_s, beam, T))
+        log_probs = torch.gather(log_probs, 1, order.expand(b_s, beam, T))
+        outputs, log_probs = outputs.contiguous()[:, :out_size], log_probs.contiguous()[:, :out_size]
+        if out_size == 1:
+            outputs, log_probs = outputs.squeeze(1), log_probs.squeeze(1)
+        return outputs, log_probs
+
 
 class GraphedBeamSearch:
     """The WHOLE decode of a batch -- every decoder step, the candidate selection and the reorder of every state buffer,
@@ -114,9 +155,12 @@ class GraphedBeamSearch:
     ``decoder(prev_tokens, encoder_features, encoder_attention_mask) -> log-probabilities`` is the reference's
     ``Decoder.forward`` as ``model.step`` calls it (base_transformer.py:31-44)."""
 
-    def __init__(self, decoder, b_s: int, max_len: int, bos_idx: int, eos_idx: int, beam_size: int, out_size: int = 1):
+    def __init__(self, decoder, b_s: int, max_len: int, bos_idx: int, eos_idx: int, beam_size: int, out_size: int = 1,
+                 fused: bool = True):
+        """``fused``: selection and bookkeeping as two kernels per step (BeamSearch._apply_fused); off = the torch ops."""
         self.decoder, self.b_s, self.max_len, self.bos, self.eos, self.beam = decoder, b_s, max_len, bos_idx, eos_idx, beam_size
         self.out_size = out_size
+        self.fused = fused
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -125,7 +169,7 @@ class GraphedBeamSearch:
         b_s, beam, dev = self.b_s, self.beam, enc.device
         st = {}
 
-        def step(t, prev):
+        def step(t, prev, **kw):
             if t == 0:
                 st["e"], st["m"] = enc, mask
                 prev = torch.full((b_s, 1), self.bos, dtype=torch.long, device=dev)
@@ -133,9 +177,11 @@ class GraphedBeamSearch:
                 # a state and gathers copies, beam_search.py:61; the decoder's encoder attention shares one projection)
                 st["e"] = enc.unsqueeze(1).expand(-1, beam, -1, -1).reshape(b_s * beam, *enc.shape[1:])
                 st["m"] = mask.unsqueeze(1).expand(-1, beam, -1, -1, -1).reshape(b_s * beam, *mask.shape[1:])
-            return self.decoder(prev, st["e"], st["m"])
+            return self.decoder(prev, st["e"], st["m"], **kw)
+        logits_step = (lambda t, prev: step(t, prev, return_logits=True)) if self.fused else None
         with torch.no_grad(), self.decoder.statefulness(b_s):
-            return BeamSearch(self.decoder, step, b_s, self.max_len, self.eos, beam, dev).apply(self.out_size)
+            return BeamSearch(self.decoder, step, b_s, self.max_len, self.eos, beam, dev,
+                              logits_step=logits_step).apply(self.out_size)
 
     def __call__(self, enc, mask, use_graph: bool = True):
         if not use_graph or not enc.is_cuda:

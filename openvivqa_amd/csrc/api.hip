@@ -369,6 +369,48 @@ int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, 
   return ovqa::attention_decode(dtype, a, as_stream(stream));
 }
 
+int ovqa_decode_embed(int out_dtype, const int64_t* tokens, const float* emb, int64_t ld_emb, int64_t vocab,
+                      const float* pos, int64_t ld_pos, int64_t n_pos, int64_t* seq, int64_t pad_idx, float mask_value,
+                      float* mask, int64_t ld_mask, int64_t col, float* x32, void* x, int64_t R, int64_t D, void* stream) {
+  OVQA_REQUIRE(dtype_ok(out_dtype), OVQA_ERR_BAD_ARG, "decode_embed: bad dtype %d", out_dtype);
+  OVQA_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && vocab > 0 && n_pos > 0, OVQA_ERR_BAD_ARG, "decode_embed: bad sizes");
+  if (R == 0) return OVQA_OK;
+  OVQA_REQUIRE(tokens && emb && pos && seq && (x32 || x), OVQA_ERR_BAD_ARG, "decode_embed: null pointer");
+  OVQA_REQUIRE(ld_emb >= D && ld_pos >= D && ld_emb % 4 == 0 && ld_pos % 4 == 0 && (!mask || (ld_mask > col && col >= 0)),
+               OVQA_ERR_BAD_ARG, "decode_embed: row strides");
+  OVQA_REQUIRE((((uintptr_t)emb | (uintptr_t)pos | (uintptr_t)x32) & 15) == 0, OVQA_ERR_UNSUPPORTED,
+               "decode_embed: tables and x32 must be 16-byte aligned");
+  return ovqa::decode_embed(out_dtype, tokens, emb, ld_emb, vocab, pos, ld_pos, n_pos, seq, pad_idx, mask_value, mask,
+                            ld_mask, col, x32, x, R, D, as_stream(stream));
+}
+
+int ovqa_beam_candidates(int dtype, const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k,
+                         const float* seq_logprob, float* seq_mask, const int64_t* prev_words, int64_t eos, float* vals,
+                         int64_t* idx, float* wl, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "beam_candidates: bad dtype %d", dtype);
+  OVQA_REQUIRE(R >= 0 && V >= 1 && k >= 1 && k <= 8 && k <= V && ld >= V && R <= 0x7fffffff && V <= 0x7ffffffe,
+               OVQA_ERR_BAD_ARG, "beam_candidates: bad sizes");
+  if (R == 0) return OVQA_OK;
+  OVQA_REQUIRE(logits && seq_logprob && seq_mask && vals && idx && wl, OVQA_ERR_BAD_ARG, "beam_candidates: null pointer");
+  return ovqa::beam_candidates(dtype, logits, ld, R, V, (int)k, seq_logprob, seq_mask, prev_words, eos, vals, idx, wl,
+                               as_stream(stream));
+}
+
+int ovqa_beam_commit(const float* vals, const int64_t* idx, const float* wl, const float* seq_mask_in,
+                     const int64_t* out_in, const float* lp_in, int64_t* out_out, float* lp_out, float* seq_logprob_out,
+                     float* seq_mask_out, int32_t* selected_beam, int64_t* words, int64_t b_s, int64_t cur, int64_t k,
+                     int64_t beam, int64_t t, int64_t T, void* stream) {
+  OVQA_REQUIRE(b_s >= 0 && cur >= 1 && k >= 1 && beam >= 1 && beam <= 8 && cur * k <= 64 && beam <= cur * k && t >= 0 &&
+                   t < T, OVQA_ERR_BAD_ARG, "beam_commit: bad sizes (beam <= 8, cur * k <= 64, t < T)");
+  if (b_s == 0) return OVQA_OK;
+  OVQA_REQUIRE(vals && idx && wl && seq_mask_in && out_out && lp_out && seq_logprob_out && seq_mask_out && selected_beam &&
+                   words && (t == 0 || (out_in && lp_in)), OVQA_ERR_BAD_ARG, "beam_commit: null pointer");
+  OVQA_REQUIRE(out_in != out_out && lp_in != lp_out, OVQA_ERR_BAD_ARG, "beam_commit: the histories are double-buffered");
+  ovqa::BeamCommitArgs a{vals, idx, wl, seq_mask_in, out_in, lp_in, out_out, lp_out, seq_logprob_out, seq_mask_out,
+                         selected_beam, words, (int)cur, (int)k, (int)beam, (int)t, (int)T};
+  return ovqa::beam_commit(a, b_s, as_stream(stream));
+}
+
 int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream) {
   OVQA_REQUIRE(R >= 0 && V >= 1 && k >= 1 && k <= 8 && k <= V && ldx >= V, OVQA_ERR_BAD_ARG, "topk_rows: bad sizes");
   if (R == 0) return OVQA_OK;

@@ -494,6 +494,61 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
   gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR, KSP>(g, tc * BC, tr * BR, epi, smem);
 }
 
+// ---- skinny products (a decoding step: M = batch * beam <= 256 activation rows against a whole weight matrix) ----------
+// One 16 x 16 output tile per wave, no LDS staging: every lane loads its own MFMA operand pieces (16 B: row lane & 15,
+// k-group lane >> 4) of BOTH operands straight from global memory -- all of them up front (<= 16 K steps of 32 per wave,
+// 128 VGPRs), so the wave pays ONE memory round trip, then issues its MFMAs back to back.  Longer reductions are split
+// over up to 4 waves of the workgroup (K = 2048: 4 x 512) and summed through LDS.  512 x 512 weights against 192 rows are
+// 32 x 12 = 384 one-wave workgroups: every CU streams its slice of the weights once (the 12 row tiles of a weight slab
+// hit in L2).  The tiled kernels put such a product on 48 workgroups that each walk 8 K steps behind barriers: 5-7 us
+// per launch in a decoding step where this form takes ~3.
+template <typename Epi, int S>
+__global__ __launch_bounds__(64 * S) void gemm_bf16_skinny_kernel(GemmArgs g, Epi epi) {
+  constexpr int KCH = 16;  // K steps (of 32) per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;  // r: the P operand's rows (output features), c: Q's (tokens)
+  int pr = r0 + (lane & 15), qc = c0 + (lane & 15);
+  pr = pr < g.R ? pr : g.R - 1;
+  qc = qc < g.C ? qc : g.C - 1;
+  const int nk = g.K / 32;
+  const int per = (nk + S - 1) / S;      // K steps of this wave: [k_lo, k_hi)
+  const int k_lo = wave * per, k_hi = min(nk, k_lo + per);
+  const bf16* pp = g.P + (int64_t)pr * g.ldp + (lane >> 4) * 8;
+  const bf16* qp = g.Q + (int64_t)qc * g.ldq + (lane >> 4) * 8;
+  bf16x8 pa[KCH], qa[KCH];
+#pragma unroll
+  for (int i = 0; i < KCH; i++) {  // (past the wave's share: re-read its last step, zeroed below -- no branch around a load)
+    const int ks = min(k_lo + i, nk - 1);
+    pa[i] = *reinterpret_cast<const bf16x8*>(pp + ks * 32);
+    qa[i] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all 32 loads in flight before the first MFMA waits (the scheduler would
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};  // otherwise interleave them ~10 deep: three round trips instead of one)
+#pragma unroll
+  for (int i = 0; i < KCH; i++) {
+    bf16x8 a = pa[i];
+    if (k_lo + i >= k_hi) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) a[e] = (bf16)0.f;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qa[i], acc, 0, 0, 0);
+  }
+  if constexpr (S > 1) {
+    __shared__ f32x4 part[S - 1][64];
+    if (wave > 0) part[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < S - 1; w++) {
+      const f32x4 o = part[w][lane];
+      acc = f32x4{acc[0] + o[0], acc[1] + o[1], acc[2] + o[2], acc[3] + o[3]};
+    }
+  }
+  epi.init();
+  const int c = c0 + (lane & 15), r = r0 + (lane >> 4) * 4;
+  if (c < g.C && r < g.R) epi(c, r, acc);
+}
+
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][P | Q][16 KiB]
@@ -813,6 +868,19 @@ inline int ksplit_min_k() {
   return v;
 }
 
+// activation rows up to which a row-major x row-major product takes the one-wave-per-tile form (0 = never).
+// MEASURED (bench.py --workload decode, B = 64): 64 rows (greedy) 250 -> 197 us per decoding step; 192 rows (beam 3)
+// 259 -> 258: there the 64 x 32 tiles are as fast (512-wide outputs 5.6 vs 5.0 us, 2048-wide ones 7.9 vs 5.2: 1536
+// one-wave workgroups queue up six deep per CU), so the form stops at 128 rows.
+inline int skinny_max_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OVQA_GEMM_SKINNY_MAXROWS");
+    v = e ? atoi(e) : 128;
+  }
+  return v;
+}
+
 inline int gemm_variant() {
   static int v = -1;
   if (v < 0) {
@@ -859,6 +927,21 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
                       st, g, epi);                                                                                 \
   }
 #define OVQA_GLDS(NBUF, NW, BCV) OVQA_GLDS_K(NBUF, NW, BCV, 1)
+  if constexpr (!QK && !PK) {
+    // a decoding step's products: few activation rows against a whole weight matrix
+    if (variant >= 10 && C <= skinny_max_rows() && K % 32 == 0 && K <= 2048 && R % 4 == 0) {
+      const dim3 gs((unsigned)((R + 15) / 16), (unsigned)((C + 15) / 16));
+      const int nk = (int)(K / 32);
+      if (nk <= 16) {
+        OVQA_LAUNCH_TIMED((gemm_bf16_skinny_kernel<Epi, 1>), gs, dim3(64), 0, st, g, epi);
+      } else if (nk <= 32) {
+        OVQA_LAUNCH_TIMED((gemm_bf16_skinny_kernel<Epi, 2>), gs, dim3(128), 0, st, g, epi);
+      } else {
+        OVQA_LAUNCH_TIMED((gemm_bf16_skinny_kernel<Epi, 4>), gs, dim3(256), 0, st, g, epi);
+      }
+      return ovqa_check_launch(what);
+    }
+  }
   if constexpr (!QK && !PK) {
     // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of the 128 x 32
     // tier (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step

@@ -74,6 +74,24 @@ int topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int k, float* v
 bool attention_decode_supported(const AttnDecodeArgs& a, int esize);
 int attention_decode(int dtype, const AttnDecodeArgs& a, hipStream_t st);
 
+// ---- decode_glue.hip: the index / elementwise work around a decoding step ---------------
+struct BeamCommitArgs {
+  const float* vals; const int64_t* idx; const float* wl;  // [b_s, cur, k] survivors of beam_candidates
+  const float* seq_mask_in;                                // [b_s, cur]
+  const int64_t* out_in; const float* lp_in;               // [b_s, cur, T] histories (columns < t live)
+  int64_t* out_out; float* lp_out;                         // [b_s, beam, T]
+  float* seq_logprob_out; float* seq_mask_out;             // [b_s, beam]
+  int32_t* selected_beam; int64_t* words;                  // [b_s, beam]
+  int cur, k, beam, t, T;
+};
+int decode_embed(int out_dtype, const int64_t* tokens, const float* emb, int64_t ld_emb, int64_t vocab, const float* pos,
+                 int64_t ld_pos, int64_t n_pos, int64_t* seq, int64_t pad_idx, float mask_value, float* mask,
+                 int64_t ld_mask, int64_t col, float* x32, void* x, int64_t R, int64_t D, hipStream_t st);
+int beam_candidates(int dtype, const void* logits, int64_t ld, int64_t R, int64_t V, int k, const float* seq_logprob,
+                    float* seq_mask, const int64_t* prev_words, int64_t eos, float* vals, int64_t* idx, float* wl,
+                    hipStream_t st);
+int beam_commit(const BeamCommitArgs& a, int64_t b_s, hipStream_t st);
+
 int simple_attention_fwd(int dtype, const AttnArgs& a, hipStream_t st);
 int simple_attention_bwd(int dtype, const AttnBwdArgs& a, hipStream_t st);
 

@@ -377,6 +377,8 @@ class MultiHeadAttention(Module):
         m = mask.reshape(mask.shape[0], mask.shape[-1])
         if m.shape[0] != R:
             m = m.expand(R, m.shape[1])
+        if m.stride(1) == 1 and m.stride(0) >= m.shape[1]:  # dense rows (the live prefix of an in-place mask buffer)
+            return m
         return m.contiguous()
 
     def _stateful_step(self, arena, queries, keys, values, mask):

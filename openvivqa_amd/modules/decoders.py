@@ -56,11 +56,99 @@ class Decoder(Module):
         self.fc = nn.Linear(config.D_MODEL, len(vocab), bias=False)
         self.register_state("running_mask_self_attention", torch.zeros((1, 1, 0)).bool())
         self.register_state("running_seq", torch.zeros((1,)).long())
+        self._mask_cache = self._mask_spare = self._enc_mask = None
+
+    # ------------------------------------------------------------------ one-position decoding step
+    def enable_statefulness(self, batch_size: int) -> None:
+        super().enable_statefulness(batch_size)
+        self._mask_cache = self._mask_spare = self._enc_mask = None
+
+    def disable_statefulness(self) -> None:
+        super().disable_statefulness()
+        self._mask_cache = self._mask_spare = self._enc_mask = None
+
+    def _seat_mask(self, R, dev):
+        """The running self-attention mask as an in-place fp32 (R, max_len + 1) buffer; the state buffer is its live
+        prefix viewed as (R, 1, 1, t) -- same name and shape as the reference's concatenated mask (decoders.py:55-57),
+        so ``apply_to_states`` / ``reorder_states`` keep working (whatever they store is copied back in here)."""
+        cur = self._buffers["running_mask_self_attention"]
+        cache = getattr(self, "_mask_cache", None)
+        n = cur.shape[-1] if cur.dim() == 4 else 0
+        if (cache is not None and cache.shape[0] == R and n < cache.shape[1] and cur.dim() == 4 and cur.shape[0] == R
+                and cur.dtype == torch.float32 and cur.data_ptr() == cache.data_ptr()):
+            return cache, n
+        cap = max(self.max_len + 1, 2 * (n + 1))
+        new = torch.zeros(R, cap, dtype=torch.float32, device=dev)
+        if n > 0:
+            assert cur.shape[0] == R, "the state buffers' batch dimension must follow the tokens'"
+            new[:, :n].copy_(cur.reshape(R, n))
+        self._mask_cache, self._mask_spare = new, None
+        return new, n
+
+    def _cache_destination(self, name, rows):
+        """reorder_states: the gathered mask rows go into the live prefix of the spare buffer (see MultiHeadAttention)."""
+        cache = getattr(self, "_mask_cache", None)
+        if cache is None or name != "running_mask_self_attention":
+            return None
+        s = self._buffers[name]
+        if s.dim() != 4 or s.data_ptr() != cache.data_ptr():
+            return None
+        spare = getattr(self, "_mask_spare", None)
+        if spare is None or spare.shape[0] != rows or spare.shape[1] != cache.shape[1]:
+            spare = self._mask_spare = torch.zeros(rows, cache.shape[1], dtype=torch.float32, device=cache.device)
+        return spare[:, None, None, :s.shape[-1]]
+
+    def _caches_reordered(self):
+        cur, spare = self._buffers.get("running_mask_self_attention"), getattr(self, "_mask_spare", None)
+        if spare is not None and cur is not None and cur.dim() == 4 and cur.data_ptr() == spare.data_ptr():
+            self._mask_cache, self._mask_spare = spare, self._mask_cache
+
+    def _float_mask(self, mask):
+        """The encoder attention mask in fp32, converted once per decode (the layers would each convert it per step)."""
+        if mask is None or mask.dtype == torch.float32:
+            return mask
+        ident = (mask.data_ptr(), tuple(mask.shape), mask._version)
+        held = getattr(self, "_enc_mask", None)
+        if held is None or held[0] != ident:
+            held = self._enc_mask = (ident, mask.float())
+        return held[1]
+
+    def _decode_step(self, tokens, encoder_features, encoder_attention_mask, return_logits):
+        """Stateful step for one new position per row with the embedding sum, the position counter and the new mask column
+        in ONE launch (ovqa_decode_embed) instead of ~12 index / elementwise launches."""
+        from .. import ops
+        from ..utils import MASK_VALUE
+        arena = rt.ensure_arena(self.fc)
+        T = arena.compute_dtype
+        R, dev = tokens.shape[0], tokens.device
+        cache, n = self._seat_mask(R, dev)
+        seq = self._buffers["running_seq"]
+        if not (seq.dtype == torch.int64 and seq.is_contiguous() and seq.numel() == R):
+            seq = self._buffers["running_seq"] = seq.to(torch.int64).reshape(R, -1)[:, :1].contiguous()
+        x32, x = ops.decode_embed(tokens.reshape(-1).contiguous(), self.word_emb.components.weight.detach(),
+                                  self.pos_emb.weight.detach(), seq.view(-1), self.padding_idx, float(MASK_VALUE), cache,
+                                  n, T)
+        self_mask = self._buffers["running_mask_self_attention"] = cache[:, None, None, :n + 1]
+        out = x32.view(R, 1, -1)
+        if T == torch.bfloat16:
+            out = Fn.attach_residual(x.view(R, 1, -1), out)
+        enc_mask = self._float_mask(encoder_attention_mask)
+        for layer in self.layers:
+            out = layer(queries=out, keys=encoder_features, values=encoder_features,
+                        self_attention_mask=self_mask, enc_attention_mask=enc_mask)
+        logits = Fn.linear(out.to(T), self.fc, arena)
+        return logits if return_logits else F.log_softmax(logits.float(), dim=-1)
 
     def forward(self, answer_tokens: torch.Tensor, encoder_features: torch.Tensor,
-                encoder_attention_mask: torch.Tensor):
+                encoder_attention_mask: torch.Tensor, return_logits: bool = False):
+        """``return_logits`` (an addition, default off): hand back the vocabulary logits instead of their log-softmax --
+        the fused beam-search step takes the log-softmax inside its candidate kernel."""
         b_s, seq_len = answer_tokens.shape
         dev = answer_tokens.device
+        if (self._is_stateful and seq_len == 1 and answer_tokens.is_cuda and not torch.is_grad_enabled()
+                and type(self.word_emb).__name__ == "UsualEmbedding" and self.d_model % 4 == 0
+                and self.pos_emb.weight.dtype == torch.float32):
+            return self._decode_step(answer_tokens, encoder_features, encoder_attention_mask, return_logits)
         pad_mask = generate_padding_mask(answer_tokens, self.padding_idx).to(dev)
         self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len, device=dev))
         if self._is_stateful:  # decoders.py:55-57
@@ -78,4 +166,4 @@ class Decoder(Module):
                         self_attention_mask=self_mask, enc_attention_mask=encoder_attention_mask)
         arena = rt.ensure_arena(self.fc)
         logits = Fn.linear(out.to(arena.compute_dtype), self.fc, arena)
-        return F.log_softmax(logits.float(), dim=-1)
+        return logits if return_logits else F.log_softmax(logits.float(), dim=-1)

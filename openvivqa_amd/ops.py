@@ -628,6 +628,63 @@ def topk_rows(x, k):
     return vals.view(*x.shape[:-1], k), idx.view(*x.shape[:-1], k)
 
 
+def decode_embed(tokens, emb, pos, seq, pad_idx, mask_value, mask, col, out_dtype, x32=None, x=None):
+    """One decoding step's inputs (``ovqa_decode_embed``): seq += 1 in place; x32 / x [R, D] = emb[tokens] + pos[seq] in
+    fp32 / ``out_dtype``; mask[:, col] = mask_value where tokens == pad_idx else 0 (mask fp32 [R, >= col + 1] or None).
+    Returns (x32, x); either may be None when not asked for (x is None iff out_dtype is fp32 and x32 is given)."""
+    _dev(emb)
+    R, D = tokens.numel(), emb.shape[1]
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and seq.dtype == torch.int64 and seq.is_contiguous()
+    assert seq.numel() == R and emb.dtype == torch.float32 and pos.dtype == torch.float32
+    assert emb.stride(1) == 1 and pos.stride(1) == 1 and pos.shape[1] == D
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.dim() == 2 and mask.shape[0] == R and mask.stride(1) == 1
+    if x32 is None:
+        x32 = torch.empty(R, D, dtype=torch.float32, device=emb.device)
+    if x is None and out_dtype != torch.float32:
+        x = torch.empty(R, D, dtype=out_dtype, device=emb.device)
+    _lib.check(_lib.load().ovqa_decode_embed(_dt(x) if x is not None else OVQA_F32, _p(tokens), _p(emb), emb.stride(0),
+                                             emb.shape[0], _p(pos), pos.stride(0), pos.shape[0], _p(seq), int(pad_idx),
+                                             float(mask_value), _p(mask), 0 if mask is None else mask.stride(0), int(col),
+                                             _p(x32), _p(x), R, D, _stream()), "decode_embed")
+    return x32, x
+
+
+def beam_candidates(logits, seq_logprob, seq_mask, prev_words, eos, k):
+    """(vals, idx, wl) [R, k] of ``ovqa_beam_candidates``: log-softmax of the logits [R, V], candidate scores of
+    beam_search.py:41-57 and the k best per row; seq_mask [R] is updated in place (prev_words == eos)."""
+    _dev(logits)
+    R, V = logits.shape
+    assert logits.stride(1) == 1 and seq_logprob.numel() == R and seq_mask.numel() == R
+    assert seq_logprob.dtype == torch.float32 and seq_mask.dtype == torch.float32
+    assert seq_logprob.is_contiguous() and seq_mask.is_contiguous()
+    if prev_words is not None:
+        assert prev_words.dtype == torch.int64 and prev_words.numel() == R and prev_words.is_contiguous()
+    vals = torch.empty(R, k, dtype=torch.float32, device=logits.device)
+    wl = torch.empty(R, k, dtype=torch.float32, device=logits.device)
+    idx = torch.empty(R, k, dtype=torch.int64, device=logits.device)
+    _lib.check(_lib.load().ovqa_beam_candidates(_dt(logits), _p(logits), logits.stride(0), R, V, k, _p(seq_logprob),
+                                                _p(seq_mask), _p(prev_words), int(eos), _p(vals), _p(idx), _p(wl),
+                                                _stream()), "beam_candidates")
+    return vals, idx, wl
+
+
+def beam_commit(vals, idx, wl, seq_mask_in, hist_in, hist_out, seq_logprob_out, seq_mask_out, selected_beam, words,
+                b_s, cur, k, beam, t):
+    """``ovqa_beam_commit``: hist_in / hist_out = (outputs int64, log_probs fp32) [b_s, cur | beam, T] pairs."""
+    _dev(vals)
+    T = hist_out[0].shape[-1]
+    for a in (vals, idx, wl, seq_mask_in, *hist_out, seq_logprob_out, seq_mask_out, selected_beam, words):
+        assert a.is_contiguous()
+    assert selected_beam.dtype == torch.int32 and words.dtype == torch.int64 and hist_out[0].dtype == torch.int64
+    assert vals.numel() == b_s * cur * k and seq_mask_in.numel() == b_s * cur and hist_out[0].numel() == b_s * beam * T
+    _lib.check(_lib.load().ovqa_beam_commit(_p(vals), _p(idx), _p(wl), _p(seq_mask_in),
+                                            _p(hist_in[0]) if t > 0 else None, _p(hist_in[1]) if t > 0 else None,
+                                            _p(hist_out[0]), _p(hist_out[1]), _p(seq_logprob_out), _p(seq_mask_out),
+                                            _p(selected_beam), _p(words), b_s, cur, k, beam, t, T, _stream()),
+               "beam_commit")
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None, o_lo=None):
     _dev(q)

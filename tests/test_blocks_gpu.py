@@ -459,22 +459,27 @@ def test_beam_search_decode_matches_oracle(beam, mode):
     enc[1, 30:] = 0
     emask = O.padding_mask(enc, 0)
 
-    def search(dec, dev, reorder):
+    def search(dec, dev, reorder, kernels=False):
         e, m = enc.to(dev), emask.to(dev)
         st = {}
 
-        def step(t, prev):
+        def step(t, prev, **kw):
             if t == 0:
                 st["e"], st["m"] = e, m
                 prev = torch.full((b_s, 1), 1, dtype=torch.long, device=dev)
             elif t == 1 and beam > 1:
                 st["e"], st["m"] = e.repeat_interleave(beam, 0), m.repeat_interleave(beam, 0)
-            return dec(prev, st["e"], st["m"])
+            return dec(prev, st["e"], st["m"], **kw)
         with torch.no_grad(), dec.statefulness(b_s):
-            return BeamSearch(dec, step, b_s, T, 2, beam, dev, reorder=reorder).apply(1)
+            return BeamSearch(dec, step, b_s, T, 2, beam, dev, reorder=reorder,
+                              logits_step=(lambda t, prev: step(t, prev, return_logits=True)) if kernels else None).apply(1)
     out_f, lp_f = search(h, DEV, "fused")
     out_r, lp_r = search(h, DEV, "reference")
     assert torch.equal(out_f, out_r) and torch.equal(lp_f, lp_r)
+    # selection + bookkeeping as two kernels per step (ovqa_beam_candidates / ovqa_beam_commit): the same search
+    out_k, lp_k = search(h, DEV, "fused", kernels=True)
+    assert torch.equal(out_k, out_f), (out_k, out_f)
+    assert (lp_k - lp_f).abs().max().item() < 1e-4
     out_o, lp_o = search(o, "cpu", "reference")
     if mode == F32:
         assert torch.equal(out_f.cpu(), out_o), (out_f, out_o)

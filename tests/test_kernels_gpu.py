@@ -790,3 +790,90 @@ def test_attention_probability_dropout_and_lse_gradient(dtype, B, H, nq, nk, d):
     dq, dk, dv = o.attention_bwd(d_o, q, k, v, out, lse, mask, H, d_lse=d_lse, att_drop=drop)
     t = t * (3 if dtype == BF16 else 1)
     assert nerr(dq, qd.grad) < t and nerr(dk, kd.grad) < t and nerr(dv, vd.grad) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_embed_matches_torch_ops(dtype):
+    """ovqa_decode_embed against the stateful branch of Decoder.forward written with torch ops (decoders.py:46-66):
+    position counter, embedding sum (bit-exact in fp32, its rounding in bf16) and the new mask column."""
+    g = torch.Generator().manual_seed(5)
+    R, V, D, P = 37, 91, 512, 21
+    emb = torch.randn(V, D, generator=g).to(DEV)
+    pos = torch.randn(P, D, generator=g).to(DEV)
+    tok = torch.randint(0, V, (R,), generator=g).to(DEV)
+    tok[3] = 0
+    tok[11] = 0
+    seq = torch.randint(0, P - 1, (R, 1), generator=g).to(DEV)
+    mask = torch.full((R, 32), 7.0, device=DEV)
+    seq0 = seq.clone()
+    x32, x = ops().decode_embed(tok, emb, pos, seq.view(-1), 0, -1e5, mask, 5, dtype)
+    assert torch.equal(seq, seq0 + 1)
+    ref = emb[tok] + pos[(seq0 + 1).view(-1)]
+    assert torch.equal(x32, ref)
+    if dtype == torch.bfloat16:
+        assert torch.equal(x, ref.to(dtype))
+    else:
+        assert x is None
+    want = torch.full((R, 32), 7.0, device=DEV)
+    want[:, 5] = (tok == 0).float() * -1e5
+    assert torch.equal(mask, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("beam,cur", [(3, 3), (3, 1), (1, 1), (8, 8), (5, 5)])
+def test_beam_step_kernels_match_reference_step(dtype, beam, cur):
+    """ovqa_beam_candidates + ovqa_beam_commit against ONE step of models/modules/beam_search.py:41-83 written with
+    torch ops (log-softmax, candidate scores with finished sequences, full descending sort, gathers)."""
+    g = torch.Generator().manual_seed(beam * 10 + cur)
+    b_s, V, T, t, eos = 6, 203, 9, (0 if cur == 1 else 4), 2
+    logits = (torch.randn(b_s * cur, V, generator=g) * 3).to(DEV).to(dtype)
+    seq_logprob = (-torch.rand(b_s, cur, generator=g) * 5).to(DEV)
+    seq_mask = (torch.rand(b_s, cur, generator=g) > 0.25).float().to(DEV)
+    prev = torch.randint(0, V, (b_s * cur,), generator=g).to(DEV)
+    prev[1::4] = eos
+    out_in = torch.randint(0, V, (b_s, cur, T), generator=g).to(DEV)
+    lp_in = -torch.rand(b_s, cur, T, generator=g).to(DEV)
+    if t == 0:
+        seq_mask.fill_(1.0)
+        seq_logprob.zero_()
+    # ---- the reference step
+    word_logprob = torch.log_softmax(logits.float(), -1).view(b_s, cur, V)
+    cand = seq_logprob.unsqueeze(-1) + word_logprob
+    m_ref = seq_mask.clone()
+    if t > 0:
+        m_ref = m_ref * (prev.view(b_s, cur) != eos).float()
+        word_logprob = word_logprob * m_ref.unsqueeze(-1)
+        old = seq_logprob.unsqueeze(-1).expand_as(cand).contiguous()
+        old[:, :, 1:] = -999
+        cand = m_ref.unsqueeze(-1) * cand + old * (1 - m_ref.unsqueeze(-1))
+    val, idx = torch.sort(cand.view(b_s, -1), dim=-1, descending=True, stable=True)
+    val, idx = val[:, :beam], idx[:, :beam]
+    sel_ref = idx // V
+    words_ref = idx - sel_ref * V
+    this_ref = torch.gather(word_logprob.reshape(b_s, -1), 1, idx)
+    # ---- the kernels
+    k = min(beam, V)
+    sm = seq_mask.clone().view(-1)
+    vals, i1, wl = ops().beam_candidates(logits, seq_logprob.view(-1).contiguous(), sm, prev if t > 0 else None, eos, k)
+    assert torch.equal(sm.view(b_s, cur), m_ref)
+    out_out = torch.zeros(b_s, beam, T, dtype=torch.long, device=DEV)
+    lp_out = torch.zeros(b_s, beam, T, device=DEV)
+    sl_out, sm_out = torch.empty(b_s * beam, device=DEV), torch.empty(b_s * beam, device=DEV)
+    sel = torch.empty(b_s, beam, dtype=torch.int32, device=DEV)
+    words = torch.empty(b_s * beam, 1, dtype=torch.long, device=DEV)
+    ops().beam_commit(vals, i1, wl, sm, (out_in, lp_in), (out_out, lp_out), sl_out, sm_out, sel, words, b_s, cur, k, beam, t)
+    assert torch.allclose(sl_out.view(b_s, beam), val, rtol=0, atol=2e-5)
+    # (equal scores: any order of the tied candidates is the reference's -- compare where the scores are distinct)
+    distinct = torch.ones_like(val, dtype=torch.bool)
+    distinct[:, 1:] &= (val[:, 1:] - val[:, :-1]).abs() > 1e-4
+    distinct[:, :-1] &= (val[:, 1:] - val[:, :-1]).abs() > 1e-4
+    assert distinct.float().mean() > 0.6
+    assert torch.equal(sel.long()[distinct], sel_ref[distinct])
+    assert torch.equal(words.view(b_s, beam)[distinct], words_ref[distinct])
+    assert torch.allclose(lp_out[:, :, t][distinct], this_ref[distinct], rtol=0, atol=2e-5)
+    assert torch.equal(out_out[:, :, t], words.view(b_s, beam))
+    assert torch.equal(sm_out.view(b_s, beam), torch.gather(m_ref, 1, sel.long()))
+    if t > 0:
+        sel3 = sel.long().unsqueeze(-1).expand(b_s, beam, t)
+        assert torch.equal(out_out[:, :, :t], torch.gather(out_in[:, :, :t], 1, sel3))
+        assert torch.equal(lp_out[:, :, :t], torch.gather(lp_in[:, :, :t], 1, sel3))
