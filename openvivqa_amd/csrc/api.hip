@@ -449,7 +449,11 @@ int ovqa_pointer_score(int dtype, const void* q, const void* k, const float* add
   OVQA_REQUIRE(B >= 0 && T >= 0 && Nk >= 0 && D > 0, OVQA_ERR_BAD_ARG, "pointer_score: bad sizes");
   if (B == 0 || T == 0 || Nk == 0) return OVQA_OK;
   OVQA_REQUIRE(q && k && scores, OVQA_ERR_BAD_ARG, "pointer_score: null pointer");
-  g_dispatch = "simple";
+  if (dtype == OVQA_BF16 && !force_simple() && ovqa::mfma_batched_nt_supported(q, D, T * D, k, D, Nk * D, B, T, Nk, D)) {
+    g_dispatch = "mfma";
+    return ovqa::mfma_pointer_score(q, k, add_mask, key_fill, query_fill, scores, B, T, Nk, D, scale, as_stream(stream));
+  }
+  OVQA_FALLBACK("pointer_score");
   return ovqa::simple_pointer_score(dtype, q, k, add_mask, key_fill, query_fill, scores, B, T, Nk, D, scale,
                                     as_stream(stream));
 }
@@ -461,7 +465,13 @@ int ovqa_batched_gemm(int dtype, int c_dtype, int trans_a, int trans_b, const vo
   OVQA_REQUIRE(batch >= 0 && M >= 0 && N >= 0 && K >= 0, OVQA_ERR_BAD_ARG, "batched_gemm: bad sizes");
   if (batch == 0 || M == 0 || N == 0) return OVQA_OK;
   OVQA_REQUIRE(A && Bm && C, OVQA_ERR_BAD_ARG, "batched_gemm: null pointer");
-  g_dispatch = "simple";
+  if (dtype == OVQA_BF16 && !trans_a && trans_b && !force_simple() &&
+      ovqa::mfma_batched_nt_supported(A, lda, stride_a, Bm, ldb, stride_b, batch, M, N, K)) {
+    g_dispatch = "mfma";
+    return ovqa::mfma_batched_nt(c_dtype, A, lda, stride_a, Bm, ldb, stride_b, C, ldc, stride_c, batch, M, N, K, alpha,
+                                 as_stream(stream));
+  }
+  g_dispatch = "simple";  // (NN / TN forms and fp32: the gradient products of the pointer scorers, 12 x 50 x 768 each)
   return ovqa::simple_batched_gemm(dtype, c_dtype, trans_a, trans_b, A, lda, stride_a, Bm, ldb, stride_b, C, ldc,
                                    stride_c, batch, M, N, K, alpha, as_stream(stream));
 }

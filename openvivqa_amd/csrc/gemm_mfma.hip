@@ -502,19 +502,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
 // 32 x 12 = 384 one-wave workgroups: every CU streams its slice of the weights once (the 12 row tiles of a weight slab
 // hit in L2).  The tiled kernels put such a product on 48 workgroups that each walk 8 K steps behind barriers: 5-7 us
 // per launch in a decoding step where this form takes ~3.
-template <typename Epi, int S>
-__global__ __launch_bounds__(64 * S) void gemm_bf16_skinny_kernel(GemmArgs g, Epi epi) {
+// acc (valid on wave 0 only; returns false on the other waves) = the 16 x 16 tile  P[r0.., :] Q[c0.., :]^T
+template <int S>
+__device__ __forceinline__ bool skinny_tile(const bf16* __restrict__ P, int64_t ldp, int R, const bf16* __restrict__ Q,
+                                            int64_t ldq, int C, int K, int r0, int c0, f32x4& acc) {
   constexpr int KCH = 16;  // K steps (of 32) per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;  // r: the P operand's rows (output features), c: Q's (tokens)
   int pr = r0 + (lane & 15), qc = c0 + (lane & 15);
-  pr = pr < g.R ? pr : g.R - 1;
-  qc = qc < g.C ? qc : g.C - 1;
-  const int nk = g.K / 32;
+  pr = pr < R ? pr : R - 1;
+  qc = qc < C ? qc : C - 1;
+  const int nk = K / 32;
   const int per = (nk + S - 1) / S;      // K steps of this wave: [k_lo, k_hi)
   const int k_lo = wave * per, k_hi = min(nk, k_lo + per);
-  const bf16* pp = g.P + (int64_t)pr * g.ldp + (lane >> 4) * 8;
-  const bf16* qp = g.Q + (int64_t)qc * g.ldq + (lane >> 4) * 8;
+  const bf16* pp = P + (int64_t)pr * ldp + (lane >> 4) * 8;
+  const bf16* qp = Q + (int64_t)qc * ldq + (lane >> 4) * 8;
   bf16x8 pa[KCH], qa[KCH];
 #pragma unroll
   for (int i = 0; i < KCH; i++) {  // (past the wave's share: re-read its last step, zeroed below -- no branch around a load)
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(64 * S) void gemm_bf16_skinny_kernel(GemmArgs g, Ep
     qa[i] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
   }
   __builtin_amdgcn_sched_barrier(0);  // all 32 loads in flight before the first MFMA waits (the scheduler would
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};  // otherwise interleave them ~10 deep: three round trips instead of one)
+  acc = f32x4{0.f, 0.f, 0.f, 0.f};    // otherwise interleave them ~10 deep: three round trips instead of one)
 #pragma unroll
   for (int i = 0; i < KCH; i++) {
     bf16x8 a = pa[i];
@@ -537,16 +538,46 @@ __global__ __launch_bounds__(64 * S) void gemm_bf16_skinny_kernel(GemmArgs g, Ep
     __shared__ f32x4 part[S - 1][64];
     if (wave > 0) part[wave - 1][lane] = acc;
     __syncthreads();
-    if (wave > 0) return;
+    if (wave > 0) return false;
 #pragma unroll
     for (int w = 0; w < S - 1; w++) {
       const f32x4 o = part[w][lane];
       acc = f32x4{acc[0] + o[0], acc[1] + o[1], acc[2] + o[2], acc[3] + o[3]};
     }
   }
+  return true;
+}
+
+template <typename Epi, int S>
+__global__ __launch_bounds__(64 * S) void gemm_bf16_skinny_kernel(GemmArgs g, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;  // r: the P operand's rows (output features), c: Q's (tokens)
+  f32x4 acc;
+  if (!skinny_tile<S>(g.P, g.ldp, g.R, g.Q, g.ldq, g.C, g.K, r0, c0, acc)) return;
   epi.init();
   const int c = c0 + (lane & 15), r = r0 + (lane >> 4) * 4;
   if (c < g.C && r < g.R) epi(c, r, acc);
+}
+
+// Batched C[b] = alpha * A[b] B[b]^T on the same one-wave tiles (A [M, K], B [N, K], both with K contiguous): the pointer
+// scorers of M4C (OcrPtrNet mmf_m4c.py:391-394, DynamicPointerNetwork m4c.py:30-31: 12 x 50 scores per sample over 768
+// features) and ovqa_batched_gemm's NT form.  The epilogue gets one element at a time: (batch, m, n, value).
+struct BatchedNT {
+  const bf16* A; int64_t lda, sa;
+  const bf16* B; int64_t ldb, sb;
+  int M, N, K;
+};
+template <typename Epi, int S>
+__global__ __launch_bounds__(64 * S) void batched_nt_skinny_kernel(BatchedNT g, Epi epi) {
+  const int lane = threadIdx.x & 63, b = blockIdx.z;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  f32x4 acc;  // P = B's rows (n: the MFMA's row operand), Q = A's rows (m)
+  if (!skinny_tile<S>(g.B + (int64_t)b * g.sb, g.ldb, g.N, g.A + (int64_t)b * g.sa, g.lda, g.M, g.K, n0, m0, acc)) return;
+  const int m = m0 + (lane & 15), n = n0 + (lane >> 4) * 4;
+  if (m >= g.M) return;
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    if (n + e < g.N) epi(b, m, n + e, acc[e]);
 }
 
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi>
@@ -1039,9 +1070,60 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
   }
 }
 
+struct MEpiPointerScore {  // OcrPtrNet / DynamicPointerNetwork scores: scale, additive key mask, -inf fills
+  float* s; int T_; int Nk; float scale; const float* add_mask; const uint8_t* key_fill; const uint8_t* query_fill;
+  __device__ __forceinline__ void operator()(int b, int m, int n, float acc) const {
+    float v = acc * scale;
+    if (add_mask) v += add_mask[(int64_t)b * Nk + n];
+    if (key_fill && key_fill[(int64_t)b * Nk + n]) v = -INFINITY;
+    if (query_fill && query_fill[(int64_t)b * T_ + m]) v = -INFINITY;
+    s[((int64_t)b * T_ + m) * Nk + n] = v;
+  }
+};
+template <typename TC>
+struct MEpiBatchedOut {
+  TC* c; int64_t ldc; int64_t stride_c; float alpha;
+  __device__ __forceinline__ void operator()(int b, int m, int n, float acc) const {
+    c[(int64_t)b * stride_c + (int64_t)m * ldc + n] = from_f32<TC>(alpha * acc);
+  }
+};
+
+template <typename Epi>
+int launch_batched_nt(const BatchedNT& g, int64_t batch, Epi epi, hipStream_t st, const char* what) {
+  const dim3 grid((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16), (unsigned)batch);
+  const int nk = g.K / 32;
+  if (nk <= 16) hipLaunchKernelGGL((batched_nt_skinny_kernel<Epi, 1>), grid, dim3(64), 0, st, g, epi);
+  else if (nk <= 32) hipLaunchKernelGGL((batched_nt_skinny_kernel<Epi, 2>), grid, dim3(128), 0, st, g, epi);
+  else hipLaunchKernelGGL((batched_nt_skinny_kernel<Epi, 4>), grid, dim3(256), 0, st, g, epi);
+  return ovqa_check_launch(what);
+}
+
 }  // namespace
 
 namespace ovqa {
+
+bool mfma_batched_nt_supported(const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb,
+                               int64_t batch, int64_t M, int64_t N, int64_t K) {
+  return M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && K <= 2048 && lda % 8 == 0 && ldb % 8 == 0 && sa % 8 == 0 &&
+         sb % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && batch <= 65535 && (M + 15) / 16 <= 65535 &&
+         M < (1 << 30) && N < (1 << 30);
+}
+
+int mfma_pointer_score(const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,
+                       const uint8_t* query_fill, float* scores, int64_t B, int64_t T, int64_t Nk, int64_t D, float scale,
+                       hipStream_t st) {
+  BatchedNT g{(const bf16*)q, D, T * D, (const bf16*)k, D, Nk * D, (int)T, (int)Nk, (int)D};
+  return launch_batched_nt(g, B, MEpiPointerScore{scores, (int)T, (int)Nk, scale, add_mask, key_fill, query_fill}, st,
+                           "pointer_score");
+}
+
+int mfma_batched_nt(int c_dtype, const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb, void* C,
+                    int64_t ldc, int64_t sc, int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, hipStream_t st) {
+  BatchedNT g{(const bf16*)A, lda, sa, (const bf16*)B, ldb, sb, (int)M, (int)N, (int)K};
+  if (c_dtype == OVQA_F32)
+    return launch_batched_nt(g, batch, MEpiBatchedOut<float>{(float*)C, ldc, sc, alpha}, st, "batched_gemm NT");
+  return launch_batched_nt(g, batch, MEpiBatchedOut<bf16>{(bf16*)C, ldc, sc, alpha}, st, "batched_gemm NT");
+}
 
 bool mfma_gemm_supported(int64_t R, int64_t C, int64_t K, int64_t ld_p, int64_t ld_q) {
   return R >= 8 && C >= 1 && K >= 8 && R % 8 == 0 && K % 8 == 0 && ld_p % 8 == 0 && ld_q % 8 == 0 &&

@@ -138,6 +138,13 @@ int grouped_row_gather(const ovqa_gather_problem* probs, int n_problems, const i
 
 // ---- gemm_mfma.hip (bf16, MFMA) ----------------------------------------------
 bool mfma_gemm_supported(int64_t R, int64_t C, int64_t K, int64_t ld_p, int64_t ld_q);
+bool mfma_batched_nt_supported(const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb,
+                               int64_t batch, int64_t M, int64_t N, int64_t K);
+int mfma_pointer_score(const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,
+                       const uint8_t* query_fill, float* scores, int64_t B, int64_t T, int64_t Nk, int64_t D, float scale,
+                       hipStream_t st);
+int mfma_batched_nt(int c_dtype, const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb, void* C,
+                    int64_t ldc, int64_t sc, int64_t batch, int64_t M, int64_t N, int64_t K, float alpha, hipStream_t st);
 bool mfma_linear_bwd_data_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t lddx);
 int mfma_linear_bwd_data(const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx, const void* preact,
                          const void* addend, int64_t ldadd, int64_t M, int64_t N, int64_t K, const DropArgs& da,

@@ -126,14 +126,18 @@ def gpu_rank_batch(rank, B):
     return (v, vm, t, tm), (tv, tt)
 
 
+DP_GPU_BATCH = 8  # samples per rank: 160 question rows -- every product on the tiled GEMM kernels in the ranks AND in the
+# single process that replays their shards (<= 128 rows take the one-wave form: same values, another summation order)
+
+
 def dp_gpu_worker(rank, world, rdv, comm_bf16, steps, q):
     """One data-parallel rank with the real kernels on cuda:0, gradients exchanged over gloo (RCCL refuses several
     ranks on one device; the exchange arithmetic -- cast, sum, scale -- is the product's either way)."""
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="file://" + rdv, rank=rank, world_size=world)
     try:
-        model, ts, tgt = gpu_stack_step(4, torch.bfloat16 if comm_bf16 else torch.float32)
-        batch, (tv, tt) = gpu_rank_batch(rank, 4)
+        model, ts, tgt = gpu_stack_step(DP_GPU_BATCH, torch.bfloat16 if comm_bf16 else torch.float32)
+        batch, (tv, tt) = gpu_rank_batch(rank, DP_GPU_BATCH)
         tgt["v"], tgt["t"] = tv, tt
         for _ in range(steps):
             ts.step(*batch)

@@ -503,6 +503,36 @@ def test_pointer_score_and_batched_gemm(dtype):
     assert nerr(o.batched_gemm(a, b, alpha=0.5), 0.5 * a.double() @ b.double()) < tol(dtype) * 4
     assert nerr(o.batched_gemm(a, q, trans_a=True), a.double().transpose(1, 2) @ q.double()) < tol(dtype) * 4
     assert nerr(o.batched_gemm(q, k, trans_b=True), q.double() @ k.double().transpose(1, 2)) < tol(dtype) * 4
+    if dtype == BF16 and not FORCED_SIMPLE:
+        from openvivqa_amd import _lib
+        assert _lib.last_dispatch() == "mfma"  # the NT form runs on the matrix cores
+
+
+@pytest.mark.parametrize("B,T,N,D", [(5, 12, 50, 768), (2, 33, 17, 64), (1, 1, 1, 32), (3, 12, 50, 1536), (2, 20, 100, 2048)])
+def test_pointer_score_mfma_shapes(B, T, N, D):
+    """The one-wave MFMA tiles of the pointer scorers (bf16): M4C's 12 x 50 x 768 (mmf_m4c.py:391-394), ragged tile
+    edges, reductions split over 1 / 2 / 4 waves; masks and fills as in the VALU form."""
+    o = ops()
+    q, k = rnd(B, T, D, dtype=BF16), rnd(B, N, D, dtype=BF16, seed=1)
+    s0 = q.double() @ k.double().transpose(1, 2) / math.sqrt(D)
+    am = torch.zeros(B, N, device=DEV)
+    am[B - 1, N // 2:] = -1e5
+    kf = torch.zeros(B, N, dtype=torch.uint8, device=DEV)
+    kf[0, N - 1:] = 1
+    qf = torch.zeros(B, T, dtype=torch.uint8, device=DEV)
+    qf[0, T - 1:] = 1
+    s = o.pointer_score(q, k, 1 / math.sqrt(D), add_mask=am, key_fill=kf, query_fill=qf)
+    if not FORCED_SIMPLE:
+        from openvivqa_amd import _lib
+        assert _lib.last_dispatch() == "mfma"
+    want = s0 + am.double()[:, None]
+    want[0, :, N - 1:] = -math.inf
+    want[0, T - 1:] = -math.inf
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(s), fin.to(s.device))
+    assert nerr(torch.where(fin.to(s.device), s, torch.zeros_like(s)), torch.where(fin, want, torch.zeros_like(want))) < 1e-2
+    c = o.batched_gemm(q, k, trans_b=True, alpha=0.25, out_dtype=F32)
+    assert nerr(c, 0.25 * q.double() @ k.double().transpose(1, 2)) < 1e-2
 
 
 @pytest.mark.parametrize("grad_dtype", [F32, BF16])

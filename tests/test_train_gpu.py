@@ -305,7 +305,7 @@ def test_tiled_adam_equals_flat_adam_plus_transpose(monkeypatch):
 def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
     """FOUR real ranks (real kernels, all on this one GPU, gradients over gloo) take two optimiser
     steps with the gradient exchange in bf16 (the default: half the bytes per xGMI link) and in fp32; a single process
-    takes the same two steps on the four shards concatenated (mean loss over 4 B samples = the average of the ranks'
+    takes the same two steps on the four shards concatenated (mean loss over 4 B samples, B = 8 = the average of the ranks'
     means).  Measured, post-step fp32 master weights:
       * fp32 exchange vs the single process: accumulation order only;
       * bf16 exchange vs fp32 exchange: no weight moves by more than one bf16 step of its own value plus 2 % of an
@@ -327,8 +327,8 @@ def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
             p.join(timeout=120)
             assert p.exitcode == 0
     # the single process: all shards at once
-    model, ts, tgt = H.gpu_stack_step(4 * world, torch.float32)
-    shards = [H.gpu_rank_batch(r, 4) for r in range(world)]
+    model, ts, tgt = H.gpu_stack_step(H.DP_GPU_BATCH * world, torch.float32)
+    shards = [H.gpu_rank_batch(r, H.DP_GPU_BATCH) for r in range(world)]
     batch = tuple(torch.cat([s[0][i] for s in shards], 0) for i in range(4))
     tgt["v"], tgt["t"] = torch.cat([s[1][0] for s in shards], 0), torch.cat([s[1][1] for s in shards], 0)
     w0 = ts.arena.master.detach().clone().cpu()
@@ -347,7 +347,7 @@ def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
     rec("dp[4 ranks, gloo, 1 GPU]", "update, fp32 exchange vs single process (rel L2)", e32, 1e-2)
     rec("dp[4 ranks, gloo, 1 GPU]", "update, bf16 exchange vs fp32 exchange (rel L2)", e16, 5e-2)
     # (Adam normalises every element, so a gradient's relative error IS the update's: where the four ranks' gradients of
-    # an element cancel -- B = 4 per rank is the noisy extreme -- the bf16 sum's 2^-9 is relative to their magnitudes,
+    # an element cancel -- B = 8 per rank is a noisy extreme -- the bf16 sum's 2^-9 is relative to their magnitudes,
     # not to the sum: ~2 % of the update in L2, measured; far below what the weights' bf16 shadow resolves, next check)
     assert e32 < 1e-2 and e16 < 5e-2, (e32, e16)
     # weight level.  fc_k.bias is left out as everywhere (its gradient is analytically zero: pure rounding noise that
