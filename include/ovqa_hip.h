@@ -288,6 +288,13 @@ int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, 
  * (beam_search.py:36-39 takes them from a full sort of the cur_beam * |V| candidates). */
 int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream);
 
+/* Three products of one input in one launch (ABI 5): y_i[m, :] = x[m, :] W_i^T + b_i, i = 0..2, for three weight matrices
+ * stacked as w [3 F, K] (bias [3 F] or NULL), every output with its own base pointer and row stride.  A decoding step's
+ * fc_q / fc_k / fc_v (attentions.py:49-51 on the one new position): q into a buffer, k and v straight into their slots of
+ * the in-place caches.  bf16: MFMA kernels (F % 8 == 0, 16-byte aligned pointers and rows); otherwise three VALU products. */
+int ovqa_linear_fwd_split3(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* y0, int64_t ld0,
+                           void* y1, int64_t ld1, void* y2, int64_t ld2, int64_t M, int64_t F, int64_t K, void* stream);
+
 /* ---- the index / elementwise work around one autoregressive decoding step (ABI 5) -------------------------------------
  * Three launches instead of the ~55 stock elementwise launches a decoding step with beam search spends on it.
  *

@@ -94,6 +94,8 @@ SIGNATURES = {
     "ovqa_attention_decode": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
                               c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_topk_rows": [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "ovqa_linear_fwd_split3": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64,
+                               c_vp],
     "ovqa_decode_embed": [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_i64,
                           c_vp, c_vp, c_i64, c_i64, c_vp],
     "ovqa_beam_candidates": [c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],

@@ -154,6 +154,34 @@ int ovqa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const v
   return ovqa::simple_linear_fwd(dtype, epilogue, x, ldx, w, bias, residual, ldres, y, ldy, preact, M, N, K, da, st);
 }
 
+int ovqa_linear_fwd_split3(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* y0, int64_t ld0,
+                           void* y1, int64_t ld1, void* y2, int64_t ld2, int64_t M, int64_t F, int64_t K, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "linear_fwd_split3: bad dtype %d", dtype);
+  OVQA_REQUIRE(M >= 0 && F > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_fwd_split3: bad sizes");
+  if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && w && y0 && y1 && y2, OVQA_ERR_BAD_ARG, "linear_fwd_split3: null pointer");
+  OVQA_REQUIRE(ldx >= K && ld0 >= F && ld1 >= F && ld2 >= F, OVQA_ERR_BAD_ARG, "linear_fwd_split3: ld smaller than the row");
+  OVQA_REQUIRE(M * (3 * F > K ? 3 * F : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_fwd_split3: more than 2^32 elements");
+  hipStream_t st = as_stream(stream);
+  if (dtype == OVQA_BF16 && !force_simple() &&
+      ovqa::mfma_linear_fwd_split3_supported(x, ldx, w, bias, y0, ld0, y1, ld1, y2, ld2, M, F, K)) {
+    g_dispatch = "mfma";
+    return ovqa::mfma_linear_fwd_split3(x, ldx, w, bias, y0, ld0, y1, ld1, y2, ld2, M, F, K, st);
+  }
+  OVQA_FALLBACK("linear_fwd_split3");  // the three products one after the other on the VALU kernels
+  const size_t es = dtype == OVQA_BF16 ? 2 : 4;
+  void* ys[3] = {y0, y1, y2};
+  const int64_t lds[3] = {ld0, ld1, ld2};
+  const DropArgs none = make_drop_args(nullptr);
+  for (int i = 0; i < 3; i++) {
+    int rc = ovqa::simple_linear_fwd(dtype, OVQA_EPI_BIAS, x, ldx, (const char*)w + (size_t)i * F * K * es,
+                                     bias ? bias + (size_t)i * F : nullptr, nullptr, 0, ys[i], lds[i], nullptr, M, F, K,
+                                     none, st);
+    if (rc != OVQA_OK) return rc;
+  }
+  return OVQA_OK;
+}
+
 int ovqa_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
                           int64_t ldres, const ovqa_ln_ref* ln, float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K,
                           const ovqa_dropout* drop, void* stream) {

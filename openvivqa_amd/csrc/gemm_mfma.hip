@@ -632,6 +632,28 @@ struct MEpiBias {
     store4(y + (int64_t)m * ldy + n, a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
   }
 };
+// y_i = x W_i^T + b_i for three stacked weight matrices [3 F, K], each output with its own base and row stride (a
+// decoding step's q -> a buffer, k and v -> their slots of the in-place caches, in ONE launch)
+struct MEpiBiasSplit3 {
+  static constexpr bool kWide = true;
+  bf16* y0; int64_t ld0; bf16* y1; int64_t ld1; bf16* y2; int64_t ld2; int F; const float* bias;
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ bf16* dest(int m, int n) const {
+    const int which = n >= 2 * F ? 2 : (n >= F ? 1 : 0);
+    bf16* base = which == 2 ? y2 : (which == 1 ? y1 : y0);
+    const int64_t ld = which == 2 ? ld2 : (which == 1 ? ld1 : ld0);
+    return base + (int64_t)m * ld + (n - which * F);
+  }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    bias8(bias, n, lo, hi, u);
+    store8(dest(m, n), u);
+  }
+  __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
+    const float4 b = bias4(bias, n);
+    store4(dest(m, n), a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+  }
+};
 struct MEpiBiasGelu {
   static constexpr bool kWide = true;
   bf16* y; int64_t ldy; const float* bias; bf16* preact; int N; DropArgs da; DropState ds;
@@ -1159,6 +1181,20 @@ int mfma_linear_fwd(int epilogue, const void* x, int64_t ldx, const void* w, con
   }
   ovqa_set_error("linear_fwd: unknown epilogue %d", epilogue);
   return OVQA_ERR_BAD_ARG;
+}
+
+bool mfma_linear_fwd_split3_supported(const void* x, int64_t ldx, const void* w, const float* bias, const void* y0,
+                                      int64_t ld0, const void* y1, int64_t ld1, const void* y2, int64_t ld2, int64_t M,
+                                      int64_t F, int64_t K) {
+  return mfma_gemm_supported(3 * F, M, K, K, ldx) && F % 8 == 0 && ld0 % 8 == 0 && ld1 % 8 == 0 && ld2 % 8 == 0 &&
+         aligned16(x) && aligned16(w) && aligned16(y0) && aligned16(y1) && aligned16(y2) && (!bias || aligned16(bias));
+}
+
+int mfma_linear_fwd_split3(const void* x, int64_t ldx, const void* w, const float* bias, void* y0, int64_t ld0, void* y1,
+                           int64_t ld1, void* y2, int64_t ld2, int64_t M, int64_t F, int64_t K, hipStream_t st) {
+  return launch<false, false>(w, K, x, ldx, 3 * F, M, K,
+                              MEpiBiasSplit3{(bf16*)y0, ld0, (bf16*)y1, ld1, (bf16*)y2, ld2, (int)F, bias}, st,
+                              "linear_fwd_split3", true);
 }
 
 int mfma_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,

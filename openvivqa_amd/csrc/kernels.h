@@ -138,6 +138,11 @@ int grouped_row_gather(const ovqa_gather_problem* probs, int n_problems, const i
 
 // ---- gemm_mfma.hip (bf16, MFMA) ----------------------------------------------
 bool mfma_gemm_supported(int64_t R, int64_t C, int64_t K, int64_t ld_p, int64_t ld_q);
+bool mfma_linear_fwd_split3_supported(const void* x, int64_t ldx, const void* w, const float* bias, const void* y0,
+                                      int64_t ld0, const void* y1, int64_t ld1, const void* y2, int64_t ld2, int64_t M,
+                                      int64_t F, int64_t K);
+int mfma_linear_fwd_split3(const void* x, int64_t ldx, const void* w, const float* bias, void* y0, int64_t ld0, void* y1,
+                           int64_t ld1, void* y2, int64_t ld2, int64_t M, int64_t F, int64_t K, hipStream_t st);
 bool mfma_batched_nt_supported(const void* A, int64_t lda, int64_t sa, const void* B, int64_t ldb, int64_t sb,
                                int64_t batch, int64_t M, int64_t N, int64_t K);
 int mfma_pointer_score(const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,

@@ -392,10 +392,26 @@ class MultiHeadAttention(Module):
         (ovqa_attention_decode: one wave per (row, head), K / V streamed once).  Same outputs."""
         from .. import ops
         a = self.attention
-        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
         nq = queries.shape[1]
-        single = (nq == 1 and keys.shape[1] == 1 and q.is_cuda and a.d_k == a.d_v and a.d_k in (32, 64, 128)
+        single = (nq == 1 and keys.shape[1] == 1 and queries.is_cuda and a.d_k == a.d_v and a.d_k in (32, 64, 128)
                   and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1)))
+        if single and Fn.same_tensor(queries, keys) and Fn.same_tensor(keys, values):
+            # self-attention over the new position: fc_q / fc_k / fc_v in ONE launch, k and v straight into their cache slots
+            try:
+                w3 = arena.packed([a.fc_q.weight, a.fc_k.weight, a.fc_v.weight])
+                b3 = arena.packed([a.fc_q.bias, a.fc_k.bias, a.fc_v.bias], "master")
+            except RuntimeError:  # (not adjacent in this arena: the three launches below)
+                w3 = None
+            if w3 is not None and w3.dtype == queries.dtype:
+                x = queries.reshape(queries.shape[0], -1)
+                q = torch.empty(x.shape[0], a.h * a.d_k, dtype=x.dtype, device=x.device)
+                (kc, vc), n = self._seat_cache(q)
+                ops.linear_fwd_split3(x, w3, b3, (q, kc[:, n], vc[:, n]))
+                n += 1
+                self._buffers["running_keys"], self._buffers["running_values"] = kc[:, :n], vc[:, :n]
+                o = ops.attention_decode(q.view(x.shape[0], 1, -1), kc, vc, n, a.h, mask=self._row_mask(mask, x.shape[0], n))
+                return self._finish_step(arena, queries, o)
+        q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
         if not single:  # several new positions at once (teacher-forced prefixes): the general kernel on a grown cache
             k_new = ops.linear_fwd(keys.contiguous(), arena.compute(a.fc_k.weight), arena.master_of(a.fc_k.bias))
             v_new = ops.linear_fwd(values.contiguous(), arena.compute(a.fc_v.weight), arena.master_of(a.fc_v.bias))

@@ -129,6 +129,24 @@ class LnRef:
         return y
 
 
+def linear_fwd_split3(x, w, bias, outs):
+    """outs[i][m, :] = x[m, :] w[i F:(i + 1) F]^T + bias[i F:(i + 1) F] for the three stacked [F, K] matrices of w, in one
+    launch (``ovqa_linear_fwd_split3``); every output has its own row stride (e.g. a slot ``cache[:, n]`` of a cache)."""
+    _dev(x)
+    ldx, M = _rows(x)
+    F3, K = w.shape
+    F = F3 // 3
+    assert F3 == 3 * F and x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype and len(outs) == 3
+    lds = []
+    for o in outs:
+        ldo, rows = _rows(o)
+        assert rows == M and o.shape[-1] == F and o.dtype == x.dtype
+        lds.append(ldo)
+    _lib.check(_lib.load().ovqa_linear_fwd_split3(_dt(x), _p(x), ldx, _p(w), _p(bias), _p(outs[0]), lds[0], _p(outs[1]),
+                                                  lds[1], _p(outs[2]), lds[2], M, F, K, _stream()), "linear_fwd_split3")
+    return outs
+
+
 def linear_fwd_res32(x, w, bias, residual, drop=None):
     """pre32 = res + drop(x w^T + bias) in fp32; ``residual`` is an fp32 tensor [.., N] or an LnRef (the previous
     block's LayerNorm, recomputed in the epilogue).  x, w bf16."""

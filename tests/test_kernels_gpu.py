@@ -907,3 +907,28 @@ def test_beam_step_kernels_match_reference_step(dtype, beam, cur):
         sel3 = sel.long().unsqueeze(-1).expand(b_s, beam, t)
         assert torch.equal(out_out[:, :, :t], torch.gather(out_in[:, :, :t], 1, sel3))
         assert torch.equal(lp_out[:, :, :t], torch.gather(lp_in[:, :, :t], 1, sel3))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M", [64, 192, 1280])
+def test_linear_fwd_split3_writes_three_strided_outputs(dtype, M):
+    """ovqa_linear_fwd_split3: fc_q / fc_k / fc_v of a decoding step in one launch, k and v into slots of in-place caches
+    (row stride = capacity * F), against three separate products."""
+    o = ops()
+    F, K, cap, n = 512, 512, 21, 7
+    x = rnd(M, K, dtype=dtype)
+    w = rnd(3 * F, K, dtype=dtype, scale=K ** -0.5, seed=1)
+    b = rnd(3 * F, seed=2)
+    q = torch.empty(M, F, dtype=dtype, device=DEV)
+    kc = torch.full((M, cap, F), 3.0, dtype=dtype, device=DEV)
+    vc = torch.full((M, cap, F), 5.0, dtype=dtype, device=DEV)
+    o.linear_fwd_split3(x, w, b, (q, kc[:, n], vc[:, n]))
+    ref = x.double() @ w.double().t() + b.double()
+    assert nerr(q, ref[:, :F]) < tol(dtype)
+    assert nerr(kc[:, n], ref[:, F:2 * F]) < tol(dtype)
+    assert nerr(vc[:, n], ref[:, 2 * F:]) < tol(dtype)
+    kc[:, n], vc[:, n] = 3.0, 5.0  # nothing else was touched
+    assert (kc == 3.0).all() and (vc == 5.0).all()
+    # the same values as three separate launches of the same kernels
+    sep = [o.linear_fwd(x, w[i * F:(i + 1) * F].contiguous(), b[i * F:(i + 1) * F].contiguous()) for i in range(3)]
+    assert torch.equal(q, sep[0])
