@@ -37,11 +37,12 @@ def parse():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "mcan_bench.yaml"))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--comm-dtype", default="auto", choices=["auto", "bf16", "fp32"],
-                    help="dtype of the gradient all-reduce; auto = the compute dtype (bf16 mode: half the bytes per xGMI "
-                         "link, the rounding of one more bf16 hand-off -- tests/test_train_gpu.py::"
-                         "test_data_parallel_exchange_bf16_vs_fp32_vs_single_process quantifies it; fp32 mode: fp32)")
-    ap.add_argument("--overlap-mb", type=float, default=96.0,
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient all-reduce.  fp32 (default) is the reference's arithmetic (DDP sums fp32 "
+                         "gradients); bf16 halves the bytes per xGMI link and moves 0.08 %% of the weights by more than "
+                         "one bf16 step of their own value after two Adam steps (tests/test_train_gpu.py::"
+                         "test_data_parallel_exchange_bf16_vs_fp32_vs_single_process, DESIGN.md section 6)")
+    ap.add_argument("--overlap-mb", type=float, default=48.0,
                     help="N>1: release a gradient segment to the all-reduce stream every this many MB (fp32) of "
                          "finished gradients during backward; 0 = one exchange after backward")
     ap.add_argument("--rehearse-comm", action="store_true",
@@ -687,8 +688,6 @@ def main():
 
         def forward_loss(feats_, toks_):  # noqa: F811
             return nll(model(SimpleNamespace(region_features=feats_, question_tokens=toks_)), ans)
-    if args.comm_dtype == "auto":
-        args.comm_dtype = args.dtype
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,

@@ -304,7 +304,7 @@ def test_tiled_adam_equals_flat_adam_plus_transpose(monkeypatch):
 
 def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
     """FOUR real ranks (real kernels, all on this one GPU, gradients over gloo) take two optimiser
-    steps with the gradient exchange in bf16 (the default: half the bytes per xGMI link) and in fp32; a single process
+    steps with the gradient exchange in bf16 (opt-in: half the bytes per xGMI link) and in fp32 (the default); a single process
     takes the same two steps on the four shards concatenated (mean loss over 4 B samples, B = 8 = the average of the ranks'
     means).  Measured, post-step fp32 master weights:
       * fp32 exchange vs the single process: accumulation order only;
