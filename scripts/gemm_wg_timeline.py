@@ -52,6 +52,15 @@ def timeline(label, fn, n_wg_hint=4096):
     # second-round workgroups: started after some workgroup had already ended
     late = st > en.min()
     print(f"   workgroups that started after the first one ended: {int(late.sum())}; their start p50 {np.median(st[late]) if late.any() else 0:.2f}")
+    if os.environ.get("OVQA_WG_PLACEMENT") == "1":  # where did the k-th workgroup of XCD x go?  (blockIdx = 8 k + x)
+        idx_live = np.nonzero(live)[0]
+        xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
+        se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(np.int64)
+        cu_in = (((hw >> np.uint64(12)) & np.uint64(1)) * 16 + ((hw >> np.uint64(8)) & np.uint64(15))).astype(np.int64)
+        for x in (0, 5):
+            sel = [i for i, b in enumerate(idx_live) if b % 8 == x]
+            print(f"   blockIdx % 8 == {x}: XCC ids {sorted(set(xcc[sel].tolist()))}; (SE, CU) of k = 0.. :",
+                  " ".join(f"{se[i]}.{cu_in[i]}" for i in sel[:72]))
     by_cnt = {c: [] for c in hist}
     for k, c in per_cu.items():
         by_cnt[c].append(en[cu == k].max())
