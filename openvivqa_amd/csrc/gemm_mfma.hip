@@ -300,10 +300,11 @@ template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
   static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || (BC == 32 && NW == 4 && !Q_KMAJOR),
                 "unsupported tile");
+  static_assert(NW == 4 || NW == 8 || (NW == 16 && BC == 128 && BR == 128 && KSP == 1), "4, 8 or (128 x 128) 16 waves");
   static_assert(BR == 128 || (BR == 64 && NW == 4 && BC == 32 && !P_KMAJOR), "unsupported tile");
   static_assert(KSP == 1 || (KSP == 2 && NW == 8 && BC >= 64 && BR == 128), "k-split form: 8 waves");
   constexpr int NWT = NW / KSP;  // waves of one tile grid
-  constexpr int WC = NWT == 8 ? (BC >= 64 ? 4 : BC / 16) : 2;  // wave grid: WC along c x WR along r
+  constexpr int WC = NWT == 16 ? 4 : (NWT == 8 ? (BC >= 64 ? 4 : BC / 16) : 2);  // wave grid: WC along c x WR along r
   constexpr int WR = NWT / WC;
   constexpr int NI = BC / (16 * WC);   // 16-wide c sub-tiles per wave
   constexpr int NJ = BR / (16 * WR);   // 16-wide r sub-tiles per wave
@@ -1006,6 +1007,39 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
       int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>, lds);
       if (rc != OVQA_OK) return rc;
       OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>), grid2, dim3(256), lds, st, g, epi);
+      return ovqa_check_launch(what);
+    }
+  }
+  if constexpr (!QK && !PK) {
+    // ONE 16-wave workgroup (4 x 4 wave grid) on a 128 x 128 tile for the products that would otherwise run two co-resident
+    // 8-wave workgroups on 128 x 64 tiles per CU (6400 x 512 outputs: 200 tiles): the 128-row weight tile is staged once per
+    // CU instead of twice -- 32 instead of 48 KB per K step through the CU's L2 fetch path, which is what these loops wait
+    // for.  MEASURED (scripts/gemm_wg_timeline.py): span 8.2-8.5 -> 7.5-7.7 us (ring of 3; 6.9-7.3 with a ring of 2, which
+    // loses in the step, where operands are cold); step 3.407 / 3.389 -> 3.371 / 3.372 ms in two alternations (ring of 4:
+    // 3.412 / 3.365).  OVQA_GEMM_BIG16 = 0 off, 2 / 3 / 4 ring depth.
+    static int big16 = -1;
+    if (big16 < 0) {
+      const char* e = getenv("OVQA_GEMM_BIG16");
+      big16 = e ? atoi(e) : 3;
+    }
+    if (big16 && small_c && !tiny_c) {
+      g.tiles_c = (int)((C + BT - 1) / BT);
+      const dim3 grid16(g.tiles_r * g.tiles_c);
+      const int nb = big16 == 2 ? 2 : (big16 == 4 ? 4 : 3);
+      const size_t lds = (size_t)nb * 2 * TILE_BYTES;
+      if (nb == 4) {
+        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 16, 128, 128, 1>, lds);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
+      } else if (nb == 2) {
+        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 2, 16, 128, 128, 1>, lds);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 2, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
+      } else {
+        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 3, 16, 128, 128, 1>, lds);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 3, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
+      }
       return ovqa_check_launch(what);
     }
   }
