@@ -73,6 +73,9 @@ class Decoder(Module):
         so ``apply_to_states`` / ``reorder_states`` keep working (whatever they store is copied back in here)."""
         cur = self._buffers["running_mask_self_attention"]
         cache = getattr(self, "_mask_cache", None)
+        if cur.numel() > 0 and cur.dim() != 4:
+            raise RuntimeError("running_mask_self_attention must keep the reference's (rows, 1, 1, t) shape, got "
+                               f"{tuple(cur.shape)}")
         n = cur.shape[-1] if cur.dim() == 4 else 0
         if (cache is not None and cache.shape[0] == R and n < cache.shape[1] and cur.dim() == 4 and cur.shape[0] == R
                 and cur.dtype == torch.float32 and cur.data_ptr() == cache.data_ptr()):
