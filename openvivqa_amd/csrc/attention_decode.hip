@@ -67,6 +67,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(ovqa::AttnDecodeArgs a
       for (int e = 0; e < NV; e++) qf[g][l * NV + e] = to_f32<T>(v[e]) * a.scale;
     }
   }
+  // ---- the first V rows this lane will need are requested NOW, next to the K rows: they do not depend on the scores, and
+  // the wave's time is its chain of dependent memory round trips (K -> scores -> softmax -> V -> o was two of them + one
+  // more per further 32 keys; a quarter of 237 keys is now ONE round trip for K and V together)
+  constexpr int CH = D * (int)sizeof(T) / 16;  // 16-byte chunks per V row: 8 (bf16, d = 64)
+  constexpr int KG = 64 / CH;                  // keys in flight per pass
+  static_assert(CH >= 1 && CH <= 64 && 64 % CH == 0, "chunks per row divide the wave");
+  const int c = lane % CH, kg = lane / CH;
+  constexpr int UV = 8;  // V rows in flight per lane
+  vec_t vpre[UV];
+#pragma unroll
+  for (int u = 0; u < UV; u++)
+    vpre[u] = *reinterpret_cast<const vec_t*>(vb + (int64_t)min(j_lo + kg + KG * u, max(n - 1, 0)) * a.ldv + c * NV);
   // ---- scores: 16 keys per pass, every key row loaded once for the G queries
   float mx[G];
 #pragma unroll
@@ -74,12 +86,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(ovqa::AttnDecodeArgs a
   constexpr int UK = 4;  // passes in flight: the loads of 64 keys are issued before the first dot product
   for (int j0 = j_lo; j0 < n; j0 += 16 * UK) {
     vec_t kv[UK][NL];
+    float mk[UK][G];  // the additive mask of these keys: requested with the K rows, not one dependent load per use
 #pragma unroll
     for (int u = 0; u < UK; u++) {
       const int j = min(j0 + 16 * u + kk, n - 1);  // (clamped: always a valid row; results beyond n are dropped)
       const T* kr = kb + (int64_t)j * a.ldk + part * PER;
 #pragma unroll
       for (int l = 0; l < NL; l++) kv[u][l] = *reinterpret_cast<const vec_t*>(kr + l * NV);
+#pragma unroll
+      for (int g = 0; g < G; g++) mk[u][g] = a.mask ? a.mask[(int64_t)(r0 + g) * a.ldmask + j] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < UK; u++) {
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(ovqa::AttnDecodeArgs a
         dot[g] += __shfl_xor(dot[g], 1, 64);
         dot[g] += __shfl_xor(dot[g], 2, 64);
         if (j < n) {
-          const float sv = dot[g] + (a.mask ? a.mask[(int64_t)(r0 + g) * a.ldmask + j] : 0.f);
+          const float sv = dot[g] + mk[u][g];
           if (part == 0) sc[wave][g][j - j_lo] = sv;
           mx[g] = fmaxf(mx[g], sv);
         }
@@ -127,21 +142,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(ovqa::AttnDecodeArgs a
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   // ---- o = P V: lane -> 16-byte chunk c of key group kg
-  constexpr int CH = D * (int)sizeof(T) / 16;  // 16-byte chunks per V row: 8 (bf16, d = 64)
-  constexpr int KG = 64 / CH;                  // keys in flight per pass
-  static_assert(CH >= 1 && CH <= 64 && 64 % CH == 0, "chunks per row divide the wave");
-  const int c = lane % CH, kg = lane / CH;
   float acc[G][NV];
 #pragma unroll
   for (int g = 0; g < G; g++)
 #pragma unroll
     for (int e = 0; e < NV; e++) acc[g][e] = 0.f;
-  constexpr int UV = 4;  // V rows in flight per lane
-  for (int j0 = j_lo + kg; j0 < n; j0 += KG * UV) {
+  bool first = true;
+  for (int j0 = j_lo + kg; j0 < n; j0 += KG * UV, first = false) {
     vec_t vv[UV];
+    if (first) {  // (the first trip's rows are already here)
 #pragma unroll
-    for (int u = 0; u < UV; u++)
-      vv[u] = *reinterpret_cast<const vec_t*>(vb + (int64_t)min(j0 + KG * u, n - 1) * a.ldv + c * NV);
+      for (int u = 0; u < UV; u++) vv[u] = vpre[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UV; u++)
+        vv[u] = *reinterpret_cast<const vec_t*>(vb + (int64_t)min(j0 + KG * u, n - 1) * a.ldv + c * NV);
+    }
 #pragma unroll
     for (int u = 0; u < UV; u++) {
       const int j = j0 + KG * u;
