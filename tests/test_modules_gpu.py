@@ -663,3 +663,39 @@ def test_train_step_reference_trajectory_on_gpu(graph):
         assert nerr(head.weight, case.out["w2/head.weight"]) < 1e-3
     finally:
         A.set_compute_dtype(BF16)
+
+
+def test_npy_ingestion_feeds_feature_embedding(tmp_path, mode):
+    """``.npy`` dict-of-arrays files -> FeatureCollator (pinned staging, side-stream copy, fixed padded length) ->
+    FeatureEmbedding: the same features and zero-row padding mask as the oracle's embedding on the reference-collated
+    batch (utils/instance.py:31-54,155-170; vision_embeddings.py:10-25)."""
+    import numpy as np
+    import oracle as O
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.ingest import FeatureCollator, load_features
+    rng = np.random.default_rng(3)
+    lens = [100, 37, 81, 64]
+    for i, n in enumerate(lens):
+        np.save(tmp_path / f"{i}.npy", {"region_features": rng.standard_normal((n, 2048)).astype(np.float32)},
+                allow_pickle=True)
+    samples = [load_features(str(tmp_path / f"{i}.npy")) for i in range(len(lens))]
+    col = FeatureCollator(["region_features"], DEV, pad_to={"region_features": 100})
+    cfg = ConfigNode(dict(ARCHITECTURE="FeatureEmbedding", D_FEATURE=2048, D_MODEL=512, DROPOUT=0.1))
+    torch.manual_seed(1)
+    o = O.OracleFeatureEmbedding(cfg).eval()
+    h = M.FeatureEmbedding(cfg)
+    h.load_state_dict(o.state_dict())
+    h = h.to(DEV).eval()
+    ref = torch.zeros(len(lens), 100, 2048)
+    for i, s_ in enumerate(samples):
+        ref[i, :lens[i]] = torch.tensor(s_["region_features"])
+    for _ in range(3):  # the buffers are reused from the third batch on
+        batch = col.collate(samples)
+        col.wait()
+        assert torch.equal(batch["region_features"].cpu(), ref)
+    with torch.no_grad():
+        fh, mh = h(batch["region_features"])
+        fo, mo = o(ref)
+    assert torch.equal(mh.cpu() != 0, mo != 0)
+    assert nerr(fh, fo) < (1e-3 if mode == F32 else 1e-2)

@@ -427,3 +427,38 @@ def test_fp32_twin_is_dropped_after_an_in_place_change():
     assert torch.equal(Fn.finalize(w, torch.float32), x32)
     w.mul_(2)
     assert torch.equal(Fn.finalize(w, torch.float32), w.float())
+
+
+def test_npy_feature_ingestion_matches_reference_collation(tmp_path):
+    """SURVEY 8f row 2 (second half): per-image pickled-dict ``.npy`` files (data_utils/datasets/base_dataset.py:27-34)
+    collated like utils/instance.py:31-54,155-170 -- zero-pad every array field to the longest sample, stack -- into reused
+    buffers; ``pad_to`` fixes the padded length (more zero rows = more padding positions for the row mask)."""
+    import numpy as np
+    from openvivqa_amd.ingest import FeatureCollator, load_features
+    rng = np.random.default_rng(0)
+    lens = [7, 3, 5]
+    for i, n in enumerate(lens):
+        np.save(tmp_path / f"{i}.npy", {"region_features": rng.standard_normal((n, 16)).astype(np.float32),
+                                        "region_boxes": rng.random((n, 4)).astype(np.float32),
+                                        "width": 640, "texts": ["a"] * n}, allow_pickle=True)
+    samples = [load_features(str(tmp_path / f"{i}.npy")) for i in range(3)]
+    assert isinstance(samples[0]["texts"], list) and samples[0]["width"] == 640
+
+    def reference_collate(values):  # InstanceList.pad_values + cat, restated
+        vals = [torch.tensor(v) for v in values]
+        m = max(v.shape[0] for v in vals)
+        return torch.cat([torch.cat([v, torch.zeros(m - v.shape[0], v.shape[-1])], 0).unsqueeze(0) for v in vals], 0)
+    col = FeatureCollator(["region_features", "region_boxes"], "cpu")
+    out = col.collate(samples)
+    for k in ("region_features", "region_boxes"):
+        assert torch.equal(out[k], reference_collate([s[k] for s in samples]))
+    # a second, shorter batch through the same (reused) buffers: no stale rows of the first one
+    first = out["region_features"].clone()
+    col2 = FeatureCollator(["region_features"], "cpu", pad_to={"region_features": 10}, depth=1)
+    a = col2.collate(samples)["region_features"]
+    assert a.shape == (3, 10, 16) and torch.equal(a[:, :7], first) and not a[:, 7:].any()
+    b = col2.collate([samples[1], samples[2], samples[1]])["region_features"]
+    assert b.data_ptr() == a.data_ptr() and not b[0, 3:].any() and not b[1, 5:].any()
+    assert torch.equal(b[1, :5], torch.tensor(samples[2]["region_features"]))
+    with pytest.raises(ValueError):
+        FeatureCollator(["region_features"], "cpu", pad_to={"region_features": 4}).collate(samples)
