@@ -288,6 +288,18 @@ int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, 
  * (beam_search.py:36-39 takes them from a full sort of the cur_beam * |V| candidates). */
 int ovqa_topk_rows(const float* x, int64_t ldx, int64_t R, int64_t V, int64_t k, float* vals, int64_t* idx, void* stream);
 
+/* Cross / guided attention forward with the QUERY projection inside (ABI 5): q = x W_q^T + b_q (written: backward reads
+ * it), o, lse = attention(q, k, v, key mask) for keys and values that are ALREADY projected -- the hoisted K / V
+ * projection of GuidedAttentionEncoder (encoders.py:83-96 applies fc_k / fc_v of every layer to the same language
+ * features) or a packed K | V projection; MultiHeadAttention.forward with queries != keys (attentions.py:316-326 ->
+ * :49-57).  x [B * nq, d_model], w = fc_q weight [H * d, d_model]; k / v [B * nk, >= H * d] with their row strides; mask:
+ * fp32 additive key mask, element (b, h, j) at mask[b * msb + h * msh + j], or NULL.  bf16, d = 64, nq <= 128, nk <= 128,
+ * d_model a multiple of 64: one kernel; otherwise ovqa_linear_fwd + ovqa_attention_fwd inside. */
+int ovqa_attention_q_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* q, int64_t ldq,
+                         const void* k, int64_t ldk, const void* v, int64_t ldv, const float* mask, int64_t msb, int64_t msh,
+                         void* o, int64_t ldo, float* lse, void* o_lo, int64_t B, int64_t H, int64_t nq, int64_t nk,
+                         int64_t d_model, int64_t d, float scale, void* stream);
+
 /* Three products of one input in one launch (ABI 5): y_i[m, :] = x[m, :] W_i^T + b_i, i = 0..2, for three weight matrices
  * stacked as w [3 F, K] (bias [3 F] or NULL), every output with its own base pointer and row stride.  A decoding step's
  * fc_q / fc_k / fc_v (attentions.py:49-51 on the one new position): q into a buffer, k and v straight into their slots of

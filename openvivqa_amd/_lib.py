@@ -91,6 +91,8 @@ SIGNATURES = {
     "ovqa_launch_timing_end": [c_vp, c_int],
     "ovqa_attention_qkv_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
                                c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
+    "ovqa_attention_q_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64,
+                             c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_attention_decode": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
                               c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_topk_rows": [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],

@@ -379,6 +379,32 @@ int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w,
                             n, n, d, d, scale, nullptr, stream);
 }
 
+int ovqa_attention_q_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* q, int64_t ldq,
+                         const void* k, int64_t ldk, const void* v, int64_t ldv, const float* mask, int64_t msb, int64_t msh,
+                         void* o, int64_t ldo, float* lse, void* o_lo, int64_t B, int64_t H, int64_t nq, int64_t nk,
+                         int64_t d_model, int64_t d, float scale, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_q_fwd: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 1 && d > 0 && d_model > 0, OVQA_ERR_BAD_ARG, "attention_q_fwd: bad sizes");
+  if (B == 0 || nq == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && w && q && k && v && o, OVQA_ERR_BAD_ARG, "attention_q_fwd: null pointer");
+  OVQA_REQUIRE(ldx >= d_model && ldq >= H * d && ldk >= H * d && ldv >= H * d && ldo >= H * d, OVQA_ERR_BAD_ARG,
+               "attention_q_fwd: row stride smaller than the row");
+  OVQA_REQUIRE(B * H <= 0x7fffffff && B * nq <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_q_fwd: batch too large");
+  ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, mask, msb, msh, 0, o, ldo, lse, nullptr,
+                   (int)B, (int)H, (int)nq, (int)nk, (int)d, (int)d, scale, make_drop_args(nullptr)};
+  a.o_lo = dtype == OVQA_BF16 ? o_lo : nullptr;
+  if (dtype == OVQA_BF16 && !force_simple() && !no_fused_qkv() &&
+      ovqa::mfma_attention_q_supported(a, d_model, ldx, ldq, x, w, q)) {
+    g_dispatch = "mfma-fused";
+    return ovqa::mfma_attention_q_fwd(a, x, ldx, w, bias, q, ldq, d_model, as_stream(stream));
+  }
+  int rc = ovqa_linear_fwd(dtype, OVQA_EPI_BIAS, x, ldx, w, bias, nullptr, 0, q, ldq, nullptr, B * nq, H * d, d_model,
+                           nullptr, stream);
+  if (rc != OVQA_OK) return rc;
+  return ovqa_attention_fwd(dtype, q, ldq, k, ldk, v, ldv, mask, msb, msh, 0, o, ldo, lse, nullptr, o_lo, B, H, nq, nk, d,
+                            d, scale, nullptr, stream);
+}
+
 int ovqa_attention_decode(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                           int64_t kv_batch_stride, int64_t group, const float* mask, int64_t ldmask, void* o, int64_t ldo,
                           int64_t R, int64_t H, int64_t n, int64_t d, float scale, void* stream) {

@@ -500,6 +500,131 @@ __global__ __launch_bounds__(512) void attn_qkv_fwd_mfma_kernel(QkvAttnArgs g) {
   OVQA_PROBE(5);
 }
 
+// ------------------------------------------------------------------------- fused Q projection + attention (round 3)
+// Cross / guided attention forward with the QUERY projection inside: the keys and values are already projected (the
+// hoisted K / V GEMM of the guided stack, or a packed K | V projection), only q = x W_q^T + b_q is computed here -- the
+// main loop of attn_qkv_fwd_mfma_kernel on 64 weight rows instead of 192 -- stored to HBM (backward reads it) and into
+// the LDS image the attention core reads; K / V of the head (NKT * 32 padded keys) are staged next to it.  One launch
+// instead of a 6400 x 512 <- 512 GEMM + the attention kernel, and q is not re-read.
+// RP = 128 query rows of ONE sample per workgroup (8 waves as 4 (rows) x 2 (features): 32 x 32 per wave), K steps of 64,
+// ring of NBUF stages.
+struct QAttnArgs {
+  const bf16* x; int64_t ldx;       // [B * nq, Dm]
+  const bf16* w;                    // fc_q weight [H * 64, Dm]
+  const float* bias;                // [H * 64] or nullptr
+  bf16* q; int64_t ldq;             // [B * nq, H * 64] out
+  ovqa::AttnArgs att;               // k, v (+ strides), o, lse, o_lo, key mask row, B, H, nq, nk, scale
+  int Dm;
+};
+
+template <int NKT, int NBUF>
+__global__ __launch_bounds__(512) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
+  constexpr int RP = 128, BKF = 64, NI = 2, NJ = 2, TQ = RP / 32, KP = NKT * 32;
+  constexpr int PROWS = 8, CHR = 8;                  // a 1 KiB staging piece = 8 rows of 128 B
+  constexpr int WCH = 64 / PROWS, XCH = RP / PROWS;  // 8 + 16 pieces per stage: 3 per wave
+  constexpr int PER = (WCH + XCH) / 8;
+  constexpr int STAGE = (WCH + XCH) * 1024;
+  static_assert((WCH + XCH) % 8 == 0, "every wave stages the same number of pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ovqa::AttnArgs& a = g.att;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wr = wave & 1;
+  const int h = blockIdx.y, b = blockIdx.x, nq = a.nq, nk = a.nk;
+
+  f32x4 acc[NJ][NI];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto off32 = [&](int row, int ch) { return row * (BKF * 2) + ((ch ^ (row & 7)) << 4); };
+  const bf16* src[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int ci = wave + 8 * i;
+    const int prow = lane / CHR, pch = lane % CHR;
+    if (ci < WCH) {  // this head's 64 fc_q rows, permuted within 32 (a lane then owns 8 consecutive output features)
+      const int row = ci * PROWS + prow;
+      src[i] = g.w + (int64_t)(h * 64 + perm32(row)) * g.Dm + ((pch ^ (row & 7)) << 3);
+    } else {         // x rows of the sample, clamped to its last row
+      const int row = (ci - WCH) * PROWS + prow;
+      const int r = row < nq ? row : nq - 1;
+      src[i] = g.x + ((int64_t)b * nq + r) * g.ldx + ((pch ^ (row & 7)) << 3);
+    }
+  }
+  float4 bias_r[2];
+  {
+    const int f = wr * 32 + (lane >> 4) * 8;
+    bias_r[0] = g.bias ? *reinterpret_cast<const float4*>(g.bias + h * 64 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias_r[1] = g.bias ? *reinterpret_cast<const float4*>(g.bias + h * 64 + f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt % NBUF) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  const int nkt = g.Dm / BKF;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nkt) issue(p);
+  for (int kt = 0; kt < nkt; kt++) {
+    if (kt + NBUF - 2 >= nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NBUF - 2)) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
+    const char* Ws = smem + (kt % NBUF) * STAGE;
+    const char* Xs = Ws + WCH * 1024;
+#pragma unroll
+    for (int ks = 0; ks < BKF / 32; ks++) {
+      bf16x8 pf[NJ], qf[NI];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 32 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * 32 + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with the staging buffers: they become the Q | K | V images
+
+  // ---- images: Q [RP][64] from the accumulators (+ bias; also to HBM), K | V [KP][64] of this (sample, head) from HBM
+  char* Qs = smem;
+  char* Ks = Qs + RP * 128;
+  char* Vs = Ks + KP * 128;
+  float* mrow_s = reinterpret_cast<float*>(Vs + KP * 128);
+  const ImgDesc kv[2] = {{Ks, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, KP},
+                         {Vs, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, KP}};
+  if (tid < 256) {
+    load_images<2, 64>(kv, tid);
+    load_mask_row(mrow_s, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, KP, tid);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int r = wc * 32 + i * 16 + (lane & 15);
+    const int col = wr * 32 + (lane >> 4) * 8;
+    bf16x8 o8;
+    o8[0] = (bf16)(acc[0][i][0] + bias_r[0].x); o8[1] = (bf16)(acc[0][i][1] + bias_r[0].y);
+    o8[2] = (bf16)(acc[0][i][2] + bias_r[0].z); o8[3] = (bf16)(acc[0][i][3] + bias_r[0].w);
+    o8[4] = (bf16)(acc[1][i][0] + bias_r[1].x); o8[5] = (bf16)(acc[1][i][1] + bias_r[1].y);
+    o8[6] = (bf16)(acc[1][i][2] + bias_r[1].z); o8[7] = (bf16)(acc[1][i][3] + bias_r[1].w);
+    *reinterpret_cast<bf16x8*>(Qs + Img<64>::off(r, col >> 3)) = o8;
+    if (r < nq) *reinterpret_cast<bf16x8*>(g.q + ((int64_t)b * nq + r) * g.ldq + h * 64 + col) = o8;
+  }
+  __syncthreads();
+
+  // ---- attention on the images: one wave per 32-query tile (waves 4-7 are done)
+  const int tq = wave;
+  if (tq >= TQ || tq * 32 >= nq) return;
+  attn_fwd_core<NKT, true, false, 64>(a, b, h, tq * 32, tq * 32, Qs, Ks, Vs, mrow_s, lane);
+}
+
 // ------------------------------------------------------------------------------------------ backward
 // Kernel A: one wave = 32 queries (columns).  delta_q = dO_q . O_q ;  for every key tile:
 //   S^T = K Q^T, dP^T = V dO^T, P^T = exp(S^T*scale + mask - lse_q), dS^T = P^T (dP^T - delta_q),
@@ -1552,6 +1677,46 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
   else OVQA_QKV(128, 2, 32, 4)
 #undef OVQA_QKV
   return ovqa_check_launch("attention_qkv_fwd(mfma)");
+}
+
+bool mfma_attention_q_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldq, const void* x, const void* w,
+                                const void* q) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return a.dk == 64 && a.dv == 64 && a.nq >= 1 && a.nq <= 128 && a.nk >= 1 && a.nk <= 128 && Dm % 64 == 0 && Dm >= 64 &&
+         ldx % 8 == 0 && ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0 && a.msq == 0 &&
+         a.att == nullptr && a.drop.p <= 0.f && al(x) && al(w) && al(q) && al(a.k) && al(a.v) &&
+         (((uintptr_t)a.o & 7) == 0);
+}
+
+int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* q,
+                         int64_t ldq, int64_t Dm, hipStream_t st) {
+  QAttnArgs g{(const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)q, ldq, a, (int)Dm};
+  const dim3 grid((unsigned)a.B, (unsigned)a.H);
+#define OVQA_QATT(NKTV)                                                                                      \
+  {                                                                                                          \
+    const size_t stage = (size_t)(64 + 128) * 64 * 2, images = (size_t)(128 + 2 * NKTV * 32) * 128 + NKTV * 32 * 4; \
+    if (nbuf == 3) {                                                                                         \
+      const size_t lds = 3 * stage > images ? 3 * stage : images;                                            \
+      int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, 3>, lds, "attention_q_fwd");                          \
+      if (rc != OVQA_OK) return rc;                                                                          \
+      hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, 3>), grid, dim3(512), lds, st, g);                    \
+    } else {                                                                                                 \
+      const size_t lds = 2 * stage > images ? 2 * stage : images;                                            \
+      int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, 2>, lds, "attention_q_fwd");                          \
+      if (rc != OVQA_OK) return rc;                                                                          \
+      hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, 2>), grid, dim3(512), lds, st, g);                    \
+    }                                                                                                        \
+  }
+  static int nbuf = -1;
+  if (nbuf < 0) {
+    const char* e = getenv("OVQA_QATT_NBUF");  // ring depth of the projection loop (A/B switch)
+    nbuf = e ? atoi(e) : 3;
+  }
+  if (a.nk <= 32) OVQA_QATT(1)
+  else if (a.nk <= 64) OVQA_QATT(2)
+  else OVQA_QATT(4)
+#undef OVQA_QATT
+  return ovqa_check_launch("attention_q_fwd(mfma)");
 }
 
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st) {

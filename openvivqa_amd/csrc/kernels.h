@@ -100,6 +100,10 @@ bool mfma_attention_supported(const AttnArgs& a);
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st);
 bool mfma_attention_qkv_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldqkv, const void* x, const void* w,
                                   const void* qkv);
+bool mfma_attention_q_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int64_t ldq, const void* x, const void* w,
+                                const void* q);
+int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* q,
+                         int64_t ldq, int64_t Dm, hipStream_t st);
 int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
                            int64_t ldqkv, int64_t Dm, hipStream_t st);
 bool mfma_attention_bwd_supported(const AttnBwdArgs& a);

@@ -313,6 +313,16 @@ def _project_and_attend(st, queries, keys, values, mask, save_lse=True, lo_out=N
                                             arena.packed([a.fc_q.bias, a.fc_k.bias, a.fc_v.bias], "master"), mask, a.h,
                                             save_lse=save_lse, lo_out=lo_out)
         return o, lse, "self", (qkv,)
+    if (st.get("pre_kv") is not None and st.get("att_drop") is None and (mask is None or mask.shape[2] == 1)
+            and a.fc_q.weight.shape[0] == a.fc_v.weight.shape[0] and queries.dim() == 3
+            and os.environ.get("OVQA_NO_FUSED_Q", "0") != "1"):
+        # guided / cross attention on hoisted K | V projections: the query projection inside the attention kernel
+        wk, nv = a.fc_k.weight, a.fc_v.weight.shape[0]
+        base = st["pre_kv"][0] * (wk.shape[0] + nv)
+        k, v = keys[..., base:base + wk.shape[0]], keys[..., base + wk.shape[0]:base + wk.shape[0] + nv]
+        q, o, lse = ops.attention_q_fwd(queries, arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias), k, v, mask,
+                                        a.h, save_lse=save_lse, lo_out=lo_out)
+        return o, lse, "pre", (q,)
     q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
     o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"), lo_out=lo_out)
     return o, lse, mode, bufs

@@ -607,6 +607,33 @@ def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=Non
     return qkv, o, lse
 
 
+def attention_q_fwd(x, w, bias, k, v, mask, H, scale=None, save_lse=True, lo_out=None):
+    """Cross / guided attention forward with the query projection inside (``ovqa_attention_q_fwd``): x [B,nq,d_model],
+    w = fc_q weight [H*d, d_model], bias fp32 [H*d]; k, v [B,nk,H*d] already projected (strided views of a packed buffer
+    are fine) -> (q [B,nq,H*d], o [B,nq,H*d], lse).  ``mask``: key mask (b|1, h|1, 1, nk) or None."""
+    _dev(x)
+    lib = _lib.load()
+    B, nq, Dm = x.shape
+    nk = k.shape[1]
+    d = w.shape[0] // H
+    assert w.shape[0] == H * d and w.shape[1] == Dm and w.is_contiguous() and w.dtype == x.dtype
+    assert k.shape[0] == B and v.shape[:2] == k.shape[:2] and k.shape[2] == H * d == v.shape[2] and k.dtype == x.dtype
+    ldx, _ = _rows(x)
+    ldk, _ = _rows(k)
+    ldv, _ = _rows(v)
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    q = torch.empty(B, nq, H * d, dtype=x.dtype, device=x.device)
+    o = torch.empty(B, nq, H * d, dtype=x.dtype, device=x.device)
+    lse = torch.empty(B, H, nq, dtype=torch.float32, device=x.device) if save_lse else None
+    mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    assert sq == 0, "attention_q_fwd takes a key mask (one row per (b, h))"
+    lo = _lo_buffer(lo_out, o)
+    _lib.check(lib.ovqa_attention_q_fwd(_dt(x), _p(x), ldx, _p(w), _p(bias), _p(q), H * d, _p(k), ldk, _p(v), ldv, _p(mask),
+                                        sb, sh, _p(o), H * d, _p(lse), _p(lo), B, H, nq, nk, Dm, d, float(scale),
+                                        _stream()), "attention_q_fwd")
+    return q, o, lse
+
+
 def attention_decode(q, k_cache, v_cache, n, H, mask=None, group=1, scale=None, out=None):
     """One decoding step's attention (``ovqa_attention_decode``): q [R, 1, H*d] or [R, H*d]; k_cache / v_cache
     [R // group, Lmax, H*d] in-place caches of which the first ``n`` keys are live (the ``group`` beams of a sample

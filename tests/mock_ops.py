@@ -193,6 +193,12 @@ def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=Non
     return qkv, o, lse
 
 
+def attention_q_fwd(x, w, bias, k, v, mask, H, scale=None, save_lse=True, lo_out=None):
+    q = linear_fwd(x, w, bias)
+    o, lse, _ = attention_fwd(q, k, v, mask, H, scale, save_lse=save_lse, lo_out=lo_out)
+    return q, o, lse
+
+
 def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, d_att=None, d_lse=None,
                   att_drop=None, o_lo=None):
     assert att_drop is None or att_drop.p == 0

@@ -932,3 +932,32 @@ def test_linear_fwd_split3_writes_three_strided_outputs(dtype, M):
     # the same values as three separate launches of the same kernels
     sep = [o.linear_fwd(x, w[i * F:(i + 1) * F].contiguous(), b[i * F:(i + 1) * F].contiguous()) for i in range(3)]
     assert torch.equal(q, sep[0])
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 64), (2, 37, 100), (5, 20, 1), (4, 100, 33)])
+def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
+    """ovqa_attention_q_fwd (query projection inside the attention kernel; K / V already projected, as strided views of
+    a packed buffer) against ovqa_linear_fwd + ovqa_attention_fwd: q bit-equal, o / lse within the kernels' tolerance,
+    and the rounding residual o_lo written."""
+    o_ = ops()
+    H, d, Dm = 8, 64, 512
+    x = rnd(B, nq, Dm, dtype=dtype)
+    w = rnd(H * d, Dm, dtype=dtype, scale=Dm ** -0.5, seed=1)
+    b = rnd(H * d, seed=2)
+    kv = rnd(B, nk, 3 * 2 * H * d, dtype=dtype, seed=3)  # packed K | V of three layers: slot 1 is ours
+    k, v = kv[..., 2 * H * d:3 * H * d], kv[..., 3 * H * d:4 * H * d]
+    mask = torch.zeros(B, 1, 1, nk, device=DEV)
+    if nk > 3:
+        mask[0, :, :, nk - 3:] = -1e5
+    lo, lo2 = [], []
+    q, o, lse = o_.attention_q_fwd(x, w, b, k, v, mask, H, lo_out=lo)
+    if dtype == BF16 and not FORCED_SIMPLE and not NO_FUSED_QKV:
+        from openvivqa_amd import _lib
+        assert _lib.last_dispatch() == "mfma-fused"
+    q2 = o_.linear_fwd(x, w, b)
+    o2, lse2, _ = o_.attention_fwd(q2, k, v, mask, H, lo_out=lo2)
+    assert torch.equal(q, q2) if dtype == BF16 else nerr(q, q2) < 1e-5
+    assert nerr(o, o2) < tol(dtype) and nerr(lse, lse2) < 1e-3
+    if dtype == BF16:
+        assert len(lo) == 1 and nerr(o.float() + lo[0].float(), o2.float() + lo2[0].float()) < 2e-3
