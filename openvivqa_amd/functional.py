@@ -323,6 +323,16 @@ def _project_and_attend(st, queries, keys, values, mask, save_lse=True, lo_out=N
         q, o, lse = ops.attention_q_fwd(queries, arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias), k, v, mask,
                                         a.h, save_lse=save_lse, lo_out=lo_out)
         return o, lse, "pre", (q,)
+    if (st.get("pre_kv") is None and keys is values and queries is not keys and st.get("att_drop") is None
+            and (mask is None or mask.shape[2] == 1) and a.fc_q.weight.shape[0] == a.fc_k.weight.shape[0] == a.fc_v.weight.shape[0]
+            and queries.dim() == 3 and keys.dim() == 3 and os.environ.get("OVQA_NO_FUSED_Q", "0") != "1"):
+        # cross attention (keys is values): the packed K | V projection, then the query projection inside the attention
+        wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
+        kv = ops.linear_fwd(keys, arena.packed([wk, wv]), arena.packed([a.fc_k.bias, a.fc_v.bias], "master"))
+        nqk = wq.shape[0]
+        q, o, lse = ops.attention_q_fwd(queries, arena.compute(wq), arena.master_of(a.fc_q.bias), kv[..., :nqk],
+                                        kv[..., nqk:], mask, a.h, save_lse=save_lse, lo_out=lo_out)
+        return o, lse, "cross", (q, kv)
     q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
     o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"), lo_out=lo_out)
     return o, lse, mode, bufs
