@@ -385,7 +385,8 @@ def test_attention_bwd_delta_uses_the_output_residual(B, H, nq, nk):
     e1, e0 = (rel(dq1, qd.grad), rel(dk1, kd.grad)), (rel(dq0, qd.grad), rel(dk0, kd.grad))
     assert rel(dv1, vd.grad) < 1e-2 and rel(dv0, vd.grad) < 1e-2
     assert e1[0] < 2e-2 and e1[1] < 2e-2, (e1, e0)           # bf16 dS into the matrix cores is what is left
-    assert e1[0] < 0.2 * e0[0] and e1[1] < 0.2 * e0[1], (e1, e0)  # ... and the rounded-O delta was most of the error
+    if not FORCED_SIMPLE:  # (the VALU kernels take delta = rowsum(P dP) from fp32 probabilities: no O involved)
+        assert e1[0] < 0.2 * e0[0] and e1[1] < 0.2 * e0[1], (e1, e0)  # ... and the rounded-O delta was most of the error
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
