@@ -936,7 +936,8 @@ def test_linear_fwd_split3_writes_three_strided_outputs(dtype, M):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 64), (2, 37, 100), (5, 20, 1), (4, 100, 33)])
+@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 64), (2, 37, 100), (5, 20, 1), (4, 100, 33), (2, 150, 20),
+                                     (2, 100, 200)])
 def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
     """ovqa_attention_q_fwd (query projection inside the attention kernel; K / V already projected, as strided views of
     a packed buffer) against ovqa_linear_fwd + ovqa_attention_fwd: q bit-equal, o / lse within the kernels' tolerance,
@@ -953,9 +954,9 @@ def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
         mask[0, :, :, nk - 3:] = -1e5
     lo, lo2 = [], []
     q, o, lse = o_.attention_q_fwd(x, w, b, k, v, mask, H, lo_out=lo)
-    if dtype == BF16 and not FORCED_SIMPLE and not NO_FUSED_QKV:
+    if dtype == BF16 and not FORCED_SIMPLE and not NO_FUSED_QKV and nq <= 128 and nk <= 128:
         from openvivqa_amd import _lib
-        assert _lib.last_dispatch() == "mfma-fused"
+        assert _lib.last_dispatch() == "mfma-fused"  # (longer sequences: the two separate kernels inside the library)
     q2 = o_.linear_fwd(x, w, b)
     o2, lse2, _ = o_.attention_fwd(q2, k, v, mask, H, lo_out=lo2)
     assert torch.equal(q, q2) if dtype == BF16 else nerr(q, q2) < 1e-5
