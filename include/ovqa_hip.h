@@ -300,6 +300,20 @@ int ovqa_attention_q_fwd(int dtype, const void* x, int64_t ldx, const void* w, c
                          void* o, int64_t ldo, float* lse, void* o_lo, int64_t B, int64_t H, int64_t nq, int64_t nk,
                          int64_t d_model, int64_t d, float scale, void* stream);
 
+/* Attention backward with the dO projection inside (ABI 5): the gradient reaches the attention core through fc_o,
+ * dO = dY W_o (autograd of attentions.py:58), and the fc_o dX product is folded into the backward kernel -- per head,
+ * dO_h = dY wt[h*d:(h+1)*d, :]^T from the TRANSPOSED weight copy wt [H*d, d_model] (what ovqa_adam_step_tiled maintains) --
+ * so dO never travels through HBM.  dy [B*nq, d_model]; everything else as ovqa_attention_bwd with a key mask (msq = 0),
+ * no d_att / d_lse / dropout.  bf16, d = 64, 64 < nq <= 128, nk <= 32 (guided attention: 100 queries x 20 keys): one
+ * kernel; otherwise, if `d_o_scratch` [B*nq, lddo] is given, ovqa_linear_bwd_data_wt into it + ovqa_attention_bwd;
+ * otherwise OVQA_ERR_UNSUPPORTED. */
+int ovqa_attention_bwd_do(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, void* d_o_scratch,
+                          int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const void* o, int64_t ldo, const void* o_lo, const float* lse, const float* mask, int64_t msb,
+                          int64_t msh, void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv, float* delta,
+                          int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t d_model, int64_t d, float scale,
+                          void* stream);
+
 /* Three products of one input in one launch (ABI 5): y_i[m, :] = x[m, :] W_i^T + b_i, i = 0..2, for three weight matrices
  * stacked as w [3 F, K] (bias [3 F] or NULL), every output with its own base pointer and row stride.  A decoding step's
  * fc_q / fc_k / fc_v (attentions.py:49-51 on the one new position): q into a buffer, k and v straight into their slots of

@@ -496,6 +496,36 @@ int ovqa_attention_bwd(int dtype, const void* d_o, int64_t lddo, const void* q, 
   return ovqa::simple_attention_bwd(dtype, a, as_stream(stream));
 }
 
+int ovqa_attention_bwd_do(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, void* d_o_scratch,
+                          int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                          const void* o, int64_t ldo, const void* o_lo, const float* lse, const float* mask, int64_t msb,
+                          int64_t msh, void* dq, int64_t lddq, void* dk_, int64_t lddk, void* dv_, int64_t lddv, float* delta,
+                          int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t d_model, int64_t d, float scale,
+                          void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "attention_bwd_do: bad dtype %d", dtype);
+  OVQA_REQUIRE(B >= 0 && H > 0 && nq >= 0 && nk >= 0 && d > 0 && d_model > 0, OVQA_ERR_BAD_ARG, "attention_bwd_do: bad sizes");
+  if (B == 0 || nq == 0) return OVQA_OK;
+  OVQA_REQUIRE(dy && wt && q && k && v && o && dq && dk_ && dv_ && lse, OVQA_ERR_BAD_ARG, "attention_bwd_do: null pointer");
+  OVQA_REQUIRE(lddy >= d_model && ldwt >= d_model, OVQA_ERR_BAD_ARG, "attention_bwd_do: row stride smaller than the row");
+  OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_bwd_do: B*H too large");
+  ovqa::AttnBwdArgs a{d_o_scratch, q, k, v, o, nullptr, lddo, ldq, ldk, ldv, ldo, lse, mask, msb, msh, 0, dq, dk_, dv_,
+                      lddq, lddk, lddv, delta, (int)B, (int)H, (int)nq, (int)nk, (int)d, (int)d, scale,
+                      make_drop_args(nullptr), nullptr};
+  a.o_lo = dtype == OVQA_BF16 ? o_lo : nullptr;
+  if (dtype == OVQA_BF16 && !force_simple() && !no_fused_qkv() &&
+      ovqa::mfma_attention_bwd_do_supported(a, d_model, lddy, ldwt, dy, wt)) {
+    g_dispatch = "mfma-fused";
+    return ovqa::mfma_attention_bwd_do(a, dy, lddy, wt, ldwt, d_model, as_stream(stream));
+  }
+  OVQA_REQUIRE(d_o_scratch != nullptr, OVQA_ERR_UNSUPPORTED,
+               "attention_bwd_do: shape not covered by the fused kernel and no dO buffer for the two-kernel form");
+  int rc = ovqa_linear_bwd_data_wt(dtype, dy, lddy, wt, ldwt, d_o_scratch, lddo, nullptr, nullptr, 0, B * nq, d_model, H * d,
+                                   nullptr, stream);
+  if (rc != OVQA_OK) return rc;
+  return ovqa_attention_bwd(dtype, d_o_scratch, lddo, q, ldq, k, ldk, v, ldv, o, ldo, o_lo, nullptr, lse, mask, msb, msh, 0,
+                            dq, lddq, dk_, lddk, dv_, lddv, delta, nullptr, B, H, nq, nk, d, d, scale, nullptr, stream);
+}
+
 int ovqa_pointer_score(int dtype, const void* q, const void* k, const float* add_mask, const uint8_t* key_fill,
                        const uint8_t* query_fill, float* scores, int64_t B, int64_t T, int64_t Nk, int64_t D,
                        float scale, void* stream) {

@@ -517,19 +517,22 @@ struct QAttnArgs {
   int Dm;
 };
 
-template <int NKT, int NBUF>
-__global__ __launch_bounds__(512) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
-  constexpr int RP = 128, BKF = 64, NI = 2, NJ = 2, TQ = RP / 32, KP = NKT * 32;
-  constexpr int PROWS = 8, CHR = 8;                  // a 1 KiB staging piece = 8 rows of 128 B
-  constexpr int WCH = 64 / PROWS, XCH = RP / PROWS;  // 8 + 16 pieces per stage: 3 per wave
-  constexpr int PER = (WCH + XCH) / 8;
+// NH = heads per workgroup (1: 8 waves; 2: 16 waves, the x rows are staged ONCE for both heads -- 32 instead of 48 KB per
+// K step through the CU's fetch path -- and 64 samples x 4 head pairs are exactly one workgroup per CU).
+template <int NKT, int NBUF, int NH>
+__global__ __launch_bounds__(512 * NH) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
+  constexpr int RP = 128, BKF = 64, NI = 2, NJ = 2, TQ = RP / 32, KP = NKT * 32, NW = 8 * NH;
+  constexpr int PROWS = 8, CHR = 8;                       // a 1 KiB staging piece = 8 rows of 128 B
+  constexpr int WCH = 64 * NH / PROWS, XCH = RP / PROWS;  // weight / x pieces per stage
+  constexpr int PER = (WCH + XCH) / NW;
   constexpr int STAGE = (WCH + XCH) * 1024;
-  static_assert((WCH + XCH) % 8 == 0, "every wave stages the same number of pieces");
+  constexpr int IMG = (RP + 2 * KP) * 128;                // Q | K | V images of one head
+  static_assert((WCH + XCH) % NW == 0, "every wave stages the same number of pieces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ovqa::AttnArgs& a = g.att;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave >> 1, wr = wave & 1;
-  const int h = blockIdx.y, b = blockIdx.x, nq = a.nq, nk = a.nk;
+  const int wc = wave / (2 * NH), wr = wave % (2 * NH);  // 4 row quarters x 2 NH feature slabs of 32
+  const int h0 = blockIdx.y * NH, b = blockIdx.x, nq = a.nq, nk = a.nk;
 
   f32x4 acc[NJ][NI];
 #pragma unroll
@@ -540,11 +543,11 @@ __global__ __launch_bounds__(512) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
   const bf16* src[PER];
 #pragma unroll
   for (int i = 0; i < PER; i++) {
-    const int ci = wave + 8 * i;
+    const int ci = wave + NW * i;
     const int prow = lane / CHR, pch = lane % CHR;
-    if (ci < WCH) {  // this head's 64 fc_q rows, permuted within 32 (a lane then owns 8 consecutive output features)
+    if (ci < WCH) {  // the heads' fc_q rows, permuted within 32 (a lane then owns 8 consecutive output features)
       const int row = ci * PROWS + prow;
-      src[i] = g.w + (int64_t)(h * 64 + perm32(row)) * g.Dm + ((pch ^ (row & 7)) << 3);
+      src[i] = g.w + (int64_t)(h0 * 64 + perm32(row)) * g.Dm + ((pch ^ (row & 7)) << 3);
     } else {         // x rows of the sample, clamped to its last row
       const int row = (ci - WCH) * PROWS + prow;
       const int r = row < nq ? row : nq - 1;
@@ -553,15 +556,15 @@ __global__ __launch_bounds__(512) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
   }
   float4 bias_r[2];
   {
-    const int f = wr * 32 + (lane >> 4) * 8;
-    bias_r[0] = g.bias ? *reinterpret_cast<const float4*>(g.bias + h * 64 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    bias_r[1] = g.bias ? *reinterpret_cast<const float4*>(g.bias + h * 64 + f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int f = h0 * 64 + wr * 32 + (lane >> 4) * 8;
+    bias_r[0] = g.bias ? *reinterpret_cast<const float4*>(g.bias + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias_r[1] = g.bias ? *reinterpret_cast<const float4*>(g.bias + f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
 #pragma unroll
     for (int i = 0; i < PER; i++)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + 8 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + NW * i) * 1024), 16, 0, 0);
   };
   const int nkt = g.Dm / BKF;
 #pragma unroll
@@ -594,35 +597,40 @@ __global__ __launch_bounds__(512) void attn_q_fwd_mfma_kernel(QAttnArgs g) {
   }
   __syncthreads();  // every wave is done with the staging buffers: they become the Q | K | V images
 
-  // ---- images: Q [RP][64] from the accumulators (+ bias; also to HBM), K | V [KP][64] of this (sample, head) from HBM
-  char* Qs = smem;
-  char* Ks = Qs + RP * 128;
-  char* Vs = Ks + KP * 128;
-  float* mrow_s = reinterpret_cast<float*>(Vs + KP * 128);
-  const ImgDesc kv[2] = {{Ks, (const bf16*)a.k + (int64_t)b * nk * a.ldk + h * 64, a.ldk, nk, KP},
-                         {Vs, (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64, a.ldv, nk, KP}};
-  if (tid < 256) {
-    load_images<2, 64>(kv, tid);
-    load_mask_row(mrow_s, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : nullptr, nk, KP, tid);
+  // ---- images per head: Q [RP][64] from the accumulators (+ bias; also to HBM), K | V [KP][64] from HBM; mask rows behind
+  float* mrow_all = reinterpret_cast<float*>(smem + NH * IMG);
+  if (tid < 256 * NH) {
+    const int hh = tid >> 8, t = tid & 255;
+    char* base = smem + hh * IMG;
+    const ImgDesc kv[2] = {{base + RP * 128, (const bf16*)a.k + (int64_t)b * nk * a.ldk + (h0 + hh) * 64, a.ldk, nk, KP},
+                           {base + (RP + KP) * 128, (const bf16*)a.v + (int64_t)b * nk * a.ldv + (h0 + hh) * 64, a.ldv, nk, KP}};
+    load_images<2, 64>(kv, t);
+    load_mask_row(mrow_all + hh * KP, a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)(h0 + hh) * a.msh : nullptr, nk, KP, t);
   }
+  {
+    const int hh = wr >> 1;
+    char* Qs = smem + hh * IMG;
 #pragma unroll
-  for (int i = 0; i < NI; i++) {
-    const int r = wc * 32 + i * 16 + (lane & 15);
-    const int col = wr * 32 + (lane >> 4) * 8;
-    bf16x8 o8;
-    o8[0] = (bf16)(acc[0][i][0] + bias_r[0].x); o8[1] = (bf16)(acc[0][i][1] + bias_r[0].y);
-    o8[2] = (bf16)(acc[0][i][2] + bias_r[0].z); o8[3] = (bf16)(acc[0][i][3] + bias_r[0].w);
-    o8[4] = (bf16)(acc[1][i][0] + bias_r[1].x); o8[5] = (bf16)(acc[1][i][1] + bias_r[1].y);
-    o8[6] = (bf16)(acc[1][i][2] + bias_r[1].z); o8[7] = (bf16)(acc[1][i][3] + bias_r[1].w);
-    *reinterpret_cast<bf16x8*>(Qs + Img<64>::off(r, col >> 3)) = o8;
-    if (r < nq) *reinterpret_cast<bf16x8*>(g.q + ((int64_t)b * nq + r) * g.ldq + h * 64 + col) = o8;
+    for (int i = 0; i < NI; i++) {
+      const int r = wc * 32 + i * 16 + (lane & 15);
+      const int col = (wr & 1) * 32 + (lane >> 4) * 8;
+      bf16x8 o8;
+      o8[0] = (bf16)(acc[0][i][0] + bias_r[0].x); o8[1] = (bf16)(acc[0][i][1] + bias_r[0].y);
+      o8[2] = (bf16)(acc[0][i][2] + bias_r[0].z); o8[3] = (bf16)(acc[0][i][3] + bias_r[0].w);
+      o8[4] = (bf16)(acc[1][i][0] + bias_r[1].x); o8[5] = (bf16)(acc[1][i][1] + bias_r[1].y);
+      o8[6] = (bf16)(acc[1][i][2] + bias_r[1].z); o8[7] = (bf16)(acc[1][i][3] + bias_r[1].w);
+      *reinterpret_cast<bf16x8*>(Qs + Img<64>::off(r, col >> 3)) = o8;
+      if (r < nq) *reinterpret_cast<bf16x8*>(g.q + ((int64_t)b * nq + r) * g.ldq + (h0 + hh) * 64 + col) = o8;
+    }
   }
   __syncthreads();
 
-  // ---- attention on the images: one wave per 32-query tile (waves 4-7 are done)
-  const int tq = wave;
-  if (tq >= TQ || tq * 32 >= nq) return;
-  attn_fwd_core<NKT, true, false, 64>(a, b, h, tq * 32, tq * 32, Qs, Ks, Vs, mrow_s, lane);
+  // ---- attention on the images: one wave per (head, 32-query tile); the other waves are done
+  const int hh = wave / TQ, tq = wave % TQ;
+  if (hh >= NH || tq * 32 >= nq) return;
+  const char* Qs = smem + hh * IMG;
+  attn_fwd_core<NKT, true, false, 64>(a, b, h0 + hh, tq * 32, tq * 32, Qs, Qs + RP * 128, Qs + (RP + KP) * 128,
+                                      mrow_all + hh * KP, lane);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -884,116 +892,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(ovqa::AttnBwdArg
 // W (query tiles per problem: 1, 2 or 4) is a template parameter: G = 4 / W problems are packed per workgroup, and all
 // staging index arithmetic folds to shifts.  These kernels are latency chains (launch -> loads -> ~20 MFMAs -> stores),
 // so instruction count matters like nowhere else: a wave64 VALU instruction is 4 cycles, 600 instructions are 1 us.
-template <bool ROWMASK, int W, int G = 4 / W>
-__global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a) {
-  static_assert(W * G == 4 || (W == 1 && G == 2), "problems per workgroup: 4 / W, or 2 single-tile problems");
-  constexpr int NT = W == 1 ? 128 * G : 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// The compute half of the merged backward (everything after the staging barrier): reads the images Q | dO | K | V, the
+// mask row, lse and delta of its problem from LDS.  `pid_base` = first problem of the workgroup; waves with `extra`
+// (a launch wider than this kernel's own NT threads: the fused dO-projection form) only keep the barriers company.
+template <bool ROWMASK, int W, int G>
+__device__ __forceinline__ void smallk_bwd_compute(const ovqa::AttnBwdArgs& a, char* smem, int pid_base, int wave, int lane,
+                                                   bool extra) {
   const int nk = a.nk, nq = a.nq;
   constexpr int q_rows = 32 * W, k_rows = 32;
-  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
-  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | P,dS
-  // 512 threads (W == 1: the 20 x 20 question attention): waves 0-3 take the dQ role, waves 4-7 the dK/dV role of
-  // the same 4 packed problems -- half the dependent chain per wave.  256 threads (W >= 2): every wave does both
-  // (with 4 query tiles per problem the doubled wave count only adds VALU contention: 14.8 vs 18.3 us).
-  // (W == 1, G == 2: the same role split with 2 + 2 waves -- 256 instead of 128 workgroups for 64 samples x 8 heads)
+  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;
+  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;
   constexpr bool both = W > 1;
-  constexpr bool stage_all = NT == 256;  // every thread stages a chunk of every image
   const int role = W == 1 ? wave / G : 0, w4 = W == 1 ? wave % G : wave & 3;
   const int slot = w4 / W, tq = w4 % W;
-  OVQA_PROBE(0);
-
-  // ---- staging: ONE round of global loads for everything the workgroup needs (all loads of all G problems are
-  // issued before the first LDS store).  Q / dO: W 16-byte chunks per thread and problem, K / V: one.  The thread that
-  // owns a dO chunk also fetches the matching chunk of O: delta = dO . O falls out of the staging (8 consecutive lanes
-  // hold a row) instead of a second pass over dO and O behind the first one; mask row and log-sum-exp ride along.
-  // W == 1: threads 0-255 stage Q and K, threads 256-511 dO (+ O) and V.
-  {
-    const int pid0 = (int)blockIdx.x * G, nprob = a.B * a.H;
-    const bool ld_q = stage_all || tid < 256, ld_d = stage_all || tid >= 256;  // wave-uniform
-    const int t = tid & 255;
-    const int ch = t & 7;
-    float mval = 0.f;  // mask row entries: thread -> (problem tid / 32, key tid % 32)
-    const bool mtask = a.msq == 0 && tid < G * k_rows && pid0 + tid / k_rows < nprob;
-    if (mtask) {
-      const int pid = pid0 + tid / k_rows;
-      const int key = tid % k_rows;
-      const int mb = pid / a.H, mh = pid - mb * a.H;
-      mval = key < nk ? (a.mask ? a.mask[(int64_t)mb * a.msb + (int64_t)mh * a.msh + key] * LOG2E : 0.f) : -INFINITY;
-    }
-    uint4 vq[G][W], vd[G][W], vo[G][W], vl[G][W], vk[G], vv[G];
-    float lse_r[G][W];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int pid = pid0 + g;  // uniform
-      const bool ok = pid < nprob;
-      const int b = ok ? pid / a.H : 0, h = ok ? pid - (pid / a.H) * a.H : 0;
-      const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
-      const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
-      const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
-      const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + h * 64 + ch * 8 : nullptr;
-      const float* lb = a.lse + ((int64_t)b * a.H + h) * nq;
-#pragma unroll
-      for (int i = 0; i < W; i++) {
-        const int row = (t >> 3) + 32 * i;
-        const bool v = ok && row < nq;
-        vq[g][i] = zero4; vd[g][i] = zero4; vo[g][i] = zero4; vl[g][i] = zero4; lse_r[g][i] = INFINITY;  // p = 0 beyond nq
-        if (ld_q && v) vq[g][i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
-        if (ld_d && v) {
-          vd[g][i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
-          vo[g][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
-          if (lob) vl[g][i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
-          if (ch == 0) lse_r[g][i] = lb[row] * LOG2E;
-        }
-      }
-      const int krow = t >> 3;
-      const bool kv = ok && krow < nk;
-      vk[g] = zero4; vv[g] = zero4;
-      if (ld_q && kv) vk[g] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + krow) * a.ldk + h * 64 + ch * 8);
-      if (ld_d && kv) vv[g] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + krow) * a.ldv + h * 64 + ch * 8);
-    }
-    OVQA_PROBE(1);
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      char* base = smem + g * prob_bytes;
-      float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
-      const int pid = pid0 + g;
-#pragma unroll
-      for (int i = 0; i < W; i++) {
-        const int row = (t >> 3) + 32 * i;
-        if (ld_q) *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[g][i];
-        if (ld_d) {
-          *reinterpret_cast<uint4*>(base + q_rows * 128 + img_off(row, ch)) = vd[g][i];
-          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[g][i]);
-          const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[g][i]);
-          const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[g][i]);
-          float dl = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
-          dl += __shfl_xor(dl, 1, 64);
-          dl += __shfl_xor(dl, 2, 64);
-          dl += __shfl_xor(dl, 4, 64);
-          if (ch == 0) {
-            lse_g[row] = lse_r[g][i];
-            lse_g[q_rows + row] = dl;
-            if (row < nq && pid < nprob) a.delta[(int64_t)pid * nq + row] = dl;
-          }
-        }
-      }
-      const int krow = t >> 3;
-      if (ld_q) *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(krow, ch)) = vk[g];
-      if (ld_d) *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(krow, ch)) = vv[g];
-    }
-    if (mtask) reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] = mval;
-  }
-  OVQA_PROBE(2);
-  __syncthreads();
-  OVQA_PROBE(3);
-
-  const int pidw = (int)blockIdx.x * G + slot;
-  const bool prob_ok = slot < G && pidw < a.B * a.H;
+  const int pidw = pid_base + slot;
+  const bool prob_ok = !extra && slot < G && pidw < a.B * a.H;
   const bool active = prob_ok && tq * 32 < nq;  // this wave's query tile exists
   const int b = prob_ok ? pidw / a.H : 0, h = prob_ok ? pidw - (pidw / a.H) * a.H : 0;
   const char* Qs = smem + (prob_ok ? slot : 0) * prob_bytes;
@@ -1198,6 +1111,294 @@ __global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_k
   OVQA_PROBE(7);
 }
 
+template <bool ROWMASK, int W, int G = 4 / W>
+__global__ __launch_bounds__(W == 1 ? 128 * G : 256) void attn_bwd_smallk_mfma_kernel(ovqa::AttnBwdArgs a) {
+  static_assert(W * G == 4 || (W == 1 && G == 2), "problems per workgroup: 4 / W, or 2 single-tile problems");
+  constexpr int NT = W == 1 ? 128 * G : 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = a.nk, nq = a.nq;
+  constexpr int q_rows = 32 * W, k_rows = 32;
+  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;                       // Q | dO | K | V
+  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;   // + mask row | lse | delta | P,dS
+  // 512 threads (W == 1: the 20 x 20 question attention): waves 0-3 take the dQ role, waves 4-7 the dK/dV role of
+  // the same 4 packed problems -- half the dependent chain per wave.  256 threads (W >= 2): every wave does both
+  // (with 4 query tiles per problem the doubled wave count only adds VALU contention: 14.8 vs 18.3 us).
+  // (W == 1, G == 2: the same role split with 2 + 2 waves -- 256 instead of 128 workgroups for 64 samples x 8 heads)
+  constexpr bool stage_all = NT == 256;  // every thread stages a chunk of every image
+  OVQA_PROBE(0);
+
+  // ---- staging: ONE round of global loads for everything the workgroup needs (all loads of all G problems are
+  // issued before the first LDS store).  Q / dO: W 16-byte chunks per thread and problem, K / V: one.  The thread that
+  // owns a dO chunk also fetches the matching chunk of O: delta = dO . O falls out of the staging (8 consecutive lanes
+  // hold a row) instead of a second pass over dO and O behind the first one; mask row and log-sum-exp ride along.
+  // W == 1: threads 0-255 stage Q and K, threads 256-511 dO (+ O) and V.
+  {
+    const int pid0 = (int)blockIdx.x * G, nprob = a.B * a.H;
+    const bool ld_q = stage_all || tid < 256, ld_d = stage_all || tid >= 256;  // wave-uniform
+    const int t = tid & 255;
+    const int ch = t & 7;
+    float mval = 0.f;  // mask row entries: thread -> (problem tid / 32, key tid % 32)
+    const bool mtask = a.msq == 0 && tid < G * k_rows && pid0 + tid / k_rows < nprob;
+    if (mtask) {
+      const int pid = pid0 + tid / k_rows;
+      const int key = tid % k_rows;
+      const int mb = pid / a.H, mh = pid - mb * a.H;
+      mval = key < nk ? (a.mask ? a.mask[(int64_t)mb * a.msb + (int64_t)mh * a.msh + key] * LOG2E : 0.f) : -INFINITY;
+    }
+    uint4 vq[G][W], vd[G][W], vo[G][W], vl[G][W], vk[G], vv[G];
+    float lse_r[G][W];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int pid = pid0 + g;  // uniform
+      const bool ok = pid < nprob;
+      const int b = ok ? pid / a.H : 0, h = ok ? pid - (pid / a.H) * a.H : 0;
+      const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + h * 64 + ch * 8;
+      const bf16* gb = (const bf16*)a.d_o + (int64_t)b * nq * a.lddo + h * 64 + ch * 8;
+      const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + h * 64 + ch * 8;
+      const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + h * 64 + ch * 8 : nullptr;
+      const float* lb = a.lse + ((int64_t)b * a.H + h) * nq;
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        const int row = (t >> 3) + 32 * i;
+        const bool v = ok && row < nq;
+        vq[g][i] = zero4; vd[g][i] = zero4; vo[g][i] = zero4; vl[g][i] = zero4; lse_r[g][i] = INFINITY;  // p = 0 beyond nq
+        if (ld_q && v) vq[g][i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
+        if (ld_d && v) {
+          vd[g][i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
+          vo[g][i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+          if (lob) vl[g][i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
+          if (ch == 0) lse_r[g][i] = lb[row] * LOG2E;
+        }
+      }
+      const int krow = t >> 3;
+      const bool kv = ok && krow < nk;
+      vk[g] = zero4; vv[g] = zero4;
+      if (ld_q && kv) vk[g] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + krow) * a.ldk + h * 64 + ch * 8);
+      if (ld_d && kv) vv[g] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + krow) * a.ldv + h * 64 + ch * 8);
+    }
+    OVQA_PROBE(1);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      char* base = smem + g * prob_bytes;
+      float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
+      const int pid = pid0 + g;
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        const int row = (t >> 3) + 32 * i;
+        if (ld_q) *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[g][i];
+        if (ld_d) {
+          *reinterpret_cast<uint4*>(base + q_rows * 128 + img_off(row, ch)) = vd[g][i];
+          const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[g][i]);
+          const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[g][i]);
+          const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[g][i]);
+          float dl = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
+          dl += __shfl_xor(dl, 1, 64);
+          dl += __shfl_xor(dl, 2, 64);
+          dl += __shfl_xor(dl, 4, 64);
+          if (ch == 0) {
+            lse_g[row] = lse_r[g][i];
+            lse_g[q_rows + row] = dl;
+            if (row < nq && pid < nprob) a.delta[(int64_t)pid * nq + row] = dl;
+          }
+        }
+      }
+      const int krow = t >> 3;
+      if (ld_q) *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(krow, ch)) = vk[g];
+      if (ld_d) *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(krow, ch)) = vv[g];
+    }
+    if (mtask) reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] = mval;
+  }
+  OVQA_PROBE(2);
+  __syncthreads();
+  OVQA_PROBE(3);
+
+  smallk_bwd_compute<ROWMASK, W, G>(a, smem, (int)blockIdx.x * G, wave, lane, false);
+}
+
+
+// ------------------------------------------------ merged backward with the dO projection inside (round 3)
+// Guided attention backward (65-128 queries x <= 32 keys): dO of the head is NOT read from HBM -- it is computed here
+// from the gradient of the block's pre-LayerNorm sum, dO_h = dY W_o[:, head]  (the fc_o dX product restricted to the
+// head's 64 features: dY [128 rows, d_model] against 64 rows of the transposed weight shadow), with the projection loop
+// of attn_q_fwd_mfma_kernel; rounded to bf16 into the dO image, as the separate GEMM would have stored it.  Then Q, K, V,
+// the mask row and log-sum-exp are staged, delta = dO . (O + o_lo) is taken from the image and the O rows, and
+// smallk_bwd_compute runs on waves 0-3.  One launch instead of a 6400 x 512 <- 512 GEMM + the backward kernel; dO never
+// travels through HBM.
+struct DoBwdArgs {
+  const bf16* dy; int64_t lddy;     // [B * nq, Dm]: gradient w.r.t. the fc_o output
+  const bf16* wt; int64_t ldwt;     // transposed fc_o weights [H * 64, Dm]: row = head-major input feature of fc_o
+  ovqa::AttnBwdArgs att;            // q, k, v, o, o_lo, lse, mask, dq, dk, dv, delta, sizes (d_o unused)
+  int Dm;
+};
+
+// NH = heads per workgroup (1: 8 waves, two workgroups per CU; 2: 16 waves, dY staged once for both heads, one workgroup
+// per CU and 64 samples x 4 head pairs = one workgroup on every CU).
+template <int NBUF, int NH>
+__global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_mfma_kernel(DoBwdArgs g) {
+  constexpr int RP = 128, BKF = 64, NI = 2, NJ = 2, W = 4, NW = 8 * NH;
+  constexpr int PROWS = 8, CHR = 8, WCH = 64 * NH / PROWS, XCH = RP / PROWS, PER = (WCH + XCH) / NW;
+  constexpr int STAGE = (WCH + XCH) * 1024;
+  constexpr int q_rows = 32 * W, k_rows = 32;
+  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;
+  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;  // (smallk_bwd_compute's layout)
+  static_assert((WCH + XCH) % NW == 0, "every wave stages the same number of pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ovqa::AttnBwdArgs& a = g.att;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / (2 * NH), wr = wave % (2 * NH);
+  const int h0 = blockIdx.y * NH, b = blockIdx.x, nq = a.nq, nk = a.nk;
+
+  f32x4 acc[NJ][NI];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto off32 = [&](int row, int ch) { return row * (BKF * 2) + ((ch ^ (row & 7)) << 4); };
+  const bf16* src[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int ci = wave + NW * i;
+    const int prow = lane / CHR, pch = lane % CHR;
+    if (ci < WCH) {
+      const int row = ci * PROWS + prow;
+      src[i] = g.wt + (int64_t)(h0 * 64 + perm32(row)) * g.ldwt + ((pch ^ (row & 7)) << 3);
+    } else {
+      const int row = (ci - WCH) * PROWS + prow;
+      const int r = row < nq ? row : nq - 1;
+      src[i] = g.dy + ((int64_t)b * nq + r) * g.lddy + ((pch ^ (row & 7)) << 3);
+    }
+  }
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt % NBUF) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + NW * i) * 1024), 16, 0, 0);
+  };
+  const int nkt = g.Dm / BKF;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nkt) issue(p);
+  for (int kt = 0; kt < nkt; kt++) {
+    if (kt + NBUF - 2 >= nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NBUF - 2)) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
+    const char* Ws = smem + (kt % NBUF) * STAGE;
+    const char* Xs = Ws + WCH * 1024;
+#pragma unroll
+    for (int ks = 0; ks < BKF / 32; ks++) {
+      bf16x8 pf[NJ], qf[NI];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 32 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * 32 + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  // ---- everything else the backward needs is requested now (one round of loads, as in the plain kernel); per head 512
+  // threads: the first 256 take Q (4 chunks) and K, the other 256 O / o_lo (4 chunks each), V, lse; the mask row by 32
+  const int hs = tid >> 9, t5 = tid & 511;   // staging head and thread within its 512
+  const int hst = h0 + hs;
+  const int t = t5 & 255, ch = t & 7;
+  const bool ld_q = t5 < 256;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 vq[W], vo[W], vl[W], vkv = zero4;
+  float lse_r[W];
+  float mval = 0.f;
+  if (t5 < k_rows)
+    mval = t5 < nk ? (a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)hst * a.msh + t5] * LOG2E : 0.f) : -INFINITY;
+  {
+    const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + hst * 64 + ch * 8;
+    const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8;
+    const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8 : nullptr;
+    const float* lb = a.lse + ((int64_t)b * a.H + hst) * nq;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const int row = (t >> 3) + 32 * i;
+      const bool v = row < nq;
+      vq[i] = zero4; vo[i] = zero4; vl[i] = zero4; lse_r[i] = INFINITY;  // p = 0 beyond nq
+      if (ld_q && v) vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
+      if (!ld_q && v) {
+        vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
+        if (lob) vl[i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
+        if (ch == 0) lse_r[i] = lb[row] * LOG2E;
+      }
+    }
+    const int krow = t >> 3;
+    if (krow < nk) {
+      if (ld_q) vkv = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + krow) * a.ldk + hst * 64 + ch * 8);
+      else vkv = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + krow) * a.ldv + hst * 64 + ch * 8);
+    }
+  }
+  __syncthreads();  // every wave is done with the staging ring: it becomes the images
+
+  // ---- dO image [128][64] (bf16) of the wave's head from the accumulators; rows beyond nq are zero (p = 0 there anyway)
+  {
+    char* Gs = smem + (wr >> 1) * prob_bytes + q_rows * 128;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int r = wc * 32 + i * 16 + (lane & 15);
+      const int col = (wr & 1) * 32 + (lane >> 4) * 8;
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        o8[e] = r < nq ? (bf16)acc[0][i][e] : (bf16)0.f;
+        o8[4 + e] = r < nq ? (bf16)acc[1][i][e] : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(Gs + img_off(r, col >> 3)) = o8;
+    }
+  }
+  __syncthreads();  // the dO images are complete: delta reads them
+  {
+    char* base = smem + hs * prob_bytes;
+    const char* Gs = base + q_rows * 128;
+    float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
+    const int pid = b * a.H + hst;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const int row = (t >> 3) + 32 * i;
+      if (ld_q) {
+        *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[i];
+      } else {
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(Gs + img_off(row, ch));
+        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
+        const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
+        dl += __shfl_xor(dl, 1, 64);
+        dl += __shfl_xor(dl, 2, 64);
+        dl += __shfl_xor(dl, 4, 64);
+        if (ch == 0) {
+          lse_g[row] = lse_r[i];
+          lse_g[q_rows + row] = dl;
+          if (row < nq && a.delta) a.delta[(int64_t)pid * nq + row] = dl;
+        }
+      }
+    }
+    const int krow = t >> 3;
+    if (ld_q) *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(krow, ch)) = vkv;
+    else *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(krow, ch)) = vkv;
+    if (t5 < k_rows) reinterpret_cast<float*>(base + img_bytes)[t5] = mval;
+  }
+  __syncthreads();
+  // waves 0 .. 4 NH - 1: head wave / 4, query tile wave % 4; the others keep the barriers company
+  const int hc = wave >> 2;
+  smallk_bwd_compute<true, W, 1>(a, smem + (hc < NH ? hc : 0) * prob_bytes, b * a.H + h0 + (hc < NH ? hc : 0), wave & 3, lane,
+                                 hc >= NH);
+}
 
 // ------------------------------------------------------- role-split backward, 32 < n_k <= 128 and n_q <= 128
 // Image self-attention (100 x 100): ONE launch, 8 waves.  Q, dO, K, V of a (batch, head) are staged once; waves
@@ -1691,32 +1892,73 @@ bool mfma_attention_q_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int6
 int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* q,
                          int64_t ldq, int64_t Dm, hipStream_t st) {
   QAttnArgs g{(const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)q, ldq, a, (int)Dm};
-  const dim3 grid((unsigned)a.B, (unsigned)a.H);
-#define OVQA_QATT(NKTV)                                                                                      \
-  {                                                                                                          \
-    const size_t stage = (size_t)(64 + 128) * 64 * 2, images = (size_t)(128 + 2 * NKTV * 32) * 128 + NKTV * 32 * 4; \
-    if (nbuf == 3) {                                                                                         \
-      const size_t lds = 3 * stage > images ? 3 * stage : images;                                            \
-      int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, 3>, lds, "attention_q_fwd");                          \
-      if (rc != OVQA_OK) return rc;                                                                          \
-      hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, 3>), grid, dim3(512), lds, st, g);                    \
-    } else {                                                                                                 \
-      const size_t lds = 2 * stage > images ? 2 * stage : images;                                            \
-      int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, 2>, lds, "attention_q_fwd");                          \
-      if (rc != OVQA_OK) return rc;                                                                          \
-      hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, 2>), grid, dim3(512), lds, st, g);                    \
-    }                                                                                                        \
-  }
-  static int nbuf = -1;
+  static int nbuf = -1, pair = -1;
   if (nbuf < 0) {
     const char* e = getenv("OVQA_QATT_NBUF");  // ring depth of the projection loop (A/B switch)
     nbuf = e ? atoi(e) : 3;
+    e = getenv("OVQA_QATT_PAIR");              // two heads per 16-wave workgroup (A/B switch)
+    pair = e ? atoi(e) : 1;
+  }
+  const int NHv = (pair && a.H % 2 == 0) ? 2 : 1;
+  const dim3 grid((unsigned)a.B, (unsigned)(a.H / NHv));
+#define OVQA_QATT_L(NKTV, NBV, NHV)                                                                            \
+  {                                                                                                            \
+    const size_t stage = (size_t)(64 * NHV + 128) * 64 * 2;                                                    \
+    const size_t images = (size_t)NHV * ((128 + 2 * NKTV * 32) * 128 + NKTV * 32 * 4);                         \
+    const size_t lds = NBV * stage > images ? NBV * stage : images;                                            \
+    int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>, lds, "attention_q_fwd");                       \
+    if (rc != OVQA_OK) return rc;                                                                              \
+    hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>), grid, dim3(512 * NHV), lds, st, g);           \
+  }
+#define OVQA_QATT(NKTV)                                                     \
+  {                                                                         \
+    if (NHv == 2) {                                                         \
+      if (nbuf == 3) OVQA_QATT_L(NKTV, 3, 2) else OVQA_QATT_L(NKTV, 2, 2)   \
+    } else {                                                                \
+      if (nbuf == 3) OVQA_QATT_L(NKTV, 3, 1) else OVQA_QATT_L(NKTV, 2, 1)   \
+    }                                                                       \
   }
   if (a.nk <= 32) OVQA_QATT(1)
   else if (a.nk <= 64) OVQA_QATT(2)
   else OVQA_QATT(4)
 #undef OVQA_QATT
+#undef OVQA_QATT_L
   return ovqa_check_launch("attention_q_fwd(mfma)");
+}
+
+bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t lddy, int64_t ldwt, const void* dy,
+                                     const void* wt) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return a.dk == 64 && a.dv == 64 && a.nq > 64 && a.nq <= 128 && a.nk >= 1 && a.nk <= 32 && a.msq == 0 &&
+         a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && Dm % 64 == 0 && Dm >= 64 && lddy % 8 == 0 &&
+         ldwt % 8 == 0 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.lddq % 4 == 0 &&
+         a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(dy) && al(wt) && al(a.q) && al(a.k) && al(a.v) && al(a.o) &&
+         (a.o_lo == nullptr || al(a.o_lo)) && a.lse != nullptr;
+}
+
+int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, int64_t Dm,
+                          hipStream_t st) {
+  DoBwdArgs g{(const bf16*)dy, lddy, (const bf16*)wt, ldwt, a, (int)Dm};
+  static int pair = -1;
+  if (pair < 0) {
+    const char* e = getenv("OVQA_QATT_PAIR");  // two heads per 16-wave workgroup (A/B switch, shared with the forward form)
+    pair = e ? atoi(e) : 1;
+  }
+  const size_t prob = (size_t)(2 * 128 + 2 * 32) * 128 + 32 * 4 + 2 * 128 * 4 + 4096 * 4;
+  if (pair && a.H % 2 == 0) {
+    const size_t stage = (size_t)(128 + 128) * 64 * 2;
+    const size_t lds = 3 * stage > 2 * prob ? 3 * stage : 2 * prob;
+    int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 2>, lds, "attention_bwd_do");
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_do_smallk_mfma_kernel<3, 2>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(1024), lds, st, g);
+  } else {
+    const size_t stage = (size_t)(64 + 128) * 64 * 2;
+    const size_t lds = 3 * stage > prob ? 3 * stage : prob;
+    int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 1>, lds, "attention_bwd_do");
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_do_smallk_mfma_kernel<3, 1>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g);
+  }
+  return ovqa_check_launch("attention_bwd_do(mfma)");
 }
 
 int mfma_attention_fwd(const AttnArgs& a, hipStream_t st) {

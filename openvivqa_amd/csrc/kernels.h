@@ -107,6 +107,10 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
 int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
                            int64_t ldqkv, int64_t Dm, hipStream_t st);
 bool mfma_attention_bwd_supported(const AttnBwdArgs& a);
+bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t lddy, int64_t ldwt, const void* dy,
+                                     const void* wt);
+int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, int64_t Dm,
+                          hipStream_t st);
 int mfma_attention_bwd(const AttnBwdArgs& a, hipStream_t st);
 
 // ---- layernorm.hip -----------------------------------------------------------

@@ -369,8 +369,12 @@ class _MHABlock(Function):
         dpre, dpre_d = _ln_bwd(arena, _c(dy), pre, ln.weight, ln.bias, mean, rstd, drop=drop)
         # fc_o
         _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
-        d_o = _dx(arena, dpre_d, [a.fc_o.weight])
         nqk = a.fc_q.weight.shape[0]
+        wt_o = arena.transposed([a.fc_o.weight]) if mode == "pre" else None
+        fuse_do = (mode == "pre" and st.get("att_drop") is None and os.environ.get("OVQA_NO_FUSED_DO", "0") != "1"
+                   and ops.attention_bwd_do_ok(dpre_d, wt_o, bufs[0], keys, ctx.mask, a.h))
+        # (guided attention: the fc_o dX product runs inside the attention backward kernel, dO never leaves the CU)
+        d_o = None if fuse_do else _dx(arena, dpre_d, [a.fc_o.weight])
         wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
         bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
         B, nq, nk = queries.shape[0], queries.shape[1], keys.shape[1]
@@ -393,8 +397,14 @@ class _MHABlock(Function):
                 shared["dkv"] = torch.empty_like(keys)  # fills its slot, module 0 hands it to autograd
             dkv = shared["dkv"]
             dq = torch.empty_like(q)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dq, dk=dkv[..., base:base + wk.shape[0]],
-                              dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
+            if fuse_do:
+                ops.attention_bwd_do(dpre_d, wt_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, dq=dq,
+                                     dk=dkv[..., base:base + wk.shape[0]],
+                                     dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
+            else:
+                ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dq,
+                                  dk=dkv[..., base:base + wk.shape[0]],
+                                  dv=dkv[..., base + wk.shape[0]:base + wk.shape[0] + wv.shape[0]])
             _wgrad(arena, dq, queries, [wq], [bq])
             dx = _dx(arena, dq, [wq], addend=dpre)
             return dx, (dkv if slot == 0 else None), None, None, None, *([None] * len(st["params"]))

@@ -756,6 +756,39 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
     return dq, dk, dv
 
 
+def attention_bwd_do_ok(dy, wt, q, k, mask, H):
+    """Shapes the fused form of ``attention_bwd_do`` covers (``ovqa_attention_bwd_do``): bf16, d = 64, 65-128 queries,
+    <= 32 keys, key mask or none."""
+    return (dy.is_cuda and dy.dtype == torch.bfloat16 and wt is not None and wt.dtype == torch.bfloat16 and q.dim() == 3
+            and q.shape[2] == H * 64 and 64 < q.shape[1] <= 128 and k.shape[1] <= 32 and dy.shape[-1] % 64 == 0
+            and (mask is None or mask.shape[2] == 1) and wt.shape[0] == H * 64 and wt.shape[1] == dy.shape[-1])
+
+
+def attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, dv=None, o_lo=None):
+    """Attention backward with the fc_o dX product inside (``ovqa_attention_bwd_do``): dy [B,nq,d_model] = gradient
+    w.r.t. fc_o's output, wt [H*d, d_model] = the transposed weight copy; returns (dq, dk, dv).  The caller checks
+    ``attention_bwd_do_ok`` (there is no scratch buffer for the two-kernel form here)."""
+    _dev(q)
+    lib = _lib.load()
+    B, nq = q.shape[0], q.shape[1]
+    nk, d = k.shape[1], q.shape[2] // H
+    Dm = dy.shape[-1]
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    dq = dq if dq is not None else torch.empty(B, nq, H * d, dtype=q.dtype, device=q.device)
+    dk = dk if dk is not None else torch.empty(B, nk, H * d, dtype=q.dtype, device=q.device)
+    dv = dv if dv is not None else torch.empty(B, nk, H * d, dtype=q.dtype, device=q.device)
+    delta = torch.empty(B, H, nq, dtype=torch.float32, device=q.device)
+    mask, sb, sh, sq = _mask_strides(mask, B, H, nq, nk)
+    assert sq == 0 and wt.stride(1) == 1 and dy.stride(-1) == 1
+    if o_lo is not None:
+        assert o_lo.dtype == o.dtype == torch.bfloat16 and o_lo.shape == o.shape and _rows(o_lo)[0] == _rows(o)[0]
+    _lib.check(lib.ovqa_attention_bwd_do(
+        _dt(q), _p(dy), _rows(dy)[0], _p(wt), wt.stride(0), None, 0, _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v),
+        _rows(v)[0], _p(o), _rows(o)[0], _p(o_lo), _p(lse), _p(mask), sb, sh, _p(dq), _rows(dq)[0], _p(dk), _rows(dk)[0],
+        _p(dv), _rows(dv)[0], _p(delta), B, H, nq, nk, Dm, d, float(scale), _stream()), "attention_bwd_do")
+    return dq, dk, dv
+
+
 def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
     """scores[b,t,n] = q[b,t].k[b,n]*scale (+ add_mask[b,n]) (-inf where key_fill[b,n] / query_fill[b,t])."""
     _dev(q)

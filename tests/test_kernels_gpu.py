@@ -963,3 +963,36 @@ def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
     assert nerr(o, o2) < tol(dtype) and nerr(lse, lse2) < 1e-3
     if dtype == BF16:
         assert len(lo) == 1 and nerr(o.float() + lo[0].float(), o2.float() + lo2[0].float()) < 2e-3
+
+
+@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 32), (2, 65, 1), (5, 97, 13)])
+def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
+    """ovqa_attention_bwd_do (the fc_o dX product inside the guided-attention backward kernel, from the transposed weight
+    copy) against ovqa_linear_bwd_data_wt + ovqa_attention_bwd: same dq, dk, dv."""
+    o_ = ops()
+    H, d, Dm = 8, 64, 512
+    q = rnd(B, nq, H * d, dtype=BF16)
+    kv = rnd(B, nk, 4 * H * d, dtype=BF16, seed=1)  # packed K | V of two layers: slot 1 is ours
+    k, v = kv[..., 2 * H * d:3 * H * d], kv[..., 3 * H * d:]
+    mask = torch.zeros(B, 1, 1, nk, device=DEV)
+    if nk > 3:
+        mask[0, :, :, nk - 3:] = -1e5
+    lo = []
+    o, lse, _ = o_.attention_fwd(q, k, v, mask, H, lo_out=lo)
+    dy = rnd(B, nq, Dm, dtype=BF16, seed=2)
+    group = rnd(Dm, 4 * Dm, dtype=BF16, scale=Dm ** -0.5, seed=3)  # transposed copies of an adjacency group [in, 4 x out]
+    wt = group[:, 3 * Dm:]                                          # fc_o's slice: rows = input features, strided
+    dkv1, dkv0 = torch.zeros_like(kv), torch.zeros_like(kv)
+    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (nq > 64)
+    if nq <= 64:
+        return
+    dq1, _, _ = o_.attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, o_lo=lo[0], dk=dkv1[..., 2 * H * d:3 * H * d],
+                                    dv=dkv1[..., 3 * H * d:])
+    if not FORCED_SIMPLE and not NO_FUSED_QKV:
+        from openvivqa_amd import _lib
+        assert _lib.last_dispatch() == "mfma-fused"
+    d_o = o_.linear_bwd_data_wt(dy.reshape(B * nq, Dm), wt).view(B, nq, H * d)
+    dq0, _, _ = o_.attention_bwd(d_o, q, k, v, o, lse, mask, H, o_lo=lo[0], dk=dkv0[..., 2 * H * d:3 * H * d],
+                                 dv=dkv0[..., 3 * H * d:])
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    assert rel(dq1, dq0) < 2e-3 and rel(dkv1, dkv0) < 2e-3, (rel(dq1, dq0), rel(dkv1, dkv0))
