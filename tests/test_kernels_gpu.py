@@ -53,6 +53,8 @@ def gelu_grad(x):
 
 LIN_SHAPES = [(37, 50, 29), (64, 64, 16), (256, 128, 64), (300, 256, 128), (6400, 512, 512), (1280, 1536, 512),
               (128, 512, 2048),
+              # a decoding step's products: few activation rows (one-wave tiles, reductions split over 1 / 2 / 4 waves)
+              (1, 512, 512), (17, 4000, 512), (64, 768, 768), (128, 2048, 32), (100, 512, 1024),
               # the BASELINE products (and ragged row counts of the same widths)
               (6400, 2048, 512), (6400, 1536, 512), (6400, 512, 2048), (6001, 2048, 512), (5555, 512, 512)]
 
@@ -851,12 +853,14 @@ def test_decode_embed_matches_torch_ops(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [203, 5000])
 @pytest.mark.parametrize("beam,cur", [(3, 3), (3, 1), (1, 1), (8, 8), (5, 5)])
-def test_beam_step_kernels_match_reference_step(dtype, beam, cur):
+def test_beam_step_kernels_match_reference_step(dtype, beam, cur, V):
     """ovqa_beam_candidates + ovqa_beam_commit against ONE step of models/modules/beam_search.py:41-83 written with
     torch ops (log-softmax, candidate scores with finished sequences, full descending sort, gathers)."""
+    # (V = 203: unaligned rows, element loads; V = 5000 in bf16: longer than the row a wave keeps in registers)
     g = torch.Generator().manual_seed(beam * 10 + cur)
-    b_s, V, T, t, eos = 6, 203, 9, (0 if cur == 1 else 4), 2
+    b_s, T, t, eos = 6, 9, (0 if cur == 1 else 4), 2
     logits = (torch.randn(b_s * cur, V, generator=g) * 3).to(DEV).to(dtype)
     seq_logprob = (-torch.rand(b_s, cur, generator=g) * 5).to(DEV)
     seq_mask = (torch.rand(b_s, cur, generator=g) > 0.25).float().to(DEV)
