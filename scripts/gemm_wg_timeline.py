@@ -43,7 +43,7 @@ def timeline(label, fn, n_wg_hint=4096):
         ((hw >> np.uint64(12)) & np.uint64(1)).astype(np.int64) * 50 + ((hw >> np.uint64(8)) & np.uint64(15)).astype(np.int64)
     per_cu = collections.Counter(cu.tolist())
     hist = collections.Counter(per_cu.values())
-    print(f"== [qreg={os.environ.get('OVQA_GEMM_QREG', 'default')}] {label}: {n} workgroups on {len(per_cu)} CUs; workgroups per CU histogram {dict(sorted(hist.items()))}")
+    print(f"== {label}: {n} workgroups on {len(per_cu)} CUs; workgroups per CU histogram {dict(sorted(hist.items()))}")
     print(f"   span (first start -> last end) {en.max():.2f} us")
     print(f"   start   p0/10/50/90/100: {pct(st)}")
     print(f"   end     p0/10/50/90/100: {pct(en)}")
