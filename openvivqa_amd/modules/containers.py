@@ -80,7 +80,7 @@ class Module(nn.Module):
                 continue
             s = m._buffers[n]
             shape = [int(x) for x in s.shape]
-            beam = selected_beam
+            beam = selected_beam.long()  # (the fused search hands over int32 indices; torch.gather wants int64)
             for _ in shape[1:]:
                 beam = beam.unsqueeze(-1)
             s = torch.gather(s.view(*([b_s, cur_beam_size] + shape[1:])), 1,
