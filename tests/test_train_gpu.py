@@ -373,3 +373,24 @@ def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
     max_step = (w16 - w32).abs().max().item() / (lr * steps)
     rec(tag, "largest |w_bf16x - w_fp32x| in units of lr*steps (2 = opposite full steps)", max_step, 2.001)
     assert frac < 2e-3 and max_step <= 2.001, (frac, worst, max_step)
+
+
+def test_bench_launcher_two_ranks_on_this_gpu():
+    """The contract form `python bench.py --gpus N` end to end with the real kernels: the parent starts two ranks through
+    torch.distributed.run (both on this GPU, gradients over gloo: OVQA_REHEARSE_BACKEND), they agree on the segment plan,
+    exchange every step, and rank 0 prints ONE JSON line with n_gpus = world_size = 2 and a global batch of 128."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OVQA_REHEARSE_BACKEND="gloo", OVQA_NO_BUILD="1", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 128 and d["config"]["comm_dtype"] == "fp32" and d["config"]["grad_segments"] >= 2
+    assert d["value"] > 0 and d["gradient_exchange"]["world"] == 2
