@@ -304,8 +304,8 @@ int ovqa_attention_q_fwd(int dtype, const void* x, int64_t ldx, const void* w, c
  * dO = dY W_o (autograd of attentions.py:58), and the fc_o dX product is folded into the backward kernel -- per head,
  * dO_h = dY wt[h*d:(h+1)*d, :]^T from the TRANSPOSED weight copy wt [H*d, d_model] (what ovqa_adam_step_tiled maintains) --
  * so dO never travels through HBM.  dy [B*nq, d_model]; everything else as ovqa_attention_bwd with a key mask (msq = 0),
- * no d_att / d_lse / dropout.  bf16, d = 64, 64 < nq <= 128, nk <= 32 (guided attention: 100 queries x 20 keys): one
- * kernel; otherwise, if `d_o_scratch` [B*nq, lddo] is given, ovqa_linear_bwd_data_wt into it + ovqa_attention_bwd;
+ * no d_att / d_lse / dropout.  bf16, d = 64, nk <= 32 and either 64 < nq <= 128 (guided attention: 100 queries x 20 keys) or
+ * nq <= 32 with an even head count (the 20 x 20 question self-attention: q, k, v slices of the packed projection): one kernel; otherwise, if `d_o_scratch` [B*nq, lddo] is given, ovqa_linear_bwd_data_wt into it + ovqa_attention_bwd;
  * otherwise OVQA_ERR_UNSUPPORTED. */
 int ovqa_attention_bwd_do(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, void* d_o_scratch,
                           int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,

@@ -1400,6 +1400,150 @@ __global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_
                                  hc >= NH);
 }
 
+// The same for <= 32 queries x <= 32 keys (the question self-attention, 20 x 20): a 4-wave workgroup takes TWO heads of a
+// sample -- dO of both from dY [32 rows (nq, padded), d_model] against their 128 rows of the transposed fc_o weights --
+// and runs the single-tile merged backward (waves 0-1: dQ of the two heads, waves 2-3: dK / dV).
+template <int NBUF>
+__global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs g) {
+  constexpr int BKF = 64, NI = 2, NJ = 2, G = 2, NW = 4;
+  constexpr int PROWS = 8, CHR = 8, WCH = 128 / PROWS, XCH = 32 / PROWS, PER = (WCH + XCH) / NW;
+  constexpr int STAGE = (WCH + XCH) * 1024;
+  constexpr int q_rows = 32, k_rows = 32;
+  constexpr int img_bytes = (2 * q_rows + 2 * k_rows) * 128;
+  constexpr int prob_bytes = img_bytes + k_rows * 4 + 2 * q_rows * 4 + 4096 * 4;  // (smallk_bwd_compute's layout)
+  static_assert((WCH + XCH) % NW == 0, "every wave stages the same number of pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ovqa::AttnBwdArgs& a = g.att;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave;  // feature slab of 32: head wr >> 1
+  const int h0 = blockIdx.y * G, b = blockIdx.x, nq = a.nq, nk = a.nk;
+
+  f32x4 acc[NJ][NI];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int i = 0; i < NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto off32 = [&](int row, int ch) { return row * (BKF * 2) + ((ch ^ (row & 7)) << 4); };
+  const bf16* src[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int ci = wave + NW * i;
+    const int prow = lane / CHR, pch = lane % CHR;
+    if (ci < WCH) {
+      const int row = ci * PROWS + prow;
+      src[i] = g.wt + (int64_t)(h0 * 64 + perm32(row)) * g.ldwt + ((pch ^ (row & 7)) << 3);
+    } else {
+      const int row = (ci - WCH) * PROWS + prow;
+      const int r = row < nq ? row : nq - 1;
+      src[i] = g.dy + ((int64_t)b * nq + r) * g.lddy + ((pch ^ (row & 7)) << 3);
+    }
+  }
+  auto issue = [&](int kt) {
+    char* buf = smem + (kt % NBUF) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + NW * i) * 1024), 16, 0, 0);
+  };
+  const int nkt = g.Dm / BKF;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nkt) issue(p);
+  for (int kt = 0; kt < nkt; kt++) {
+    if (kt + NBUF - 2 >= nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (NBUF - 2)) : "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1);
+    const char* Ws = smem + (kt % NBUF) * STAGE;
+    const char* Xs = Ws + WCH * 1024;
+#pragma unroll
+    for (int ks = 0; ks < BKF / 32; ks++) {
+      bf16x8 pf[NJ], qf[NI];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 32 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int i = 0; i < NI; i++)
+        qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  // ---- one round of loads for both heads: every thread owns chunk (row tid >> 3, 16 bytes tid & 7) of every image
+  const int ch = tid & 7, row = tid >> 3;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 vq[G], vo[G], vl[G], vk[G], vv[G];
+  float lse_r[G];
+  float mval = 0.f;
+  if (tid < G * k_rows) {
+    const int key = tid % k_rows;
+    mval = key < nk ? (a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)(h0 + tid / k_rows) * a.msh + key] * LOG2E : 0.f) : -INFINITY;
+  }
+#pragma unroll
+  for (int gi = 0; gi < G; gi++) {
+    const int hh = h0 + gi;
+    vq[gi] = zero4; vo[gi] = zero4; vl[gi] = zero4; vk[gi] = zero4; vv[gi] = zero4; lse_r[gi] = INFINITY;  // p = 0 beyond nq
+    if (row < nq) {
+      vq[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.q + ((int64_t)b * nq + row) * a.ldq + hh * 64 + ch * 8);
+      vo[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.o + ((int64_t)b * nq + row) * a.ldo + hh * 64 + ch * 8);
+      if (a.o_lo) vl[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.o_lo + ((int64_t)b * nq + row) * a.ldo + hh * 64 + ch * 8);
+      if (ch == 0) lse_r[gi] = a.lse[((int64_t)b * a.H + hh) * nq + row] * LOG2E;
+    }
+    if (row < nk) {
+      vk[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + row) * a.ldk + hh * 64 + ch * 8);
+      vv[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + row) * a.ldv + hh * 64 + ch * 8);
+    }
+  }
+  __syncthreads();  // every wave is done with the staging ring: it becomes the images
+
+  // ---- dO image [32][64] (bf16) of the wave's head from the accumulators; rows beyond nq are zero
+  {
+    char* Gs = smem + (wr >> 1) * prob_bytes + q_rows * 128;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int r = i * 16 + (lane & 15);
+      const int col = (wr & 1) * 32 + (lane >> 4) * 8;
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        o8[e] = r < nq ? (bf16)acc[0][i][e] : (bf16)0.f;
+        o8[4 + e] = r < nq ? (bf16)acc[1][i][e] : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(Gs + img_off(r, col >> 3)) = o8;
+    }
+  }
+  __syncthreads();  // the dO images are complete: delta reads them
+#pragma unroll
+  for (int gi = 0; gi < G; gi++) {
+    char* base = smem + gi * prob_bytes;
+    float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
+    *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[gi];
+    const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(base + q_rows * 128 + img_off(row, ch));
+    const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[gi]);
+    const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[gi]);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    dl += __shfl_xor(dl, 4, 64);
+    if (ch == 0) {
+      lse_g[row] = lse_r[gi];
+      lse_g[q_rows + row] = dl;
+      if (row < nq && a.delta) a.delta[((int64_t)b * a.H + h0 + gi) * nq + row] = dl;
+    }
+    *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(row, ch)) = vk[gi];
+    *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(row, ch)) = vv[gi];
+  }
+  if (tid < G * k_rows) reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] = mval;
+  __syncthreads();
+  smallk_bwd_compute<true, 1, G>(a, smem, b * a.H + h0, wave, lane, false);
+}
+
 // ------------------------------------------------------- role-split backward, 32 < n_k <= 128 and n_q <= 128
 // Image self-attention (100 x 100): ONE launch, 8 waves.  Q, dO, K, V of a (batch, head) are staged once; waves
 // 0-3 play kernel A (one 32-query tile each, all key tiles: dQ), waves 4-7 play kernel B (one 32-key tile each, all
@@ -1929,7 +2073,8 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
 bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t lddy, int64_t ldwt, const void* dy,
                                      const void* wt) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  return a.dk == 64 && a.dv == 64 && a.nq > 64 && a.nq <= 128 && a.nk >= 1 && a.nk <= 32 && a.msq == 0 &&
+  const bool guided = a.nq > 64 && a.nq <= 128, single = a.nq >= 1 && a.nq <= 32 && a.H % 2 == 0;
+  return a.dk == 64 && a.dv == 64 && (guided || single) && a.nk >= 1 && a.nk <= 32 && a.msq == 0 &&
          a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && Dm % 64 == 0 && Dm >= 64 && lddy % 8 == 0 &&
          ldwt % 8 == 0 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.lddq % 4 == 0 &&
          a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(dy) && al(wt) && al(a.q) && al(a.k) && al(a.v) && al(a.o) &&
@@ -1943,6 +2088,15 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
   if (pair < 0) {
     const char* e = getenv("OVQA_QATT_PAIR");  // two heads per 16-wave workgroup (A/B switch, shared with the forward form)
     pair = e ? atoi(e) : 1;
+  }
+  if (a.nq <= 32) {  // single query tile (20 x 20): two heads per 4-wave workgroup
+    const size_t stage1 = (size_t)(128 + 32) * 64 * 2;
+    const size_t prob1 = (size_t)(2 * 32 + 2 * 32) * 128 + 32 * 4 + 2 * 32 * 4 + 4096 * 4;
+    const size_t lds1 = 3 * stage1 > 2 * prob1 ? 3 * stage1 : 2 * prob1;
+    int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<3>, lds1, "attention_bwd_do");
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_do_smallk1_mfma_kernel<3>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), lds1, st, g);
+    return ovqa_check_launch("attention_bwd_do(mfma)");
   }
   const size_t prob = (size_t)(2 * 128 + 2 * 32) * 128 + 32 * 4 + 2 * 128 * 4 + 4096 * 4;
   if (pair && a.H % 2 == 0) {

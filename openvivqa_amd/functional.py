@@ -370,10 +370,13 @@ class _MHABlock(Function):
         # fc_o
         _wgrad(arena, dpre_d, o, [a.fc_o.weight], [a.fc_o.bias])
         nqk = a.fc_q.weight.shape[0]
-        wt_o = arena.transposed([a.fc_o.weight]) if mode == "pre" else None
-        fuse_do = (mode == "pre" and st.get("att_drop") is None and os.environ.get("OVQA_NO_FUSED_DO", "0") != "1"
-                   and ops.attention_bwd_do_ok(dpre_d, wt_o, bufs[0], keys, ctx.mask, a.h))
-        # (guided attention: the fc_o dX product runs inside the attention backward kernel, dO never leaves the CU)
+        # guided attention and the 20 x 20 question self-attention: the fc_o dX product runs inside the attention backward
+        # kernel (ovqa_attention_bwd_do), dO never travels through HBM
+        fuse_do = False
+        if mode in ("pre", "self") and st.get("att_drop") is None and os.environ.get("OVQA_NO_FUSED_DO", "0") != "1":
+            wt_o = arena.transposed([a.fc_o.weight])
+            q_chk = bufs[0] if mode == "pre" else bufs[0][..., :nqk]
+            fuse_do = ops.attention_bwd_do_ok(dpre_d, wt_o, q_chk, keys if mode == "pre" else q_chk, ctx.mask, a.h)
         d_o = None if fuse_do else _dx(arena, dpre_d, [a.fc_o.weight])
         wq, wk, wv = a.fc_q.weight, a.fc_k.weight, a.fc_v.weight
         bq, bk, bv = a.fc_q.bias, a.fc_k.bias, a.fc_v.bias
@@ -383,8 +386,12 @@ class _MHABlock(Function):
             (qkv,) = bufs
             q, k, v = qkv[..., :nqk], qkv[..., nqk:2 * nqk], qkv[..., 2 * nqk:]
             dqkv = torch.empty_like(qkv)
-            ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"), dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk],
-                              dv=dqkv[..., 2 * nqk:])
+            if fuse_do:
+                ops.attention_bwd_do(dpre_d, wt_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, dq=dqkv[..., :nqk],
+                                     dk=dqkv[..., nqk:2 * nqk], dv=dqkv[..., 2 * nqk:])
+            else:
+                ops.attention_bwd(d_o, q, k, v, o, lse, ctx.mask, a.h, o_lo=o_lo, att_drop=st.get("att_drop"),
+                                  dq=dqkv[..., :nqk], dk=dqkv[..., nqk:2 * nqk], dv=dqkv[..., 2 * nqk:])
             _wgrad(arena, dqkv, queries, [wq, wk, wv], [bq, bk, bv])
             dx = _dx(arena, dqkv, [wq, wk, wv], addend=dpre)
             return dx, None, None, None, None, *([None] * len(st["params"]))

@@ -969,7 +969,8 @@ def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
         assert len(lo) == 1 and nerr(o.float() + lo[0].float(), o2.float() + lo2[0].float()) < 2e-3
 
 
-@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 32), (2, 65, 1), (5, 97, 13)])
+@pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 32), (2, 65, 1), (5, 97, 13), (64, 20, 20), (3, 32, 32), (2, 1, 1),
+                                     (4, 17, 29), (2, 50, 20)])
 def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     """ovqa_attention_bwd_do (the fc_o dX product inside the guided-attention backward kernel, from the transposed weight
     copy) against ovqa_linear_bwd_data_wt + ovqa_attention_bwd: same dq, dk, dv."""
@@ -987,8 +988,8 @@ def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     group = rnd(Dm, 4 * Dm, dtype=BF16, scale=Dm ** -0.5, seed=3)  # transposed copies of an adjacency group [in, 4 x out]
     wt = group[:, 3 * Dm:]                                          # fc_o's slice: rows = input features, strided
     dkv1, dkv0 = torch.zeros_like(kv), torch.zeros_like(kv)
-    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (nq > 64)
-    if nq <= 64:
+    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (nq > 64 or nq <= 32)
+    if 32 < nq <= 64:
         return
     dq1, _, _ = o_.attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, o_lo=lo[0], dk=dkv1[..., 2 * H * d:3 * H * d],
                                     dv=dkv1[..., 3 * H * d:])
