@@ -761,6 +761,8 @@ def attention_bwd_do_ok(dy, wt, q, k, mask, H):
     queries (guided attention) or <= 32 queries with an even head count (the 20 x 20 question self-attention), key mask
     or none."""
     nq = q.shape[1] if q.dim() == 3 else 0
+    if os.environ.get("OVQA_FORCE_SIMPLE", "0") == "1" or os.environ.get("OVQA_NO_FUSED_QKV", "0") == "1":
+        return False  # (the library's A/B switches that turn the fused attention forms off)
     return (dy.is_cuda and dy.dtype == torch.bfloat16 and wt is not None and wt.dtype == torch.bfloat16 and q.dim() == 3
             and q.shape[2] == H * 64 and (64 < nq <= 128 or (1 <= nq <= 32 and H % 2 == 0)) and k.shape[1] <= 32
             and dy.shape[-1] % 64 == 0

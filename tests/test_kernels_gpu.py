@@ -988,8 +988,9 @@ def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     group = rnd(Dm, 4 * Dm, dtype=BF16, scale=Dm ** -0.5, seed=3)  # transposed copies of an adjacency group [in, 4 x out]
     wt = group[:, 3 * Dm:]                                          # fc_o's slice: rows = input features, strided
     dkv1, dkv0 = torch.zeros_like(kv), torch.zeros_like(kv)
-    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (nq > 64 or nq <= 32)
-    if 32 < nq <= 64:
+    fused_on = not FORCED_SIMPLE and not NO_FUSED_QKV
+    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (fused_on and (nq > 64 or nq <= 32))
+    if 32 < nq <= 64 or not fused_on:
         return
     dq1, _, _ = o_.attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, o_lo=lo[0], dk=dkv1[..., 2 * H * d:3 * H * d],
                                     dv=dkv1[..., 3 * H * d:])
