@@ -167,17 +167,14 @@ class GraphedBeamSearch:
 
     def _decode(self, enc, mask):
         b_s, beam, dev = self.b_s, self.beam, enc.device
-        st = {}
 
         def step(t, prev, **kw):
             if t == 0:
-                st["e"], st["m"] = enc, mask
                 prev = torch.full((b_s, 1), self.bos, dtype=torch.long, device=dev)
-            elif t == 1 and beam > 1:  # the encoder features of a sample serve all its beams (the reference keeps them as
-                # a state and gathers copies, beam_search.py:61; the decoder's encoder attention shares one projection)
-                st["e"] = enc.unsqueeze(1).expand(-1, beam, -1, -1).reshape(b_s * beam, *enc.shape[1:])
-                st["m"] = mask.unsqueeze(1).expand(-1, beam, -1, -1, -1).reshape(b_s * beam, *mask.shape[1:])
-            return self.decoder(prev, st["e"], st["m"], **kw)
+            # from t = 1 on a sample's encoder features serve all its beams: the reference keeps them as a model state
+            # and gathers a copy per beam (base_transformer.py:21-22, beam_search.py:61); here the decoder is TOLD the
+            # relation (encoder_group) and gets the per-sample tensors, so its encoder attention projects K / V once
+            return self.decoder(prev, enc, mask, encoder_group=(1 if t == 0 else beam), **kw)
         logits_step = (lambda t, prev: step(t, prev, return_logits=True)) if self.fused else None
         with torch.no_grad(), self.decoder.statefulness(b_s):
             return BeamSearch(self.decoder, step, b_s, self.max_len, self.eos, beam, dev,

@@ -35,8 +35,26 @@ def _headers():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [inc]
 
 
+STAMP = os.path.join(CSRC, "_build", "flags.stamp")
+
+
+def _flag_stamp() -> str:
+    """The compile flags this build would use, development extras (OVQA_EXTRA_HIPCC_FLAGS, e.g. -DOVQA_PHASE_PROBE)
+    included.  Stored next to the objects: a library left behind by a probe build is NOT taken for the product build
+    (mtimes alone cannot tell), and vice versa."""
+    return " ".join(FLAGS + os.environ.get("OVQA_EXTRA_HIPCC_FLAGS", "").split())
+
+
+def _stamp_matches() -> bool:
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() == _flag_stamp()
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not _stamp_matches():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in _sources() + _headers())
@@ -55,6 +73,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
+    if not _stamp_matches():  # objects compiled with other flags (a probe build, or none recorded): recompile them all
+        force = True
+        if os.path.exists(STAMP):
+            os.remove(STAMP)
     hdr_t = max(os.path.getmtime(p) for p in _headers())
     jobs = []
     for src in _sources():
@@ -73,6 +95,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        f.write(_flag_stamp() + "\n")
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB)} bytes)", file=sys.stderr)
     return LIB

@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(const T* __restric
     }
   };
   float m = -INFINITY, s = 0.f;
-  auto fold = [&](float v) {
-    const float nm = fmaxf(m, v);
-    s = s * __expf(m - nm) + __expf(v - nm);
+  auto fold = [&](float v) {  // online log-sum-exp; a -inf logit (a masked word) contributes 0, also as the first
+    const float nm = fmaxf(m, v);  // value of a lane: exp(-inf - -inf) would be NaN (F.log_softmax handles -inf, so do we)
+    s = (m == -INFINITY ? 0.f : s * __expf(m - nm)) + (v == -INFINITY ? 0.f : __expf(v - nm));
     m = nm;
   };
   if (cached) {

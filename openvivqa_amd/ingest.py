@@ -30,8 +30,9 @@ class FeatureCollator:
     """``collate(samples) -> {key: device tensor (B, L, D)}`` for the array fields named in ``keys``.
 
     L = the longest sample of the batch (the reference's padding, utils/instance.py:155-170) or ``pad_to``; shorter
-    samples are zero-padded at the end.  Buffers are allocated once per (key, shape) and reused alternately (``depth``
-    of them), host buffers pinned when the target is a GPU.  ``collate`` returns after QUEUING the copies on its side
+    samples are zero-padded at the end.  ``depth`` buffers per key, reused strictly alternately and grown to the largest
+    batch seen, host buffers pinned when the target is a GPU: the tensors of ``depth`` consecutive collates are distinct
+    memory, whatever their shapes.  ``collate`` returns after QUEUING the copies on its side
     stream; ``wait()`` makes the current stream wait for them (call it before the step that consumes the batch).  A copy
     starts once the work queued on the current stream AT THE TIME OF THE CALL is done (that work may still read the
     device buffer being refilled), so to overlap staging with compute collate batch i + 1 BEFORE queuing step i:
@@ -43,22 +44,29 @@ class FeatureCollator:
         self.keys, self.device = list(keys), torch.device(device)
         self.pad_to = dict(pad_to or {})
         self.dtype, self.depth = dtype, depth
-        self._slots: Dict[tuple, list] = {}
-        self._turn = 0
+        self._slots: Dict[str, list] = {}   # key -> `depth` slots [flat host staging, flat device buffer, last-copy event]
+        self._next: Dict[str, int] = {}     # key -> slot of its NEXT collate (round-robin per key, whatever the shapes)
         self._stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._event = None
 
     def _buffers(self, key, shape):
-        slots = self._slots.setdefault((key,) + tuple(shape), [])
-        if len(slots) < self.depth:
-            host = torch.zeros(shape, dtype=self.dtype, pin_memory=self.device.type == "cuda")
-            dev = host if self.device.type == "cpu" else torch.empty(shape, dtype=self.dtype, device=self.device)
-            slots.append([host, dev, None])  # (host staging, device buffer, event of the last copy out of `host`)
-            return slots[-1]
-        slot = slots[self._turn % self.depth]
-        if slot[2] is not None:
+        """Slot of this collate for ``key``: strictly alternating per key, so that the tensors of two consecutive
+        collates never share memory whatever their shapes (a slot index shared by all keys and shapes, with slots created
+        on first use, could hand two consecutive batches of one shape the same buffer).  A slot is ONE flat buffer per
+        side, sized for the largest batch it has held and viewed as (B, L, D): memory is bounded by depth x the largest
+        batch per key instead of growing with every distinct padded length."""
+        slots = self._slots.setdefault(key, [None] * self.depth)
+        i = self._next.get(key, 0)
+        self._next[key] = (i + 1) % self.depth
+        numel = int(np.prod(shape))
+        slot = slots[i]
+        if slot is not None and slot[2] is not None:
             slot[2].synchronize()  # the H2D copy that last read this host buffer is done before the CPU rewrites it
-        return slot
+        if slot is None or slot[0].numel() < numel:
+            host = torch.zeros(numel, dtype=self.dtype, pin_memory=self.device.type == "cuda")
+            dev = host if self.device.type == "cpu" else torch.empty(numel, dtype=self.dtype, device=self.device)
+            slot = slots[i] = [host, dev, None]
+        return slot, slot[0][:numel].view(shape), slot[1][:numel].view(shape)
 
     def collate(self, samples: List[Dict[str, object]]) -> Dict[str, torch.Tensor]:
         if not samples:
@@ -75,14 +83,13 @@ class FeatureCollator:
             L = self.pad_to.get(key, longest)
             if longest > L:
                 raise ValueError(f"field {key!r}: a sample has {longest} rows, pad_to allows {L}")
-            slot = self._buffers(key, (len(arrs), L, D))
-            host, dev = slot[0], slot[1]
+            slot, host, dev = self._buffers(key, (len(arrs), L, D))
             hv = host.numpy()
             for i, a in enumerate(arrs):
                 n = a.shape[0]
                 hv[i, :n] = a.astype(np_dtype, copy=False)
                 hv[i, n:] = 0  # (the buffer is reused: clear what an earlier, longer sample left)
-            if dev is not host:
+            if self._stream is not None:
                 cur = torch.cuda.current_stream(self.device)
                 self._stream.wait_stream(cur)  # the previous consumer of this device buffer is done before we overwrite it
                 with torch.cuda.stream(self._stream):
@@ -91,7 +98,6 @@ class FeatureCollator:
             out[key] = dev
         if self._stream is not None:
             self._event = self._stream.record_event()
-        self._turn += 1
         return out
 
     def wait(self) -> None:

@@ -248,7 +248,10 @@ class MultiHeadAttention(Module):
         self._site = rt.new_dropout_site()
         self._drop_decode_caches()
 
-    def forward(self, queries, keys, values, attention_mask, projected_kv=None, **kwargs):
+    def forward(self, queries, keys, values, attention_mask, projected_kv=None, encoder_group: int = 1, **kwargs):
+        """``encoder_group`` (an addition, default 1): query rows r*g .. r*g+g-1 attend to keys / values row r -- the
+        beams of a sample over that sample's encoder features, handed over UN-expanded (the reference gathers a copy
+        per beam, beam_search.py:19-34,61).  The relation is stated by the caller, never inferred."""
         arena = rt.ensure_arena(self)
         T = arena.compute_dtype
         if projected_kv is not None and (type(self.attention) is not ScaledDotProductAttention
@@ -261,8 +264,15 @@ class MultiHeadAttention(Module):
         if (self._is_stateful and not self.can_be_stateful and not torch.is_grad_enabled() and same_kv and not same_all
                 and type(self.attention) is ScaledDotProductAttention and queries.shape[1] == 1 and queries.is_cuda
                 and self.attention.d_k == self.attention.d_v and self.attention.d_k in (32, 64, 128)
-                and keys.shape[1] <= 512 and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1))):
-            return self._encoder_step(arena, queries, keys, mask)  # (keys as given: the cache is keyed on that tensor)
+                and keys.shape[1] <= 512 and (mask is None or (mask.shape[-2] == 1 and mask.shape[1] == 1))
+                and queries.shape[0] == keys.shape[0] * encoder_group
+                and (mask is None or mask.shape[0] in (1, queries.shape[0]))):
+            return self._encoder_step(arena, queries, keys, mask, encoder_group)  # (keys as given: the cache is keyed on that tensor)
+        if encoder_group > 1:  # any other path: the reference's per-beam copies
+            keys = keys.repeat_interleave(encoder_group, 0)
+            values = keys if same_kv else values.repeat_interleave(encoder_group, 0)
+            if mask is not None and mask.shape[0] * encoder_group == queries.shape[0]:
+                mask = mask.repeat_interleave(encoder_group, 0)
         keys = queries if same_all else keys.to(T)
         values = keys if same_kv else values.to(T)
         if self.can_be_stateful and self._is_stateful:
@@ -307,7 +317,6 @@ class MultiHeadAttention(Module):
         self._kv = None       # self-attention: [k cache, v cache] (R, capacity, H*d) written in place, + spare pair
         self._kv_spare = None
         self._enc = None      # encoder attention: (source identity, packed K|V (rows, nk, 2*H*d)) of the encoder features
-        self._beam = None     # (b_s, beam) declared by Module.reorder_states: rows b*beam .. b*beam+beam-1 are one sample
 
     def _seat_cache(self, like_q):
         """The in-place K / V caches behind ``running_keys / running_values``.  The state buffers are live-prefix VIEWS
@@ -430,24 +439,22 @@ class MultiHeadAttention(Module):
         o = ops.attention_decode(q, kc, vc, n, a.h, mask=self._row_mask(mask, q.shape[0], n))
         return self._finish_step(arena, queries, o)
 
-    def _encoder_step(self, arena, queries, keys, mask):
+    def _encoder_step(self, arena, queries, keys, mask, group=1):
         """Decoding step of an attention over the ENCODER positions (the non-stateful enc_attn of a DecoderLayer inside
         a stateful decoder, decoders.py:21-27): the reference re-applies fc_k / fc_v to all encoder positions at every
-        step and for every beam.  The projections are computed ONCE per sample and decode: cached for the tensor they
-        were computed from, and -- once ``reorder_states`` has declared the beam structure (rows b*beam .. b*beam+beam-1
-        are the beams of sample b, which see the same encoder features: beam_search.py:19-34 gathers copies) -- shared
-        by the beams of a sample through the attention kernel's ``group``."""
+        step and for every beam.  The projections are computed ONCE per tensor of encoder features: cached under the
+        identity (address, shape, version) of the tensor they were computed from and recomputed whenever a different one
+        arrives.  ``group`` beams of a sample share that sample's projected row through the attention kernel's ``group``
+        -- only when the caller says so (``encoder_group``) and hands over the un-expanded per-sample features."""
         from .. import ops
         a = self.attention
         q = ops.linear_fwd(queries.contiguous(), arena.compute(a.fc_q.weight), arena.master_of(a.fc_q.bias))
-        R, nk, F = keys.shape[0], keys.shape[1], a.h * a.d_k
-        ident = (keys.data_ptr(), tuple(keys.shape), keys._version)
-        enc, beam, group = getattr(self, "_enc", None), getattr(self, "_beam", None), 1
-        if enc is not None and enc[0] == ident:
+        R, nk, F = queries.shape[0], keys.shape[1], a.h * a.d_k
+        assert keys.shape[0] * group == R
+        ident = (keys.data_ptr(), tuple(keys.shape), keys._version, keys.dtype)
+        enc = getattr(self, "_enc", None)
+        if enc is not None and enc[0] == ident and enc[1].dtype == q.dtype:
             kv = enc[1]
-        elif (enc is not None and beam is not None and R == beam[0] * beam[1] and enc[1].shape[0] == beam[0]
-              and enc[1].shape[1] == nk):
-            kv, group = enc[1], beam[1]
         else:
             kv = ops.linear_fwd(keys.to(q.dtype).contiguous(), arena.packed([a.fc_k.weight, a.fc_v.weight]),
                                 arena.packed([a.fc_k.bias, a.fc_v.bias], "master"))

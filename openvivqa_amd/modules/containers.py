@@ -55,7 +55,6 @@ class Module(nn.Module):
         tensor) per buffer (beam_search.py:19-34).  ``selected_beam`` is (b_s, beam_size).  State tensors that are not
         on the GPU, or whose leading dimension is not b_s * cur_beam_size, take the reference's gather."""
         from .. import ops
-        self._declare_beams(b_s, beam_size)
         slots = [(m, n) for m, n in self._state_slots() if m._buffers[n] is not None]
         fused = [(m, n) for m, n in slots
                  if m._buffers[n].is_cuda and m._buffers[n].dim() >= 1 and m._buffers[n].shape[0] == b_s * cur_beam_size
@@ -86,13 +85,6 @@ class Module(nn.Module):
             s = torch.gather(s.view(*([b_s, cur_beam_size] + shape[1:])), 1,
                              beam.expand(*([b_s, beam_size] + shape[1:])))
             m._buffers[n] = s.view(*([-1] + shape[1:]))
-
-    def _declare_beams(self, b_s: int, beam_size: int) -> None:
-        """``reorder_states`` knows what ``apply_to_states(fn)`` cannot: rows b*beam .. b*beam+beam-1 are the beams of
-        sample b.  Modules that keep per-SAMPLE decode caches (the projected encoder K / V of an attention) use it."""
-        self._beam = (b_s, beam_size)
-        for child in self._stateful_children():
-            child._declare_beams(b_s, beam_size)
 
     def _fresh(self, name: str, batch_size: Optional[int]):
         default = self._state_defaults[name]
@@ -137,3 +129,25 @@ class ModuleList(nn.ModuleList, Module):
 
 class ModuleDict(nn.ModuleDict, Module):
     pass
+
+
+def _refuse_foreign_stateful_parent(parent, name, child):
+    """Module-registration hook.  The state machinery recurses with ``isinstance(child, Module)`` against the class of
+    THIS file -- and so does the reference's, against ITS class (containers.py:20-31,50-63).  A reference-side stateful
+    parent (``BaseTransformer(Module)`` with the reference's own ``Module``) that holds this package's ``Decoder`` would
+    therefore never switch it to stateful decoding, never reorder its caches, and beam search would step a stateless
+    decoder on one token at a time: wrong answers without an error.  Make that loud at construction time; the fix is the
+    one-line alias of INTEGRATION.md section A (``models/modules/containers.py`` re-exports this file's classes)."""
+    if (isinstance(child, Module) and not isinstance(parent, Module)
+            and hasattr(parent, "_state_names") and hasattr(parent, "apply_to_states")):
+        raise TypeError(
+            f"{type(parent).__module__}.{type(parent).__name__}.{name}: a stateful container that is not "
+            f"openvivqa_amd.modules.containers.Module is adopting {type(child).__name__} from openvivqa_amd; its "
+            "statefulness()/apply_to_states() would skip this child (isinstance against a different Module class) and "
+            "beam search would decode statelessly.  Resolve `models.modules.containers` to "
+            "`openvivqa_amd.modules.containers` (INTEGRATION.md section A: "
+            "`from openvivqa_amd.modules.containers import Module, ModuleList, ModuleDict`).")
+    return None
+
+
+_hook_handle = torch.nn.modules.module.register_module_module_registration_hook(_refuse_foreign_stateful_parent)

@@ -31,9 +31,11 @@ class DecoderLayer(Module):
         self.enc_attn = MultiHeadAttention(config.ENC_ATTENTION)
         self.pwff = PositionWiseFeedForward(config.ENC_ATTENTION)
 
-    def forward(self, queries, keys, values, self_attention_mask, enc_attention_mask, **kwargs):
+    def forward(self, queries, keys, values, self_attention_mask, enc_attention_mask, encoder_group: int = 1, **kwargs):
+        """``encoder_group`` (an addition, default 1): the encoder features / mask have one row per SAMPLE and serve
+        ``encoder_group`` consecutive query rows (its beams); see MultiHeadAttention.forward."""
         x = self.self_attn(queries, queries, queries, attention_mask=self_attention_mask, **kwargs)
-        x = self.enc_attn(x, keys, values, attention_mask=enc_attention_mask, **kwargs)
+        x = self.enc_attn(x, keys, values, attention_mask=enc_attention_mask, encoder_group=encoder_group, **kwargs)
         return self.pwff(x)
 
 
@@ -106,17 +108,21 @@ class Decoder(Module):
         if spare is not None and cur is not None and cur.dim() == 4 and cur.data_ptr() == spare.data_ptr():
             self._mask_cache, self._mask_spare = spare, self._mask_cache
 
-    def _float_mask(self, mask):
-        """The encoder attention mask in fp32, converted once per decode (the layers would each convert it per step)."""
-        if mask is None or mask.dtype == torch.float32:
+    def _float_mask(self, mask, group=1):
+        """The encoder attention mask in fp32 with one row per query row, converted / expanded to the ``group`` beams of
+        each sample once per decode (the layers would each do it per step); keyed on the identity of the given tensor."""
+        if mask is None or (mask.dtype == torch.float32 and (group == 1 or mask.shape[0] == 1)):
             return mask
-        ident = (mask.data_ptr(), tuple(mask.shape), mask._version)
+        ident = (mask.data_ptr(), tuple(mask.shape), mask._version, mask.dtype, group)
         held = getattr(self, "_enc_mask", None)
         if held is None or held[0] != ident:
-            held = self._enc_mask = (ident, mask.float())
+            m = mask.float()
+            if group > 1 and m.shape[0] != 1:
+                m = m.repeat_interleave(group, 0)
+            held = self._enc_mask = (ident, m)
         return held[1]
 
-    def _decode_step(self, tokens, encoder_features, encoder_attention_mask, return_logits):
+    def _decode_step(self, tokens, encoder_features, encoder_attention_mask, return_logits, encoder_group=1):
         """Stateful step for one new position per row with the embedding sum, the position counter and the new mask column
         in ONE launch (ovqa_decode_embed) instead of ~12 index / elementwise launches."""
         from .. import ops
@@ -135,23 +141,34 @@ class Decoder(Module):
         out = x32.view(R, 1, -1)
         if T == torch.bfloat16:
             out = Fn.attach_residual(x.view(R, 1, -1), out)
-        enc_mask = self._float_mask(encoder_attention_mask)
+        enc_mask = self._float_mask(encoder_attention_mask, encoder_group)
         for layer in self.layers:
             out = layer(queries=out, keys=encoder_features, values=encoder_features,
-                        self_attention_mask=self_mask, enc_attention_mask=enc_mask)
+                        self_attention_mask=self_mask, enc_attention_mask=enc_mask, encoder_group=encoder_group)
         logits = Fn.linear(out.to(T), self.fc, arena)
         return logits if return_logits else F.log_softmax(logits.float(), dim=-1)
 
     def forward(self, answer_tokens: torch.Tensor, encoder_features: torch.Tensor,
-                encoder_attention_mask: torch.Tensor, return_logits: bool = False):
+                encoder_attention_mask: torch.Tensor, return_logits: bool = False, encoder_group: int = 1):
         """``return_logits`` (an addition, default off): hand back the vocabulary logits instead of their log-softmax --
-        the fused beam-search step takes the log-softmax inside its candidate kernel."""
+        the fused beam-search step takes the log-softmax inside its candidate kernel.  ``encoder_group`` (an addition,
+        default 1 = the reference's contract): ``encoder_features`` / ``encoder_attention_mask`` carry one row per SAMPLE
+        and each serves ``encoder_group`` consecutive token rows (the beams of that sample), instead of the per-beam
+        copies beam_search.py:19-34,61 gathers -- the encoder K / V projections are then computed once per sample."""
         b_s, seq_len = answer_tokens.shape
         dev = answer_tokens.device
+        if encoder_group > 1 and encoder_features.shape[0] * encoder_group != b_s:
+            raise ValueError(f"encoder_group={encoder_group}: {encoder_features.shape[0]} encoder rows cannot serve "
+                             f"{b_s} token rows")
         if (self._is_stateful and seq_len == 1 and answer_tokens.is_cuda and not torch.is_grad_enabled()
                 and type(self.word_emb).__name__ == "UsualEmbedding" and self.d_model % 4 == 0
                 and self.pos_emb.weight.dtype == torch.float32):
-            return self._decode_step(answer_tokens, encoder_features, encoder_attention_mask, return_logits)
+            return self._decode_step(answer_tokens, encoder_features, encoder_attention_mask, return_logits,
+                                     encoder_group)
+        if encoder_group > 1:  # the general path works on the reference's per-beam copies
+            encoder_features = encoder_features.repeat_interleave(encoder_group, 0)
+            if encoder_attention_mask is not None and encoder_attention_mask.shape[0] != 1:
+                encoder_attention_mask = encoder_attention_mask.repeat_interleave(encoder_group, 0)
         pad_mask = generate_padding_mask(answer_tokens, self.padding_idx).to(dev)
         self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len, device=dev))
         if self._is_stateful:  # decoders.py:55-57

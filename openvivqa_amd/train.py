@@ -134,6 +134,8 @@ class FlatAdam:
         step = float(self.step_t.item())
         if step > 0:
             for i, p in enumerate(params):
+                if not p.requires_grad:  # torch.optim.Adam never creates state for a frozen parameter (a decoder's
+                    continue             # pos_emb, from_pretrained(freeze=True)): keep the reference's checkpoint layout
                 o = a.offsets[id(p)]
                 state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}

@@ -29,7 +29,7 @@ __all__ = [
     "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
     "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "OracleMLP", "OracleMCAN",
     "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "OracleM4CDecodingHead", "batch_gather",
-    "noam_lambda", "oracle_train_step", "build_oracle_encoder",
+    "noam_lambda", "oracle_train_step", "build_oracle_encoder", "oracle_beam_search", "oracle_generate",
 ]
 
 
@@ -984,6 +984,86 @@ class OracleM4CDecodingHead(nn.Module):
             if last_ids.mean() == eos_idx:
                 break
         return scores, prev_inds, passes, trace
+
+
+# --------------------------------------------------------------------------
+# beam search (row f1 / N1)   models/modules/beam_search.py:19-118, models/base_transformer.py:31-54
+# --------------------------------------------------------------------------
+def oracle_beam_search(step, reorder, b_s: int, max_len: int, eos_idx: int, beam_size: int, out_size: int = 1,
+                       trace: Optional[list] = None):
+    """The reference's batched beam search, restated (pinned by tests/golden/G16_beam_search.npz = the reference's own
+    ``BeamSearch`` over its own ``Decoder``).
+
+    ``step(t, prev_words) -> (b_s * cur_beam, 1, |V|)`` log-probabilities is ``model.step`` (base_transformer.py:31-44);
+    ``reorder(fn)`` is ``model.apply_to_states`` (beam_search.py:61).  Per step (beam_search.py:41-83): candidates =
+    running score + word log-probabilities; a sequence that has produced <eos> keeps its score on word 0 and gets -999
+    on every other word (:49-55); the ``beam`` best of the cur_beam * |V| candidates by a full descending sort (:36-39);
+    beam = index // |V|, word = index % |V| (:58-59); every state buffer, the mask and both histories follow their beams
+    (:61-66,78-81); the recorded word score is the MASKED word log-probability, i.e. 0 once a sequence is finished
+    (:52,74-77).  Finally the beams are sorted by score and the best ``out_size`` returned (:99-118).  ``trace`` (a list)
+    receives per step what the search saw and chose: the step's log-probabilities, the source beam and the word of every
+    new beam -- so that a test can drive another decoder through the SAME choices."""
+    seq_mask = torch.ones(b_s, beam_size, 1)
+    seq_logprob = torch.zeros(b_s, 1, 1)
+    words_hist, score_hist, prev = [], [], None
+    for t in range(max_len):
+        cur = 1 if t == 0 else beam_size
+        word_lp = word_lp_raw = step(t, prev).view(b_s, cur, -1)
+        n_words = word_lp.shape[-1]
+        cand = seq_logprob + word_lp
+        if t > 0:
+            alive = (prev.view(b_s, cur) != eos_idx).float().unsqueeze(-1)
+            seq_mask = seq_mask * alive
+            word_lp = word_lp * seq_mask
+            frozen = seq_logprob.expand(b_s, cur, n_words).clone()
+            frozen[:, :, 1:] = -999
+            cand = seq_mask * cand + frozen * (1 - seq_mask)
+        best, flat = torch.sort(cand.view(b_s, -1), -1, descending=True)
+        best, flat = best[:, :beam_size], flat[:, :beam_size]
+        from_beam = torch.div(flat, n_words, rounding_mode="trunc")
+        word = flat - from_beam * n_words
+
+        def follow(s, from_beam=from_beam, cur=cur):  # beam_search.py:19-34
+            tail = list(s.shape[1:])
+            idx = from_beam.view(b_s, beam_size, *([1] * len(tail))).expand(b_s, beam_size, *tail)
+            return torch.gather(s.view(b_s, cur, *tail), 1, idx).view(-1, *tail)
+        reorder(follow)
+        if trace is not None:
+            trace.append(dict(t=t, cur=cur, step_logp=word_lp_raw, from_beam=from_beam.clone(), word=word.clone()))
+        seq_logprob = best.unsqueeze(-1)
+        seq_mask = torch.gather(seq_mask, 1, from_beam.unsqueeze(-1))
+        pick = from_beam.unsqueeze(-1)
+        words_hist = [torch.gather(w, 1, pick) for w in words_hist] + [word.unsqueeze(-1)]
+        chosen = torch.gather(word_lp.expand(b_s, cur, n_words), 1, pick.expand(b_s, beam_size, n_words))
+        chosen = torch.gather(chosen, 2, word.unsqueeze(-1))
+        score_hist = [torch.gather(s, 1, pick) for s in score_hist] + [chosen]
+        prev = word.reshape(-1, 1)
+    _, order = torch.sort(seq_logprob, 1, descending=True)
+    order = order.expand(b_s, beam_size, max_len)
+    tokens = torch.gather(torch.cat(words_hist, -1), 1, order)[:, :out_size]
+    scores = torch.gather(torch.cat(score_hist, -1), 1, order)[:, :out_size]
+    if out_size == 1:
+        tokens, scores = tokens.squeeze(1), scores.squeeze(1)
+    return tokens, scores
+
+
+def oracle_generate(decoder, encoder_features, encoder_mask, bos_idx: int, eos_idx: int, beam_size: int,
+                    max_len: Optional[int] = None, out_size: int = 1, trace: Optional[list] = None):
+    """``BaseTransformer.beam_search`` (base_transformer.py:31-54) over a stateful decoder: inside ``statefulness(b_s)``
+    the encoder features and their mask are STATES of the model, so they are expanded to the beams by the same reorder
+    as the decoder's caches (beam_search.py:61); step 0 feeds <bos>, later steps the previously selected words."""
+    b_s = encoder_features.shape[0]
+    held = {"enc": encoder_features, "mask": encoder_mask}
+
+    def step(t, prev):
+        tokens = torch.full((b_s, 1), bos_idx, dtype=torch.long) if t == 0 else prev
+        return decoder(tokens, held["enc"], held["mask"])
+
+    def reorder(fn):
+        held["enc"], held["mask"] = fn(held["enc"]), fn(held["mask"])
+        decoder.apply_to_states(fn)
+    with torch.no_grad(), decoder.statefulness(b_s):
+        return oracle_beam_search(step, reorder, b_s, max_len or decoder.max_len, eos_idx, beam_size, out_size, trace)
 
 
 # --------------------------------------------------------------------------

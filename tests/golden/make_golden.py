@@ -46,6 +46,8 @@ import models.modules.text_embeddings as R_txt  # noqa: E402,F401  (registers Us
 import models.modules.decoders as R_dec  # noqa: E402
 import models.mmf_m4c as R_m4c  # noqa: E402
 import models.iterative_m4c as R_im4c  # noqa: E402
+import models.base_transformer as R_bt  # noqa: E402  (BaseTransformer: step / beam_search, base_transformer.py:9-54)
+import models.modules.beam_search as R_bs  # noqa: E402
 
 from openvivqa_amd.config import ConfigNode, attention_config  # noqa: E402
 
@@ -773,12 +775,106 @@ def g15():
     finish(c)
 
 
+# ---------------------------------------------------------------- G16 beam search through the reference's own classes
+class GenVocab:
+    """What BaseTransformer / Decoder / UsualEmbedding read from a vocab (base_transformer.py:13-16,34; decoders.py:35-44)."""
+    max_answer_length = 8
+    padding_idx = 0
+    bos_idx = 1
+    eos_idx = 2
+
+    def __len__(self):
+        return 13
+
+
+def g16():
+    """The reference's UNMODIFIED ``BaseTransformer.beam_search`` (base_transformer.py:46-54: statefulness ->
+    encoder_forward -> BeamSearch.apply) over its own ``Decoder`` and ``BeamSearch`` (beam_search.py:4-118), beam 1 and
+    3, all beams returned.  The vocabulary projection is scaled up so that candidate scores are well separated (a search
+    over near-ties pins nothing), and the seed is the first one for which (i) some sample's best sequence reaches <eos>
+    early (after 1-4 words), (ii) some sample's does not reach it at all, (iii) no two candidates that decide a selection are closer than
+    5e-3, (iv) at least 48 words over all beams were chosen while live and before any pad word was fed back (those
+    are comparable with a teacher-forced pass), (v) a live sequence emits the pad word at least once -- recorded in ``meta``."""
+    class Gen(R_bt.BaseTransformer):
+        def __init__(self, cfg, vocab):
+            super().__init__(cfg, vocab)
+            self.device = torch.device("cpu")
+            self.decoder = R_dec.Decoder(cfg, vocab)
+
+        def encoder_forward(self, inp):
+            return inp["enc"], inp["enc_mask"]
+
+    class GapSearch(R_bs.BeamSearch):  # same search; records how close the deciding candidates were
+        gaps = []
+
+        def select(self, candidate_logprob):
+            v, _ = torch.sort(candidate_logprob.view(self.b_s, -1), -1, descending=True)
+            GapSearch.gaps.append(float((v[:, :self.beam_size] - v[:, 1:self.beam_size + 1]).min()))
+            return super().select(candidate_logprob)
+
+    vocab, b_s = GenVocab(), 5
+    T = vocab.max_answer_length
+    for seed in range(400):
+        gen = torch.Generator().manual_seed(1600 + seed)
+        enc = feats(b_s, 9, D, gen, pad_rows={1: [7, 8], 3: [5, 6, 7, 8]})
+        emask = R_utils.generate_padding_mask(enc, 0)
+        torch.manual_seed(1600 + seed)
+        m = Gen(dec_cfg(), vocab)
+        m.eval()
+        with torch.no_grad():
+            m.decoder.fc.weight.mul_(12.0)
+        res, ok = {}, True
+        GapSearch.gaps = []
+        saved = R_bt.BeamSearch
+        R_bt.BeamSearch = GapSearch
+        try:
+            with torch.no_grad():
+                for beam in (1, 3):
+                    res[beam] = m.beam_search({"enc": enc, "enc_mask": emask}, batch_size=b_s, beam_size=beam,
+                                              out_size=beam)
+        finally:
+            R_bt.BeamSearch = saved
+        top = res[3][0][:, 0]
+        eos_pos = [(row == vocab.eos_idx).nonzero() for row in top]
+        early = sum(1 for e in eos_pos if len(e) and 1 <= int(e[0]) <= 4)
+        never = sum(1 for e in eos_pos if len(e) == 0)
+        g1_eos = int((res[1][0].reshape(b_s, T) == vocab.eos_idx).any(-1).sum())
+        allb = res[3][0].reshape(b_s * 3, T)
+        is_eos = (allb == vocab.eos_idx).long()
+        live = (torch.cumsum(is_eos, 1) - is_eos) == 0            # no <eos> BEFORE this position
+        fed = torch.cat([torch.ones(b_s * 3, 1, dtype=torch.long), allb[:, :-1]], 1)
+        clean = torch.cumsum((fed == vocab.padding_idx).long(), 1) == 0   # no pad word fed back so far
+        n_scored = int((live & clean).sum())
+        n_live_pad = int((live & (allb == vocab.padding_idx)).sum())
+        if (early >= 1 and never >= 1 and 1 <= g1_eos < b_s and min(GapSearch.gaps) > 5e-3 and n_scored >= 48
+                and n_live_pad >= 1):
+            break
+    else:
+        raise RuntimeError("no seed satisfied the G16 conditions")
+    c = Case("G16_beam_search")
+    c.meta.update(cfg=json.loads(json.dumps(dec_cfg())), seed=1600 + seed, min_gap=min(GapSearch.gaps),
+                  vocab=dict(len=len(vocab), max_answer_length=T, padding_idx=0, bos_idx=1, eos_idx=2),
+                  early_eos=early, never_eos=never, fc_scale=12.0, n_scored=n_scored,
+                  n_live_pad=n_live_pad)
+    for k, v in m.decoder.state_dict().items():
+        c.add("w", k, v)
+    c.add("in", "enc", enc)
+    c.add("in", "enc_mask", emask)
+    for beam in (1, 3):
+        toks, lp = res[beam]
+        c.add("out", f"beam{beam}_tokens", toks.reshape(b_s, beam, T))
+        c.add("out", f"beam{beam}_logp", lp.reshape(b_s, beam, T))
+    # the model the search walked, for the record: states registered by BaseTransformer + the decoder's
+    c.meta["n_states"] = len(list(m.states()))
+    finish(c)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g8k=g8k, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g8k=g8k, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

@@ -29,6 +29,32 @@ class FakeVocab:
         return 11
 
 
+class GenVocab:
+    """The vocab of G16 (beam search through the reference's BaseTransformer): what BaseTransformer, Decoder and
+    UsualEmbedding read (base_transformer.py:13-16,34; decoders.py:35-44)."""
+
+    def __init__(self, meta):
+        v = meta["vocab"]
+        self.n, self.max_answer_length = v["len"], v["max_answer_length"]
+        self.padding_idx, self.bos_idx, self.eos_idx = v["padding_idx"], v["bos_idx"], v["eos_idx"]
+
+    def __len__(self):
+        return self.n
+
+
+def teacher_forced_inputs(tokens, bos_idx, eos_idx, padding_idx):
+    """For sequences a search produced, (b, T): the decoder input [<bos>, w_0 .. w_{T-2}]; ``live`` = positions whose
+    word was chosen before the sequence had produced <eos> (only there is the recorded score the word's log-probability,
+    beam_search.py:52 zeroes it afterwards); ``clean`` = positions before any pad word was fed back (a pad input keeps
+    its position embedding in the stateful pass and loses it teacher-forced, decoders.py:59-63: not comparable after)."""
+    b, T = tokens.shape
+    inp = torch.cat([torch.full((b, 1), bos_idx, dtype=tokens.dtype), tokens[:, :-1]], 1)
+    is_eos = (tokens == eos_idx).long()
+    live = (torch.cumsum(is_eos, 1) - is_eos) == 0
+    clean = torch.cumsum((inp == padding_idx).long(), 1) == 0
+    return inp, live, clean
+
+
 class ModelVocab:
     padding_idx = 0
 

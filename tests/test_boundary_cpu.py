@@ -407,9 +407,9 @@ def test_bench_refuses_fewer_ranks_than_asked():
 
 @pytest.mark.parametrize("beam", [1, 3])
 def test_beam_search_driver_equals_reference_algorithm(beam):
-    """openvivqa_amd.beam.BeamSearch (two-stage top-k selection, whole-buffer history gathers) against a line-by-line
+    """openvivqa_amd.beam.BeamSearch (two-stage top-k selection, whole-buffer history gathers) against the oracle's
     restatement of the reference's list-based algorithm (models/modules/beam_search.py:36-118: full sort, per-element
-    history gathers) on a random step function that depends on the previous words; <eos> reachable."""
+    history gathers; pinned by G16) on a random step function that depends on the previous words; <eos> reachable."""
     from openvivqa_amd.beam import BeamSearch
 
     class NoStates:
@@ -424,34 +424,7 @@ def test_beam_search_driver_equals_reference_algorithm(beam):
         return torch.log_softmax(x, -1)
     out, lp = BeamSearch(NoStates(), step, b_s, T, eos, beam, "cpu").apply(1)
 
-    def reference():
-        seq_mask, seq_logprob = torch.ones((b_s, beam, 1)), torch.zeros((b_s, 1, 1))
-        log_probs, outputs, sw = [], [], None
-        for t in range(T):
-            cur = 1 if t == 0 else beam
-            wl = step(t, sw).view(b_s, cur, -1)
-            cand = seq_logprob + wl
-            if t > 0:
-                mask = (sw.view(b_s, cur) != eos).float().unsqueeze(-1)
-                seq_mask = seq_mask * mask
-                wl = wl * seq_mask.expand_as(wl)
-                old = seq_logprob.expand_as(cand).contiguous()
-                old[:, :, 1:] = -999
-                cand = seq_mask * cand + old * (1 - seq_mask)
-            v, i = torch.sort(cand.view(b_s, -1), -1, descending=True)
-            v, i = v[:, :beam], i[:, :beam]
-            sb = torch.div(i, cand.shape[-1], rounding_mode="trunc")
-            w = i - sb * cand.shape[-1]
-            seq_logprob = v.unsqueeze(-1)
-            seq_mask = torch.gather(seq_mask, 1, sb.unsqueeze(-1))
-            outputs = [torch.gather(o, 1, sb.unsqueeze(-1)) for o in outputs] + [w.unsqueeze(-1)]
-            this = torch.gather(torch.gather(wl, 1, sb.unsqueeze(-1).expand(b_s, beam, wl.shape[-1])), 2, w.unsqueeze(-1))
-            log_probs = [torch.gather(o, 1, sb.unsqueeze(-1).expand(b_s, beam, 1)) for o in log_probs] + [this]
-            sw = w.view(-1, 1)
-        _, order = torch.sort(seq_logprob, 1, descending=True)
-        o = torch.gather(torch.cat(outputs, -1), 1, order.expand(b_s, beam, T))
-        lpr = torch.gather(torch.cat(log_probs, -1), 1, order.expand(b_s, beam, T))
-        return o[:, 0], lpr[:, 0]
-    o2, l2 = reference()
+    import oracle as O  # (the restated reference search, pinned by G16: tests/test_oracle_golden.py)
+    o2, l2 = O.oracle_beam_search(step, lambda fn: None, b_s, T, eos, beam, 1)
     assert torch.equal(out, o2) and torch.allclose(lp, l2)
     assert (out == eos).any()  # the finished-sequence branch was exercised

@@ -914,6 +914,27 @@ def test_beam_step_kernels_match_reference_step(dtype, beam, cur, V):
         assert torch.equal(lp_out[:, :, :t], torch.gather(lp_in[:, :, :t], 1, sel3))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [203, 4000])
+def test_beam_candidates_with_masked_vocabulary_entries(dtype, V):
+    """-inf logits (masked words): F.log_softmax gives them -inf and leaves the rest finite; the candidate kernel's online
+    log-sum-exp must do the same when a lane's FIRST value is -inf (exp(-inf - -inf) = NaN poisoned the row)."""
+    g = torch.Generator().manual_seed(V)
+    b_s, beam = 5, 3
+    logits = (torch.randn(b_s, V, generator=g) * 3)
+    logits[:, :70] = float("-inf")          # every lane's first word (vector and scalar loads alike)
+    logits[2, 100:150] = float("-inf")
+    logits = logits.to(DEV).to(dtype)
+    ref = torch.log_softmax(logits.float(), -1)
+    val_ref, idx_ref = torch.topk(ref, beam, dim=-1)
+    sm = torch.ones(b_s, device=DEV)
+    vals, i1, wl = ops().beam_candidates(logits, torch.zeros(b_s, device=DEV), sm, None, 2, beam)
+    assert torch.isfinite(vals).all()
+    assert torch.allclose(vals.view(b_s, beam), val_ref, rtol=0, atol=2e-5)
+    distinct = (val_ref[:, 1:] - val_ref[:, :-1]).abs().min(dim=1).values > 1e-4
+    assert distinct.any() and torch.equal(i1.view(b_s, beam)[distinct], idx_ref[distinct])
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M", [64, 192, 1280])
 def test_linear_fwd_split3_writes_three_strided_outputs(dtype, M):

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 import oracle as O
-from golden_cases import CASES, GOLDEN_DIR, FakeVocab, load_case, oracle_namespace, run_case
+from golden_cases import (CASES, GOLDEN_DIR, FakeVocab, GenVocab, load_case, oracle_namespace, run_case,
+                          teacher_forced_inputs)
 from openvivqa_amd.config import ConfigNode
 
 FWD_TOL, GRAD_TOL = 1e-6, 1e-5
@@ -85,6 +86,37 @@ def test_decoder_stateful_steps():
             assert torch.equal(m.running_seq, case.out["running_seq_final"])
     _close(torch.cat(steps, 1), case.out["step_logp"], 2e-6, "stateful decoder steps")
     _close(torch.cat(steps, 1), case.out["logp"][:, :4], 1e-5, "steps == teacher forced prefix")
+
+
+@pytest.mark.parametrize("beam", [1, 3])
+def test_beam_search_matches_reference_search(beam):
+    """G16 = the reference's unmodified BaseTransformer.beam_search over its own Decoder and BeamSearch
+    (base_transformer.py:46-54, beam_search.py:36-118), every beam returned; the oracle's decoder under the oracle's
+    restated search must give the same words (exactly) and word scores (1e-5), <eos> reached at different steps by
+    different beams, pad words fed back included.  And the recorded scores are the teacher-forced log-probabilities of
+    the same words wherever the sequence was live -- the property the bf16 GPU test holds the HIP decoder to."""
+    case = load_case("G16_beam_search")
+    vocab = GenVocab(case.meta)
+    dec = O.OracleDecoder(ConfigNode(case.meta["cfg"]), vocab)
+    dec.load_state_dict(case.w)
+    dec.eval()
+    enc, mask = case.inputs["enc"], case.inputs["enc_mask"]
+    toks, lp = O.oracle_generate(dec, enc, mask, vocab.bos_idx, vocab.eos_idx, beam, out_size=beam)
+    ref_t, ref_lp = case.out[f"beam{beam}_tokens"], case.out[f"beam{beam}_logp"]
+    assert torch.equal(toks.reshape(ref_t.shape), ref_t)
+    _close(lp.reshape(ref_lp.shape), ref_lp, 1e-5, "word scores")
+    assert not dec._is_stateful and dec.running_seq.shape == (1,)  # statefulness left, defaults restored
+    assert (ref_t == vocab.eos_idx).any() and case.meta["early_eos"] >= 1 and case.meta["never_eos"] >= 1
+    b_s, T = ref_t.shape[0], ref_t.shape[-1]
+    seqs, seq_lp = ref_t.reshape(b_s * beam, T), ref_lp.reshape(b_s * beam, T)
+    inp, live, clean = teacher_forced_inputs(seqs, vocab.bos_idx, vocab.eos_idx, vocab.padding_idx)
+    with torch.no_grad():
+        tf = dec(inp, enc.repeat_interleave(beam, 0), mask.repeat_interleave(beam, 0))
+    tf = tf.gather(-1, seqs.unsqueeze(-1)).squeeze(-1)
+    sel = live & clean
+    assert int(sel.sum()) >= (20 if beam == 1 else case.meta["n_scored"])
+    assert float((tf - seq_lp)[sel].abs().max()) < 1e-5
+    assert float(seq_lp[~live].abs().max()) == 0.0
 
 
 def test_positions_and_masks():

@@ -462,3 +462,31 @@ def test_npy_feature_ingestion_matches_reference_collation(tmp_path):
     assert torch.equal(b[1, :5], torch.tensor(samples[2]["region_features"]))
     with pytest.raises(ValueError):
         FeatureCollator(["region_features"], "cpu", pad_to={"region_features": 4}).collate(samples)
+
+
+def test_feature_collator_alternating_shapes_never_alias_consecutive_batches():
+    """without ``pad_to`` the padded length follows the batch, so shapes alternate.  Batch i must still hold
+    its own data after batch i + 1 was collated (the documented pipeline collates i + 1 before step i is queued), for
+    every interleaving of shapes; and the buffers stop growing once the largest batch has been seen."""
+    import numpy as np
+    from openvivqa_amd.ingest import FeatureCollator
+    rng = np.random.default_rng(3)
+
+    def batch(n_rows, b=2):
+        return [{"f": rng.standard_normal((n_rows - i, 8)).astype(np.float32)} for i in range(b)]
+    col = FeatureCollator(["f"], "cpu")
+    order = [5, 9, 5, 5, 9, 9, 5, 7, 5, 5]  # (the advisor's sequence S, other, S, S is its first four entries)
+    prev = prev_expected = None
+    for n in order:
+        samples = batch(n)
+        cur = col.collate(samples)["f"]
+        expected = torch.zeros(2, n, 8)
+        for i, smp in enumerate(samples):
+            expected[i, :smp["f"].shape[0]] = torch.from_numpy(smp["f"])
+        assert torch.equal(cur, expected)
+        if prev is not None:
+            assert torch.equal(prev, prev_expected), "collate(i + 1) overwrote batch i"
+            lo, hi = prev.data_ptr(), prev.data_ptr() + prev.numel() * 4
+            assert not (lo <= cur.data_ptr() < hi or cur.data_ptr() <= lo < cur.data_ptr() + cur.numel() * 4)
+        prev, prev_expected = cur, expected
+    assert len(col._slots["f"]) == 2 and all(s[0].numel() == 2 * 9 * 8 for s in col._slots["f"])
