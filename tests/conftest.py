@@ -53,11 +53,24 @@ def parity_record(test, what, value, bar):
     return value
 
 
-def grad_close(e_hip_vs_emu, e_emu_vs_fp32, bar):
+ESCAPE_CEILING = 0.15  # no gradient tensor passes further than this from the emulation, whatever the format's own error
+ESCAPES = []           # (test tag, tensor, measured, bar, format error) of every pass through the second arm
+
+
+def grad_close(e_hip_vs_emu, e_emu_vs_fp32, bar, tag=None, what=None, allow_escape=True):
     """Criterion for ONE gradient tensor of the bf16 mode.  e_hip_vs_emu: relative L2 distance of the HIP gradient from
     the bf16-emulating oracle's; e_emu_vs_fp32: distance of the emulating oracle's from the fp32 oracle's -- the error
     the bf16 storage format itself puts on this tensor, no kernel involved.  A tensor passes when the HIP path is within
     ``bar`` of the emulation, or -- for gradients that are cancellations far below their terms (fc_q / fc_k behind a
     near-uniform softmax: up to 3000x smaller than the FFN gradients of the same layer), which the format itself cannot
-    resolve to ``bar`` -- within TWICE the format's own error."""
-    return e_hip_vs_emu < bar or e_hip_vs_emu < 2.0 * e_emu_vs_fp32
+    resolve to ``bar`` -- within TWICE the format's own error AND within ESCAPE_CEILING (round 4: the second arm had no
+    ceiling).  Every pass through the second arm is listed in ESCAPES and, with OVQA_PARITY_REPORT, written to the report
+    as an ``[escape clause]`` row; ``allow_escape=False`` (the non-degenerate operating points) disables it."""
+    if e_hip_vs_emu < bar:
+        return True
+    if allow_escape and e_hip_vs_emu < 2.0 * e_emu_vs_fp32 and e_hip_vs_emu < ESCAPE_CEILING:
+        ESCAPES.append((tag, what, e_hip_vs_emu, bar, e_emu_vs_fp32))
+        if tag is not None:
+            parity_record(tag, f"[escape clause] {what} (format's own error {e_emu_vs_fp32:.3e})", e_hip_vs_emu, bar)
+        return True
+    return False

@@ -91,7 +91,7 @@ def test_hip_modules_match_reference_golden(name, mode):
     for k, ref in case.gin.items():
         assert rec(tag, f"gin/{k} vs fp32 reference", rel_l2(gin[k], ref), 3e-2) < 3e-2, f"{name} gin/{k}"
         rec(tag, f"gin/{k} vs emulation", rel_l2(gin[k], egin[k]), EMU_GRAD_BAR)
-        assert grad_close(rel_l2(gin[k], egin[k]), rel_l2(egin[k], ref), EMU_GRAD_BAR), \
+        assert grad_close(rel_l2(gin[k], egin[k]), rel_l2(egin[k], ref), EMU_GRAD_BAR, tag, f"gin/{k}"), \
             f"{name} gin/{k} vs emulation: {rel_l2(gin[k], egin[k]):.3e}"
     keys = [k for k in case.gw if not k.endswith(ZERO_GRAD)]
     for k in case.gw:
@@ -103,7 +103,7 @@ def test_hip_modules_match_reference_golden(name, mode):
     for k in keys:
         e, fmt = rel_l2(gw[k], egw[k]), rel_l2(egw[k], case.gw[k])
         rec(tag, f"gw/{k} vs emulation", e, EMU_GRAD_BAR)
-        assert grad_close(e, fmt, EMU_GRAD_BAR), f"{name} gw/{k} vs emulation: {e:.3e} (format itself: {fmt:.3e})"
+        assert grad_close(e, fmt, EMU_GRAD_BAR, tag, f"gw/{k}"), f"{name} gw/{k} vs emulation: {e:.3e} (format itself: {fmt:.3e})"
 
 
 def test_state_dict_manifest_matches_reference():
@@ -252,7 +252,7 @@ def test_fullsize_mcan_against_reference_checksum(mode):
         e, fmt = rel_l2(ghip[k], gem[k]), rel_l2(gem[k], g32[k])
         rec(tag, f"{k} vs emulation", e, G9_EMU_BAR)
         rec(tag, f"{k}: emulation vs fp32 oracle (no kernel involved)", fmt, 0.0)
-        if not grad_close(e, fmt, G9_EMU_BAR):
+        if not grad_close(e, fmt, G9_EMU_BAR, tag, k):
             bad.append((k, e, fmt))
     assert not bad, bad
 
@@ -304,29 +304,56 @@ def test_baseline_size_vs_oracle_bf16(B):
         assert nerr(vo_h, vo[:32]) < 2e-2 and nerr(lo_h, lo[:32]) < 2e-2
 
 
-@pytest.mark.parametrize("layers", [1, 6])
-def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers):
-    """The bug detector: MCAN stacks, B=16, 100x20 -- the HIP bf16 path against the oracle in bf16-EMULATION mode
+def _sharpen(modules, factor, value=0.3):
+    """A NON-DEGENERATE operating point for the attention gradients: every fc_q x ``factor`` (attention scores x factor)
+    and every fc_v x ``value``.
+
+    Why the fresh-weight point is degenerate (measured, round 4): with i.i.d. inputs and Xavier weights every attention
+    sub-layer adds nearly the SAME vector (the mean of V under a near-uniform softmax) to all tokens, the common component
+    grows from layer to layer, and in the last guided layer the tokens are almost identical.  dQ_i = sum_j dS_ij K_j with
+    sum_j dS_ij = 0 then cancels everything but the tokens' small individual parts: |d fc_q| / |d fc_v| falls 0.22 ->
+    0.062 -> 0.016 -> 0.004 -> 0.001 -> 0.0003 over the six image self-attentions, and bf16 STORAGE alone (the emulating
+    oracle against the fp32 one, no kernel involved) is 8e-2 off on that tensor -- the only tensors that ever needed
+    grad_close's second arm.  Damping the value path (x0.3) keeps the tokens apart (ratio 0.08 in the last layer, the
+    format's own error <= 1.4e-2 on EVERY tensor: scripts/operating_point.py) and sharper scores (x2) move the softmax
+    away from uniform: there the fc_q / fc_k gradients of the last layers are ordinary numbers."""
+    with torch.no_grad():
+        for m in modules:
+            for k, p in m.named_parameters():
+                if ".fc_q." in k:
+                    p.mul_(factor)
+                if ".fc_v." in k:
+                    p.mul_(value)
+
+
+@pytest.mark.parametrize("layers,B,sharp", [(1, 16, 1.0), (6, 16, 1.0), (6, 16, 2.0), (6, 64, 2.0)],
+                         ids=["L1", "L6", "L6-sharp", "L6-B64-sharp"])
+def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers, B, sharp):
+    """The bug detector: MCAN stacks, 100x20 -- the HIP bf16 path against the oracle in bf16-EMULATION mode
     (oracle.emulate_bf16: values and gradients rounded where the HIP path stores bf16, fp32 everywhere else).
     At L=1 (5 chained blocks) nothing but accumulation order and fast exp/erf separates the two: forward <= 2e-3.
     At L=6 a 1-ulp bf16 flip early in the stack has been amplified through 30 blocks, so the gap approaches the
     rounding noise itself: forward <= 6e-3 (measured 3.3e-3 text / 4.6e-3 vision; against the fp32 oracle the same
-    outputs are at 6e-3 / 7e-3 and held to 1e-2 by test_baseline_size_vs_oracle_bf16)."""
+    outputs are at 6e-3 / 7e-3 and held to 1e-2 by test_baseline_size_vs_oracle_bf16).
+    ``sharp`` (round 4): the same stacks at a NON-DEGENERATE operating point (attention scores x2,
+    value path x0.3: ``_sharpen``), the second one at the BASELINE batch (B = 64, configs[1]): there EVERY gradient tensor -- fc_q / fc_k
+    of the last layers included -- is held to the bar against the emulation with NO escape clause."""
     import openvivqa_amd as A
     import openvivqa_amd.utils as U
     import oracle as O
     A.set_compute_dtype(BF16)
     te_o, ve_o = _mcan_pair(oracle_namespace(), layers, 41)
     te, ve = _mcan_pair(hip_namespace(), layers, 42)
+    if sharp != 1.0:
+        _sharpen((te_o, ve_o), sharp)
     te.load_state_dict(te_o.state_dict())
     ve.load_state_dict(ve_o.state_dict())
     te, ve = te.to(DEV).eval(), ve.to(DEV).eval()
     te_o.eval(), ve_o.eval()
     gen = torch.Generator().manual_seed(8)
-    B = 16
     v, l = torch.randn(B, 100, 512, generator=gen), torch.randn(B, 20, 512, generator=gen)
     for i in range(B):
-        v[i, 84 + i:] = 0
+        v[i, 84 + i % 16:] = 0
         l[i, 8 + i % 12:] = 0
     wv, wl = torch.randn(v.shape, generator=gen), torch.randn(l.shape, generator=gen)
     v_r, l_r = v.clone().requires_grad_(), l.clone().requires_grad_()
@@ -335,6 +362,7 @@ def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers):
     ((vo_r * wv).mean() + (lo_r * wl).mean()).backward()
     g32 = {(pre + k): p.grad.clone() for pre, m in (("self_encoder.", te_o), ("guided_encoder.", ve_o))
            for k, p in m.named_parameters()}
+    lo32, vo32 = lo_r.detach(), vo_r.detach()
     te_o.zero_grad(set_to_none=True), ve_o.zero_grad(set_to_none=True)
     v_r, l_r = v.clone().requires_grad_(), l.clone().requires_grad_()
     with O.emulate_bf16():
@@ -346,23 +374,39 @@ def test_stack_forward_and_gradients_vs_bf16_emulating_oracle(layers):
     lo = te(features=ld, padding_mask=lm)
     vo = ve(vision_features=vd, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
     ((vo.float() * wv.to(DEV)).mean() + (lo.float() * wl.to(DEV)).mean()).backward()
-    from conftest import parity_record as rec
+    from conftest import ESCAPES, grad_close, parity_record as rec
+    tag = f"stack-emulation[L={layers}]" if sharp == 1.0 else f"stack-emulation[L={layers},B={B},scores x{sharp:g}]"
     ftol, gtol, wtol = (2e-3, 8e-3, 1.2e-2) if layers == 1 else (6e-3, 2e-2, 2.5e-2)
+    if sharp != 1.0:  # the operating point itself: how far from uniform the last layer's attention is (recorded)
+        rec(tag, "vision out vs fp32 oracle (north-star bar)", nerr(vo, vo32), 1e-2)
+        rec(tag, "language out vs fp32 oracle (north-star bar)", nerr(lo, lo32), 1e-2)
+        assert nerr(vo, vo32) < 1e-2 and nerr(lo, lo32) < 1e-2
+    rec(tag, "language out vs emulation", nerr(lo, lo_r), ftol)
+    rec(tag, "vision out vs emulation", nerr(vo, vo_r), ftol)
     assert nerr(lo, lo_r) < ftol and nerr(vo, vo_r) < ftol, (nerr(lo, lo_r), nerr(vo, vo_r))
-    assert rel_l2(vd.grad, v_r.grad) < gtol and rel_l2(ld.grad, l_r.grad) < gtol, \
-        (rel_l2(vd.grad, v_r.grad), rel_l2(ld.grad, l_r.grad))
-    from conftest import grad_close
-    bad = []
+    assert rec(tag, "d vision vs emulation", rel_l2(vd.grad, v_r.grad), gtol) < gtol
+    assert rec(tag, "d language vs emulation", rel_l2(ld.grad, l_r.grad), gtol) < gtol
+    bad, n_before = [], len(ESCAPES)
     for (pre, hip_m, ref_m) in (("self_encoder.", te, te_o), ("guided_encoder.", ve, ve_o)):
         gref = dict(ref_m.named_parameters())
         for k, p in hip_m.named_parameters():
             if k.endswith("fc_k.bias"):  # analytically zero
                 continue
             e, fmt = rel_l2(p.grad, gref[k].grad), rel_l2(gref[k].grad, g32[pre + k])
-            rec(f"stack-emulation[L={layers}]", f"gw/{pre}{k} vs emulation", e, wtol)
-            if not grad_close(e, fmt, wtol):
+            rec(tag, f"gw/{pre}{k} vs emulation", e, wtol)
+            if ".fc_q." in k or ".fc_k." in k:  # how non-degenerate: size of this gradient next to the layer's fc_v one
+                rec(tag, f"gw/{pre}{k}: norm / norm of the same block's fc_v gradient (recorded)",
+                    float(p.grad.norm() / dict(hip_m.named_parameters())[k.replace("fc_q", "fc_v").replace("fc_k", "fc_v")].grad.norm()),
+                    float("nan"))
+            if sharp != 1.0:  # the operating point is non-degenerate iff the FORMAT resolves every tensor
+                rec(tag, f"gw/{pre}{k}: emulation vs fp32 oracle (no kernel involved)", fmt, wtol)
+                assert fmt < wtol, (pre + k, fmt)
+            if not grad_close(e, fmt, wtol, tag, pre + k, allow_escape=(sharp == 1.0)):
                 bad.append((pre + k, e, fmt))
+    rec(tag, "gradient tensors that passed through the escape clause", float(len(ESCAPES) - n_before), 0.0)
     assert not bad, bad
+    if sharp != 1.0:
+        assert len(ESCAPES) == n_before
 
 
 @pytest.mark.parametrize("arch,layers", [("CrossModalityEncoder", 6), ("CoAttentionEncoder", 4), ("CoAttentionEncoder", 6)])
@@ -417,17 +461,14 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
     emu_gap = max(rec(tag, "emulation vs fp32 oracle (no kernel involved), vision", nerr(ae, a), 1e-2),
                   rec(tag, "emulation vs fp32 oracle (no kernel involved), language", nerr(be, b), 1e-2))
     assert e_e < 8e-3, (e_e, e_f)
-    if arch == "CoAttentionEncoder" and layers == 6:
-        # documented miss: held to 1.5e-2 against fp32, and the storage format itself must account for the excess
-        assert e_f < 1.5e-2 and (e_f < 1e-2 or emu_gap > 0.6 * e_f), (e_f, emu_gap)
-    else:
-        assert e_f < 1e-2 and rel_l2(ah, a) < 1e-2 and rel_l2(bh, b) < 1e-2, (e_f, rel_l2(ah, a), rel_l2(bh, b))
+    # (round 3 carried a 1.5e-2 escape for CoAttention L=6, 48 chained blocks: it measures 9.0e-3 since the delta fix)
+    assert e_f < 1e-2 and rel_l2(ah, a) < 1e-2 and rel_l2(bh, b) < 1e-2, (e_f, emu_gap, rel_l2(ah, a), rel_l2(bh, b))
     from conftest import grad_close
     gbar = G9_EMU_BAR  # 24-48 chained blocks
     bad = []
     for what, gh, ge in (("d vision", vd.grad, vo_r.grad), ("d language", ld.grad, lo_r.grad)):
         e, fmt = rec(tag, f"{what} vs emulation", rel_l2(gh, ge), gbar), rel_l2(ge, g32[what])
-        if not grad_close(e, fmt, gbar):
+        if not grad_close(e, fmt, gbar, tag, what):
             bad.append((what, e, fmt))
     gref = dict(ref.named_parameters())
     for k, p in hip.named_parameters():
@@ -437,7 +478,7 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
         if k.endswith("fc_k.bias"):
             continue
         e, fmt = rec(tag, f"gw/{k} vs emulation", rel_l2(p.grad, gref[k].grad), gbar), rel_l2(gref[k].grad, g32[k])
-        if not grad_close(e, fmt, gbar):
+        if not grad_close(e, fmt, gbar, tag, "gw/" + k):
             bad.append((k, e, fmt))
     assert not bad, bad
 
