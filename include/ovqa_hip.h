@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 5
+#define OVQA_ABI_VERSION 6
 
 typedef enum {
   OVQA_OK = 0,
@@ -219,14 +219,17 @@ int ovqa_layernorm_bwd(int dtype, int dx_dtype, const void* dy, const void* x, i
  * its row-slab partials in `ws` as fp32 [blocks][2][D] (dgamma partials, then dbeta partials), where
  * blocks = ovqa_layernorm_bwd_blocks(M, D).  ovqa_grouped_partial_reduce then sums the partials of MANY LayerNorms
  * in one launch (each ~5 us dependent launch saved matters: the MCAN step has 32 of them):
- *   out0[D] (+)= sum_b partial[b][0][:],  out1[D] (+)= sum_b partial[b][1][:]   (fp32 atomics across row groups:
- *   outputs must hold zeros or the value to accumulate into).  `problems` is a DEVICE array. */
+ *   out0[D] (+)= sum_b partial[b][0][:],  out1[D] (+)= sum_b partial[b][1][:].  ABI 6: DETERMINISTIC -- a fixed summation
+ *   order and plain stores (ABI <= 5 used fp32 atomics across row groups and needed pre-zeroed outputs); `accumulate`
+ *   selects = or +=.  No two problems of one call may share an output.  `problems` is a DEVICE array. */
 typedef struct ovqa_reduce_problem {
   const float* partial;
   float* out0;
   float* out1;
   int32_t blocks;
   int32_t D;
+  int32_t accumulate; /* 0: out = sum, 1: out += sum */
+  int32_t reserved_;
 } ovqa_reduce_problem;
 int ovqa_layernorm_bwd_blocks(int64_t M, int64_t D);
 int ovqa_grouped_partial_reduce(const ovqa_reduce_problem* problems, int32_t n_problems, int32_t max_blocks,

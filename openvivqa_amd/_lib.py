@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -41,7 +41,7 @@ class AdamTile(C.Structure):
 class ReduceProblem(C.Structure):
     """ovqa_reduce_problem (include/ovqa_hip.h)."""
     _fields_ = [("partial", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
-                ("blocks", C.c_int32), ("D", C.c_int32)]
+                ("blocks", C.c_int32), ("D", C.c_int32), ("accumulate", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class LnRef(C.Structure):

@@ -206,43 +206,24 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
   }
 }
 
-// dgamma/dbeta += column sums of the per-workgroup partials [nblocks][2*D]: grid (2D/64, row groups),
-// 64 columns x 4 partial rows in flight per workgroup, fp32 atomics across row groups (outputs pre-zeroed
-// unless accumulating).
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows_per_group) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + c;  // over 2*D
-  const int b0 = blockIdx.y * rows_per_group, b1 = min(nblocks, b0 + rows_per_group);
-  float s = 0.f;
-  if (i < 2 * D)
-    for (int b = b0 + r; b < b1; b += 4) s += partial[(int64_t)b * 2 * D + i];
-  red[r][c] = s;
-  __syncthreads();
-  if (r != 0 || i >= 2 * D) return;
-  s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-  float* base = (i < D) ? dgamma : dbeta;
-  if (base == nullptr) return;
-  atomicAdd(base + ((i < D) ? i : i - D), s);
-}
-
-// Deferred form of the reduce: every LayerNorm of a backward pass leaves its partials in its own buffer and ONE
-// launch sums them all.  grid (column blocks of 256 over 2*max_D, row groups of 32 partial rows, problems); a thread
-// owns 4 consecutive columns (16-byte loads: the kernel streams ~90 MB per MCAN step) of every 4th row of the group.
-__global__ __launch_bounds__(256) void ln_bwd_grouped_reduce_kernel(const ovqa_reduce_problem* __restrict__ probs) {
-  __shared__ float4 red[4][64];
+// dgamma / dbeta (+)= column sums of the per-workgroup partials [blocks][2*D], for every queued LayerNorm of a backward
+// pass in ONE launch (the deferred form) or for one LayerNorm (the immediate form).  DETERMINISTIC (round 4; rounds 1-3
+// combined row groups with fp32 atomics, so two runs of the same step differed in the last bits and drifted apart): one
+// workgroup owns 256 columns of one problem and sums ALL its partial rows in a fixed order -- row lane r = 0..7 takes
+// rows r, r + 8, ... (16-byte loads, 4 in flight per thread), the eight lane sums are added r = 0..7 -- then writes the
+// outputs, or adds to them when the problem says `accumulate`, with plain stores: no pre-zeroed outputs, no memset.
+// grid (column blocks of 256 over 2*max_D, 1, problems); 512 partial rows x 1 KB per workgroup at D = 512.
+__global__ __launch_bounds__(512) void ln_bwd_grouped_reduce_kernel(const ovqa_reduce_problem* __restrict__ probs) {
+  __shared__ float4 red[8][64];
   const ovqa_reduce_problem pr = probs[blockIdx.z];
   const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
   const int i = (blockIdx.x * 64 + c) * 4;  // over 2*D (D % 8 == 0: a float4 never straddles dgamma | dbeta)
   const int D = pr.D;
-  const int b0 = blockIdx.y * 32, b1 = min(pr.blocks, b0 + 32);
-  if (b0 >= pr.blocks || blockIdx.x * 256 >= 2 * D) return;
+  if (blockIdx.x * 256 >= 2 * D) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < 2 * D) {
-#pragma unroll 8
-    for (int b = b0 + r; b < b1; b += 4) {
+#pragma unroll 4
+    for (int b = r; b < pr.blocks; b += 8) {
       const float4 v = *reinterpret_cast<const float4*>(pr.partial + (int64_t)b * 2 * D + i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -253,11 +234,44 @@ __global__ __launch_bounds__(256) void ln_bwd_grouped_reduce_kernel(const ovqa_r
   float* base = (i < D) ? pr.out0 : pr.out1;
   if (base == nullptr) return;
   base += (i < D) ? i : i - D;
-  const float4 a0 = red[0][c], a1 = red[1][c], a2 = red[2][c], a3 = red[3][c];
-  atomicAdd(base + 0, a0.x + a1.x + a2.x + a3.x);
-  atomicAdd(base + 1, a0.y + a1.y + a2.y + a3.y);
-  atomicAdd(base + 2, a0.z + a1.z + a2.z + a3.z);
-  atomicAdd(base + 3, a0.w + a1.w + a2.w + a3.w);
+  float4 t = red[0][c];
+#pragma unroll
+  for (int w = 1; w < 8; w++) {
+    const float4 a = red[w][c];
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+  }
+  if (pr.accumulate) { t.x += base[0]; t.y += base[1]; t.z += base[2]; t.w += base[3]; }
+  base[0] = t.x; base[1] = t.y; base[2] = t.z; base[3] = t.w;
+}
+
+// The immediate form: the same kernel on a one-problem table passed BY VALUE (no device table, nothing to upload).
+__global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const ovqa_reduce_problem pr) {
+  __shared__ float4 red[8][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int i = (blockIdx.x * 64 + c) * 4;
+  const int D = pr.D;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < 2 * D) {
+#pragma unroll 4
+    for (int b = r; b < pr.blocks; b += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(pr.partial + (int64_t)b * 2 * D + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[r][c] = s;
+  __syncthreads();
+  if (r != 0 || i >= 2 * D) return;
+  float* base = (i < D) ? pr.out0 : pr.out1;
+  if (base == nullptr) return;
+  base += (i < D) ? i : i - D;
+  float4 t = red[0][c];
+#pragma unroll
+  for (int w = 1; w < 8; w++) {
+    const float4 a = red[w][c];
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+  }
+  if (pr.accumulate) { t.x += base[0]; t.y += base[1]; t.z += base[2]; t.w += base[3]; }
+  base[0] = t.x; base[1] = t.y; base[2] = t.z; base[3] = t.w;
 }
 
 template <typename TIN, typename TOUT>
@@ -303,19 +317,8 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
   int rc = ovqa_check_launch("layernorm_bwd");
   if (rc != OVQA_OK) return rc;
   if (dgamma == nullptr && dbeta == nullptr) return OVQA_OK;  // partials stay in ws (deferred grouped reduce)
-  if (!accumulate) {
-    hipError_t e = hipSuccess;
-    if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st);
-    if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st);
-    if (e != hipSuccess) {
-      ovqa_set_error("layernorm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-      return OVQA_ERR_LAUNCH;
-    }
-  }
-  const int rows_per_group = 64;
-  const int groups = (nblocks + rows_per_group - 1) / rows_per_group;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 63) / 64), groups), dim3(256), 0, st, partial,
-                     nblocks, (int)D, dgamma, dbeta, rows_per_group);
+  const ovqa_reduce_problem pr{partial, dgamma, dbeta, nblocks, (int32_t)D, accumulate ? 1 : 0, 0};
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((2 * D + 255) / 256)), dim3(512), 0, st, pr);
   return ovqa_check_launch("layernorm_bwd_reduce");
 }
 
@@ -351,8 +354,9 @@ int layernorm_bwd_blocks(int64_t M, int64_t D) {
 
 int grouped_partial_reduce(const ovqa_reduce_problem* probs, int n, int max_blocks, int max_D, hipStream_t st) {
   if (n <= 0) return OVQA_OK;
-  dim3 grid((unsigned)((2 * max_D + 255) / 256), (unsigned)((max_blocks + 31) / 32), (unsigned)n);
-  hipLaunchKernelGGL(ln_bwd_grouped_reduce_kernel, grid, dim3(256), 0, st, probs);
+  (void)max_blocks;  // (a workgroup walks all partial rows of its columns: the grid no longer depends on their number)
+  dim3 grid((unsigned)((2 * max_D + 255) / 256), 1u, (unsigned)n);
+  hipLaunchKernelGGL(ln_bwd_grouped_reduce_kernel, grid, dim3(512), 0, st, probs);
   return ovqa_check_launch("grouped_partial_reduce");
 }
 

@@ -225,10 +225,20 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __
     out[i] = (!ds.on || drop_keep(ds, (uint32_t)i)) ? 1 : 0;
 }
 
+// Loss scalar without atomics and without a memset (round 4: deterministic).  Every workgroup stores its partial sum;
+// the LAST one to arrive (a ticket counter) adds all partials in index order -- the same order whatever the arrival
+// order -- stores (or, with `accumulate`, adds to) the loss, and resets the counter for the next launch.  The scratch
+// is per device and process; launches that share it are ordered by the stream they run on (a training step has one).
+constexpr int kLossBlocks = 1024;
+__device__ float g_loss_partial[kLossBlocks];
+__device__ unsigned int g_loss_ticket;
+
 template <typename T>
 __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, const T* __restrict__ tgt,
-                                                      T* __restrict__ dx, float* __restrict__ loss, int64_t n, int vec) {
+                                                      T* __restrict__ dx, float* __restrict__ loss, int64_t n, int vec,
+                                                      int accumulate) {
   __shared__ float red[4];
+  __shared__ bool last;
   const float inv_n = 1.f / (float)n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,7 +265,26 @@ __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, c
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+  if (threadIdx.x == 0) {
+    g_loss_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+    __threadfence();  // the partial is visible device-wide before the ticket says so
+    last = atomicAdd(&g_loss_ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)  // thread k: partials k, k + 256, ... in index order
+    t += g_loss_partial[b];
+  t = wave_sum(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);
+    *loss = accumulate ? *loss + total : total;
+    g_loss_ticket = 0u;
+  }
 }
 
 inline int blocks_for(int64_t n) {
@@ -372,24 +401,17 @@ int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t s
 int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                     int accumulate_loss, hipStream_t st) {
   OVQA_REQUIRE(n > 0, OVQA_ERR_BAD_ARG, "sq_loss: n must be > 0");
-  if (!accumulate_loss) {
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-    if (e != hipSuccess) {
-      ovqa_set_error("sq_loss: hipMemsetAsync: %s", hipGetErrorString(e));
-      return OVQA_ERR_LAUNCH;
-    }
-  }
   const int vec = (((uintptr_t)x | (uintptr_t)target | (uintptr_t)dx) & 15) == 0;
   const int64_t per = dtype == OVQA_F32 ? 4 : 8;  // elements per thread and pass
   int blocks = blocks_for((n + per - 1) / per);
-  if (blocks > 256) blocks = 256;  // one atomicAdd on the loss scalar per block: ~10 ns each, serialised in L2
+  if (blocks > kLossBlocks) blocks = kLossBlocks;  // one partial per workgroup, summed in index order by the last one
   dim3 grid(blocks), block(256);
   if (dtype == OVQA_F32)
     hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)target, (float*)dx,
-                       loss, n, vec);
+                       loss, n, vec, accumulate_loss);
   else
     hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (const bf16*)target, (bf16*)dx, loss,
-                       n, vec);
+                       n, vec, accumulate_loss);
   return ovqa_check_launch("sq_loss");
 }
 

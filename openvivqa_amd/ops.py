@@ -324,21 +324,38 @@ class WgradQueue:
                         return True
         return False
 
-    def add_reduce(self, partial, blocks, D, out0, out1):
+    def add_reduce(self, partial, blocks, D, out0, out1, accumulate=False):
         assert out0.dtype == torch.float32 and out1.dtype == torch.float32 and partial.dtype == torch.float32
         self._note_producer(partial)
-        self.reduces.append((partial, blocks, D, out0, out1))
+        self.reduces.append((partial, blocks, D, out0, out1, bool(accumulate)))
 
     def _flush_reduces(self):
         """One launch summing the row-slab partials of every queued LayerNorm backward (main stream)."""
         if not self.reduces:
             return
-        import numpy as np
         red, self.reduces = self.reduces, []
+        # The reduce is deterministic: plain stores, a fixed summation order.  Two problems of ONE launch must therefore
+        # not share an output (a LayerNorm applied twice in a pass): later uses of an output go to a later launch, in
+        # order, and add to what the earlier one stored.
+        waves = []
+        for item in red:
+            key = (item[3].data_ptr(), item[4].data_ptr())
+            for w in waves:
+                if key not in w[0]:
+                    w[0].add(key)
+                    w[1].append(item)
+                    break
+            else:
+                waves.append(({key}, [item]))
+        for _, items in waves:
+            self._launch_reduces(items)
+
+    def _launch_reduces(self, red):
+        import numpy as np
         dev = red[0][0].device
         probs = (_lib.ReduceProblem * len(red))()
-        for i, (partial, blocks, D, out0, out1) in enumerate(red):
-            probs[i] = _lib.ReduceProblem(_p(partial), _p(out0), _p(out1), blocks, D)
+        for i, (partial, blocks, D, out0, out1, acc) in enumerate(red):
+            probs[i] = _lib.ReduceProblem(_p(partial), _p(out0), _p(out1), blocks, D, int(acc), 0)
         raw = np.frombuffer(bytes(probs), dtype=np.uint8)
         capturing = torch.cuda.is_current_stream_capturing()
         entry = self._buffers(raw.size, dev, capturing)
@@ -531,10 +548,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, drop=None, dx_dtype=N
                                       _p(dx), _p(dxd), _p(gout), _p(bout), M, D, int(accumulate), _drop(drop),
                                       _p(ws), _stream()), "layernorm_bwd")
     if defer is not None and M > 0:
-        if not accumulate:  # the grouped reduce adds into its outputs
-            dgamma.zero_()
-            dbeta.zero_()
-        defer.add_reduce(ws, blocks, D, dgamma, dbeta)
+        defer.add_reduce(ws, blocks, D, dgamma, dbeta, accumulate)  # (= or +=: the reduce stores, no pre-zeroing)
     return dx, (dxd if has_drop else dx)
 
 

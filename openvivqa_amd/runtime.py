@@ -321,10 +321,10 @@ class ParamArena:
         self._written_pass = set()
 
     def end_backward_pass(self) -> None:
-        """Harness mode: zero the gradient of every kernel-owned matrix that this pass did NOT write (a branch that
+        """Harness mode: zero the gradient of every kernel-owned parameter that this pass did NOT write (a branch that
         was skipped this time), so that a stale gradient of an earlier step never reaches the optimiser."""
         for p in self.params:
-            if p.dim() >= 2 and id(p) in self.kernel_written and id(p) not in self._written_pass:
+            if id(p) in self.kernel_written and id(p) not in self._written_pass:
                 self.grad_of(p).zero_()
 
     def attach_grads(self) -> None:
@@ -341,14 +341,13 @@ class ParamArena:
         views = [self.grad_of(p) for p in ps]
         self.kernel_written.update(id(p) for p in ps)
         if self.overwrite_grads:
-            # harness mode: the FIRST product of a pass overwrites a matrix, later products of the same pass (a
-            # weight applied twice in one forward) accumulate; the 1-D tail was zeroed for this step and is always
-            # accumulated into (atomic column sums)
+            # harness mode: the FIRST product of a pass overwrites a gradient, later products of the same pass (a
+            # weight applied twice in one forward) accumulate.  Round 4: the 1-D tail (biases, LayerNorm parameters)
+            # follows the same rule -- its producers store deterministically (fused column sums of the grouped dW,
+            # the fixed-order LayerNorm reduce) instead of adding atomically into a region zeroed once per step
             for p, v in zip(ps, views):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
-            if ps[0].dim() < 2:
-                return self.packed(ps, "grad"), True
             seen = [id(p) in self._written_pass for p in ps]
             if any(seen) and not all(seen):  # a packed group of which only some members were written before
                 for p, v, was in zip(ps, views, seen):

@@ -401,11 +401,9 @@ class TrainStep:
         def first():
             a = self.arena
             a.begin_backward_pass()
-            if a.small_lo < a.numel:  # bias / LayerNorm gradients: atomically reduced, so zero them (one memset)
-                a.grad[a.small_lo:].zero_()
-            for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes
-                if s < a.small_lo:
-                    a.grad[s:min(e, a.small_lo)].zero_()
+            for s, e in self._foreign:  # grads that autograd accumulates into / that nobody writes: zeroed per step.
+                a.grad[s:e].zero_()    # Kernel-owned gradients -- the 1-D tail included -- are OVERWRITTEN by their
+                #                        first product of the pass (deterministic stores, no atomics: no zero fill)
             if self._cuts is not None:
                 self._cuts.reset()
                 rt.set_milestone_sink(self._cuts)
