@@ -79,6 +79,14 @@ int ovqa_launch_timing_count(void);
 int ovqa_launch_timing_end(float* us, int cap);
 /* Scratch bytes the caller must provide to the entry points that take `ws`. */
 int64_t ovqa_workspace_bytes(void);
+/* Streams for running independent parts of a step side by side (ABI 6): the latency-bound chain of the question stack
+ * next to the throughput-bound grouped weight gradients (encoders.py:101-117 vs 137-164: the two stacks only meet in the
+ * guided attention).  `cu_mask` / `n_words` (NULL / 0 = every CU): the compute units the stream's kernels may run on, bit
+ * i of word i / 32 = CU i (hipExtStreamCreateWithCUMask); otherwise `priority` within ovqa_stream_priority_range
+ * (numerically lower = served first, hipStreamCreateWithPriority).  A masked stream has the default priority. */
+int ovqa_stream_priority_range(int* least, int* greatest);
+int ovqa_stream_create(void** stream, int priority, const uint32_t* cu_mask, int32_t n_words);
+int ovqa_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------
  * nn.Linear forward (+ fused epilogue).
@@ -439,6 +447,13 @@ int ovqa_adam_step_tiled(float* param, const void* grad, int grad_dtype, float* 
 int ovqa_increment_step(uint32_t* step_ptr, void* stream);
 /* two counters in one launch (the optimiser's step and the dropout step of a training loop); `b` may be NULL */
 int ovqa_increment_steps(uint32_t* a, uint32_t* b, void* stream);
+
+/* An optimiser step begins (ABI 6): *lr_out = lr_table[*step_ptr % n_table] (the LambdaLR schedule of tasks/base_task.py:
+ * 73-76 as a DEVICE table indexed by the number of steps taken; both may be NULL), then *step_ptr += 1 and, if given,
+ * *second += 1.  With ovqa_adam_step*'s lr_scale_ptr = lr_out the whole step replays from one graph: the order of
+ * classification_task.py:129-139 (backward -> optim.step -> scheduler.step) with no host value in it. */
+int ovqa_begin_step(uint32_t* step_ptr, uint32_t* second, const float* lr_table, int32_t n_table, float* lr_out,
+                    void* stream);
 
 /* fp32 -> bf16 / bf16 -> fp32 flat casts (shadow refresh after load_state_dict). */
 int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -67,6 +67,9 @@ SIGNATURES = {
     "ovqa_last_error": [],
     "ovqa_last_dispatch": [],
     "ovqa_workspace_bytes": [],
+    "ovqa_stream_priority_range": [c_vp, c_vp],
+    "ovqa_stream_create": [c_vp, c_int, c_vp, c_int],
+    "ovqa_stream_destroy": [c_vp],
     "ovqa_linear_fwd": [c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                         c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_linear_fwd_res32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, C.POINTER(LnRef), c_vp, c_i64, c_i64, c_i64, c_i64,
@@ -117,6 +120,7 @@ SIGNATURES = {
                              c_f32, c_f32, c_f32, c_vp, c_vp],
     "ovqa_increment_step": [c_vp, c_vp],
     "ovqa_increment_steps": [c_vp, c_vp, c_vp],
+    "ovqa_begin_step": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
     "ovqa_cast": [c_int, c_int, c_vp, c_vp, c_i64, c_vp],
     "ovqa_gelu_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, _DP, c_vp],
     "ovqa_row_padding_mask": [c_int, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp],

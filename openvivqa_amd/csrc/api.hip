@@ -111,6 +111,38 @@ int ovqa_launch_timing_begin(int max_launches) {
   return OVQA_OK;
 }
 
+int ovqa_stream_priority_range(int* least, int* greatest) {
+  OVQA_REQUIRE(least && greatest, OVQA_ERR_BAD_ARG, "stream_priority_range: null pointer");
+  hipError_t e = hipDeviceGetStreamPriorityRange(least, greatest);
+  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e));
+  return OVQA_OK;
+}
+
+int ovqa_stream_create(void** stream, int priority, const uint32_t* cu_mask, int32_t n_words) {
+  OVQA_REQUIRE(stream != nullptr && n_words >= 0 && (n_words == 0 || cu_mask != nullptr), OVQA_ERR_BAD_ARG,
+               "stream_create: bad argument");
+  hipStream_t st = nullptr;
+  hipError_t e;
+  if (n_words > 0) {
+    uint32_t any = 0;
+    for (int i = 0; i < n_words; i++) any |= cu_mask[i];
+    OVQA_REQUIRE(any != 0, OVQA_ERR_BAD_ARG, "stream_create: an empty CU mask would never run anything");
+    e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask);
+  } else {
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority);
+  }
+  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "stream_create: %s", hipGetErrorString(e));
+  *stream = (void*)st;
+  return OVQA_OK;
+}
+
+int ovqa_stream_destroy(void* stream) {
+  if (stream == nullptr) return OVQA_OK;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "stream_destroy: %s", hipGetErrorString(e));
+  return OVQA_OK;
+}
+
 int ovqa_launch_timing_count(void) {
   std::lock_guard<std::mutex> lock(g_timer_mu);
   return g_timer.n;
@@ -595,6 +627,14 @@ int ovqa_increment_step(uint32_t* step_ptr, void* stream) {
 int ovqa_increment_steps(uint32_t* a, uint32_t* b, void* stream) {
   OVQA_REQUIRE(a && a != b, OVQA_ERR_BAD_ARG, "increment_steps: first counter is NULL or the two are the same");
   return ovqa::increment_step(a, b, as_stream(stream));
+}
+
+int ovqa_begin_step(uint32_t* step_ptr, uint32_t* second, const float* lr_table, int32_t n_table, float* lr_out,
+                    void* stream) {
+  OVQA_REQUIRE(step_ptr && step_ptr != second, OVQA_ERR_BAD_ARG, "begin_step: the step counter is NULL or given twice");
+  OVQA_REQUIRE((lr_table == nullptr) == (lr_out == nullptr) && (lr_table == nullptr || n_table > 0), OVQA_ERR_BAD_ARG,
+               "begin_step: lr_table and lr_out go together, with n_table > 0");
+  return ovqa::begin_step(step_ptr, second, lr_table, (uint32_t)n_table, lr_out, as_stream(stream));
 }
 
 int ovqa_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {

@@ -133,6 +133,8 @@ int adam_step_tiled(float* param, const void* grad, int grad_dtype, float* m, fl
                     const float* lr_scale_ptr, float b1, float b2, float eps, float wd, float grad_scale,
                     const uint32_t* step_ptr, hipStream_t st);
 int increment_step(uint32_t* step_ptr, uint32_t* second, hipStream_t st);
+int begin_step(uint32_t* step_ptr, uint32_t* second, const float* lr_table, uint32_t n_table, float* lr_out,
+               hipStream_t st);
 int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st);
 int dropout_keep_mask(const DropArgs& da, uint8_t* out, int64_t n, hipStream_t st);
 int gelu_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, const DropArgs& da, hipStream_t st);

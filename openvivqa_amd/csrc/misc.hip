@@ -154,6 +154,18 @@ __global__ void increment_kernel(uint32_t* s, uint32_t* s2) {
   }
 }
 
+// The device side of "optimiser step begins": the learning rate of THIS step out of a schedule table (entry s % n for
+// the s-th step), then the counters.  With it a whole training step -- Adam and its LambdaLR schedule included -- is ONE
+// graph: nothing about a step comes from the host any more.
+__global__ void begin_step_kernel(uint32_t* s, uint32_t* s2, const float* lr_table, uint32_t n_table, float* lr_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint32_t k = *s;
+    if (lr_table && lr_out) *lr_out = lr_table[k % n_table];
+    *s = k + 1u;
+    if (s2) *s2 = *s2 + 1u;
+  }
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -337,6 +349,12 @@ int adam_step_tiled(float* param, const void* grad, int grad_dtype, float* m, fl
 int increment_step(uint32_t* step_ptr, uint32_t* second, hipStream_t st) {
   hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, st, step_ptr, second);
   return ovqa_check_launch("increment_step");
+}
+
+int begin_step(uint32_t* step_ptr, uint32_t* second, const float* lr_table, uint32_t n_table, float* lr_out,
+               hipStream_t st) {
+  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, st, step_ptr, second, lr_table, n_table, lr_out);
+  return ovqa_check_launch("begin_step");
 }
 
 int cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, hipStream_t st) {

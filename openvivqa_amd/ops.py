@@ -85,6 +85,32 @@ def workspace(device: torch.device) -> torch.Tensor:
     return ws
 
 
+def priority_range():
+    """(least, greatest) stream priority of the device (numerically lower = served first)."""
+    lo, hi = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().ovqa_stream_priority_range(C.byref(lo), C.byref(hi)), "stream_priority_range")
+    return lo.value, hi.value
+
+
+def make_stream(device, priority: int = 0, cu_mask=None):
+    """A torch stream over ``ovqa_stream_create``: ``cu_mask`` = iterable of the compute-unit indices the stream's
+    kernels may run on (hipExtStreamCreateWithCUMask) or None; otherwise ``priority``.  The HIP stream lives as long as
+    the process (a training step keeps its streams)."""
+    dev = torch.device(device)
+    words, n = None, 0
+    if cu_mask is not None:
+        cus = sorted(set(int(c) for c in cu_mask))
+        n = cus[-1] // 32 + 1
+        arr = (C.c_uint32 * n)()
+        for c in cus:
+            arr[c // 32] |= 1 << (c % 32)
+        words = C.cast(arr, C.c_void_p)
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().ovqa_stream_create(C.byref(h), int(priority), words, n), "stream_create")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 # ---------------------------------------------------------------------------
 def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=False, drop=None, out=None,
                preact_out=None):
@@ -867,6 +893,14 @@ def increment_step(step, also=None):
         _lib.check(_lib.load().ovqa_increment_step(_p(step), _stream()), "increment_step")
     else:
         _lib.check(_lib.load().ovqa_increment_steps(_p(step), _p(also), _stream()), "increment_steps")
+
+
+def begin_step(step, also, lr_table, lr_out):
+    """``ovqa_begin_step``: lr_out = lr_table[step % len(lr_table)]; step += 1; also += 1 (if given)."""
+    _dev(step)
+    assert lr_table.dtype == torch.float32 and lr_out.dtype == torch.float32 and lr_table.is_contiguous()
+    _lib.check(_lib.load().ovqa_begin_step(_p(step), _p(also), _p(lr_table), lr_table.numel(), _p(lr_out), _stream()),
+               "begin_step")
 
 
 def cast(src, dst):

@@ -57,6 +57,41 @@ class FlatAdam:
         self.host_step = 0
         if lr_lambda is not None:
             self.lr_scale = float(lr_lambda(0))
+        # Device-side schedule (``device_schedule()``): lr_table[s % N] = lr * lr_lambda(s), the learning rate of the
+        # s-th step, read by ovqa_begin_step inside the step's graph into lr_eff (what the Adam kernels multiply by).
+        self.lr_table = None
+        self.lr_eff = None
+        self._table_from = 0   # steps [_table_from, _table_from + N) are in the table
+        self._staging = []
+
+    LR_TABLE = 4096
+
+    def _lr_of(self, step: int) -> float:
+        return self.lr * (float(self.lr_lambda(step)) if self.lr_lambda is not None else 1.0)
+
+    def _fill_table(self, lo: int, hi: int) -> None:
+        """Entries of steps [lo, hi) (hi - lo <= N) into their slots s % N: one or two stream-ordered copies from a
+        pinned staging buffer.  Called far ahead of use (see advance_host), on the stream the steps run on."""
+        N = self.LR_TABLE
+        vals = torch.tensor([self._lr_of(s) for s in range(lo, hi)], dtype=torch.float32)
+        if self.lr_table.is_cuda:
+            vals = vals.pin_memory()
+            self._staging = (self._staging + [vals])[-2:]  # keep the buffers of in-flight copies alive
+        a = lo % N
+        first = min(hi - lo, N - a)
+        self.lr_table[a:a + first].copy_(vals[:first], non_blocking=True)
+        if first < hi - lo:
+            self.lr_table[:hi - lo - first].copy_(vals[first:], non_blocking=True)
+
+    def device_schedule(self) -> None:
+        """Switch to the device-side schedule (a harness that captures Adam into its step graph calls this once before
+        the capture; idempotent).  Rebuilds the table from the current step / lr / lr_lambda."""
+        dev = self.arena.device
+        if self.lr_table is None:
+            self.lr_table = torch.empty(self.LR_TABLE, dtype=torch.float32, device=dev)
+            self.lr_eff = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._table_from = self.host_step
+        self._fill_table(self.host_step, self.host_step + self.LR_TABLE)
 
     def state_dict(self, names=None) -> dict:
         """Flat fp32 moments in arena order, step counters and the LR scale: what tasks/base_task.py:97-112 stores as
@@ -93,6 +128,7 @@ class FlatAdam:
         self.step_t.fill_(int(sd["step"]))
         self.host_step = int(sd["host_step"])
         self.lr_scale = float(sd["lr_scale"])
+        self._resync_schedule()
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
 
     def _load_torch_adam(self, sd: dict, params) -> None:
@@ -125,6 +161,14 @@ class FlatAdam:
         # LambdaLR keeps the un-scaled rate in `initial_lr`; `lr` is initial_lr * lambda(last_epoch)
         self.lr = float(g0.get("initial_lr", g0["lr"]))
         self.betas, self.eps, self.weight_decay = tuple(g0["betas"]), float(g0["eps"]), float(g0["weight_decay"])
+        self._resync_schedule()
+
+    def _resync_schedule(self) -> None:
+        """After a checkpoint load: the device table is indexed by the DEVICE step counter, which the host counter must
+        equal for the schedule to mean the same thing on both sides."""
+        if self.lr_table is not None:
+            self.host_step = int(self.step_t.item())
+            self.device_schedule()
 
     def torch_adam_state_dict(self, params) -> dict:
         """The same state in ``torch.optim.Adam.state_dict()`` form for ``params`` (the order of ``model.parameters()``):
@@ -154,14 +198,20 @@ class FlatAdam:
     # The three parts of ``step``, for callers that update the arena piecewise (TrainStep with several gradient
     # segments: the update of a segment whose exchange is complete runs while the next segment is still on the wire).
     def begin_step(self, also: Optional[torch.Tensor] = None) -> None:
-        """step_t += 1; ``also`` (another device counter, e.g. the dropout step of the loop) rides in the same launch."""
-        ops.increment_step(self.step_t, also)
+        """step_t += 1; ``also`` (another device counter, e.g. the dropout step of the loop) rides in the same launch;
+        with the device-side schedule the same launch picks this step's learning rate out of the table."""
+        if self.lr_table is not None:
+            ops.begin_step(self.step_t, also, self.lr_table, self.lr_eff)
+        else:
+            ops.increment_step(self.step_t, also)
         self._transposed_stale = False
 
     def apply(self, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0, ranges=None) -> None:
         """Adam update of ``[lo, hi)`` for every range (default: the whole arena), one launch per range."""
         a = self.arena
         g = a.grad if grad is None else grad
+        # device-side schedule: the kernels multiply 1.0 by *lr_eff (this step's rate, written by begin_step)
+        lr, lr_ptr = (1.0, self.lr_eff) if self.lr_table is not None else (self.lr * self.lr_scale, None)
         tiled_ok = hasattr(a, "adam_tiles_in") and os.environ.get("OVQA_ADAM_TILED", "1") != "0"
         for lo, hi in ([(0, a.numel)] if ranges is None else ranges):
             if hi <= lo:
@@ -171,21 +221,36 @@ class FlatAdam:
                 # one pass: update + bf16 shadow + its transpose (no separate transpose launch in end_step)
                 table, n_tiles, flat_lo, flat_hi = tiles
                 ops.adam_step_tiled(a.master, g, self.exp_avg, self.exp_avg_sq, a.shadow, a.shadow_t, table, n_tiles,
-                                    flat_lo, flat_hi, self.lr * self.lr_scale, self.step_t, betas=self.betas,
+                                    flat_lo, flat_hi, lr, self.step_t, lr_scale=lr_ptr, betas=self.betas,
                                     eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
                 continue
             self._transposed_stale = True  # a flat update: the transposed copy needs the separate pass
             ops.adam_step(a.master[lo:hi], g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
-                          None if a.shadow is None else a.shadow[lo:hi], self.lr * self.lr_scale, self.step_t,
+                          None if a.shadow is None else a.shadow[lo:hi], lr, self.step_t, lr_scale=lr_ptr,
                           betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
 
-    def end_step(self) -> None:
+    def finish_device(self) -> None:
+        """The launches that close a step (capturable): the transposed weight copy after a flat update."""
         if self._transposed_stale:
             self.arena.refresh_transposed()  # the dX GEMMs of the next step read the transposed bf16 weights
         self._transposed_stale = False
+
+    def advance_host(self) -> None:
+        """The host's share of a step: the step count and scheduler.step() (the value used by the NEXT step); with the
+        device-side schedule, every N/2 steps the table entries of steps [h + N/2, h + N) replace those of steps the
+        device has finished long ago (a stream-ordered copy issued half a table ahead of its first use)."""
         self.host_step += 1
-        if self.lr_lambda is not None:  # scheduler.step(): value used by the NEXT optimiser step
+        if self.lr_lambda is not None:
             self.lr_scale = float(self.lr_lambda(self.host_step))
+        if self.lr_table is not None:
+            half = self.LR_TABLE // 2
+            if self.host_step - self._table_from >= half:
+                self._table_from += half
+                self._fill_table(self._table_from + half, self._table_from + self.LR_TABLE)
+
+    def end_step(self) -> None:
+        self.finish_device()
+        self.advance_host()
 
 
 class GradAllReducer:
@@ -215,6 +280,29 @@ class GradAllReducer:
         self._done = []     # one event per released segment (communication stream), in release order
         self.timing = None  # list of (ready event, done event, elements) per released segment when instrumented
 
+    @property
+    def capturable(self) -> bool:
+        """The exchange can be recorded into a hipGraph: nothing to exchange, or RCCL (`nccl`) collectives on device
+        tensors.  gloo stages through the host and synchronises: it would abort a capture, not raise."""
+        if not self.active:
+            return True
+        try:
+            return self.stream is not None and str(dist.get_backend(self.group)).lower() == "nccl"
+        except Exception:  # noqa: BLE001
+            return False
+
+    def warm(self, grad: torch.Tensor) -> None:
+        """One small exchange on the communication stream before anything is captured: the communicator (and RCCL's
+        channels) are created by the first collective, and that must not happen inside a stream capture."""
+        if not self.active or self.stream is None:
+            return
+        n = min(grad.numel(), 1024)
+        scratch = torch.zeros(n, dtype=self.comm_dtype if self.staging is not None else grad.dtype, device=grad.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.group)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
     def bounds(self, numel: int, lo: int = 0):
         return [(s, min(s + self.bucket, lo + numel)) for s in range(lo, lo + numel, self.bucket)]
 
@@ -236,12 +324,35 @@ class GradAllReducer:
             if self.staging is not None and not grad.is_cuda:
                 grad[lo:hi].copy_(self.staging[lo:hi])
 
+    def _start_captured(self, grad: torch.Tensor, ranges):
+        """Inside a stream capture: the collectives are issued from the CAPTURING stream itself -- the process group
+        forks its own communication stream off it and ``wait()`` joins it back where the result is needed -- instead of
+        going through this object's communication stream.  A forked stream that forks again (capture stream ->
+        our stream -> the process group's) makes hipStreamEndCapture recurse without end on ROCm 7.0 (each of the two
+        inner streams lists the other as its parallel capture stream); one level of fork / join per collective is
+        fine.  The bf16 staging cast, if any, runs on the compute stream."""
+        handles = []
+        for lo, hi in ranges:
+            if hi <= lo:
+                continue
+            buf = grad
+            if self.staging is not None:
+                ops.cast(grad[lo:hi], self.staging[lo:hi])
+                buf = self.staging
+            handles += [dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        for s, e in self.bounds(hi - lo, lo)]
+        return handles
+
     def reduce_ranges(self, grad: torch.Tensor, ranges, after=None) -> None:
         """Start reducing ``grad[lo:hi]`` for every (lo, hi) in ``ranges`` (in place, SUM over ranks)."""
         if not self.active:
             return
         if self.stream is None:
             self._reduce(grad, ranges)
+            return
+        if torch.cuda.is_current_stream_capturing():
+            self._done.append(self._start_captured(grad, ranges))
+            self._pending = True
             return
         timed = self.timing is not None
         if after is None:
@@ -257,11 +368,22 @@ class GradAllReducer:
                 self.timing.append((after, done, sum(hi - lo for lo, hi in ranges)))
         self._pending = True
 
+    @staticmethod
+    def _join(done) -> None:
+        """Make the current stream wait for one released segment: an event of the communication stream, or the work
+        handles of collectives issued under capture (``_start_captured``)."""
+        if isinstance(done, list):
+            for h in done:
+                h.wait()
+            del done[:]
+        else:
+            torch.cuda.current_stream().wait_event(done)
+
     def wait_segment(self, i: int, grad: torch.Tensor) -> torch.Tensor:
         """Make the current stream wait for the i-th segment released since the last ``finish`` ONLY (later segments
         may still be on the wire); returns the buffer that holds that segment's summed gradients."""
         if self.stream is not None and i < len(self._done):
-            torch.cuda.current_stream(self.device).wait_event(self._done[i])
+            self._join(self._done[i])
         if self.active and self.staging is not None and grad.is_cuda:
             return self.staging
         return grad
@@ -271,7 +393,12 @@ class GradAllReducer:
         holds the summed gradients (``grad`` itself, or the bf16 staging buffer on the GPU: valid only if the
         segments covered the whole buffer)."""
         if self._pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            if any(isinstance(d, list) for d in self._done):
+                for d in self._done:
+                    if isinstance(d, list):
+                        self._join(d)
+            else:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
             self._pending = False
         self._done = []
         if self.active and self.staging is not None and grad.is_cuda:
@@ -386,6 +513,8 @@ class TrainStep:
         self.forward_loss = forward_loss
         self.use_graph = use_graph and self.arena.device.type == "cuda"
         self.graphs = None
+        self._eager_once = False     # timed_comm_step: this step runs launch by launch (events around the exchange)
+        self.whole = None            # ONE graph for the whole step (fwd, loss, bwd, exchange, Adam) when it could be captured
         self.static_inputs = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.drop_step = rt.step_tensor(self.arena.device)
@@ -549,7 +678,7 @@ class TrainStep:
                   "falling back to one gradient exchange after backward on every rank", file=sys.stderr)
             torch.cuda.synchronize()
             self.overlap_mb = 0.0
-            self._cuts, self._live, self.graphs = None, None, None
+            self._cuts, self._live, self.graphs, self.whole = None, None, None, None
             self.segments = [[(0, self.arena.numel)]]
             self._warm_and_capture()
         self._check_plan_identical()
@@ -585,6 +714,16 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW / LayerNorm-reduce launches of the capture
+        if self.use_graph and os.environ.get("OVQA_WHOLE_STEP_GRAPH", "1") != "0" and self.reducer.capturable:
+            try:
+                self._capture_whole_step()
+                return
+            except Exception as exc:  # noqa: BLE001 -- e.g. a collective that cannot be captured: the phase graphs below
+                import sys
+                print(f"openvivqa_amd.TrainStep: whole-step capture failed ({type(exc).__name__}: {exc}); "
+                      "capturing forward / backward phases only, exchange and Adam launched per step", file=sys.stderr)
+                torch.cuda.synchronize()
+                self.whole, self._live = None, None
         if self.use_graph:
             first, later = self._phase_fns()
             graphs = [torch.cuda.CUDAGraph()]
@@ -605,6 +744,62 @@ class TrainStep:
             if len(graphs) != len(self.segments):
                 raise RuntimeError(f"{len(graphs)} captured phases for {len(self.segments)} gradient segments")
             self.graphs = graphs
+
+    def _whole_step_body(self):
+        """Everything a step does on the device, in stream order (what ``_capture_whole_step`` records): zero the foreign
+        gradients, forward, loss, backward in its phases -- after each of which that phase's gradient ranges go to the
+        communication stream (the collective is captured on a forked branch of the SAME graph; RCCL collectives are
+        capturable) -- then ovqa_begin_step (counters + this step's learning rate out of the device table) and Adam,
+        range by range behind the exchange of that range.  Nothing about a step comes from the host."""
+        first, later = self._phase_fns()
+        first()
+        ncut = len(self._live["cuts"])
+        self._release(0)
+        for j, k in enumerate(reversed(range(ncut))):
+            later(k)()
+            self._release(j + 1)
+        self._live = None
+        self._optimiser_tail(host=False)
+
+    def _optimiser_tail(self, host: bool = True) -> None:
+        scale = 1.0 / self.reducer.world
+        if self.reducer.active and len(self.segments) > 1:
+            # segment by segment: the update of a segment that has arrived overlaps the exchange of the later ones
+            # (only the LAST segment's exchange is exposed, and the earlier segments' share of Adam now hides part of it)
+            self.optim.begin_step(also=self.drop_step)  # (the dropout step is next read by the NEXT forward)
+            for k, seg in enumerate(self.segments):
+                self.optim.apply(self.reducer.wait_segment(k, self.arena.grad), scale, ranges=seg)
+            self.reducer.finish(self.arena.grad)
+        else:
+            self.optim.begin_step(also=self.drop_step)
+            self.optim.apply(self.reducer.finish(self.arena.grad), scale)
+        self.optim.finish_device()
+        if host:
+            self.optim.advance_host()
+
+    def _capture_whole_step(self):
+        from . import functional as _fn
+        self.optim.device_schedule()
+        self.reducer.warm(self.arena.grad)
+        # lazily built device tables of the optimiser path (tile table of the tiled Adam, problem table of the grouped
+        # transpose): their host-to-device uploads must not fall inside the capture
+        if hasattr(self.arena, "adam_tiles"):
+            self.arena.adam_tiles()
+        if getattr(self.arena, "shadow_t", None) is not None and getattr(self.arena, "_tr_table", None) is None:
+            self.arena.refresh_transposed()
+        torch.cuda.synchronize()
+        # the step is captured at a fixed point of the counters: put them back afterwards (capture does not execute)
+        q = _fn.wgrad_queue()
+        q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graph
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self._whole_step_body()
+        finally:
+            q.defer_uploads = False
+        q.upload_deferred()
+        self._live = None
+        self.whole = g
 
     def _release(self, k):
         """Phase k is enqueued: hand its gradient ranges to the communication stream."""
@@ -650,23 +845,17 @@ class TrainStep:
         for dst, src in zip(self.static_inputs, inputs):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        if self.graphs is not None:
+        if self.whole is not None and not self._eager_once:
+            self.whole.replay()  # forward, loss, backward, gradient exchange, Adam + schedule: one graph launch
+            self.optim.advance_host()
+            return self.loss
+        if self.graphs is not None and not self._eager_once:
             for k, g in enumerate(self.graphs):
                 g.replay()
                 self._release(k)
         else:
             self._fwd_bwd(on_phase=self._release)
-        scale = 1.0 / self.reducer.world
-        if self.reducer.active and len(self.segments) > 1:
-            # segment by segment: the update of a segment that has arrived overlaps the exchange of the later ones
-            # (only the LAST segment's exchange is exposed, and the earlier segments' share of Adam now hides part of it)
-            self.optim.begin_step(also=self.drop_step)  # (the dropout step is next read by the NEXT forward)
-            for k, seg in enumerate(self.segments):
-                self.optim.apply(self.reducer.wait_segment(k, self.arena.grad), scale, ranges=seg)
-            self.reducer.finish(self.arena.grad)
-            self.optim.end_step()
-        else:
-            self.optim.step(self.reducer.finish(self.arena.grad), grad_scale=scale, also=self.drop_step)
+        self._optimiser_tail()
         return self.loss
 
     def timed_comm_step(self, *inputs: torch.Tensor) -> dict:
@@ -677,6 +866,7 @@ class TrainStep:
             return {}
         self.reducer.timing = []
         end = torch.cuda.Event(enable_timing=True)
+        self._eager_once = True  # (timing events cannot live inside a replayed graph: this one step is launched eagerly)
         try:
             self.step(*inputs)
             # step() has queued Adam behind reducer.finish(): the compute stream's position right after the LAST
@@ -686,6 +876,7 @@ class TrainStep:
             recs = self.reducer.timing
         finally:
             self.reducer.timing = None
+            self._eager_once = False
         if not recs:
             return {}
         last_ready = recs[-1][0]
@@ -700,3 +891,8 @@ class TrainStep:
     @property
     def graph(self):  # single-graph view kept for callers that replay the captured fwd+bwd themselves
         return self.graphs[0] if self.graphs is not None and len(self.graphs) == 1 else None
+
+    @property
+    def captured(self) -> bool:
+        """The step replays from hipGraphs: the whole step as one graph (``whole``) or its forward / backward phases."""
+        return self.whole is not None or self.graphs is not None

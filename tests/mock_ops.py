@@ -260,6 +260,13 @@ def increment_step(step, also=None):
         also.add_(1)
 
 
+def begin_step(step, also, lr_table, lr_out):
+    lr_out.copy_(lr_table[int(step.item()) % lr_table.numel()].reshape(lr_out.shape))
+    step += 1
+    if also is not None:
+        also += 1
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, step, lr_scale=None, betas=(0.9, 0.98), eps=1e-8,
               weight_decay=0.0, grad_scale=1.0):
     t = float(step.item())

@@ -73,9 +73,10 @@ def test_phased_backward_with_comm_stream_matches_single_graph(single_rank_group
     for _ in range(3):
         ts.step(*batch)
     torch.cuda.synchronize()
-    assert ref.graphs is not None and len(ref.graphs) == 1 and len(ref.segments) == 1
+    assert ref.whole is not None and len(ref.segments) == 1
     assert len(ts.segments) >= 4, ts.segments
-    assert (ts.graphs is not None and len(ts.graphs) == len(ts.segments)) if use_graph else ts.graphs is None
+    # one graph for the whole step, the exchange of every segment captured on a forked branch of it
+    assert (ts.whole is not None and ts.graphs is None) if use_graph else not ts.captured
     flat = sorted(r for s in ts.segments for r in s)
     assert flat[0][0] == 0 and flat[-1][1] == ts.arena.numel and all(a[1] == b[0] for a, b in zip(flat, flat[1:]))
     assert abs(float(ts.loss) - float(ref.loss)) <= 2e-3 * abs(float(ref.loss))
@@ -101,6 +102,53 @@ def test_graph_replay_equals_eager_steps():
         assert torch.equal(a.arena.grad, b.arena.grad)
         assert torch.equal(a.arena.master, b.arena.master)
         assert float(a.loss) == float(b.loss)
+
+
+@pytest.mark.parametrize("force", [False, True])
+def test_whole_step_graph_equals_phase_graphs_with_eager_adam(single_rank_group, force, monkeypatch):
+    """Round 4: the step is ONE graph -- forward, loss, backward, the gradient exchange of every segment (captured RCCL
+    collectives on a forked branch) and Adam with the Noam schedule read from a device table (ovqa_begin_step).  Against
+    the round-3 form (one graph per backward phase, exchange and Adam launched from the host with the schedule as a host
+    float): bit-identical weights, moments and losses over 5 steps of a schedule that changes every step."""
+    from openvivqa_amd.train import noam_lr_scale
+    kw = dict(lr_lambda=lambda s: noam_lr_scale(s, 512, 3), force_comm=force, overlap_mb=16.0)
+    # (dropout off: the dropout step counter is one device tensor per process, shared by every TrainStep in it, so two
+    #  harnesses stepping in turns would draw each other's masks; the two-process test below covers dropout)
+    _, a, batch = _make(2, **kw)
+    a.prepare(*batch)  # (the capture happens here, under the default switch)
+    monkeypatch.setenv("OVQA_WHOLE_STEP_GRAPH", "0")
+    _, b, _ = _make(2, **kw)
+    b.prepare(*batch)
+    for i in range(5):
+        a.step(*batch)
+        b.step(*batch)
+        torch.cuda.synchronize()
+        assert float(a.loss) == float(b.loss), i
+        assert torch.equal(a.arena.master, b.arena.master), i
+    assert a.whole is not None and a.graphs is None and b.whole is None and b.graphs is not None
+    assert len(a.segments) == len(b.segments) and (len(a.segments) >= 3 if force else len(a.segments) == 1)
+    assert torch.equal(a.optim.exp_avg, b.optim.exp_avg) and torch.equal(a.optim.exp_avg_sq, b.optim.exp_avg_sq)
+    assert int(a.optim.step_t.item()) == 5 == a.optim.host_step and abs(float(a.optim.lr_eff) - 1e-4 * noam_lr_scale(4, 512, 3)) < 1e-12
+
+
+def test_device_schedule_table_wraps_and_refills():
+    """FlatAdam's device-side LambdaLR table (4096 entries, half refilled every 2048 steps, a stream-ordered copy issued
+    half a table ahead): the rate ovqa_begin_step hands Adam equals lr * lr_lambda(step) for 3 x 4096 steps."""
+    from openvivqa_amd import ops
+    from openvivqa_amd.train import FlatAdam, noam_lr_scale
+
+    class Arena:
+        device = torch.device("cuda", 0)
+        master = torch.zeros(8, device="cuda")
+    opt = FlatAdam(Arena(), lr=0.5, lr_lambda=lambda s: noam_lr_scale(s, 512, 100))
+    opt.device_schedule()
+    seen = torch.zeros(3 * opt.LR_TABLE, device="cuda")
+    for s in range(3 * opt.LR_TABLE):
+        ops.begin_step(opt.step_t, None, opt.lr_table, opt.lr_eff)
+        seen[s:s + 1].copy_(opt.lr_eff)
+        opt.advance_host()
+    want = torch.tensor([0.5 * noam_lr_scale(s, 512, 100) for s in range(3 * opt.LR_TABLE)], dtype=torch.float32)
+    assert torch.equal(seen.cpu(), want)
 
 
 _DETERMINISM_SCRIPT = """
@@ -269,7 +317,7 @@ def test_crossmodality_train_step_with_comm(single_rank_group):
         for _ in range(2):
             ts.step(v, vm, t, tm)
         torch.cuda.synchronize()
-        assert len(ts.segments) == (1 if not force else len(ts.graphs)) and (not force or len(ts.segments) >= 2)
+        assert ts.whole is not None and (len(ts.segments) >= 2 if force else len(ts.segments) == 1)
         dead = [k for k in w0 if "language_vision_mhattn" in k or "vision_language_mhattn" in k]
         assert dead
         for k in dead:
