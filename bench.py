@@ -114,7 +114,8 @@ KERNEL_OF_FAMILY = {
 }
 
 
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
 
 
 def pmc_traffic(kernel_prefix):
@@ -237,10 +238,41 @@ def instep_probe(ts, dom_hint=None):
     def fam_dx(dy, wt, **kw):
         return "dx", 2.0 * rows(dy) * wt.shape[0] * wt.shape[1]
 
-    saved = (ops.linear_fwd, ops.linear_fwd_res32, ops.linear_bwd_data_wt)
-    ops.linear_fwd = tagged(fam_fwd, saved[0])
-    ops.linear_fwd_res32 = tagged(fam_res32, saved[1])
-    ops.linear_bwd_data_wt = tagged(fam_dx, saved[2])
+    # the attention kernels of the step (the library times their launches the same way): per launch the ALGORITHMIC
+    # bytes -- every operand once, bf16 unless said -- and flops, so that each kernel can be put on its own roofline
+    def shp(q, k):
+        B, nq, F = q.shape
+        return B, nq, k.shape[1], F
+
+    def fam_qkv(x, w, bias, mask, H, **kw):  # x, W (3F x D), qkv out, o + o_lo out, lse (fp32)
+        B, n, Dm = x.shape
+        F = w.shape[0] // 3
+        nbytes = 2 * (B * n * Dm + w.numel() + B * n * 3 * F + 2 * B * n * F) + 4 * B * H * n
+        return f"attn_qkv_fwd {n}x{n}", 2.0 * B * n * Dm * 3 * F + 4.0 * B * n * n * F, nbytes
+
+    def fam_q(x, w, bias, k, v, mask, H, **kw):  # x, W_q, q out, k, v in, o + o_lo out, lse
+        (B, nq, _), F, nk = x.shape, w.shape[0], k.shape[1]
+        nbytes = 2 * (x.numel() + w.numel() + B * nq * F + 2 * B * nk * F + 2 * B * nq * F) + 4 * B * H * nq
+        return f"attn_q_fwd {nq}x{nk}", 2.0 * B * nq * x.shape[-1] * F + 4.0 * B * nq * nk * F, nbytes
+
+    def fam_bwd(d_o, q, k, v, o, lse, mask, H, **kw):  # dO, q, o, o_lo in; k, v in; dq, dk, dv out
+        B, nq, nk, F = shp(q, k)
+        nbytes = 2 * (4 * B * nq * F + 2 * B * nk * F + B * nq * F + 2 * B * nk * F) + 4 * B * H * nq
+        return f"attn_bwd {nq}x{nk}", 10.0 * B * nq * nk * F, nbytes
+
+    def fam_bwd_do(dy, wt, q, k, v, o, lse, mask, H, **kw):  # dY, W_o^T in instead of dO
+        B, nq, nk, F = shp(q, k)
+        nbytes = 2 * (dy.numel() + wt.numel() + 3 * B * nq * F + 2 * B * nk * F + B * nq * F + 2 * B * nk * F) + 4 * B * H * nq
+        return f"attn_bwd_do {nq}x{nk}", 2.0 * B * nq * dy.shape[-1] * F + 10.0 * B * nq * nk * F, nbytes
+
+    def fam_att(q, k, v, mask, H, **kw):
+        B, nq, nk, F = shp(q, k)
+        return f"attn_fwd {nq}x{nk}", 4.0 * B * nq * nk * F, 2 * (2 * B * nq * F + 2 * B * nk * F) + 4 * B * H * nq
+    names = ("linear_fwd", "linear_fwd_res32", "linear_bwd_data_wt", "attention_qkv_fwd", "attention_q_fwd",
+             "attention_bwd", "attention_bwd_do", "attention_fwd")
+    saved = tuple(getattr(ops, n) for n in names)
+    for n, fam in zip(names, (fam_fwd, fam_res32, fam_dx, fam_qkv, fam_q, fam_bwd, fam_bwd_do, fam_att)):
+        setattr(ops, n, tagged(fam, getattr(ops, n)))
     cap = 4096
     us = (C.c_float * cap)()
     torch.cuda.synchronize()
@@ -249,57 +281,65 @@ def instep_probe(ts, dom_hint=None):
         torch.cuda._sleep(200_000_000)  # gate (~0.1 s): the host queues the whole step behind it
         ts._fwd_bwd()
     finally:
-        ops.linear_fwd, ops.linear_fwd_res32, ops.linear_bwd_data_wt = saved
+        for nm, fn in zip(names, saved):
+            setattr(ops, nm, fn)
         n = lib.ovqa_launch_timing_end(us, cap)
     if n < 0:
         _lib.check(n, "launch_timing_end")
     torch.cuda.synchronize()
     fams = {}
-    for idx, fam, flops in recs:
-        f = fams.setdefault(fam, {"launches": 0, "time_s": 0.0, "flops": 0.0})
+    for rec in recs:
+        idx, fam, flops = rec[:3]
+        f = fams.setdefault(fam, {"launches": 0, "time_s": 0.0, "flops": 0.0, "bytes": 0.0})
         f["launches"] += 1
         f["time_s"] += us[idx] * 1e-6
         f["flops"] += flops
+        f["bytes"] += rec[3] if len(rec) > 3 else 0.0
     return fams
 
 
-def attention_probe(device, B, NV, NT, D, H, reps=20):
-    """The attention core against the HBM roofline: algorithmic bytes = bf16 Q, K, V read + O written
-    (+ log-sum-exp) per launch, time from a hipGraph replay of the forward kernel alone with HIP events."""
-    from openvivqa_amd import ops
+# family of the in-step probe -> the kernel instantiation the library picks for it (rocprofv3's name, as a prefix)
+ATTN_KERNEL_OF = {"attn_qkv_fwd 100x100": "attn_qkv_fwd_mfma_kernel<128, 1,", "attn_qkv_fwd 20x20": "attn_qkv_fwd_mfma_kernel<32, 2,",
+                  "attn_qkv_fwd": "attn_qkv_fwd_mfma_kernel", "attn_q_fwd": "attn_q_fwd_mfma_kernel",
+                  "attn_bwd 100x100": "attn_bwd_roles_mfma_kernel", "attn_bwd_do 100x20": "attn_bwd_do_smallk_mfma_kernel",
+                  "attn_bwd_do 20x20": "attn_bwd_do_smallk1_mfma_kernel", "attn_bwd": "attn_bwd_smallk_mfma_kernel",
+                  "attn_fwd": "attn_fwd_mfma_kernel"}
+
+
+def pmc_mfma_busy(kernel):
+    """`mfma_busy_frac` of a kernel from the newest committed PMC summary (profiles/rNN_pmc_summary.json), or None."""
+    for f in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(path):
+            vals = [v.get("mfma_busy_frac") for k, v in json.load(open(path)).items() if kernel in k and v.get("launches_sampled")]
+            vals = [v for v in vals if v is not None]
+            return (round(max(vals), 4), "profiles/" + f) if vals else (None, "profiles/" + f)
+    return None, None
+
+
+def attention_rooflines(fams):
+    """The attention kernels that are IN the timed step (the old figure probed a kernel the step no
+    longer launches), from the same in-step launch timing as the GEMM families: launches per step, average duration, the
+    algorithmic bytes and flops of a launch, and both rooflines -- HBM (the bound SURVEY 8d names for the attention core)
+    and MFMA (the fused-projection forms are GEMM-shaped) -- plus the matrix-pipe busy fraction out of the committed PMC
+    pass of the same step."""
     out = {}
-    for name, (nq, nk) in {"image self (100x100)": (NV, NV), "guided (100x20)": (NV, NT),
-                           "question self (20x20)": (NT, NT)}.items():
-        qkv = torch.randn(B, nq, 3 * D, device=device).bfloat16()
-        kv = torch.randn(B, nk, 2 * D, device=device).bfloat16()
-        q = qkv[..., :D]
-        k, v = (qkv[..., D:2 * D], qkv[..., 2 * D:]) if nq == nk else (kv[..., :D], kv[..., D:])
-        mask = torch.zeros(B, 1, 1, nk, device=device)
-        mask[:, :, :, nk - 3:] = -1e5
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            ops.attention_fwd(q, k, v, mask, H)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(10):
-                ops.attention_fwd(q, k, v, mask, H)
-        g.replay()
-        torch.cuda.synchronize()
-        st = torch.cuda.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(reps):
-            g.replay()
-        e1.record(st)
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / (reps * 10)
-        nbytes = B * H * (2 * nq + 2 * nk) * (D // H) * 2 + B * H * nq * 4
-        out[name] = {"us_per_launch": round(t * 1e6, 2), "algorithmic_bytes": nbytes,
-                     "achieved_GBps": round(nbytes / t / 1e9, 1), "frac_of_hbm_peak": round(nbytes / t / 8e12, 4)}
-    return {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel": "attn_fwd_mfma_kernel", "shapes": out}
+    for fam, f in sorted(fams.items()):
+        if not fam.startswith("attn_"):
+            continue
+        kern = next((v for k, v in ATTN_KERNEL_OF.items() if fam.startswith(k)), None)
+        t = f["time_s"] / f["launches"]
+        busy, src = pmc_mfma_busy(kern) if kern else (None, None)
+        out[fam] = {"kernel": kern, "launches_per_step": f["launches"], "avg_launch_us": round(t * 1e6, 2),
+                    "algorithmic_bytes_per_launch": round(f["bytes"] / f["launches"]),
+                    "achieved_GBps": round(f["bytes"] / f["time_s"] / 1e9, 1),
+                    "frac_of_hbm_peak": round(f["bytes"] / f["time_s"] / 8e12, 4),
+                    "algorithmic_flops_per_launch": round(f["flops"] / f["launches"]),
+                    "tflops": round(f["flops"] / f["time_s"] / 1e12, 1),
+                    "frac_of_mfma_peak": round(f["flops"] / f["time_s"] / PEAK_BF16, 4),
+                    "mfma_busy_frac": busy, "mfma_busy_source": src}
+    return {"peak_hbm_GBps": 8000.0, "peak_mfma_TFLOPs": PEAK_BF16 / 1e12, "method": "in-step launch timing, as `roofline`",
+            "kernels": out}
 
 
 def cpu_model():
@@ -793,7 +833,8 @@ def main():
             warm = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
                                   cfg.MODEL.SELF_ENCODER.LAYERS)
             fams = instep_probe(ts)
-            dom = max(fams, key=lambda k: fams[k]["time_s"])
+            gemm_fams = {k: v for k, v in fams.items() if not k.startswith("attn_")}
+            dom = max(gemm_fams, key=lambda k: gemm_fams[k]["time_s"])
             f = fams[dom]
             achieved = f["flops"] / f["time_s"] / 1e12
             traffic, tfile = pmc_traffic(KERNEL_OF_FAMILY[dom])
@@ -808,14 +849,14 @@ def main():
                 "method": "in-step: every launch of the family inside one eager step of the real workload carries its own "
                           "start/stop HIP events (hipExtLaunchKernel via ovqa_launch_timing_begin/_end: the dispatch "
                           "packet's begin/end timestamps on the launch stream; gate kernel first; cold operands); "
-                          "profiles/r03_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
+                          "profiles/r04_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
                           "the same step",
                 "families_in_step": {k: {"launches": v["launches"], "avg_launch_us": round(v["time_s"] / v["launches"] * 1e6, 2),
-                                         "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in fams.items()},
+                                         "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in gemm_fams.items()},
                 "families_warm_replay": warm["families"],
             }
-            # secondary: the (HBM-bound) attention core on its own roofline
-            out["roofline_attention"] = attention_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.HEAD)
+            # secondary: the attention kernels of the step, each on its rooflines
+            out["roofline_attention"] = attention_rooflines(fams)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_threads)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

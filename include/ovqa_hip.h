@@ -67,7 +67,8 @@ const char* ovqa_last_error(void);
 const char* ovqa_last_dispatch(void);
 /* Launch timing (diagnostic, used by bench.py's roofline figure).  Between ovqa_launch_timing_begin(max) and
  * ovqa_launch_timing_end(), every launch of the bf16 GEMM kernels behind ovqa_linear_fwd / ovqa_linear_fwd_res32 /
- * ovqa_linear_bwd_data / ovqa_linear_bwd_data_wt made by this PROCESS (any thread: autograd runs backward on its
+ * ovqa_linear_bwd_data / ovqa_linear_bwd_data_wt and (ABI 6) of the MFMA attention kernels behind ovqa_attention_fwd / _bwd /
+ * _qkv_fwd / _q_fwd / _bwd_do made by this PROCESS (any thread: autograd runs backward on its
  * own) carries a start / stop event pair
  * (hipExtLaunchKernel): the dispatch packet's own begin / end timestamps, i.e. the kernel's execution time as
  * rocprofv3 --kernel-trace reports it.  ovqa_launch_timing_count() = launches recorded so far (a caller maps its

@@ -1839,7 +1839,7 @@ int launch_fwd_t(const ovqa::AttnArgs& a, hipStream_t st) {
   if (rc != OVQA_OK) return rc;
   const int64_t nprob = (int64_t)a.B * a.H;
   dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT, D>), grid, dim3(256), lds, st, a, W, G);
+  OVQA_LAUNCH_TIMED((attn_fwd_mfma_kernel<NKT, ROWMASK, WANT_ATT, D>), grid, dim3(256), lds, st, a, W, G);
   return ovqa_check_launch("attention_fwd(mfma)");
 }
 
@@ -1877,8 +1877,8 @@ int launch_bwd_two(const ovqa::AttnBwdArgs& a, hipStream_t st) {
                      : ensure_lds(attn_bwd_dq_mfma_kernel<false, D>, lds, "attention_bwd(mfma,dq)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nq + 32 * W - 1) / (32 * W)));
-    if (rowmask) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nkt);
-    else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nkt);
+    if (rowmask) OVQA_LAUNCH_TIMED((attn_bwd_dq_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nkt);
+    else OVQA_LAUNCH_TIMED((attn_bwd_dq_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nkt);
     rc = ovqa_check_launch("attention_bwd(mfma,dq)");
     if (rc != OVQA_OK) return rc;
   }
@@ -1892,8 +1892,8 @@ int launch_bwd_two(const ovqa::AttnBwdArgs& a, hipStream_t st) {
                      : ensure_lds(attn_bwd_dkv_mfma_kernel<false, D>, lds, "attention_bwd(mfma,dkv)");
     if (rc != OVQA_OK) return rc;
     dim3 grid((unsigned)((nprob + G - 1) / G), (unsigned)((a.nk + 32 * W - 1) / (32 * W)));
-    if (rowmask) hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nqt);
-    else hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nqt);
+    if (rowmask) OVQA_LAUNCH_TIMED((attn_bwd_dkv_mfma_kernel<true, D>), grid, dim3(256), lds, st, a, W, G, nqt);
+    else OVQA_LAUNCH_TIMED((attn_bwd_dkv_mfma_kernel<false, D>), grid, dim3(256), lds, st, a, W, G, nqt);
     return ovqa_check_launch("attention_bwd(mfma,dkv)");
   }
 }
@@ -1915,7 +1915,7 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   {                                                                                                                   \
     int rc = ensure_lds(attn_bwd_roles_mfma_kernel<NQ, NK, RM>, lds, "attention_bwd(mfma,roles)");                    \
     if (rc != OVQA_OK) return rc;                                                                                     \
-    hipLaunchKernelGGL((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt); \
+    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt); \
   }
     if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
       if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
@@ -1938,7 +1938,7 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   {                                                                                                                   \
     int rc = ensure_lds(attn_bwd_smallk_mfma_kernel<RM, WV, GV>, lds, "attention_bwd(mfma,merged)");                  \
     if (rc != OVQA_OK) return rc;                                                                                     \
-    hipLaunchKernelGGL((attn_bwd_smallk_mfma_kernel<RM, WV, GV>), grid, dim3(WV == 1 ? 128 * GV : 256), lds, st, a);  \
+    OVQA_LAUNCH_TIMED((attn_bwd_smallk_mfma_kernel<RM, WV, GV>), grid, dim3(WV == 1 ? 128 * GV : 256), lds, st, a);  \
   }
     if (W == 1 && G == 2) {
       if (rowmask) OVQA_SMALLK(true, 1, 2) else OVQA_SMALLK(false, 1, 2)
@@ -2002,7 +2002,7 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
     const dim3 grid((unsigned)((a.B + SV - 1) / SV), (unsigned)a.H);                                               \
     int rc = ensure_lds(attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>, lds, "attention_qkv_fwd");              \
     if (rc != OVQA_OK) return rc;                                                                                  \
-    hipLaunchKernelGGL((attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>), grid, dim3(512), lds, st, g);          \
+    OVQA_LAUNCH_TIMED((attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>), grid, dim3(512), lds, st, g);          \
   }
   static int form = -1;
   if (form < 0) {
@@ -2052,7 +2052,7 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
     const size_t lds = NBV * stage > images ? NBV * stage : images;                                            \
     int rc = ensure_lds(attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>, lds, "attention_q_fwd");                       \
     if (rc != OVQA_OK) return rc;                                                                              \
-    hipLaunchKernelGGL((attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>), grid, dim3(512 * NHV), lds, st, g);           \
+    OVQA_LAUNCH_TIMED((attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>), grid, dim3(512 * NHV), lds, st, g);           \
   }
 #define OVQA_QATT(NKTV)                                                     \
   {                                                                         \
@@ -2095,7 +2095,7 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
     const size_t lds1 = 3 * stage1 > 2 * prob1 ? 3 * stage1 : 2 * prob1;
     int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<3>, lds1, "attention_bwd_do");
     if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_do_smallk1_mfma_kernel<3>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), lds1, st, g);
+    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk1_mfma_kernel<3>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), lds1, st, g);
     return ovqa_check_launch("attention_bwd_do(mfma)");
   }
   const size_t prob = (size_t)(2 * 128 + 2 * 32) * 128 + 32 * 4 + 2 * 128 * 4 + 4096 * 4;
@@ -2104,13 +2104,13 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
     const size_t lds = 3 * stage > 2 * prob ? 3 * stage : 2 * prob;
     int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 2>, lds, "attention_bwd_do");
     if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_do_smallk_mfma_kernel<3, 2>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(1024), lds, st, g);
+    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk_mfma_kernel<3, 2>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(1024), lds, st, g);
   } else {
     const size_t stage = (size_t)(64 + 128) * 64 * 2;
     const size_t lds = 3 * stage > prob ? 3 * stage : prob;
     int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 1>, lds, "attention_bwd_do");
     if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_do_smallk_mfma_kernel<3, 1>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g);
+    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk_mfma_kernel<3, 1>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g);
   }
   return ovqa_check_launch("attention_bwd_do(mfma)");
 }

@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __
     out[i] = (!ds.on || drop_keep(ds, (uint32_t)i)) ? 1 : 0;
 }
 
-// Loss scalar without atomics and without a memset (round 4: deterministic).  Every workgroup stores its partial sum;
-// the LAST one to arrive (a ticket counter) adds all partials in index order -- the same order whatever the arrival
-// order -- stores (or, with `accumulate`, adds to) the loss, and resets the counter for the next launch.  The scratch
-// is per device and process; launches that share it are ordered by the stream they run on (a training step has one).
-constexpr int kLossBlocks = 1024;
+// Loss scalar without a memset and without order-dependent arithmetic (round 4: deterministic).  Every workgroup
+// publishes its partial sum; the LAST one to arrive (a ticket counter) adds all partials in index order -- the same order
+// whatever the arrival order -- stores (or, with `accumulate`, adds to) the loss, and resets the counter for the next
+// launch.  The partials travel through device-scope atomics (exchange in, fetch-add of 0 out): those are performed at the
+// point where the 8 XCDs' L2s agree, so no device-wide fence is needed -- a __threadfence() per workgroup writes back the
+// XCD's whole L2 (the 6.5 MB of dx just stored included) and made the first version of this kernel 23 us instead of 8.
+// The scratch is per device and process; launches that share it are ordered by the stream they run on.
+constexpr int kLossBlocks = 256;
 __device__ float g_loss_partial[kLossBlocks];
 __device__ unsigned int g_loss_ticket;
 
@@ -278,16 +281,18 @@ __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, c
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    g_loss_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
-    __threadfence();  // the partial is visible device-wide before the ticket says so
-    last = atomicAdd(&g_loss_ticket, 1u) == gridDim.x - 1;
+    const float mine = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+    // the exchange RETURNS (so it has been performed) before the ticket is taken: the ticket's increment depends on it
+    const float before = atomicExch(&g_loss_partial[blockIdx.x], mine);
+    unsigned int one = 1u;
+    asm volatile("; the ticket waits for the returned value of the exchange" : "+v"(one) : "v"(before));
+    last = atomicAdd(&g_loss_ticket, one) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   float t = 0.f;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)  // thread k: partials k, k + 256, ... in index order
-    t += g_loss_partial[b];
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)  // thread k: partial k (at most one: <= 256 workgroups)
+    t += atomicAdd(&g_loss_partial[b], 0.f);               // (a device-scope read of what the other XCDs published)
   t = wave_sum(t);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, c
   if (threadIdx.x == 0) {
     const float total = (red[0] + red[1]) + (red[2] + red[3]);
     *loss = accumulate ? *loss + total : total;
-    g_loss_ticket = 0u;
+    atomicExch(&g_loss_ticket, 0u);
   }
 }
 
