@@ -171,7 +171,8 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from openvivqa_amd import runtime as rt
+        with torch.cuda.graph(g, capture_error_mode=rt.capture_error_mode()):
             run_all()
         g.replay()
         torch.cuda.synchronize()

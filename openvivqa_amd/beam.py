@@ -193,7 +193,8 @@ class GraphedBeamSearch:
             torch.cuda.current_stream(enc.device).wait_stream(side)
             torch.cuda.synchronize(enc.device)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            from . import runtime as rt
+            with torch.cuda.graph(self.graph, capture_error_mode=rt.capture_error_mode()):
                 self.static_out = self._decode(*self.static_in)
         assert enc.shape == self.static_in[0].shape and mask.shape == self.static_in[1].shape, "static input shapes"
         if enc.data_ptr() != self.static_in[0].data_ptr():

@@ -45,6 +45,20 @@ def manual_seed(seed: int) -> None:
     _state["call"] = 0
 
 
+def capture_error_mode() -> str:
+    """`capture_error_mode` for torch.cuda.graph: "thread_local" while a torch.distributed process group is alive.  Its
+    watchdog thread polls the events of eagerly issued collectives every ~100 ms until it has seen them complete; such a
+    poll during a capture in the default GLOBAL mode invalidates the capture and terminates the process from the watchdog
+    thread (measured: a collective issued just before a capture is enough)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return "thread_local"
+    except Exception:  # noqa: BLE001
+        pass
+    return "global"
+
+
 def new_dropout_site() -> int:
     return next(_site_counter)
 

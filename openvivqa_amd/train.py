@@ -302,6 +302,19 @@ class GradAllReducer:
         with torch.cuda.stream(self.stream):
             dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.group)
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        # The process group's watchdog thread polls the events of eagerly issued collectives (every 100 ms) until it has
+        # seen them complete.  Such a poll DURING a stream capture in the default (global) capture mode invalidates the
+        # capture and terminates the process from the watchdog thread: let it retire this one first -- and capture in
+        # thread-local mode (``capture_mode``), where another thread's event query is legal.
+        torch.cuda.synchronize(self.device)
+        import time
+        time.sleep(0.3)
+
+    @property
+    def capture_mode(self) -> str:
+        """`capture_error_mode` for torch.cuda.graph while this exchange is active: with a process group alive its
+        watchdog thread may query an event at any time, which a GLOBAL-mode capture on another thread does not survive."""
+        return "thread_local" if self.active else rt.capture_error_mode()
 
     def bounds(self, numel: int, lo: int = 0):
         return [(s, min(s + self.bucket, lo + numel)) for s in range(lo, lo + numel, self.bucket)]
@@ -730,11 +743,12 @@ class TrainStep:
             q = _fn.wgrad_queue()
             q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graphs
             try:
-                with torch.cuda.graph(graphs[0]):
+                mode = self.reducer.capture_mode
+                with torch.cuda.graph(graphs[0], capture_error_mode=mode):
                     first()
                 for k in reversed(range(len(self._live["cuts"]))):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=graphs[0].pool()):
+                    with torch.cuda.graph(g, pool=graphs[0].pool(), capture_error_mode=mode):
                         later(k)()
                     graphs.append(g)
             finally:
@@ -793,7 +807,7 @@ class TrainStep:
         q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graph
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=self.reducer.capture_mode):
                 self._whole_step_body()
         finally:
             q.defer_uploads = False

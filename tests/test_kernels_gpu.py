@@ -1023,3 +1023,21 @@ def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
                                  dv=dkv0[..., 3 * H * d:])
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
     assert rel(dq1, dq0) < 2e-3 and rel(dkv1, dkv0) < 2e-3, (rel(dq1, dq0), rel(dkv1, dkv0))
+
+
+def test_stream_helpers_of_the_c_abi():
+    """ovqa_stream_create (priority / CU mask) hands back streams that torch can drive: a cast launched on a CU-masked
+    stream (the first 64 compute units) and on a high-priority stream gives the values of the default stream."""
+    o = ops()
+    lo, hi = o.priority_range()
+    assert hi <= lo  # (numerically lower = served first)
+    x = rnd(4096, 64)
+    want = x.to(BF16)
+    for st in (o.make_stream(DEV, priority=hi), o.make_stream(DEV, cu_mask=range(64))):
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            y = torch.empty(x.shape, dtype=BF16, device=DEV)
+            o.cast(x, y)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
