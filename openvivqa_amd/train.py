@@ -427,6 +427,10 @@ class GradAllReducer:
         return grad
 
 
+class _PeerFailed(RuntimeError):
+    """Another rank reported a failure at the rendezvous inside the warm-up: this rank falls back with it."""
+
+
 class _Cuts:
     """Milestone sink (runtime.grad_milestone): cuts the autograd graph at the ``active`` milestones (indices in
     forward call order; None = all) by handing the consumer a detached leaf.  TrainStep then differentiates in
@@ -675,16 +679,18 @@ class TrainStep:
         if self.arena.device.type != "cuda":
             self._discover_foreign()
             return
-        err = None
+        err, peer_failed = None, False
         try:
             self._warm_and_capture()
+        except _PeerFailed as exc:  # (the rendezvous inside the warm-up WAS this rank's agreement collective)
+            err, peer_failed = exc, True
         except Exception as exc:  # noqa: BLE001 -- the overlap is an optimisation: never lose the step over it
-            if self._cuts is None and len(self.segments) == 1:
+            if self._cuts is None and len(self.segments) == 1 and not self.reducer.active:
                 raise
             err = exc
         # the plan (number and bounds of the gradient segments) must be the SAME on every rank, or the all-reduce
         # sequences diverge: agree on success across the group, fall back everywhere or nowhere
-        if not self._agree(err is None):
+        if peer_failed or not self._agree(err is None):
             import sys
             why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
             print(f"openvivqa_amd.TrainStep: phased backward failed ({why}); "
@@ -726,6 +732,17 @@ class TrainStep:
         from . import functional as _fn
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.reducer.active:
+            # Rendezvous before the first gradient collective: a rank whose discovery failed is in _capture's agreement
+            # all-reduce right now (the same collective), so nobody waits for a segment exchange that never comes; then
+            # the plans are compared, and ONE step's exchange runs eagerly at its real sizes -- whatever RCCL sets up on
+            # the first collective of a size happens here, not inside the capture.
+            if not self._agree(True):
+                raise _PeerFailed("another rank failed before the gradient exchange was set up")
+            self._check_plan_identical()
+            self._fwd_bwd(on_phase=self._release)
+            self.reducer.finish(self.arena.grad)
+            torch.cuda.synchronize()
         _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW / LayerNorm-reduce launches of the capture
         if self.use_graph and os.environ.get("OVQA_WHOLE_STEP_GRAPH", "1") != "0" and self.reducer.capturable:
             try:
