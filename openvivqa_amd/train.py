@@ -128,8 +128,8 @@ class FlatAdam:
         self.step_t.fill_(int(sd["step"]))
         self.host_step = int(sd["host_step"])
         self.lr_scale = float(sd["lr_scale"])
-        self._resync_schedule()
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        self._resync_schedule()
 
     def _load_torch_adam(self, sd: dict, params) -> None:
         a = self.arena
@@ -495,7 +495,9 @@ def _complement(spans, lo, hi):
 
 
 class TrainStep:
-    """forward -> loss -> backward -> all-reduce -> Adam, with the first three captured in hipGraphs.
+    """forward -> loss -> backward -> all-reduce -> Adam, replayed from ONE hipGraph (round 4: the gradient exchange -- RCCL
+    collectives are capturable -- and Adam with its LambdaLR schedule, read from a device table, are inside the graph;
+    what cannot be captured, e.g. a gloo exchange, keeps one graph per backward phase with exchange and Adam from the host).
 
     ``forward_loss(*static_inputs)`` must run the model and return ``(outputs, grads)`` where
     ``grads[i]`` is d loss / d outputs[i] (so that the loss kernel can emit its own gradient), or a

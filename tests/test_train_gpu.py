@@ -131,6 +131,33 @@ def test_whole_step_graph_equals_phase_graphs_with_eager_adam(single_rank_group,
     assert int(a.optim.step_t.item()) == 5 == a.optim.host_step and abs(float(a.optim.lr_eff) - 1e-4 * noam_lr_scale(4, 512, 3)) < 1e-12
 
 
+def test_checkpoint_resume_inside_the_one_graph_step_is_bitwise():
+    """Save after 3 steps (model state_dict + TrainStep.state_dict), rebuild everything, load, take 2 more: the weights,
+    moments and loss of the uninterrupted 5-step run, bit for bit -- the step is deterministic, and the device-side
+    schedule table is rebuilt from the restored step count and rate (``FlatAdam._resync_schedule``)."""
+    import copy
+    from openvivqa_amd.train import noam_lr_scale
+    kw = dict(lr_lambda=lambda s: noam_lr_scale(s, 512, 3))
+    ma, a, batch = _make(2, **kw)
+    for _ in range(5):
+        a.step(*batch)
+    mb, b, _ = _make(2, **kw)
+    for _ in range(3):
+        b.step(*batch)
+    torch.cuda.synchronize()
+    ckpt = copy.deepcopy({"model": mb.state_dict(), "train": b.state_dict()})
+    mc, c, _ = _make(2, **kw)
+    c.prepare(*batch)  # (captured BEFORE the load: the graph must pick the restored state up)
+    mc.load_state_dict(ckpt["model"])
+    c.load_state_dict(ckpt["train"])
+    for _ in range(2):
+        c.step(*batch)
+    torch.cuda.synchronize()
+    assert c.whole is not None and int(c.optim.step_t.item()) == 5 == c.optim.host_step
+    assert torch.equal(c.arena.master, a.arena.master) and float(c.loss) == float(a.loss)
+    assert torch.equal(c.optim.exp_avg, a.optim.exp_avg) and torch.equal(c.optim.exp_avg_sq, a.optim.exp_avg_sq)
+
+
 def test_device_schedule_table_wraps_and_refills():
     """FlatAdam's device-side LambdaLR table (4096 entries, half refilled every 2048 steps, a stream-ordered copy issued
     half a table ahead): the rate ovqa_begin_step hands Adam equals lr * lr_lambda(step) for 3 x 4096 steps."""
