@@ -742,3 +742,73 @@ def test_npy_ingestion_feeds_feature_embedding(tmp_path, mode):
         fo, mo = o(ref)
     assert torch.equal(mh.cpu() != 0, mo != 0)
     assert nerr(fh, fo) < (1e-3 if mode == F32 else 1e-2)
+
+
+# ---- size-independent properties at the BASELINE configuration (configs[1]: B = 64, L = 6, 100 regions x 20 tokens): no
+# ---- oracle involved, so the full size costs nothing on the CPU
+def _baseline_stack(dropout_eval=True):
+    import openvivqa_amd as A
+    import openvivqa_amd.utils as U
+    A.set_compute_dtype(BF16)
+    te, ve = _mcan_pair(hip_namespace(), 6, 123)
+    te, ve = te.to(DEV).eval(), ve.to(DEV).eval()
+    gen = torch.Generator().manual_seed(17)
+    B = 64
+    v, l = torch.randn(B, 100, 512, generator=gen), torch.randn(B, 20, 512, generator=gen)
+    nv, nt = torch.randint(80, 101, (B,), generator=gen), torch.randint(8, 21, (B,), generator=gen)
+    for i in range(B):
+        v[i, nv[i]:] = 0
+        l[i, nt[i]:] = 0
+    v, l = v.to(DEV), l.to(DEV)
+    return te, ve, v, l, U.generate_padding_mask(v, 0), U.generate_padding_mask(l, 0), nv, nt
+
+
+def test_baseline_size_backward_is_linear_in_the_upstream_gradient():
+    """Backward is linear: an upstream gradient scaled by a power of two scales EVERY gradient -- inputs and all 256
+    parameter tensors of the L = 6 stacks at B = 64 -- by exactly that factor, bit for bit (scaling by 2^k commutes with
+    every rounding in the bf16 / fp32 pipeline; the kernels are deterministic).  A gradient kernel that dropped, doubled or
+    mis-accumulated a contribution anywhere in the 30 chained blocks fails this without any oracle."""
+    te, ve, v, l, vm, lm, _, _ = _baseline_stack()
+    gen = torch.Generator().manual_seed(3)
+    gv, gl = torch.randn(v.shape, generator=gen).to(DEV, BF16), torch.randn(l.shape, generator=gen).to(DEV, BF16)
+    grads = []
+    for scale in (1.0, 4.0):
+        for p in list(te.parameters()) + list(ve.parameters()):
+            p.grad = None
+        vd, ld = v.clone().requires_grad_(), l.clone().requires_grad_()
+        lo = te(features=ld, padding_mask=lm)
+        vo = ve(vision_features=vd, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
+        torch.autograd.backward([vo, lo], [gv * scale, gl * scale])
+        g = {"d vision": vd.grad.clone(), "d language": ld.grad.clone()}
+        for pre, m in (("te.", te), ("ve.", ve)):
+            g.update({pre + k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        grads.append(g)
+    assert len(grads[0]) == 2 + 98 + 158  # the two inputs, 98 tensors of the question stack, 158 of the guided stack
+    for k, g1 in grads[0].items():
+        assert torch.equal(grads[1][k], g1 * 4.0), k
+        assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0 or k.endswith("fc_k.bias"), k
+
+
+def test_baseline_size_padding_and_sample_order_properties():
+    """(1) Samples are independent (what data parallelism shards on): a permutation of the batch permutes the outputs,
+    bit for bit.  (2) The outputs of VALID positions do not depend on how many padded positions follow them: with fewer
+    padded regions per sample (96 instead of 100 columns, same masks) every sample that still fits reproduces its valid
+    rows -- the additive -1e5 mask removes padded keys exactly (exp underflows to 0), padded query rows feed only padded
+    keys of later layers."""
+    te, ve, v, l, vm, lm, nv, nt = _baseline_stack()
+    with torch.no_grad():
+        lo = te(features=l, padding_mask=lm)
+        vo = ve(vision_features=v, vision_padding_mask=vm, language_features=lo, language_padding_mask=lm)
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+        lo_p = te(features=l[perm], padding_mask=lm[perm])
+        vo_p = ve(vision_features=v[perm], vision_padding_mask=vm[perm], language_features=lo_p,
+                  language_padding_mask=lm[perm])
+        assert torch.equal(lo_p, lo[perm]) and torch.equal(vo_p, vo[perm])
+        # fewer padded positions: 100 -> 96 regions keeps every sample with <= 96 valid regions intact
+        keep = (nv <= 96).to(DEV)
+        assert int(keep.sum()) >= 20
+        vo_t = ve(vision_features=v[:, :96].contiguous(), vision_padding_mask=vm[..., :96].contiguous(),
+                  language_features=lo, language_padding_mask=lm)
+        for i in torch.nonzero(keep).flatten().tolist():
+            n = int(nv[i])
+            assert nerr(vo_t[i, :n], vo[i, :n]) < 4e-3, i  # (another tile count: the same math in another summation order)
