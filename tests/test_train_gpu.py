@@ -8,6 +8,9 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# the default: the whole step is one graph; OVQA_WHOLE_STEP_GRAPH=0 (the A/B switch, scripts/gpu_r4_alt.sh) keeps the
+# per-phase graphs, and the assertions about WHICH form was captured follow it
+ONE_GRAPH = os.environ.get("OVQA_WHOLE_STEP_GRAPH", "1") != "0"
 
 
 def _cfg(layers, dropout):
@@ -73,10 +76,10 @@ def test_phased_backward_with_comm_stream_matches_single_graph(single_rank_group
     for _ in range(3):
         ts.step(*batch)
     torch.cuda.synchronize()
-    assert ref.whole is not None and len(ref.segments) == 1
+    assert (ref.whole is not None) == ONE_GRAPH and ref.captured and len(ref.segments) == 1
     assert len(ts.segments) >= 4, ts.segments
     # one graph for the whole step, the exchange of every segment captured on a forked branch of it
-    assert (ts.whole is not None and ts.graphs is None) if use_graph else not ts.captured
+    assert ((ts.whole is not None) == ONE_GRAPH and ts.captured) if use_graph else not ts.captured
     flat = sorted(r for s in ts.segments for r in s)
     assert flat[0][0] == 0 and flat[-1][1] == ts.arena.numel and all(a[1] == b[0] for a, b in zip(flat, flat[1:]))
     assert abs(float(ts.loss) - float(ref.loss)) <= 2e-3 * abs(float(ref.loss))
@@ -153,7 +156,7 @@ def test_checkpoint_resume_inside_the_one_graph_step_is_bitwise():
     for _ in range(2):
         c.step(*batch)
     torch.cuda.synchronize()
-    assert c.whole is not None and int(c.optim.step_t.item()) == 5 == c.optim.host_step
+    assert (c.whole is not None) == ONE_GRAPH and int(c.optim.step_t.item()) == 5 == c.optim.host_step
     assert torch.equal(c.arena.master, a.arena.master) and float(c.loss) == float(a.loss)
     assert torch.equal(c.optim.exp_avg, a.optim.exp_avg) and torch.equal(c.optim.exp_avg_sq, a.optim.exp_avg_sq)
 
@@ -344,7 +347,7 @@ def test_crossmodality_train_step_with_comm(single_rank_group):
         for _ in range(2):
             ts.step(v, vm, t, tm)
         torch.cuda.synchronize()
-        assert ts.whole is not None and (len(ts.segments) >= 2 if force else len(ts.segments) == 1)
+        assert (ts.whole is not None) == ONE_GRAPH and (len(ts.segments) >= 2 if force else len(ts.segments) == 1)
         dead = [k for k in w0 if "language_vision_mhattn" in k or "vision_language_mhattn" in k]
         assert dead
         for k in dead:
@@ -446,7 +449,10 @@ def test_data_parallel_exchange_bf16_vs_fp32_vs_single_process():
     # (Adam normalises every element, so a gradient's relative error IS the update's: where the four ranks' gradients of
     # an element cancel -- B = 8 per rank is a noisy extreme -- the bf16 sum's 2^-9 is relative to their magnitudes,
     # not to the sum: ~2 % of the update in L2, measured; far below what the weights' bf16 shadow resolves, next check)
-    assert e32 < 1e-2 and e16 < 5e-2, (e32, e16)
+    # (under the k-split-everywhere A/B switch the ranks' 8-sample products and the single process' 32-sample ones take
+    #  different wave grids: a summation-order change of the size DESIGN section 6 documents, 1.9e-2 -- the bar holds for
+    #  the default tiling)
+    assert (e32 < 1e-2 or "OVQA_GEMM_KSPLIT" in os.environ) and e32 < 3e-2 and e16 < 5e-2, (e32, e16)
     # weight level.  fc_k.bias is left out as everywhere (its gradient is analytically zero: pure rounding noise that
     # Adam turns into +-lr steps of random sign in ANY two runs).  The same mechanism acts on single elements of other
     # parameters: where the ranks' gradients of an element cancel to (nearly) nothing, the sign of the sum -- and with it
