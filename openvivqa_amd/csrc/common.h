@@ -48,6 +48,23 @@ bool ovqa_timer_next(hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                      \
   } while (0)
 
+// ---- stores of the FFN pre-activation (26 MB per 6400-row launch, read again only in BACKWARD): the nt (streaming) cache
+// policy keeps it from displacing the hidden activation the NEXT kernel reads out of the 4 MB L2s and from sitting dirty in
+// them at the kernel boundary.  MEASURED (MCAN step, alternated on one box): 3.322 / 3.319 -> 3.292 / 3.295 ms.  The same
+// policy on the saved q / k / v projections and o_lo of the fused attention forwards LOST 0.03 ms (their stores sit at the
+// tail of a short kernel, where a slower store is exposed): plain stores there.  -DOVQA_NT_SAVED=0 = plain stores (A/B).
+#ifndef OVQA_NT_SAVED
+#define OVQA_NT_SAVED 1
+#endif
+template <typename V>
+__device__ __forceinline__ void store_saved(V* p, const V& v) {
+#if OVQA_NT_SAVED
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // ---- XCD-consistent ownership of activation rows -------------------------------------------------------------------
 // Workgroups are dealt to the 8 XCDs round-robin by block id, each XCD has its own L2, and a kernel's output is still in
 // the producing XCD's L2 when the next kernel starts.  The GEMM kernels' block remap gives XCD x the x-th contiguous

@@ -662,7 +662,12 @@ struct MEpiBiasGelu {
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
     bias8(bias, n, lo, hi, u);
-    if (preact) store8(preact + (int64_t)m * N + n, u);
+    if (preact) {
+      bf16x8 o_;
+#pragma unroll
+      for (int t = 0; t < 8; t++) o_[t] = (bf16)u[t];
+      store_saved(reinterpret_cast<bf16x8*>(preact + (int64_t)m * N + n), o_);
+    }
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
     float dm[8];
     drop_mul8(ds, idx, dm);
