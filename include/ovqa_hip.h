@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 6
+#define OVQA_ABI_VERSION 7
 
 typedef enum {
   OVQA_OK = 0,
@@ -174,10 +174,16 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy,
  * individual products have 16..64 output tiles each -- far fewer than 256 CUs --
  * so they are deferred and tiled together instead of being split along M).
  * `problems`/`tiles` are DEVICE arrays written by the host side: tiles[i] =
- * {problem index, tile over N (128 rows), tile over K (128 cols), 0}. bf16 only.
- * all_m_mult64 != 0 promises that every problem's M is a multiple of 64 (and its pointers 16-byte aligned,
- * lddy / ldx multiples of 8): the direct-to-LDS 8-wave tile is used then (no staging registers; within noise
- * of the register-staged tile in the MCAN step). */
+ * {problem index, tile over N, tile over K, 0} in units of the form's tile edge; an entry with problem index -1 is
+ * padding (the workgroup returns). bf16 only.
+ * form (the parameter named all_m_mult64 up to ABI 6):
+ *   0  register-staged 128 x 128 tiles, any shapes the single-product entry point accepts;
+ *   1  direct-to-LDS 128 x 128 tiles (8 waves): the caller promises that every problem's M is a multiple of 64, its
+ *      pointers 16-byte aligned, lddy / ldx multiples of 8;
+ *   2  (ABI 7) the same promise, tiles of 256 x 256 on one 16-wave workgroup per CU with 128 KB of LDS: half the
+ *      operand bytes per flop through the CU's L2 fetch path, which is what these products wait for (the MCAN step's
+ *      grouped launch: 478 -> 385 us).  The tile table indexes 256-blocks.  No register-staged fallback:
+ *      OVQA_ERR_UNSUPPORTED under OVQA_FORCE_SIMPLE. */
 typedef struct {
   const void* dy;   /* [M,N], row stride lddy */
   const void* x;    /* [M,K], row stride ldx  */
@@ -188,7 +194,7 @@ typedef struct {
   int32_t accumulate; /* bit 0: dw +=, bit 1: db += */
 } ovqa_wgrad_problem;
 int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev,
-                                   const int32_t* tiles_dev, int64_t n_tiles, int32_t all_m_mult64,
+                                   const int32_t* tiles_dev, int64_t n_tiles, int32_t form,
                                    void* stream);
 /* db (fp32 [N]) (+)= column sums of dy [M,N] (bias gradient on its own). */
 int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N,

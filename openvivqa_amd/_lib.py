@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 

@@ -260,13 +260,17 @@ int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w,
 }
 
 int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev, const int32_t* tiles_dev,
-                                   int64_t n_tiles, int32_t all_m_mult64, void* stream) {
+                                   int64_t n_tiles, int32_t form, void* stream) {
   OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: bf16 only");
   OVQA_REQUIRE(n_tiles >= 0 && (n_tiles == 0 || (problems_dev && tiles_dev)), OVQA_ERR_BAD_ARG,
                "grouped_linear_bwd_weight: bad argument");
   OVQA_REQUIRE(n_tiles < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: too many tiles");
+  OVQA_REQUIRE(form >= 0 && form <= 2, OVQA_ERR_BAD_ARG, "grouped_linear_bwd_weight: form must be 0, 1 or 2");
+  OVQA_REQUIRE(form != 2 || !force_simple(), OVQA_ERR_UNSUPPORTED,
+               "grouped_linear_bwd_weight: the 256 x 256 tile form has no register-staged fallback (OVQA_FORCE_SIMPLE)");
   g_dispatch = "mfma";
-  return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, all_m_mult64 != 0 && !force_simple(), as_stream(stream));
+  return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, form != 0 && !force_simple(), form == 2,
+                                  as_stream(stream));
 }
 
 int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate,

@@ -846,6 +846,179 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
   gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128, KSP>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
+// ---- 256 x 256 dW tiles: ONE 16-wave workgroup per CU ------------------------------------------------------------------
+// The 128 x 128 form runs two co-resident workgroups per CU, each pulling 32 KB per 64-deep K step through the CU's L2
+// fetch path: 5.65 GB per grouped launch of the MCAN step at 32 % matrix-pipe occupancy -- and behind a pending LDS-DMA the
+// compiler puts `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 BUILTIN (it cannot tell the ring slots apart), so
+// that form drains its ring in every step.  A 256 x 256 tile does four times the MFMA work on twice the bytes.
+//   * 4 x 4 wave grid, 64 x 64 outputs per wave (64 accumulator registers; 16 waves leave 128 VGPRs per lane);
+//   * operands arrive in 32-deep HALF steps -- four half images [32 k][128 columns] of 8 KB: x columns r0.., r0+128.., dy
+//     columns c0.., c0+128.. -- through a ring of 4 half steps (128 KB of the 160), three in flight while the fourth is
+//     consumed.  Same k-major image, swizzle and transposing fragment reads as the 128 x 128 form (a half image is the
+//     first 8 KB of a full one);
+//   * the fragment reads are inline asm with ONE hand-placed lgkmcnt wait tied to their registers: no compiler wait.
+// MEASURED (scripts/dw_bench.py, the MCAN step's 66 products, cold operands; profiles/README.md): 128 x 128 form 549 us,
+// this one 458-466; in the step 478 -> 385 us.  Per 32-deep half step of the critical path (400 of them; 344 if the tiles
+// balanced): fetch alone 0.72 us (44 GB/s per CU = the chip's rate for one third HBM misses, two thirds L2 hits), LDS
+// reads alone 0.39, MFMAs alone 0.57, LDS + MFMA 0.87-0.90: the reads (every wave's 16 land at the end of the workgroup's
+// read burst) and the MFMAs do not overlap.  Tried on top, none faster in the step: counted waits in front of each group
+// of MFMAs (-3 %, LDS + MFMA only); a ring of 5; an 8-wave version with two fragment sets in registers, reads of half step
+// h + 1 between the MFMAs of h, MFMAs as inline asm (LDS + MFMA 0.87 again: with 2 waves per SIMD the b64 reads issue at
+// half the rate, MFMAs alone 0.71).
+__device__ __forceinline__ bf16x4 lds_read_tr(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ bf16x4 lds_read_tr_1k(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int c0, int r0, char* smem) {
+  constexpr int NBUF = 4;
+  constexpr int HIMG = TILE_BYTES / 2;  // 8 KiB: 32 k-rows x 128 columns
+  constexpr int HSTAGE = 4 * HIMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 2, wr = wave & 3;
+  const int R = pr.K, C = pr.N;  // r: input features (x columns), c: output features (dy columns)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dy: one extra MFMA per c sub-tile against an all-ones A fragment (see gemm_tile)
+  const bool do_colsum = r0 == 0 && wr == 0 && pr.db != nullptr;
+  f32x4 cs[4];
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 4; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
+
+  // The two 1 KiB chunks this wave brings in per half step: chunk q = 2 * wave + i of 32 -> half image q >> 3 = wave >> 2
+  // (waves 0-3 x columns r0.., 4-7 r0+128.., 8-11 dy columns c0.., 12-15 c0+128..), k-rows 4 (q & 7) .. +3 of it.
+  // Wave-uniform base and LDS slot, a 32-bit lane offset; only the k offset moves over the loop.
+  const bool isP = wave < 8;
+  const int64_t ld = isP ? pr.ldx : pr.lddy;
+  const char* gbase = reinterpret_cast<const char*>(isP ? pr.x : pr.dy);
+  const int cols = isP ? R : C;
+  const int col0 = (isP ? r0 : c0) + ((wave >> 2) & 1) * 128;
+  uint32_t goff[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int ci = (wave * 2 + i) & 7;
+    const int krow = ci * 4 + (lane >> 4), pos = lane & 15;
+    const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+    const int c = ((((pos >> 1) ^ f) << 1) | (pos & 1));
+    int col = col0 + c * 8;
+    col = col <= cols - 8 ? col : cols - 8;
+    goff[i] = (uint32_t)(((int64_t)krow * ld + col) * 2);
+  }
+  const int dst0 = (wave >> 2) * HIMG + ((wave * 2) & 7) * 1024;
+  const int64_t hstep = 64 * ld;  // bytes per 32-deep half step
+  auto issue = [&](int h) {
+    char* buf = smem + (h % NBUF) * HSTAGE + dst0;
+    const char* g = gbase + (int64_t)h * hstep;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      uint32_t o = goff[i];
+      asm volatile("" : "+v"(o));  // opaque: two 32-bit offsets stay live, not two 64-bit induction pointers
+      __builtin_amdgcn_global_load_lds((gbl_void*)(g + o), (lds_void*)(buf + i * 1024), 16, 0, 0);
+    }
+  };
+  // fragment addresses inside a half step (see frag<true>): rows base .. base+15 of the wave's half image
+  uint32_t pa[4], qa[4];
+  {
+    const int kr = 8 * (lane >> 4) + ((lane >> 2) & 3);
+    const int sub = (lane & 1) * 8, chl = (lane & 3) >> 1;
+    const uint32_t s0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte offset
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      pa[j] = s0 + (wr >> 1) * HIMG + km_off(kr, (((wr & 1) * 64 + j * 16) >> 3) + chl) + sub;
+      qa[j] = s0 + (2 + (wc >> 1)) * HIMG + km_off(kr, (((wc & 1) * 64 + j * 16) >> 3) + chl) + sub;
+    }
+  }
+  const int nh = pr.M / 32;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; p++)
+    if (p < nh) issue(p);
+
+  for (int h = 0; h < nh; h++) {
+    // half step h has landed: at most the NBUF - 2 younger ones (2 loads each) may still be in flight
+    if (h + NBUF - 2 >= nh) wait_vmcnt<0>();
+    else wait_vmcnt<2 * (NBUF - 2)>();
+    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave has consumed half step h - 1 (the slot refilled now)
+    if (h + NBUF - 1 < nh) issue(h + NBUF - 1);
+    const uint32_t so = (uint32_t)((h % NBUF) * HSTAGE);
+    bf16x4 pl[4], ph[4], ql[4], qh[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      pl[j] = lds_read_tr(pa[j] + so);
+      ph[j] = lds_read_tr_1k(pa[j] + so);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      ql[i] = lds_read_tr(qa[i] + so);
+      qh[i] = lds_read_tr_1k(qa[i] + so);
+    }
+    // the compiler knows nothing of these reads: the wait is tied to their registers, ahead of the first use
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]), "+v"(pl[3]), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[2]), "+v"(ph[3])
+                 :
+                 : "memory");
+    asm volatile(""
+                 : "+v"(ql[0]), "+v"(ql[1]), "+v"(ql[2]), "+v"(ql[3]), "+v"(qh[0]), "+v"(qh[1]), "+v"(qh[2]), "+v"(qh[3])
+                 :
+                 : "memory");
+    bf16x8 pf[4], qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      pf[j] = bf16x8{pl[j][0], pl[j][1], pl[j][2], pl[j][3], ph[j][0], ph[j][1], ph[j][2], ph[j][3]};
+      qf[j] = bf16x8{ql[j][0], ql[j][1], ql[j][2], ql[j][3], qh[j][0], qh[j][1], qh[j][2], qh[j][3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, qf[i], cs[i], 0, 0, 0);
+    }
+  }
+  if (do_colsum && lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = c0 + wc * 64 + i * 16 + lane;
+      if (c < C) pr.db[c] = (pr.accumulate & 2) ? pr.db[c] + cs[i][0] : cs[i][0];
+    }
+  }
+  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, nullptr, 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = c0 + wc * 64 + i * 16 + (lane & 15);
+    if (c >= C) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int r = r0 + wr * 64 + j * 16 + (lane >> 4) * 4;
+      if (r < R) epi(c, r, acc[j][i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void gemm_bf16_grouped_wgrad256_kernel(const ovqa_wgrad_problem* __restrict__ probs,
+                                                                          const int4* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int4 t = tiles[blockIdx.x];
+  if (t.x < 0) return;
+  const ovqa_wgrad_problem pr = probs[t.x];
+  wgrad_tile256(pr, t.y * 256, t.z * 256, smem);
+}
+
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tc = blockIdx.x / g.tiles_r, tr = blockIdx.x % g.tiles_r;
@@ -1339,8 +1512,16 @@ int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t 
 }
 
 int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, bool direct_to_lds,
-                       hipStream_t st) {
+                       bool tiles256, hipStream_t st) {
   if (n_tiles == 0) return OVQA_OK;
+  if (tiles256) {
+    constexpr size_t lds = 4 * 2 * TILE_BYTES;  // ring of 4 half steps x 32 KB
+    int rc = set_max_lds(gemm_bf16_grouped_wgrad256_kernel, lds);
+    if (rc != OVQA_OK) return rc;
+    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad256_kernel, dim3((unsigned)n_tiles), dim3(1024), lds, st, probs_dev,
+                       reinterpret_cast<const int4*>(tiles_dev));
+    return ovqa_check_launch("grouped_linear_bwd_weight(mfma,256)");
+  }
   static int allow = -1;
   if (allow < 0) {
     const char* e = getenv("OVQA_DW_GLDS");

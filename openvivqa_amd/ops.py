@@ -283,6 +283,9 @@ class WgradQueue:
     chain.  The default therefore defers everything to the end (OVQA_WGRAD_FLUSH_TILES overrides)."""
 
     TILE = 128
+    # 256 x 256 tiles on one 16-wave workgroup per CU (half the L2 -> CU bytes per flop) when every queued product allows
+    # the direct-to-LDS form; OVQA_DW_TILE256=0 keeps the 128 x 128 tiles
+    BIG_TILES = os.environ.get("OVQA_DW_TILE256", "1") != "0"
     FLUSH_TILES = int(__import__("os").environ.get("OVQA_WGRAD_FLUSH_TILES", str(1 << 30)))
 
     def __init__(self):
@@ -404,9 +407,13 @@ class WgradQueue:
         dev = items[0][0].device
         probs = (_lib.WgradProblem * len(items))()
         per_problem = []
+        fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
+                   and it[1].data_ptr() % 16 == 0 for it in items)
+        big = fast and self.BIG_TILES and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0")
+        tile = 256 if big else self.TILE
         for i, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
             probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), _p(db), lddy, ldx, M, N, K, acc)
-            tn, tk = (N + self.TILE - 1) // self.TILE, (K + self.TILE - 1) // self.TILE
+            tn, tk = (N + tile - 1) // tile, (K + tile - 1) // tile
             per_problem.append((M * tn * tk, M, [(i, c, r, 0) for c in range(tn) for r in range(tk)]))
         # XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD
         # group), each XCD has a private L2, and all tiles of one problem stream the same dY / X panels.
@@ -444,10 +451,8 @@ class WgradQueue:
             side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
         with torch.cuda.stream(side):
             self._upload(host, devbuf, nbytes, capturing)
-            fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
-                       and it[1].data_ptr() % 16 == 0 for it in items)
             _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
-                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), int(fast),
+                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), 2 if big else int(fast),
                 side.cuda_stream), "grouped_linear_bwd_weight")
         self._used(entry, side, capturing)
         self._used_side = self._used_side or overlapping

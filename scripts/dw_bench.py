@@ -1,0 +1,82 @@
+"""The grouped dW launch of the MCAN L=6 B=64 step on its own (HIP events over REPS launches, operands cold-ish: the
+problems' operands are 1 GB, four times the Infinity Cache).  Env: OVQA_DW_TILE256."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import openvivqa_amd as A  # noqa: E402
+from openvivqa_amd import ops, _lib  # noqa: E402
+
+dev = torch.device("cuda", 0)
+REPS = int(os.environ.get("REPS", "20"))
+
+
+def problems():
+    out = []
+    guided = [(1536, 512, 6400), (512, 512, 6400), (512, 512, 6400), (1024, 512, 1280), (512, 512, 6400),
+              (2048, 512, 6400), (512, 2048, 6400)]
+    question = [(1536, 512, 1280), (512, 512, 1280), (2048, 512, 1280), (512, 2048, 1280)]
+    for _ in range(6):
+        out += guided
+    for _ in range(6):
+        out += question
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    q = ops.WgradQueue()
+    keep = []
+    flops = 0
+    for n, k, m in problems():
+        if os.environ.get("DATA", "randn") == "zeros":
+            dy = torch.zeros(m, n, device=dev, dtype=torch.bfloat16)
+            x = torch.zeros(m, k, device=dev, dtype=torch.bfloat16)
+        else:
+            dy = torch.randn(m, n, device=dev, dtype=torch.bfloat16)
+            x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
+        dw = torch.empty(n, k, device=dev, dtype=torch.float32)
+        db = torch.empty(n, device=dev, dtype=torch.float32)
+        keep.append((dy, x, dw, db))
+        q.add(dy, x, dw, False, db, False)
+        flops += 2 * m * n * k
+    lib = _lib.load()
+    orig, seen = lib.ovqa_grouped_linear_bwd_weight, {}
+
+    def spy(*a):
+        seen["args"] = a
+        return orig(*a)
+    lib.ovqa_grouped_linear_bwd_weight = spy
+    q.finish()
+    torch.cuda.synchronize()
+    lib.ovqa_grouped_linear_bwd_weight = orig
+    a = seen["args"]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ts = []
+    for _ in range(REPS + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(orig(a[0], a[1], a[2], a[3], a[4], st), "grouped dW")
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts = sorted(ts[3:])
+    med = ts[len(ts) // 2]
+    # spot check against fp64 on one long and one short problem
+    err = 0.0
+    for i in (0, len(keep) - 1):
+        dy, x, dw, db = keep[i]
+        ref = dy.double().t() @ x.double()
+        err = max(err, float((dw.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+    print(json.dumps({"form": int(a[4]), "n_tiles": int(a[3]), "us": round(med, 1), "min_us": round(ts[0], 1),
+                      "tflops": round(flops / med / 1e6, 1), "max_rel_err": err,
+                      "data": os.environ.get("DATA", "randn")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -198,13 +198,17 @@ def test_linear_bwd_weight(dtype, M, N, K):
     assert nerr(dw2, rw) < tol(dtype)
 
 
-@pytest.mark.parametrize("specs", [
-    [(6400, 512, 512), (1280, 1024, 512), (400, 1536, 512), (1280, 2048, 512), (6400, 512, 2048), (37, 32, 64)],
-    # every M a multiple of 64: the direct-to-LDS 8-wave tile (ragged N / K included)
-    [(6400, 512, 512), (1280, 1024, 512), (448, 1536, 512), (64, 72, 40), (128, 8, 2048), (6400, 512, 2048)],
-], ids=["register-staged", "direct-to-lds"])
-def test_grouped_wgrad_and_bias_grad(specs):
+@pytest.mark.parametrize("specs,big", [
+    ([(6400, 512, 512), (1280, 1024, 512), (400, 1536, 512), (1280, 2048, 512), (6400, 512, 2048), (37, 32, 64)], True),
+    # every M a multiple of 64: the direct-to-LDS forms (ragged N / K included) -- 8-wave 128 x 128 tiles, and the
+    # 16-wave 256 x 256 tiles (partial tiles in both directions, a reduction shorter than the ring, 300 = 256 + 44)
+    ([(6400, 512, 512), (1280, 1024, 512), (448, 1536, 512), (64, 72, 40), (128, 8, 2048), (6400, 512, 2048)], False),
+    ([(6400, 512, 512), (1280, 1024, 512), (448, 1536, 512), (64, 72, 40), (128, 8, 2048), (6400, 512, 2048),
+      (64, 304, 264), (192, 768, 3072), (1280, 2048, 512)], True),
+], ids=["register-staged", "direct-to-lds", "direct-to-lds-256"])
+def test_grouped_wgrad_and_bias_grad(specs, big, monkeypatch):
     o = ops()
+    monkeypatch.setattr(o.WgradQueue, "BIG_TILES", big)
     q = o.WgradQueue()
     refs, outs = [], []
     for i, (M, N, K) in enumerate(specs):
