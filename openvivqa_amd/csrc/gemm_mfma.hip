@@ -864,7 +864,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
 // read burst) and the MFMAs do not overlap.  Tried on top, none faster in the step: counted waits in front of each group
 // of MFMAs (-3 %, LDS + MFMA only); a ring of 5; an 8-wave version with two fragment sets in registers, reads of half step
 // h + 1 between the MFMAs of h, MFMAs as inline asm (LDS + MFMA 0.87 again: with 2 waves per SIMD the b64 reads issue at
-// half the rate, MFMAs alone 0.71).
+// half the rate, MFMAs alone 0.71); two 8-wave groups in opposite phase (one group's reads beside the other's MFMAs).
 __device__ __forceinline__ bf16x4 lds_read_tr(uint32_t addr) {
   bf16x4 v;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -890,14 +890,11 @@ __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int 
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradient = column sums of dy: one extra MFMA per c sub-tile against an all-ones A fragment (see gemm_tile)
+  // bias gradient = column sums of dy: the waves of the r0 == 0 tile that hold the first x rows add up the dy fragments
+  // they read anyway (a lane holds 8 k of one column: four VALU partials per lane, the four k-groups meet after the loop;
+  // the all-ones MFMA of gemm_tile would cost 16 more accumulator registers here)
   const bool do_colsum = r0 == 0 && wr == 0 && pr.db != nullptr;
-  f32x4 cs[4];
-  bf16x8 ones;
-#pragma unroll
-  for (int i = 0; i < 4; i++) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 8; e++) ones[e] = (bf16)1.0f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
   // The two 1 KiB chunks this wave brings in per half step: chunk q = 2 * wave + i of 32 -> half image q >> 3 = wave >> 2
   // (waves 0-3 x columns r0.., 4-7 r0+128.., 8-11 dy columns c0.., 12-15 c0+128..), k-rows 4 (q & 7) .. +3 of it.
@@ -947,14 +944,9 @@ __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int 
   for (int p = 0; p < NBUF - 1; p++)
     if (p < nh) issue(p);
 
-  for (int h = 0; h < nh; h++) {
-    // half step h has landed: at most the NBUF - 2 younger ones (2 loads each) may still be in flight
-    if (h + NBUF - 2 >= nh) wait_vmcnt<0>();
-    else wait_vmcnt<2 * (NBUF - 2)>();
-    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave has consumed half step h - 1 (the slot refilled now)
-    if (h + NBUF - 1 < nh) issue(h + NBUF - 1);
+  bf16x4 pl[4], ph[4], ql[4], qh[4];
+  auto reads = [&](int h) {
     const uint32_t so = (uint32_t)((h % NBUF) * HSTAGE);
-    bf16x4 pl[4], ph[4], ql[4], qh[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       pl[j] = lds_read_tr(pa[j] + so);
@@ -974,6 +966,8 @@ __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int 
                  : "+v"(ql[0]), "+v"(ql[1]), "+v"(ql[2]), "+v"(ql[3]), "+v"(qh[0]), "+v"(qh[1]), "+v"(qh[2]), "+v"(qh[3])
                  :
                  : "memory");
+  };
+  auto mfmas = [&]() {
     bf16x8 pf[4], qf[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -987,14 +981,33 @@ __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int 
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
     if (do_colsum) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, qf[i], cs[i], 0, 0, 0);
+      for (int i = 0; i < 4; i++) {
+        const uint4 w = __builtin_bit_cast(uint4, qf[i]);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) t += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
+        cs[i] += t;
+      }
     }
+  };
+  for (int h = 0; h < nh; h++) {
+    // half step h has landed: at most the NBUF - 2 younger ones (2 loads each) may still be in flight
+    if (h + NBUF - 2 >= nh) wait_vmcnt<0>();
+    else wait_vmcnt<2 * (NBUF - 2)>();
+    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave has read half step h - 1 (the slot refilled now)
+    if (h + NBUF - 1 < nh) issue(h + NBUF - 1);
+    reads(h);
+    mfmas();
   }
-  if (do_colsum && lane < 16) {
+  if (do_colsum) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+      float v = cs[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
       const int c = c0 + wc * 64 + i * 16 + lane;
-      if (c < C) pr.db[c] = (pr.accumulate & 2) ? pr.db[c] + cs[i][0] : cs[i][0];
+      if (lane < 16 && c < C) pr.db[c] = (pr.accumulate & 2) ? pr.db[c] + v : v;
     }
   }
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, nullptr, 0};
