@@ -144,6 +144,34 @@ __device__ __forceinline__ bf16x8 frag(const char* tile, int base, int ks, int l
   }
 }
 
+// The same k-major fragment as two inline-asm reads (lo: k-rows kr.., hi: kr + 4..; see frag<true>) that the compiler does
+// not track: behind a pending LDS-DMA it puts `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 BUILTIN (it cannot
+// tell the ring slots apart), which drains a direct-to-LDS ring in every K step.  The caller waits (`s_waitcnt
+// lgkmcnt(0)`) and ties the pieces to that wait before joining and using them.
+__device__ __forceinline__ bf16x4 lds_read_tr(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ bf16x4 lds_read_tr_1k(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_offset(const char* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void frag_tr_nowait(const char* tile, int base, int ks, int lane, bf16x4& lo, bf16x4& hi) {
+  const int kr = ks * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+  const int ch = (base >> 3) + ((lane & 3) >> 1);
+  const uint32_t a = lds_offset(tile) + km_off(kr, ch) + (lane & 1) * 8;
+  lo = lds_read_tr(a);
+  hi = lds_read_tr_1k(a);
+}
+__device__ __forceinline__ bf16x8 join8(const bf16x4& lo, const bf16x4& hi) {
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // one 128x128 output tile at (c0, r0): the whole K loop + epilogue.
 // COLSUM: the tile at r0 == 0 also reduces the Q operand over k (bias gradient = column sums of dY) with
 // one extra MFMA per c sub-tile against an all-ones A fragment -- the sums come out of the matrix pipe,
@@ -370,10 +398,29 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     for (int kk = 0; kk < 2 / KSP; kk++) {
       const int ks = KSP == 1 ? kk : ksel;
       bf16x8 pf[NJ], qf[NI];
+      if constexpr (P_KMAJOR && Q_KMAJOR) {  // (the grouped dW: untracked reads, one hand-placed wait -- see frag_tr_nowait)
+        bf16x4 plo[NJ], phi[NJ], qlo[NI], qhi[NI];
 #pragma unroll
-      for (int j = 0; j < NJ; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * (NJ * 16) + j * 16, ks, lane);
+        for (int j = 0; j < NJ; j++) frag_tr_nowait(Ps, wr * (NJ * 16) + j * 16, ks, lane, plo[j], phi[j]);
 #pragma unroll
-      for (int i = 0; i < NI; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * (NI * 16) + i * 16, ks, lane);
+        for (int i = 0; i < NI; i++) frag_tr_nowait(Qs, wc * (NI * 16) + i * 16, ks, lane, qlo[i], qhi[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          asm volatile("" : "+v"(plo[j]), "+v"(phi[j])::"memory");
+          pf[j] = join8(plo[j], phi[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+          asm volatile("" : "+v"(qlo[i]), "+v"(qhi[i])::"memory");
+          qf[i] = join8(qlo[i], qhi[i]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) pf[j] = frag<P_KMAJOR>(Ps, wr * (NJ * 16) + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < NI; i++) qf[i] = frag<Q_KMAJOR>(Qs, wc * (NI * 16) + i * 16, ks, lane);
+      }
 #pragma unroll
       for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -846,36 +893,26 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
   gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128, KSP>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
-// ---- 256 x 256 dW tiles: ONE 16-wave workgroup per CU ------------------------------------------------------------------
-// The 128 x 128 form runs two co-resident workgroups per CU, each pulling 32 KB per 64-deep K step through the CU's L2
-// fetch path: 5.65 GB per grouped launch of the MCAN step at 32 % matrix-pipe occupancy -- and behind a pending LDS-DMA the
-// compiler puts `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 BUILTIN (it cannot tell the ring slots apart), so
-// that form drains its ring in every step.  A 256 x 256 tile does four times the MFMA work on twice the bytes.
+// ---- 256 x 256 dW tiles: ONE 16-wave workgroup per CU (form 2 of the grouped launch; NOT the default) -------------------
+// Built when the 128 x 128 form (two co-resident workgroups per CU, 32 KB per 64-deep K step each) sat at 32 % matrix-pipe
+// occupancy: a 256 x 256 tile does four times the MFMA work on twice the bytes.
 //   * 4 x 4 wave grid, 64 x 64 outputs per wave (64 accumulator registers; 16 waves leave 128 VGPRs per lane);
 //   * operands arrive in 32-deep HALF steps -- four half images [32 k][128 columns] of 8 KB: x columns r0.., r0+128.., dy
 //     columns c0.., c0+128.. -- through a ring of 4 half steps (128 KB of the 160), three in flight while the fourth is
 //     consumed.  Same k-major image, swizzle and transposing fragment reads as the 128 x 128 form (a half image is the
 //     first 8 KB of a full one);
 //   * the fragment reads are inline asm with ONE hand-placed lgkmcnt wait tied to their registers: no compiler wait.
-// MEASURED (scripts/dw_bench.py, the MCAN step's 66 products, cold operands; profiles/README.md): 128 x 128 form 549 us,
-// this one 458-466; in the step 478 -> 385 us.  Per 32-deep half step of the critical path (400 of them; 344 if the tiles
-// balanced): fetch alone 0.72 us (44 GB/s per CU = the chip's rate for one third HBM misses, two thirds L2 hits), LDS
-// reads alone 0.39, MFMAs alone 0.57, LDS + MFMA 0.87-0.90: the reads (every wave's 16 land at the end of the workgroup's
-// read burst) and the MFMAs do not overlap.  Tried on top, none faster in the step: counted waits in front of each group
-// of MFMAs (-3 %, LDS + MFMA only); a ring of 5; an 8-wave version with two fragment sets in registers, reads of half step
-// h + 1 between the MFMAs of h, MFMAs as inline asm (LDS + MFMA 0.87 again: with 2 waves per SIMD the b64 reads issue at
-// half the rate, MFMAs alone 0.71); two 8-wave groups in opposite phase (one group's reads beside the other's MFMAs).
-__device__ __forceinline__ bf16x4 lds_read_tr(uint32_t addr) {
-  bf16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ bf16x4 lds_read_tr_1k(uint32_t addr) {
-  bf16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-
+// MEASURED (scripts/dw_bench.py, the MCAN step's 66 products, cold operands; profiles/README.md): 458-493 us against 549
+// for the 128 x 128 form as it was -- whose ring, it turned out while writing this one, was drained in every K step by a
+// compiler-inserted `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 builtin.  With untracked reads there too
+// (frag_tr_nowait) the 128 x 128 form takes 480 us and wins in the step (3.195 against 3.231 ms), so this form is opt-in
+// (OVQA_DW_TILE256).  Per 32-deep half step of its critical path (400 of them; 344 if the tiles balanced): fetch alone
+// 0.72 us (44 GB/s per CU = the chip's rate for one third HBM misses, two thirds L2 hits), LDS reads alone 0.39, MFMAs
+// alone 0.57, LDS + MFMA 0.87-0.90: the reads (every wave's 16 land at the end of the workgroup's read burst) and the
+// MFMAs do not overlap.  Tried on top, none faster in the step: counted waits in front of each group of MFMAs (-3 %,
+// LDS + MFMA only); a ring of 5; an 8-wave version with two fragment sets in registers, reads of half step h + 1 between
+// the MFMAs of h, MFMAs as inline asm (LDS + MFMA 0.87 again: with 2 waves per SIMD the b64 reads issue at half the rate,
+// MFMAs alone 0.71); two 8-wave groups in opposite phase (one group's reads beside the other's MFMAs).
 __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int c0, int r0, char* smem) {
   constexpr int NBUF = 4;
   constexpr int HIMG = TILE_BYTES / 2;  // 8 KiB: 32 k-rows x 128 columns
@@ -932,7 +969,7 @@ __device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int 
   {
     const int kr = 8 * (lane >> 4) + ((lane >> 2) & 3);
     const int sub = (lane & 1) * 8, chl = (lane & 3) >> 1;
-    const uint32_t s0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte offset
+    const uint32_t s0 = lds_offset(smem);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       pa[j] = s0 + (wr >> 1) * HIMG + km_off(kr, (((wr & 1) * 64 + j * 16) >> 3) + chl) + sub;

@@ -283,9 +283,15 @@ class WgradQueue:
     chain.  The default therefore defers everything to the end (OVQA_WGRAD_FLUSH_TILES overrides)."""
 
     TILE = 128
-    # 256 x 256 tiles on one 16-wave workgroup per CU (half the L2 -> CU bytes per flop) when every queued product allows
-    # the direct-to-LDS form; OVQA_DW_TILE256=0 keeps the 128 x 128 tiles
-    BIG_TILES = os.environ.get("OVQA_DW_TILE256", "1") != "0"
+    # OVQA_DW_TILE256: 256 x 256 tiles on one 16-wave workgroup per CU (half the L2 -> CU bytes per flop) -- 0 (default)
+    # never, 1 for launches with at least BIG_MIN_ROUNDS such tiles per CU, 2 whenever every queued product allows the
+    # direct-to-LDS form.  MEASURED (profiles/README.md): against the 128 x 128 form as it was (its ring drained by a
+    # compiler-inserted wait in every K step) the large tiles won 0.06 ms per step; with that wait gone the 128 x 128
+    # form is the faster one (3.195 against 3.231 ms per step, 480 against 493 us on its own), also for a backward pass
+    # flushed in five gradient segments (N > 1; ~130 large tiles per launch: 3.39 against 3.52).
+    BIG_TILES = os.environ.get("OVQA_DW_TILE256", "0") != "0"
+    BIG_FORCED = os.environ.get("OVQA_DW_TILE256", "0") == "2"
+    BIG_MIN_ROUNDS = 2
     FLUSH_TILES = int(__import__("os").environ.get("OVQA_WGRAD_FLUSH_TILES", str(1 << 30)))
 
     def __init__(self):
@@ -410,6 +416,9 @@ class WgradQueue:
         fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
                    and it[1].data_ptr() % 16 == 0 for it in items)
         big = fast and self.BIG_TILES and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0")
+        if big and not self.BIG_FORCED:
+            n256 = sum(((it[6] + 255) // 256) * ((it[7] + 255) // 256) for it in items)
+            big = n256 >= self.BIG_MIN_ROUNDS * torch.cuda.get_device_properties(dev).multi_processor_count
         tile = 256 if big else self.TILE
         for i, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
             probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), _p(db), lddy, ldx, M, N, K, acc)

@@ -209,6 +209,7 @@ def test_linear_bwd_weight(dtype, M, N, K):
 def test_grouped_wgrad_and_bias_grad(specs, big, monkeypatch):
     o = ops()
     monkeypatch.setattr(o.WgradQueue, "BIG_TILES", big)
+    monkeypatch.setattr(o.WgradQueue, "BIG_FORCED", big)  # (these few products would not fill the chip twice)
     q = o.WgradQueue()
     refs, outs = [], []
     for i, (M, N, K) in enumerate(specs):
