@@ -24,6 +24,30 @@ __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[VEC]) {
 #pragma unroll
   for (int i = 0; i < VEC; i++) o[i] = (float)a[i];
 }
+// The same 8 elements as RAW registers: issuing the load and converting / using it are separate steps, so that a row can
+// be requested one loop iteration ahead (load8 converts on the spot: a use, hence a wait, right behind the load).
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ void get(float (&o)[VEC]) const {
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+};
+template <>
+struct Raw8<bf16> {
+  bf16x8 a;
+  __device__ __forceinline__ void load(const bf16* p) { a = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void get(float (&o)[VEC]) const {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) o[i] = (float)a[i];
+  }
+};
 template <typename T>
 __device__ __forceinline__ void store8(T* p, const float (&v)[VEC]);
 template <>
@@ -133,16 +157,35 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
   const int wgp = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int row_lo = (int)((int64_t)wgp * M / (int)gridDim.x);
   const int row_hi = (int)((int64_t)(wgp + 1) * M / (int)gridDim.x);
+  // The NEXT row of the wave is requested before the current one is processed (raw registers, nothing computed from them
+  // until their turn): a wave owns 1-2 rows of a 6400-row input, and two dependent round trips were a third of the kernel.
+  Raw8<TX> xr[CHUNKS], xn[CHUNKS];
+  Raw8<TDY> dr[CHUNKS], dn[CHUNKS];
+  float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
+  // (unconditional loads at clamped positions: behind a per-lane or per-wave `if` the compiler no longer knows how many
+  // loads are in flight and waits for all of them, the next row's included, before the current row is touched)
+  auto request = [&](int row, Raw8<TX> (&xq)[CHUNKS], Raw8<TDY> (&dq)[CHUNKS], float& m, float& r) {
+    m = mean[row];
+    r = rstd[row];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = min((c * 64 + lane) * VEC, D - VEC);
+      xq[c].load(x + (int64_t)row * D + col);
+      dq[c].load(dy + (int64_t)row * D + col);
+    }
+  };
+  if (row_lo + wave < row_hi) request(row_lo + wave, xr, dr, mu, rs);
   for (int row = row_lo + wave; row < row_hi; row += NWAVES) {
-    const float mu = mean[row], rs = rstd[row];
+    const bool more = row + NWAVES < row_hi;
+    request(more ? row + NWAVES : row, xn, dn, mun, rsn);  // (the last round asks for its own row again: an L2 hit)
     float xh[CHUNKS][VEC], d[CHUNKS][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
       const int col = (c * 64 + lane) * VEC;
       if (col < D) {
-        load8<TX>(x + (int64_t)row * D + col, xh[c]);
-        load8<TDY>(dy + (int64_t)row * D + col, d[c]);
+        xr[c].get(xh[c]);
+        dr[c].get(d[c]);
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
           xh[c][i] = (xh[c][i] - mu) * rs;
@@ -172,6 +215,10 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
         }
       }
     }
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) { xr[c] = xn[c]; dr[c] = dn[c]; }
+    mu = mun;
+    rs = rsn;
   }
   // combine the 4 waves of the block
   if (wave > 0) {
@@ -347,6 +394,8 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
 int layernorm_bwd_waves(int64_t M, int64_t D) { return (M >= 4096 && 7 * 2 * D * 4 <= 64 * 1024) ? 8 : 4; }
 int layernorm_bwd_blocks(int64_t M, int64_t D) {
   const int nw = layernorm_bwd_waves(M, D);
+  // (measured in the MCAN step, 6400 rows: 512 workgroups 3.19 ms; 800 / 1024 -- one row per wave -- 3.23 / 3.24: the
+  // partial rows the deferred reduce streams grow with the workgroup count; 384 / 256: 3.20-3.24 / 3.22)
   const int64_t cap = nw == 8 ? 512 : 1024;
   int64_t nb = (M + nw - 1) / nw;
   return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
