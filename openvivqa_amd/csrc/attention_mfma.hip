@@ -1312,35 +1312,33 @@ __global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_
   const int hs = tid >> 9, t5 = tid & 511;   // staging head and thread within its 512
   const int hst = h0 + hs;
   const int t = t5 & 255, ch = t & 7;
-  const bool ld_q = t5 < 256;
+  const bool ld_q = __builtin_amdgcn_readfirstlane((int)(t5 < 256)) != 0;  // (whole waves)
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  uint4 vq[W], vo[W], vl[W], vkv = zero4;
+  // Every load is UNCONDITIONAL per lane (clamped row; a missing mask row / o_lo is read from another valid address and
+  // dropped below) and nothing is computed from a loaded value before all are issued -- see attn_bwd_roles_mfma_kernel:
+  // with per-lane `if`s this staging was seven dependent round trips.  va: the Q rows (Q waves) or the O rows; vb: o_lo.
+  const bool has_mask = a.mask != nullptr, has_lo = a.o_lo != nullptr;
+  uint4 va[W], vb[W], vkv;
   float lse_r[W];
-  float mval = 0.f;
-  if (t5 < k_rows)
-    mval = t5 < nk ? (a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)hst * a.msh + t5] * LOG2E : 0.f) : -INFINITY;
+  const float* lb = a.lse + ((int64_t)b * a.H + hst) * nq;
+  const float* mp = has_mask ? a.mask + (int64_t)b * a.msb + (int64_t)hst * a.msh : lb;
+  float mval = mp[min(t5 & (k_rows - 1), (has_mask ? nk : nq) - 1)];
   {
-    const bf16* qb = (const bf16*)a.q + (int64_t)b * nq * a.ldq + hst * 64 + ch * 8;
-    const bf16* ob = (const bf16*)a.o + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8;
-    const bf16* lob = a.o_lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8 : nullptr;
-    const float* lb = a.lse + ((int64_t)b * a.H + hst) * nq;
+    const bf16* pa = ld_q ? (const bf16*)a.q + (int64_t)b * nq * a.ldq + hst * 64 + ch * 8
+                          : (const bf16*)a.o + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8;
+    const int64_t lda = ld_q ? a.ldq : a.ldo;
+    const bool lo = !ld_q && has_lo;
+    const bf16* pb = lo ? (const bf16*)a.o_lo + (int64_t)b * nq * a.ldo + hst * 64 + ch * 8 : pa;
 #pragma unroll
     for (int i = 0; i < W; i++) {
-      const int row = (t >> 3) + 32 * i;
-      const bool v = row < nq;
-      vq[i] = zero4; vo[i] = zero4; vl[i] = zero4; lse_r[i] = INFINITY;  // p = 0 beyond nq
-      if (ld_q && v) vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
-      if (!ld_q && v) {
-        vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
-        if (lob) vl[i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
-        if (ch == 0) lse_r[i] = lb[row] * LOG2E;
-      }
+      const int rc = min((t >> 3) + 32 * i, nq - 1);
+      va[i] = *reinterpret_cast<const uint4*>(pa + (int64_t)rc * lda);
+      vb[i] = *reinterpret_cast<const uint4*>(pb + (int64_t)rc * lda);
+      lse_r[i] = lb[rc];
     }
-    const int krow = t >> 3;
-    if (krow < nk) {
-      if (ld_q) vkv = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + krow) * a.ldk + hst * 64 + ch * 8);
-      else vkv = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + krow) * a.ldv + hst * 64 + ch * 8);
-    }
+    const int kc = min(t >> 3, nk - 1);
+    const bf16* pk = ld_q ? (const bf16*)a.k + ((int64_t)b * nk + kc) * a.ldk : (const bf16*)a.v + ((int64_t)b * nk + kc) * a.ldv;
+    vkv = *reinterpret_cast<const uint4*>(pk + hst * 64 + ch * 8);
   }
   __syncthreads();  // every wave is done with the staging ring: it becomes the images
 
@@ -1369,12 +1367,15 @@ __global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_
 #pragma unroll
     for (int i = 0; i < W; i++) {
       const int row = (t >> 3) + 32 * i;
+      const bool v = row < nq;
       if (ld_q) {
-        *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[i];
+        if (!v) va[i] = zero4;
+        *reinterpret_cast<uint4*>(base + img_off(row, ch)) = va[i];
       } else {
-        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(Gs + img_off(row, ch));
-        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
-        const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
+        if (!has_lo) vb[i] = zero4;
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(Gs + img_off(row, ch));  // (zero beyond nq: dl = 0 there)
+        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&va[i]);
+        const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vb[i]);
         float dl = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; e++) dl += (float)g8[e] * ((float)o8[e] + (float)l8[e]);
@@ -1382,16 +1383,17 @@ __global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_
         dl += __shfl_xor(dl, 2, 64);
         dl += __shfl_xor(dl, 4, 64);
         if (ch == 0) {
-          lse_g[row] = lse_r[i];
+          lse_g[row] = v ? lse_r[i] * LOG2E : INFINITY;  // p = 0 beyond nq
           lse_g[q_rows + row] = dl;
-          if (row < nq && a.delta) a.delta[(int64_t)pid * nq + row] = dl;
+          if (v && a.delta) a.delta[(int64_t)pid * nq + row] = dl;
         }
       }
     }
     const int krow = t >> 3;
+    if (krow >= nk) vkv = zero4;
     if (ld_q) *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(krow, ch)) = vkv;
     else *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(krow, ch)) = vkv;
-    if (t5 < k_rows) reinterpret_cast<float*>(base + img_bytes)[t5] = mval;
+    if (t5 < k_rows) reinterpret_cast<float*>(base + img_bytes)[t5] = t5 < nk ? (has_mask ? mval * LOG2E : 0.f) : -INFINITY;
   }
   __syncthreads();
   // waves 0 .. 4 NH - 1: head wave / 4, query tile wave % 4; the others keep the barriers company
@@ -1476,27 +1478,24 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
   // ---- one round of loads for both heads: every thread owns chunk (row tid >> 3, 16 bytes tid & 7) of every image
   const int ch = tid & 7, row = tid >> 3;
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  // (unconditional loads at clamped rows, nothing computed from them here: see attn_bwd_roles_mfma_kernel)
+  const bool has_mask = a.mask != nullptr, has_lo = a.o_lo != nullptr;
   uint4 vq[G], vo[G], vl[G], vk[G], vv[G];
   float lse_r[G];
-  float mval = 0.f;
-  if (tid < G * k_rows) {
-    const int key = tid % k_rows;
-    mval = key < nk ? (a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)(h0 + tid / k_rows) * a.msh + key] * LOG2E : 0.f) : -INFINITY;
-  }
+  const int rq = min(row, nq - 1), rk = min(row, nk - 1);
+  const int mkey = min(tid & (k_rows - 1), nk - 1), mhead = h0 + ((tid / k_rows) & (G - 1));
+  const float* mp = has_mask ? a.mask + (int64_t)b * a.msb + (int64_t)mhead * a.msh + mkey : a.lse + ((int64_t)b * a.H + h0) * nq;
+  float mval = *mp;
 #pragma unroll
   for (int gi = 0; gi < G; gi++) {
     const int hh = h0 + gi;
-    vq[gi] = zero4; vo[gi] = zero4; vl[gi] = zero4; vk[gi] = zero4; vv[gi] = zero4; lse_r[gi] = INFINITY;  // p = 0 beyond nq
-    if (row < nq) {
-      vq[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.q + ((int64_t)b * nq + row) * a.ldq + hh * 64 + ch * 8);
-      vo[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.o + ((int64_t)b * nq + row) * a.ldo + hh * 64 + ch * 8);
-      if (a.o_lo) vl[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.o_lo + ((int64_t)b * nq + row) * a.ldo + hh * 64 + ch * 8);
-      if (ch == 0) lse_r[gi] = a.lse[((int64_t)b * a.H + hh) * nq + row] * LOG2E;
-    }
-    if (row < nk) {
-      vk[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + row) * a.ldk + hh * 64 + ch * 8);
-      vv[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + row) * a.ldv + hh * 64 + ch * 8);
-    }
+    const bf16* ob = (const bf16*)a.o + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8;
+    vq[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.q + ((int64_t)b * nq + rq) * a.ldq + hh * 64 + ch * 8);
+    vo[gi] = *reinterpret_cast<const uint4*>(ob);
+    vl[gi] = *reinterpret_cast<const uint4*>(has_lo ? (const bf16*)a.o_lo + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8 : ob);
+    lse_r[gi] = a.lse[((int64_t)b * a.H + hh) * nq + rq];
+    vk[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + rk) * a.ldk + hh * 64 + ch * 8);
+    vv[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + rk) * a.ldv + hh * 64 + ch * 8);
   }
   __syncthreads();  // every wave is done with the staging ring: it becomes the images
 
@@ -1521,8 +1520,11 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
   for (int gi = 0; gi < G; gi++) {
     char* base = smem + gi * prob_bytes;
     float* lse_g = reinterpret_cast<float*>(base + img_bytes) + k_rows;
+    if (row >= nq) vq[gi] = zero4;
+    if (row >= nk) { vk[gi] = zero4; vv[gi] = zero4; }
+    if (!has_lo) vl[gi] = zero4;
     *reinterpret_cast<uint4*>(base + img_off(row, ch)) = vq[gi];
-    const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(base + q_rows * 128 + img_off(row, ch));
+    const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(base + q_rows * 128 + img_off(row, ch));  // (zero beyond nq: dl = 0)
     const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[gi]);
     const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[gi]);
     float dl = 0.f;
@@ -1532,14 +1534,16 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
     dl += __shfl_xor(dl, 2, 64);
     dl += __shfl_xor(dl, 4, 64);
     if (ch == 0) {
-      lse_g[row] = lse_r[gi];
+      lse_g[row] = row < nq ? lse_r[gi] * LOG2E : INFINITY;  // p = 0 beyond nq
       lse_g[q_rows + row] = dl;
       if (row < nq && a.delta) a.delta[((int64_t)b * a.H + h0 + gi) * nq + row] = dl;
     }
     *reinterpret_cast<uint4*>(base + 2 * q_rows * 128 + img_off(row, ch)) = vk[gi];
     *reinterpret_cast<uint4*>(base + (2 * q_rows + k_rows) * 128 + img_off(row, ch)) = vv[gi];
   }
-  if (tid < G * k_rows) reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] = mval;
+  if (tid < G * k_rows)
+    reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] =
+        tid % k_rows < nk ? (has_mask ? mval * LOG2E : 0.f) : -INFINITY;
   __syncthreads();
   smallk_bwd_compute<true, 1, G>(a, smem, b * a.H + h0, wave, lane, false);
 }
@@ -1583,31 +1587,35 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     const bf16* vb = (const bf16*)a.v + (int64_t)b * nk * a.ldv + h * 64 + ch * 8;
     const float* lb = a.lse + (int64_t)pid * nq;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    // Every load is UNCONDITIONAL per lane (clamped row; branches only on kernel-uniform conditions) and nothing is
+    // computed from a loaded value before all of them are issued: behind a per-lane `if` the compiler ends the branch with
+    // `s_waitcnt vmcnt(0)` (the * LOG2E, or a register copy, lands inside it) -- four dependent round trips at the head of
+    // this kernel instead of one.  Rows beyond nq / nk become zero / +-inf where the images are written.
     uint4 vq[2], vd[2], vo[2], vl[2], vk[2], vv[2];
     float lse_r[2];
-    float mval = -INFINITY;
-    if (a.msq == 0 && tid < nk) mval = a.mask ? a.mask[(int64_t)b * a.msb + (int64_t)h * a.msh + tid] * LOG2E : 0.f;
+    // (no mask row / no o_lo: the load goes to another valid address and its result is dropped below)
+    const bool has_mrow = a.msq == 0 && a.mask != nullptr, has_lo = a.o_lo != nullptr;
+    const float* mp = has_mrow ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : lb;
+    float mval = mp[min(tid, (has_mrow ? nk : nq) - 1)];
+    const bf16* lob2 = has_lo ? lob : ob;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
-      vq[i] = zero4; vd[i] = zero4; vo[i] = zero4; vl[i] = zero4; vk[i] = zero4; vv[i] = zero4;
-      lse_r[i] = INFINITY;
-      if (row < nq) {
-        vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)row * a.ldq);
-        vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)row * a.lddo);
-        vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)row * a.ldo);
-        if (lob) vl[i] = *reinterpret_cast<const uint4*>(lob + (int64_t)row * a.ldo);
-        if (ch == 0) lse_r[i] = lb[row] * LOG2E;
-      }
-      if (row < nk) {
-        vk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk);
-        vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * a.ldv);
-      }
+      const int rq = min(row, nq - 1), rk = min(row, nk - 1);
+      vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)rq * a.ldq);
+      vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)rq * a.lddo);
+      vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)rq * a.ldo);
+      vl[i] = *reinterpret_cast<const uint4*>(lob2 + (int64_t)rq * a.ldo);
+      lse_r[i] = lb[rq];
+      vk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)rk * a.ldk);
+      vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)rk * a.ldv);
     }
     OVQA_PROBE(1);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
+      const bool qv = row < nq, kv = row < nk;
+      if (!has_lo) vl[i] = zero4;
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[i]);
       const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
       const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
@@ -1617,13 +1625,15 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
       dl += __shfl_xor(dl, 1, 64);
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);
+      if (!qv) { vq[i] = zero4; vd[i] = zero4; }
+      if (!kv) { vk[i] = zero4; vv[i] = zero4; }
       if (row < q_rows) {
         *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = vq[i];
         *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
         if (ch == 0) {
-          lse_s[row] = lse_r[i];
-          del_s[row] = dl;
-          if (row < nq) a.delta[(int64_t)pid * nq + row] = dl;
+          lse_s[row] = qv ? lse_r[i] * LOG2E : INFINITY;
+          del_s[row] = qv ? dl : 0.f;
+          if (qv) a.delta[(int64_t)pid * nq + row] = dl;
         }
       }
       if (row < k_rows) {
@@ -1631,7 +1641,7 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
         *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vv[i];
       }
     }
-    if (a.msq == 0 && tid < k_rows) mlds[tid] = mval;
+    if (a.msq == 0 && tid < k_rows) mlds[tid] = tid < nk ? (has_mrow ? mval * LOG2E : 0.f) : -INFINITY;
   }
   OVQA_PROBE(2);
   __syncthreads();
