@@ -74,13 +74,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
   const int row = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const TIN* xr = x + (int64_t)row * D;
+  // One round of loads: the row, gamma, beta (and the positional row) are all requested here, unconditionally at clamped
+  // columns -- gamma / beta used to be asked for after the two reductions, a second dependent round trip per wave.
+  Raw8<TIN> xraw[CHUNKS];
+  Raw8<float> graw[CHUNKS], braw[CHUNKS], praw[CHUNKS];
+  const float* pr = pos ? pos + (int64_t)(row % pos_rows) * D : nullptr;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const int col = min((c * 64 + lane) * VEC, D - VEC);
+    xraw[c].load(xr + col);
+    graw[c].load(gamma + col);
+    braw[c].load(beta + col);
+    if (pr) praw[c].load(pr + col);
+  }
   float v[CHUNKS][VEC];
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     const int col = (c * 64 + lane) * VEC;
+    xraw[c].get(v[c]);
     if (col < D) {
-      load8<TIN>(xr + col, v[c]);
 #pragma unroll
       for (int i = 0; i < VEC; i++) s += v[c][i];
     } else {
@@ -107,19 +120,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
     if (rstd_out) rstd_out[row] = rstd;
   }
   TOUT* yr = y + (int64_t)row * D;
-  const float* pr = pos ? pos + (int64_t)(row % pos_rows) * D : nullptr;
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     const int col = (c * 64 + lane) * VEC;
     if (col < D) {
       float g[VEC], b[VEC], o[VEC];
-      load8<float>(gamma + col, g);
-      load8<float>(beta + col, b);
+      graw[c].get(g);
+      braw[c].get(b);
 #pragma unroll
       for (int i = 0; i < VEC; i++) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
       if (pr) {
         float p[VEC];
-        load8<float>(pr + col, p);
+        praw[c].get(p);
 #pragma unroll
         for (int i = 0; i < VEC; i++) o[i] += p[i];
       }
