@@ -1555,8 +1555,14 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
 // staging.  Saves the second launch (~5 us floor) and the second staging of the same 50 KB.
 // NQT_T / NKT_T: compile-time tile counts (0 = use the runtime arguments): with constants the two tile loops are
 // fully unrolled and the MFMA chains of different tiles interleave.
+// OVQA_ROLES_WAVES_PER_EU = 4: at most 128 VGPRs, so that TWO workgroups share a CU (their 65.5 KB of LDS each allow it):
+// with the 152 registers the compiler takes when left alone, the 512 workgroups of a 64-sample, 8-head launch ran as two
+// rounds of one workgroup per CU (10 us each by the phase probe, 25 us per launch).
+#ifndef OVQA_ROLES_WAVES_PER_EU
+#define OVQA_ROLES_WAVES_PER_EU 4
+#endif
 template <int NQT_T, int NKT_T, bool ROWMASK>
-__global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt_rt, int nkt_rt) {
+__global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt_rt, int nkt_rt) {
   const int nqt = NQT_T ? NQT_T : nqt_rt, nkt = NKT_T ? NKT_T : nkt_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1732,12 +1738,9 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
     const bool kok = key < nk;
     const float* mcol = a.mask ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh + (kok ? key : 0) : nullptr;
     const float mconst = row_mask ? mlds[key] : 0.f;  // log2 units; -inf beyond nk
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      kf[ks] = frag_rows(Ks, tk * 32, ks, lane);
-      vf[ks] = frag_rows(Vs, tk * 32, ks, lane);
-    }
+    // (the wave's own K / V fragments are read from LDS again for every query tile, behind a compiler barrier that keeps
+    // the reads from being merged and the tiles from overlapping: 32 registers + one tile's accumulators fewer -- what
+    // brings the kernel under 128 VGPRs, i.e. two workgroups per CU, without spilling)
     f32x16 dvt[2], dkt[2];
 #pragma unroll
     for (int d = 0; d < 2; d++)
@@ -1748,10 +1751,11 @@ __global__ __launch_bounds__(512) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdA
       f32x16 s_, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), kf[ks], s_, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+        s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, t * 32, ks, lane), frag_rows(Ks, tk * 32, ks, lane), s_, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Gs, t * 32, ks, lane), frag_rows(Vs, tk * 32, ks, lane), dp, 0, 0, 0);
       }
       bf16x8 pb[2], db[2];
 #pragma unroll
