@@ -2100,8 +2100,11 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
   DoBwdArgs g{(const bf16*)dy, lddy, (const bf16*)wt, ldwt, a, (int)Dm};
   static int pair = -1;
   if (pair < 0) {
-    const char* e = getenv("OVQA_QATT_PAIR");  // two heads per 16-wave workgroup (A/B switch, shared with the forward form)
-    pair = e ? atoi(e) : 1;
+    // two heads per 16-wave workgroup (1) or one head per 8-wave workgroup, two workgroups per CU (0, the default since
+    // the staging became one round of loads: 3.241 / 3.239 against 3.265 / 3.256 ms per MCAN step; the forward form keeps
+    // the pair: OVQA_QATT_PAIR=0 there costs what this gains)
+    const char* e = getenv("OVQA_DOBWD_PAIR");
+    pair = e ? atoi(e) : 0;
   }
   if (a.nq <= 32) {  // single query tile (20 x 20): two heads per 4-wave workgroup
     const size_t stage1 = (size_t)(128 + 32) * 64 * 2;
