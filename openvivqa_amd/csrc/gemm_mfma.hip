@@ -75,6 +75,7 @@ struct GemmArgs {
   const bf16* Q; int64_t ldq;  // c operand
   int R, C, K;
   int tiles_r, tiles_c;
+  int c_step;  // rows of the c operand a tile OWNS (0 = the tile's full height): see the 16-wave form in launch()
 };
 
 __device__ __forceinline__ int kc_off(int row, int chunk) { return (row * 8 + (chunk ^ (row & 7))) * 16; }
@@ -364,10 +365,20 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
 
   const int nkt = g.K / BK;
   OVQA_GPROBE(0);
+  // A tile may OWN fewer c rows than it is high (c_step < BC, the 16-wave form: 6400 rows as 64 tiles of 100 instead of 50
+  // of 128, so that 4 x 64 = 256 tiles cover all 256 CUs): the waves whose 8-row piece lies past the owned rows load
+  // nothing (those LDS rows stay whatever they were: every output row depends on its own c row only, and the epilogue
+  // drops the rows past c_hi).
+  constexpr bool CSTEP = NW == 16 && QCH == NW && !Q_KMAJOR;
+  const int c_rows = (CSTEP && g.c_step) ? g.c_step : BC;
+  const int c_hi = min(g.C, c0 + c_rows);
+  const bool q_live = !CSTEP || __builtin_amdgcn_readfirstlane(wave) * 8 < c_rows;  // (a scalar condition)
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
     stage_glds<P_KMAJOR, NW, PCH, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
-    if constexpr (QCH >= NW) {
+    if constexpr (CSTEP) {
+      if (q_live) stage_glds<Q_KMAJOR, NW, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+    } else if constexpr (QCH >= NW) {
       stage_glds<Q_KMAJOR, NW, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
     } else {  // fewer Q chunks than waves (BC = 32): the first QCH waves load one chunk each
       if (wave < QCH) stage_glds<Q_KMAJOR, QCH, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
@@ -384,6 +395,9 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     // every wave has finished reading the buffer that the next issue overwrites
     if (NBUF == 2 || kt + NBUF - 2 >= nkt) {
       wait_vmcnt<0>();
+    } else if constexpr (CSTEP) {
+      if (q_live) wait_vmcnt<LOADS * (NBUF - 2)>();
+      else wait_vmcnt<(PCH / NW) * (NBUF - 2)>();
     } else if constexpr (QCH >= NW) {
       wait_vmcnt<LOADS * (NBUF - 2)>();
     } else {  // waves >= QCH issue no Q loads: their count per stage is smaller (wave-uniform branch)
@@ -490,7 +504,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
         const f32x4 m = ksel == 0 ? acc[j][ih] : acc[j][NH + ih];
         sum[j] = f32x4{m[0] + o[0], m[1] + o[1], m[2] + o[2], m[3] + o[3]};
       }
-      if (c >= g.C) continue;
+      if (c >= c_hi) continue;
       if constexpr (WIDE) {
 #pragma unroll
         for (int jp = 0; jp < NJ / 2; jp++) {
@@ -511,7 +525,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int c = c0 + wc * (NI * 16) + i * 16 + (lane & 15);
-    if (c >= g.C) continue;
+    if (c >= c_hi) continue;
     if constexpr (WIDE) {
 #pragma unroll
       for (int jp = 0; jp < NJ / 2; jp++) {
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR, KSP>(g, tc * BC, tr * BR, epi, smem);
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR, KSP>(g, tc * (g.c_step ? g.c_step : BC), tr * BR, epi, smem);
 }
 
 // ---- skinny products (a decoding step: M = batch * beam <= 256 activation rows against a whole weight matrix) ----------
@@ -1252,6 +1266,24 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     }
     if (big16 && small_c && !tiny_c) {
       g.tiles_c = (int)((C + BT - 1) / BT);
+      // all CUs instead of tiles_r * ceil(C / 128) of them: tiles that own fewer rows (>= 64) when that gives every CU one
+      // (6400 x 512: 4 x 50 = 200 tiles -> 4 x 64 of 100 rows; the activation tile of a K step shrinks from 16 to 13 pieces)
+      static int cus = -1, cstep_on = -1;
+      if (cus < 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+          cus = 256;
+        const char* e = getenv("OVQA_GEMM_CSTEP");
+        cstep_on = e ? atoi(e) : 1;
+      }
+      if (cstep_on && g.tiles_r * g.tiles_c < cus && cus / g.tiles_r > g.tiles_c) {
+        const int n_c = cus / g.tiles_r;
+        const int step = (int)((C + n_c - 1) / n_c);
+        if (step >= 64 && step < BT) {
+          g.c_step = step;
+          g.tiles_c = (int)((C + step - 1) / step);
+        }
+      }
       const dim3 grid16(g.tiles_r * g.tiles_c);
       const int nb = big16 == 2 ? 2 : (big16 == 4 ? 4 : 3);
       const size_t lds = (size_t)nb * 2 * TILE_BYTES;
