@@ -309,6 +309,16 @@ __device__ __forceinline__ void stage_glds(char* tile, const bf16* __restrict__ 
   }
 }
 
+// one 1 KiB piece (8 rows) of a row-major operand tile: piece ci of stage_glds<false, ...>
+__device__ __forceinline__ void stage_glds_piece(char* tile, const bf16* __restrict__ Op, int64_t ld, int row0, int rows, int k0,
+                                                 int lane, int ci) {
+  const int row = ci * 8 + (lane >> 3), pos = lane & 7;
+  int grow = row0 + row;
+  grow = grow < rows ? grow : rows - 1;
+  __builtin_amdgcn_global_load_lds((gbl_void*)(Op + (int64_t)grow * ld + k0 + ((pos ^ (row & 7)) << 3)),
+                                   (lds_void*)(tile + ci * 1024), 16, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -369,15 +379,22 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   // of 128, so that 4 x 64 = 256 tiles cover all 256 CUs): the waves whose 8-row piece lies past the owned rows load
   // nothing (those LDS rows stay whatever they were: every output row depends on its own c row only, and the epilogue
   // drops the rows past c_hi).
-  constexpr bool CSTEP = NW == 16 && QCH == NW && !Q_KMAJOR;
+  // (the 8-wave form with a ring of 2 can do the same -- its waits are vmcnt(0) -- but the host never asks it to)
+  constexpr bool CSTEP = !Q_KMAJOR && BC == 128 && KSP == 1 && (NW == 16 || (NW == 8 && NBUF == 2));
+  constexpr int QPW = QCH / NW;  // Q pieces per wave (CSTEP: 1 or 2)
   const int c_rows = (CSTEP && g.c_step) ? g.c_step : BC;
   const int c_hi = min(g.C, c0 + c_rows);
-  const bool q_live = !CSTEP || __builtin_amdgcn_readfirstlane(wave) * 8 < c_rows;  // (a scalar condition)
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);  // (scalar conditions below)
+  const bool q_live = !CSTEP || uwave * QPW * 8 < c_rows;  // the wave's first piece is owned
   auto issue = [&](int kt) {
     char* buf = smem + (kt % NBUF) * STAGE;
     stage_glds<P_KMAJOR, NW, PCH, WIDE>(buf, g.P, g.ldp, r0, g.R, kt * BK, lane, wave);
     if constexpr (CSTEP) {
-      if (q_live) stage_glds<Q_KMAJOR, NW, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
+#pragma unroll
+      for (int i = 0; i < QPW; i++) {
+        const int ci = uwave * QPW + i;
+        if (ci * 8 < c_rows) stage_glds_piece(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, ci);
+      }
     } else if constexpr (QCH >= NW) {
       stage_glds<Q_KMAJOR, NW, QCH>(buf + PT_BYTES, g.Q, g.ldq, c0, g.C, kt * BK, lane, wave);
     } else {  // fewer Q chunks than waves (BC = 32): the first QCH waves load one chunk each
@@ -395,7 +412,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     // every wave has finished reading the buffer that the next issue overwrites
     if (NBUF == 2 || kt + NBUF - 2 >= nkt) {
       wait_vmcnt<0>();
-    } else if constexpr (CSTEP) {
+    } else if constexpr (CSTEP) {  // (NW == 16 here: one Q piece per wave, or none)
       if (q_live) wait_vmcnt<LOADS * (NBUF - 2)>();
       else wait_vmcnt<(PCH / NW) * (NBUF - 2)>();
     } else if constexpr (QCH >= NW) {
@@ -1089,6 +1106,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWg
   gemm_tile<true, true, MEpiWgrad, true>(g, tc * BT, tr * BT, epi, smem);
 }
 
+// Rows of the c operand a 128-row tile should OWN so that the grid fills whole rounds of `per_cu` workgroups per CU (0: keep
+// full tiles): 6400 x 512 on the 16-wave form (one per CU): 4 x 50 tiles on 200 of 256 CUs -> 4 x 64 tiles of 100 rows:
+// step 3.151 / 3.165 -> 3.093 / 3.105 / 3.126 ms on one box, 3.170 -> 3.153 on another.  OVQA_GEMM_CSTEP=0 switches it off.  NOT for the 8-wave form with two
+// workgroups per CU (6400 x 2048: 16 x 50 = 800 tiles = 1.56 rounds -> 16 x 64 = two rounds exactly): measured +0.12 ms
+// per step -- its second, partial round runs with the CUs half empty and therefore fast, which two full rounds of
+// smaller tiles (more weight-tile traffic) do not beat.
+inline int owned_rows(int tiles_r, int tiles_c, int64_t C, int per_cu) {
+  static int cus = -1, on = -1;
+  if (cus < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    const char* e = getenv("OVQA_GEMM_CSTEP");
+    on = e ? atoi(e) : 1;
+  }
+  if (!on) return 0;
+  const int slots = cus * per_cu, tiles = tiles_r * tiles_c;
+  if (tiles % slots == 0) return 0;
+  const int rounds = (tiles + slots - 1) / slots;
+  const int n_c = rounds * slots / tiles_r;  // c tiles that fill `rounds` rounds
+  if (n_c <= tiles_c) return 0;
+  const int step = (int)((C + n_c - 1) / n_c);
+  return (step >= 64 && step < BT) ? step : 0;
+}
+
 inline int small_tile_threshold() {
   static int v = -1;
   if (v < 0) {
@@ -1266,23 +1308,9 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     }
     if (big16 && small_c && !tiny_c) {
       g.tiles_c = (int)((C + BT - 1) / BT);
-      // all CUs instead of tiles_r * ceil(C / 128) of them: tiles that own fewer rows (>= 64) when that gives every CU one
-      // (6400 x 512: 4 x 50 = 200 tiles -> 4 x 64 of 100 rows; the activation tile of a K step shrinks from 16 to 13 pieces)
-      static int cus = -1, cstep_on = -1;
-      if (cus < 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-          cus = 256;
-        const char* e = getenv("OVQA_GEMM_CSTEP");
-        cstep_on = e ? atoi(e) : 1;
-      }
-      if (cstep_on && g.tiles_r * g.tiles_c < cus && cus / g.tiles_r > g.tiles_c) {
-        const int n_c = cus / g.tiles_r;
-        const int step = (int)((C + n_c - 1) / n_c);
-        if (step >= 64 && step < BT) {
-          g.c_step = step;
-          g.tiles_c = (int)((C + step - 1) / step);
-        }
+      if (const int step = owned_rows(g.tiles_r, g.tiles_c, C, 1)) {
+        g.c_step = step;
+        g.tiles_c = (int)((C + step - 1) / step);
       }
       const dim3 grid16(g.tiles_r * g.tiles_c);
       const int nb = big16 == 2 ? 2 : (big16 == 4 ? 4 : 3);
