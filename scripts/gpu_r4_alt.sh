@@ -1,10 +1,12 @@
 #!/bin/bash
-# round 4: the GPU suites under the alternate code paths (A/B switches of this and earlier rounds); PART=a|b|c splits the
-# list over three calls (a call may run 1200 s: six variants of ~3 min)
+# round 4: the GPU suites under the alternate code paths (A/B switches of this and earlier rounds); PART=a|b|c|d splits the
+# list over four calls (a call may run 1200 s: six variants of ~3 min)
 mkdir -p gpurun_out
 export OVQA_NO_BUILD=1 PYTHONDONTWRITEBYTECODE=1
-if [ "${PART:-a}" = c ]; then
-  LIST=("OVQA_DW_TILE256=2" "OVQA_DW_TILE256=1" "OVQA_DOBWD_PAIR=1" "OVQA_GEMM_CSTEP=0")
+if [ "${PART:-a}" = d ]; then
+  LIST=("OVQA_DOBWD_PAIR=1" "OVQA_GEMM_CSTEP=0")
+elif [ "${PART:-a}" = c ]; then
+  LIST=("OVQA_DW_TILE256=2" "OVQA_DW_TILE256=1")
 elif [ "${PART:-a}" = a ]; then
   LIST=("OVQA_FORCE_SIMPLE=1" "OVQA_NO_FUSED_QKV=1" "OVQA_NO_FUSED_Q=1" "OVQA_NO_FUSED_DO=1" "OVQA_QATT_PAIR=0" "OVQA_DEFER_WGRAD=0")
 else
