@@ -1,10 +1,10 @@
 #!/bin/bash
-# attention backward kernels with one round of staging loads: tests, step time, per-kernel times
+# attention kernels after a staging change: suites, step time, per-kernel times (rocprofv3)
 set -o pipefail
 export OVQA_NO_BUILD=1
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_blocks_gpu.py tests/test_modules_gpu.py -q -x -p no:cacheprovider -k "attention or attn or mha or block or layer or stack or guided" > gpurun_out/attn_stage_tests.log 2>&1 || { tail -30 gpurun_out/attn_stage_tests.log; exit 1; }
-tail -2 gpurun_out/attn_stage_tests.log
+tail -1 gpurun_out/attn_stage_tests.log
 for rep in 1 2; do
 timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --repeats 3 2>/dev/null | python -c "
 import sys, json
