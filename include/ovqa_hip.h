@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 7
+#define OVQA_ABI_VERSION 8
 
 typedef enum {
   OVQA_OK = 0,
@@ -508,6 +508,35 @@ int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, vo
  * target (dtype, may be NULL = 0).  NB a NULL target on LayerNorm outputs is a constant. */
 int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                          int accumulate_loss, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * LSTM recurrence of the text embedding (ABI 8; "next" row 2):
+ *   replaces: self.lstm = nn.LSTM(D_MODEL, D_MODEL, batch_first=True); features, _ = self.lstm(features)
+ *             models/modules/text_embeddings.py:236,243   (one layer, zero initial state, gate order i, f, g, o;
+ *             padded positions are ordinary time steps: the reference does not pack the sequence)
+ *   Forward: x [T*B, I] TIME-MAJOR rows (row t*B + b; ldx), w_ih [4H, I], w_hh [4H, H] of `dtype`, b_ih / b_hh fp32 [4H]
+ *     -> y fp32 [B, T, H] (batch-major, what the module returns),
+ *        hseq `dtype` [(T+1)*B, H] time-major: block 0 = zeros, block t+1 = h_t  (the operand of the w_hh gradient:
+ *        dW_hh = dgates^T hseq[0 : T*B]), and `saved` (opaque, ovqa_lstm_saved_bytes; handed to ovqa_lstm_bwd).
+ *   Backward: dy fp32 [B, T, H] -> dgates `dtype` [T*B, 4H] time-major, columns gate*H + unit (gradient w.r.t. the
+ *     pre-activations).  The caller finishes with the library's GEMMs: dx = dgates w_ih, dW_ih = dgates^T x,
+ *     dW_hh = dgates^T hseq[0 : T*B], db_ih = db_hh = column sums of dgates.  `w_hh_t` [H, 4H] (row stride ldwt) is the
+ *     transposed copy of w_hh the bf16 persistent kernel reads (NULL in fp32 mode).
+ *   `scratch` (ovqa_lstm_scratch_bytes, uninitialised, private to the call while it runs): the hand-off counters of the
+ *     persistent kernels -- zeroed by the call itself with a memset node -- and the per-step kernels' temporaries.
+ *   bf16 with H == I == 512, B a multiple of 16 and B/16*32 <= 256: ONE persistent launch each way (weights resident in
+ *     registers, h_t / dgates_t handed between workgroups in-launch: csrc/lstm.hip); word 1000 of `scratch` (uint32) is
+ *     non-zero afterwards if a hand-off wait gave up (a workgroup of the launch never ran).  Anything else, fp32 and
+ *     OVQA_FORCE_SIMPLE=1: one VALU launch per time step.  Forward and backward of one sequence take the same route
+ *     (decided from dtype, B, I, H alone).
+ * ------------------------------------------------------------------------- */
+int64_t ovqa_lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
+int64_t ovqa_lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
+int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const void* w_hh, const float* b_ih,
+                  const float* b_hh, float* y, void* hseq, void* saved, void* scratch,
+                  int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
+int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt, const void* saved,
+                  void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
 
 #ifdef __cplusplus
 }

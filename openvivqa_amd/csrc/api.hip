@@ -685,4 +685,48 @@ int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx,
   return ovqa::sq_loss_fwd_bwd(dtype, x, target, dx, loss, n, accumulate_loss, as_stream(stream));
 }
 
+int64_t ovqa_lstm_saved_bytes(int64_t B, int64_t T, int64_t H) { return ovqa::lstm_saved_bytes(B, T, H); }
+int64_t ovqa_lstm_scratch_bytes(int64_t B, int64_t T, int64_t H) { return ovqa::lstm_scratch_bytes(B, T, H); }
+
+// forward and backward of one sequence must take the same route: the decision uses dtype and sizes only
+static bool lstm_route_persistent(int dtype, int64_t B, int64_t T, int64_t I, int64_t H) {
+  return !force_simple() && ovqa::lstm_persistent_supported(dtype, B, T, I, H, 8);
+}
+
+int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const void* w_hh, const float* b_ih,
+                  const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T, int64_t I,
+                  int64_t H, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "lstm_fwd: bad dtype");
+  OVQA_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y && hseq && saved && scratch, OVQA_ERR_BAD_ARG,
+               "lstm_fwd: null pointer");
+  OVQA_REQUIRE(B >= 1 && T >= 1 && I >= 1 && H >= 1 && ldx >= I && B * H < (1ll << 31), OVQA_ERR_BAD_ARG,
+               "lstm_fwd: bad size");
+  const bool persistent = lstm_route_persistent(dtype, B, T, I, H);
+  if (persistent)
+    OVQA_REQUIRE(ldx % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w_ih % 16 == 0 && (uintptr_t)w_hh % 16 == 0 &&
+                     (uintptr_t)hseq % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)scratch % 16 == 0,
+                 OVQA_ERR_BAD_ARG, "lstm_fwd(bf16, H = 512): x rows, weights, hseq, y and scratch must be 16-byte aligned");
+  else if (dtype == OVQA_BF16 && require_mfma() && !force_simple()) {
+    ovqa_set_error("lstm_fwd: shape not covered by the persistent MFMA kernel and OVQA_REQUIRE_MFMA=1");
+    return OVQA_ERR_UNSUPPORTED;
+  }
+  g_dispatch = persistent ? "mfma" : "simple";
+  return ovqa::lstm_fwd(dtype, persistent, x, ldx, w_ih, w_hh, b_ih, b_hh, y, hseq, saved, scratch, B, T, I, H,
+                        as_stream(stream));
+}
+
+int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt, const void* saved,
+                  void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "lstm_bwd: bad dtype");
+  OVQA_REQUIRE(dy && w_hh && saved && dgates && scratch, OVQA_ERR_BAD_ARG, "lstm_bwd: null pointer");
+  OVQA_REQUIRE(B >= 1 && T >= 1 && H >= 1 && B * H < (1ll << 31), OVQA_ERR_BAD_ARG, "lstm_bwd: bad size");
+  const bool persistent = lstm_route_persistent(dtype, B, T, I, H);
+  if (persistent)
+    OVQA_REQUIRE(w_hh_t && ldwt >= 4 * H && ldwt % 8 == 0 && (uintptr_t)w_hh_t % 16 == 0 && (uintptr_t)dgates % 16 == 0 &&
+                     (uintptr_t)scratch % 16 == 0,
+                 OVQA_ERR_BAD_ARG, "lstm_bwd(bf16, H = 512): needs the transposed w_hh copy (16-byte aligned rows)");
+  g_dispatch = persistent ? "mfma" : "simple";
+  return ovqa::lstm_bwd(dtype, persistent, dy, w_hh, w_hh_t, ldwt, saved, dgates, scratch, B, T, H, as_stream(stream));
+}
+
 }  // extern "C"

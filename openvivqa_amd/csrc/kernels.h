@@ -142,6 +142,16 @@ int row_padding_mask(int dtype, const void* x, float* mask, int64_t M, int64_t D
 int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                     int accumulate_loss, hipStream_t st);
 
+// ---- lstm.hip ------------------------------------------------------------------
+bool lstm_persistent_supported(int dtype, int64_t B, int64_t T, int64_t I, int64_t H, int64_t ldx);
+int64_t lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
+int64_t lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
+int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void* w_ih, const void* w_hh,
+             const float* b_ih, const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
+             int64_t I, int64_t H, hipStream_t st);
+int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt,
+             const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st);
+
 // ---- gather.hip -----------------------------------------------------------------
 int grouped_row_gather(const ovqa_gather_problem* probs, int n_problems, const int32_t* sel, int b_s, int cur, int beam,
                        hipStream_t st);

@@ -693,3 +693,41 @@ def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
     if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad):
         return _PointerScore.apply(q, k, scale, add_mask, key_fill, query_fill)
     return ops.pointer_score(_c(q), _c(k), scale, add_mask, key_fill, query_fill)
+
+
+# ------------------------------------------------------------------ LSTM recurrence
+class _LSTM(Function):
+    """y = LSTM(x) (text_embeddings.py:236,243) on TIME-MAJOR input rows x_tb [T*B, I]; y fp32 [B, T, H].  One persistent
+    launch each way in bf16 mode; the weight / bias gradients and dx are the library's GEMMs on ``dgates``."""
+
+    @staticmethod
+    def forward(ctx, x_tb, st, *params):
+        arena, m = st["arena"], st["mod"]
+        x_tb = _c(x_tb)
+        y, hseq, saved, _ = ops.lstm_fwd(x_tb, arena.compute(m.weight_ih_l0), arena.compute(m.weight_hh_l0),
+                                         arena.master_of(m.bias_ih_l0), arena.master_of(m.bias_hh_l0), st["B"], st["T"])
+        ctx.st = st
+        ctx.save_for_backward(x_tb, hseq, saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena, m, B, T = st["arena"], st["mod"], st["B"], st["T"]
+        x_tb, hseq, saved = ctx.saved_tensors
+        w_ih, w_hh = m.weight_ih_l0, m.weight_hh_l0
+        dgates, _ = ops.lstm_bwd(_c(dy.float()), arena.compute(w_hh), arena.transposed([w_hh]), saved, B, T, w_ih.shape[1])
+        _wgrad(arena, dgates, x_tb, [w_ih], [m.bias_ih_l0])
+        _wgrad(arena, dgates, hseq[:T * B], [w_hh], [m.bias_hh_l0])
+        dx = _dx(arena, dgates, [w_ih]) if ctx.needs_input_grad[0] else None
+        return dx, None, *([None] * len(st["params"]))
+
+
+def lstm(x_tb, mod, arena, B, T):
+    """``mod`` holds weight_ih_l0 / weight_hh_l0 / bias_ih_l0 / bias_hh_l0 (torch.nn.LSTM's parameter names)."""
+    params = [mod.weight_ih_l0, mod.weight_hh_l0, mod.bias_ih_l0, mod.bias_hh_l0]
+    st = dict(arena=arena, mod=mod, params=params, B=B, T=T)
+    if torch.is_grad_enabled():
+        return _LSTM.apply(x_tb, st, *params)
+    return ops.lstm_fwd(_c(x_tb), arena.compute(mod.weight_ih_l0), arena.compute(mod.weight_hh_l0),
+                        arena.master_of(mod.bias_ih_l0), arena.master_of(mod.bias_hh_l0), B, T)[0]

@@ -5,6 +5,8 @@ UsualEmbedding     models/modules/text_embeddings.py:56-80    (token lookup + ma
 """
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import nn
 
@@ -53,11 +55,29 @@ class UsualEmbedding(nn.Module):
         return self.components(tokens), (padding_masks, sequential_masks)
 
 
+class LSTM(nn.Module):
+    """Parameter holder of a one-layer LSTM under torch's names and initialisation (``weight_ih_l0`` [4H, I],
+    ``weight_hh_l0`` [4H, H], ``bias_ih_l0`` / ``bias_hh_l0`` [4H], gate order i, f, g, o, all U(-1/sqrt(H), 1/sqrt(H)) drawn
+    in that order), so ``lstm.*`` state_dict keys interchange with the reference's ``nn.LSTM``.  The recurrence itself is
+    ``functional.lstm`` (ovqa_lstm_fwd / ovqa_lstm_bwd)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.weight_ih_l0 = nn.Parameter(torch.empty(4 * hidden_size, input_size))
+        self.weight_hh_l0 = nn.Parameter(torch.empty(4 * hidden_size, hidden_size))
+        self.bias_ih_l0 = nn.Parameter(torch.empty(4 * hidden_size))
+        self.bias_hh_l0 = nn.Parameter(torch.empty(4 * hidden_size))
+        stdv = 1.0 / math.sqrt(hidden_size)
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+
 @META_TEXT_EMBEDDING.register()
 class LSTMTextEmbedding(nn.Module):
-    """Embedding -> Linear -> dropout -> LSTM (text_embeddings.py:222-246).  It sits in front of the hot path:
-    the projection goes through the HIP GEMM, the recurrent part is torch's LSTM (MIOpen on ROCm) -- plumbing,
-    not a kernel of this package."""
+    """Embedding -> Linear -> dropout -> LSTM (text_embeddings.py:221-246), all on the HIP path: the token rows are
+    laid out TIME-major (row t*B + b) so that every product of the recurrence's backward pass -- dx, dW_ih, dW_hh -- is a
+    plain row-major GEMM over all time steps; the recurrence is one persistent launch each way (csrc/lstm.hip)."""
 
     def __init__(self, config, vocab):
         super().__init__()
@@ -67,18 +87,14 @@ class LSTMTextEmbedding(nn.Module):
             raise NotImplementedError("pretrained word vectors are a data-loading feature outside the hot path")
         self.proj = nn.Linear(config.D_EMBEDDING, config.D_MODEL)
         self.dropout = nn.Dropout(config.DROPOUT)
-        self.lstm = nn.LSTM(input_size=config.D_MODEL, hidden_size=config.D_MODEL, batch_first=True)
+        self.lstm = LSTM(config.D_MODEL, config.D_MODEL)
 
     def forward(self, tokens):
         padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
         sequential_masks = generate_sequential_mask(tokens.shape[-1], device=tokens.device)
         arena = rt.ensure_arena(self)
-        x = self.embedding(tokens).to(arena.compute_dtype)
-        x = self.dropout(Fn.linear(x, self.proj, arena)).float()
-        if not self.training and torch.is_grad_enabled() and x.is_cuda:
-            # MIOpen's fused RNN refuses backward in eval mode; the native kernels do not
-            with torch.backends.cudnn.flags(enabled=False):
-                x, _ = self.lstm(x)
-        else:
-            x, _ = self.lstm(x)
-        return x, (padding_masks, sequential_masks)
+        B, T = tokens.shape
+        x = self.embedding(tokens.t()).to(arena.compute_dtype)          # [T, B, E]: time-major rows
+        x = self.dropout(Fn.linear(x, self.proj, arena)).reshape(T * B, -1)
+        y = Fn.lstm(x, self.lstm, arena, B, T)                            # fp32 [B, T, D]
+        return y, (padding_masks, sequential_masks)

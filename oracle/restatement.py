@@ -27,7 +27,7 @@ __all__ = [
     "OracleEncoder", "OracleGuidedAttentionEncoder", "OracleCoAttentionEncoder",
     "OracleCrossModalityEncoder", "OracleDecoderLayer", "OracleDecoder",
     "OracleUsualEmbedding", "OracleOcrPtrNet", "OracleDynamicPointerNetwork",
-    "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "OracleMLP", "OracleMCAN",
+    "OracleFeatureEmbedding", "OracleLSTMTextEmbedding", "lstm_recurrence", "OracleMLP", "OracleMCAN",
     "OracleBertEncoder", "OraclePrevPredEmbeddings", "OracleMMT", "OracleM4CDecodingHead", "batch_gather",
     "noam_lambda", "oracle_train_step", "build_oracle_encoder", "oracle_beam_search", "oracle_generate",
 ]
@@ -752,9 +752,38 @@ class OracleFeatureEmbedding(nn.Module):
         return _r(self.dropout(self.gelu(_lin(self.proj, features)))), padding_mask(features, 0)
 
 
+def lstm_recurrence(x, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTM (one layer, batch_first, zero initial state: text_embeddings.py:236,243) restated step by step:
+    gates_t = x_t W_ih^T + b_ih + h_{t-1} W_hh^T + b_hh, chunks (i, f, g, o) along the features;
+    c_t = sigmoid(f) c_{t-1} + sigmoid(i) tanh(g);  h_t = sigmoid(o) tanh(c_t);  returns all h_t, (B, T, H).
+    Padded positions are ordinary steps (the reference does not pack the sequence).
+    emulate_bf16: weights, x and the recurrent operand h_{t-1} are bf16 (MFMA operands), accumulation / gates / cell
+    state fp32, the returned h_t fp32; the gradient w.r.t. the pre-activations is stored in bf16 (it is the operand of
+    the dx / dW products and of the recurrent product of the step before)."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    if _EMU["on"]:
+        w_ih = w_ih + (w_ih.bfloat16().float() - w_ih).detach()
+        w_hh = w_hh + (w_hh.bfloat16().float() - w_hh).detach()
+    xg = F.linear(_r(x), w_ih, b_ih)
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    ys = []
+    for t in range(T):
+        h_op = h + (h.bfloat16().float() - h).detach() if _EMU["on"] else h  # (its gradient dh stays fp32)
+        gates = _gr(xg[:, t] + F.linear(h_op, w_hh, b_hh))
+        i, f, g, o = gates.chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        ys.append(h)
+    return torch.stack(ys, dim=1)
+
+
 class OracleLSTMTextEmbedding(nn.Module):
     """Embedding -> Linear -> dropout -> LSTM, plus (padding, sequential) masks.
-    models/modules/text_embeddings.py:222-246 (WORD_EMBEDDING: null form)."""
+    models/modules/text_embeddings.py:222-246 (WORD_EMBEDDING: null form).  ``self.lstm`` only holds the parameters
+    under torch's names (``lstm.weight_ih_l0`` ...); the recurrence is ``lstm_recurrence`` above, pinned against the
+    reference class (which calls torch's own LSTM) by tests/golden/G17_lstm_text_embedding.npz."""
 
     def __init__(self, cfg, vocab):
         super().__init__()
@@ -767,8 +796,9 @@ class OracleLSTMTextEmbedding(nn.Module):
     def forward(self, tokens):
         pad = padding_mask(tokens, self.padding_idx)
         seq = sequential_mask(tokens.shape[-1])
-        x = self.dropout(_r(_lin(self.proj, self.embedding(tokens))))  # (HIP path: bf16 GEMM, bf16 output, fp32 LSTM)
-        x, _ = self.lstm(x)
+        x = self.dropout(_r(_lin(self.proj, self.embedding(tokens))))  # (HIP path: bf16 GEMM, bf16 output)
+        m = self.lstm
+        x = lstm_recurrence(x, m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
         return x, (pad, seq)
 
 

@@ -869,12 +869,33 @@ def g16():
     finish(c)
 
 
+# ---------------------------------------------------------------- G17 LSTM text embedding ("next" row 2)
+def g17():
+    """models/modules/text_embeddings.py:221-246 LSTMTextEmbedding (the reference class, unmodified): embedding -> proj ->
+    dropout (eval: off) -> torch LSTM over ALL positions, padded ones included; forward + every parameter gradient
+    (the embedding's padding row gets none); a second sequence length exercises a different number of steps."""
+    cfg = ConfigNode(dict(ARCHITECTURE="LSTMTextEmbedding", D_MODEL=D, D_EMBEDDING=12, DROPOUT=0.1,
+                          WORD_EMBEDDING=None, WORD_EMBEDDING_CACHE=None))
+    torch.manual_seed(1701)
+    m = R_txt.LSTMTextEmbedding(cfg, ModelVocab())
+    tokens = torch.tensor([[3, 4, 5, 6, 7, 8, 9, 0], [8, 9, 10, 3, 0, 0, 0, 0], [4, 4, 5, 0, 0, 0, 0, 0],
+                           [0, 0, 0, 0, 0, 0, 0, 0], [10, 9, 8, 7, 6, 5, 4, 3]])
+    c = Case("G17_lstm_text_embedding")
+    c.meta.update(cfg=json.loads(json.dumps(cfg, default=dict)), vocab_len=11, total_answers=7)
+
+    def call(mod, ins):
+        feats_, (pad, seq) = mod(ins["tokens"])
+        return {"features": feats_, "pad_mask": pad, "seq_mask": seq}
+    run_with_grads(c, m, {"tokens": tokens}, call, [])
+    finish(c)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", help="e.g. g12 (default: all)")
     todo = ap.parse_args().cases
-    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g8k=g8k, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16)
+    table = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g8k=g8k, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17)
     mpath = os.path.join(HERE, "manifest.json")
     if todo and os.path.exists(mpath):
         manifest.update(json.load(open(mpath))["cases"])

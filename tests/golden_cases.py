@@ -87,6 +87,7 @@ def oracle_namespace():
         CoAttentionEncoder=O.OracleCoAttentionEncoder, CrossModalityEncoder=O.OracleCrossModalityEncoder,
         DecoderLayer=O.OracleDecoderLayer, Decoder=O.OracleDecoder, OcrPtrNet=O.OracleOcrPtrNet,
         DynamicPointerNetwork=O.OracleDynamicPointerNetwork, MCAN=O.OracleMCAN,
+        LSTMTextEmbedding=O.OracleLSTMTextEmbedding,
         BertEncoder=O.OracleBertEncoder, MMT=O.OracleMMT)
 
 
@@ -101,6 +102,7 @@ def hip_namespace():
         GuidedAttentionEncoder=M.GuidedAttentionEncoder, CoAttentionEncoder=M.CoAttentionEncoder,
         CrossModalityEncoder=M.CrossModalityEncoder, DecoderLayer=M.DecoderLayer, Decoder=M.Decoder,
         OcrPtrNet=M.OcrPtrNet, DynamicPointerNetwork=M.DynamicPointerNetwork, MCAN=_hip_mcan(),
+        LSTMTextEmbedding=M.LSTMTextEmbedding,
         BertEncoder=M.BertEncoder, MMT=M.MMT)
 
 
@@ -191,6 +193,10 @@ CASES = {
     "G12_mcan_model": (lambda ns, c: ns.MCAN(_cfg(c), ModelVocab(c.meta["vocab_len"], c.meta["total_answers"])),
                        lambda m, i: {"logp": m(SimpleNamespace(region_features=i["regions"],
                                                                question_tokens=i["tokens"]))}, ["regions"]),
+    "G17_lstm_text_embedding": (lambda ns, c: ns.LSTMTextEmbedding(_cfg(c), ModelVocab(c.meta["vocab_len"],
+                                                                                        c.meta["total_answers"])),
+                                lambda m, i: (lambda r: {"features": r[0], "pad_mask": r[1][0], "seq_mask": r[1][1]})(
+                                    m(i["tokens"])), []),
     "G13_bert_encoder": (lambda ns, c: ns.BertEncoder(SimpleNamespace(**c.meta["cfg"])),
                          lambda m, i: {"out": m(i["x"], i["mask"], head_mask=[None] * 2)[0]}, ["x"]),
     "G13_mmt": (lambda ns, c: ns.MMT(SimpleNamespace(**c.meta["cfg"])), _call_mmt, ["txt", "obj", "ocr", "ans"]),

@@ -302,3 +302,42 @@ def gelu_bwd(dy, u, drop=None):
 def row_padding_mask(x, pad_value=0.0):
     B, N, D = x.shape
     return ((x.float().sum(-1) == pad_value * D).float() * -10e4).reshape(B, 1, 1, N)
+
+
+def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T):
+    H = w_hh.shape[1]
+    xg = (x_tb.float() @ w_ih.float().t() + b_ih).view(T, B, 4 * H)
+    h = torch.zeros(B, H)
+    c = torch.zeros(B, H)
+    hseq, gates, cs, ys = [h.to(x_tb.dtype)], [], [], []
+    for t in range(T):
+        g = xg[t] + hseq[-1].float() @ w_hh.float().t() + b_hh
+        i, f, gg, o = g.chunk(4, -1)
+        i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+        c = f * c + i * gg
+        h = o * torch.tanh(c)
+        gates.append(torch.cat([i, f, gg, o], -1))
+        cs.append(c)
+        ys.append(h)
+        hseq.append(h.to(x_tb.dtype))
+    saved = torch.cat([torch.stack(gates), torch.stack(cs)], -1)  # [T, B, 5H]
+    return torch.stack(ys, 1).contiguous(), torch.cat(hseq, 0), saved, None
+
+
+def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
+    H = w_hh.shape[1]
+    gates, cs = saved[..., :4 * H], saved[..., 4 * H:]
+    dg_next, carry, out = None, torch.zeros(B, H), [None] * T
+    for t in reversed(range(T)):
+        dh = dy[:, t].float()
+        if dg_next is not None:
+            dh = dh + dg_next.float() @ w_hh.float()
+        i, f, g, o = gates[t].chunk(4, -1)
+        cp = cs[t - 1] if t > 0 else torch.zeros(B, H)
+        tc = torch.tanh(cs[t])
+        dc = dh * o * (1 - tc * tc) + carry
+        carry = dc * f
+        dg_next = torch.cat([dc * g * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - g * g), dh * tc * o * (1 - o)],
+                            -1).to(w_hh.dtype)
+        out[t] = dg_next
+    return torch.cat(out, 0), None

@@ -1046,3 +1046,123 @@ def test_stream_helpers_of_the_c_abi():
         torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
         assert torch.equal(y, want)
+
+
+# ---------------------------------------------------------------- LSTM recurrence (ovqa_lstm_fwd / ovqa_lstm_bwd)
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / max(b.norm().item(), 1e-12)).item()
+
+
+def _lstm_ref64(x_tb, w_ih, w_hh, b_ih, b_hh, dy, B, T, round_ops):
+    """fp64 math of torch.nn.LSTM's recurrence on time-major rows; ``round_ops``: the recurrent operand h_{t-1} and the
+    gradient w.r.t. the pre-activations are rounded to bf16 where the bf16 kernels store them (x and the weights are
+    bf16 values already).  Returns y [B,T,H], dgates [T*B,4H] and the gradient w.r.t. x."""
+    x = x_tb.double().cpu().requires_grad_(True)
+    wi, wh = w_ih.double().cpu(), w_hh.double().cpu()
+    H = wh.shape[1]
+    xg = (x @ wi.t() + b_ih.double().cpu()).view(T, B, 4 * H)
+    h = torch.zeros(B, H, dtype=torch.float64)
+    c = torch.zeros(B, H, dtype=torch.float64)
+    ys, pre = [], []
+    for t in range(T):
+        hop = h + (h.float().bfloat16().double() - h).detach() if round_ops else h
+        g = xg[t] + hop @ wh.t() + b_hh.double().cpu()
+        g.retain_grad()
+        pre.append(g)
+        i, f, gg, o = g.chunk(4, -1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        ys.append(h)
+    y = torch.stack(ys, 1)
+    (y * dy.double().cpu()).sum().backward()
+    return y.detach(), torch.cat([p.grad for p in pre], 0), x.grad
+
+
+@pytest.mark.parametrize("B,T,H,dtype,route", [
+    (3, 5, 32, F32, "simple"), (5, 8, 24, F32, "simple"), (4, 6, 32, BF16, "simple"),
+    (16, 3, 512, BF16, "mfma"), (64, 20, 512, BF16, "mfma"), (32, 7, 512, BF16, "mfma"), (128, 4, 512, BF16, "mfma"),
+    (24, 4, 512, BF16, "simple"), (64, 20, 512, F32, "simple")])
+def test_lstm_fwd_bwd(B, T, H, dtype, route):
+    from openvivqa_amd import _lib
+    g = torch.Generator().manual_seed(1000 + B * 7 + T)
+    s = H ** -0.5
+    x = torch.randn(T * B, H, generator=g).to(DEV, dtype)
+    w_ih = (torch.rand(4 * H, H, generator=g) * 2 - 1).mul(s).to(DEV, dtype)
+    w_hh = (torch.rand(4 * H, H, generator=g) * 2 - 1).mul(s).to(DEV, dtype)
+    b_ih = (torch.rand(4 * H, generator=g) * 2 - 1).mul(s).to(DEV)
+    b_hh = (torch.rand(4 * H, generator=g) * 2 - 1).mul(s).to(DEV)
+    dy = torch.randn(B, T, H, generator=g).to(DEV)
+    o = ops()
+    y, hseq, saved, scratch = o.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, B, T)
+    if FORCED_SIMPLE:
+        route = "simple"
+    assert _lib.last_dispatch() == route
+    wt = w_hh.t().contiguous() if dtype == BF16 else None
+    dgates, scratch_b = o.lstm_bwd(dy, w_hh, wt, saved, B, T, H)
+    assert _lib.last_dispatch() == route
+    torch.cuda.synchronize()
+    if route == "mfma":  # no hand-off wait of the persistent launches gave up
+        assert int(scratch.view(torch.int32)[1000]) == 0 and int(scratch_b.view(torch.int32)[1000]) == 0
+    y64, dg64, _ = _lstm_ref64(x, w_ih, w_hh, b_ih, b_hh, dy, B, T, round_ops=dtype == BF16)
+    tol = 1e-5 if dtype == F32 else 2e-3  # bf16: a 1-ulp flip of a rounded h_{t-1} moves later steps
+    assert nerr(y, y64) < tol, nerr(y, y64)
+    assert nerr(hseq[B:].float().view(T, B, H).transpose(0, 1), y64) < (1e-5 if dtype == F32 else 8e-3)
+    assert float(hseq[:B].float().abs().max()) == 0.0
+    assert rel_l2(dgates.float(), dg64) < (1e-5 if dtype == F32 else 6e-3), rel_l2(dgates.float(), dg64)
+
+
+@pytest.mark.skipif(FORCED_SIMPLE, reason="compares the persistent route with the per-step one")
+def test_lstm_persistent_equals_per_step_kernels_and_fence_form(monkeypatch):
+    """The persistent launches against the one-launch-per-step kernels of the same library on the same bf16 operands
+    (same arithmetic up to summation order), run-to-run bitwise determinism, and the A/B switch that adds the agent-scope
+    acquire to every hand-off: the sc1-only hand-off must give the same bits (a stale read would not)."""
+    B, T, H = 64, 20, 512
+    g = torch.Generator().manual_seed(77)
+    s = H ** -0.5
+    x = torch.randn(T * B, H, generator=g).to(DEV, BF16)
+    w_ih = (torch.rand(4 * H, H, generator=g) * 2 - 1).mul(s).to(DEV, BF16)
+    w_hh = (torch.rand(4 * H, H, generator=g) * 2 - 1).mul(s).to(DEV, BF16)
+    b = [(torch.rand(4 * H, generator=g) * 2 - 1).mul(s).to(DEV) for _ in range(2)]
+    dy = torch.randn(B, T, H, generator=g).to(DEV)
+    wt = w_hh.t().contiguous()
+
+    om = ops()
+
+    def run():
+        y, hseq, saved, _ = om.lstm_fwd(x, w_ih, w_hh, b[0], b[1], B, T)
+        dg, _ = om.lstm_bwd(dy, w_hh, wt, saved, B, T, H)
+        return y, hseq, dg
+    # busy neighbours: a chip-filling GEMM stream beside the recurrence (uneven load is where a broken hand-off shows)
+    a = torch.randn(4096, 4096, device=DEV, dtype=BF16)
+    side = torch.cuda.Stream()
+    ref = run()
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                a @ a
+        got = run()
+        for r, o in zip(ref, got):
+            assert torch.equal(r, o), f"iteration {it}: the persistent LSTM is not deterministic"
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OVQA_LSTM_FENCE", "1")
+    fenced = run()
+    monkeypatch.delenv("OVQA_LSTM_FENCE")
+    for r, o in zip(ref, fenced):
+        assert torch.equal(r, o), "sc1-only hand-off differs from the fenced form"
+    try:
+        import subprocess, sys  # the switch is read once per process: ask a fresh one for the per-step result
+        code = ("import torch, json, sys; sys.path.insert(0, %r); from openvivqa_amd import ops\n"
+                "d = torch.load(sys.argv[1]); y, hs, sv, _ = ops.lstm_fwd(d['x'], d['w_ih'], d['w_hh'], d['b0'], d['b1'], 64, 20)\n"
+                "dg, _ = ops.lstm_bwd(d['dy'], d['w_hh'], None, sv, 64, 20, 512)\n"
+                "torch.save({'y': y, 'dg': dg}, sys.argv[2])" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            torch.save({"x": x, "w_ih": w_ih, "w_hh": w_hh, "b0": b[0], "b1": b[1], "dy": dy}, tmp + "/in.pt")
+            subprocess.run([sys.executable, "-c", code, tmp + "/in.pt", tmp + "/out.pt"], check=True,
+                           env=dict(os.environ, OVQA_FORCE_SIMPLE="1"))
+            out = torch.load(tmp + "/out.pt")
+    finally:
+        pass
+    assert nerr(ref[0], out["y"]) < 2e-3
+    assert rel_l2(ref[2].float(), out["dg"].float()) < 6e-3
