@@ -725,10 +725,14 @@ def main():
         toks[torch.arange(b.TOKENS)[None, :] >= ntok[:, None]] = 0
         ans = torch.randint(0, int(b.ANSWERS), (b.BATCH_PER_GPU,), generator=g).to(device)
         v, vm, t, tm = feats.to(device=device, dtype=dtype), toks.to(device), None, None
-        nll = torch.nn.NLLLoss()
+        from openvivqa_amd.losses import NLLLoss, nll_loss_fwd_bwd
+        nll = NLLLoss()  # (drop-in for the reference's nn.NLLLoss: classification_task.py:125-127)
 
         def forward_loss(feats_, toks_):  # noqa: F811
-            return nll(model(SimpleNamespace(region_features=feats_, question_tokens=toks_)), ans)
+            out = model(SimpleNamespace(region_features=feats_, question_tokens=toks_))
+            if args.workload == "model":  # MCAN returns log-probabilities: loss and its gradient from ONE launch
+                return [out], [nll_loss_fwd_bwd(out, ans, loss_buf)]
+            return nll(out, ans)  # (CrossModalityTransformer feeds raw logits to NLLLoss, as upstream)
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,

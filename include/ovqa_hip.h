@@ -538,6 +538,61 @@ int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const
 int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt, const void* saved,
                   void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * The two ends of the model around the encoder stacks (ABI 8; "next" rows 2 and 4): csrc/model_ends.hip
+ *
+ * Token embedding rows.   replaces: self.embedding(tokens) / self.components(tokens) (nn.Embedding lookups)
+ *                          models/modules/text_embeddings.py:71-80,240 and their autograd (embedding_dense_backward)
+ *   ovqa_embed_gather: out[r][0..width) = table[tokens[b][t]][0..width) for r = t*B + b (time_major) or b*T + t; tokens int64
+ *     [B, T]; table [vocab, >= width] of `dtype` (row stride ld_table).  `width` may include the zero padding of a table
+ *     whose rows are padded to 16 bytes.  Rows 16-byte aligned.  `mask` (may be NULL): fp32 [B, T] = the additive padding
+ *     mask of the token ids, (tokens == padding_idx) * -10e4 (generate_padding_mask, models/utils.py:44-58), from the
+ *     same pass.
+ *   ovqa_embed_scatter: dtable[v][0..width) (=|+=) sum of drows[r][0..width) over the rows r with token v, in increasing r (a
+ *     fixed order; no atomics), for EVERY v < rows_table: rows no token names are stored as zeros (no memset needed), row
+ *     padding_idx gets zeros (nn.Embedding's padding_idx).  dtable fp32.
+ * ovqa_dropout_apply: y[i] = x[i] * keep(i) / (1 - p), flat index i -- forward and backward of an nn.Dropout call site whose
+ *   producer has no fused epilogue (text_embeddings.py:241).
+ *
+ * Attention pooling of MCAN / CrossModalityTransformer.   replaces: models/mcan.py:12-25 (MLP: fc2(dropout(relu(fc1 x)))),
+ *     :70-76 (softmax over dim=1, weighted sum), cross_modality_transformer.py:51-73
+ *   ovqa_pool_fwd: hpre [B*N, D] = fc1(feat) (the GEMM's output, bias inside) of `dtype`; feat [B, N, D] of `feat_dtype`;
+ *     w2 fp32 [D], b2 fp32 [1] (may be NULL) = fc2; dropout call site `drop` on relu(hpre), flat index into [B*N, D]
+ *     -> att fp32 [B, N] (the softmax weights, padded positions included as upstream), pooled [B, D] of `dtype`
+ *        (and pooled32 fp32 [B, D] if not NULL).
+ *   ovqa_pool_bwd: dpooled [B, D] of `dtype` -> dh [B*N, D] (gradient w.r.t. fc1's output), dfeat [B*N, D] (= att * dpooled, the
+ *     direct gradient of the features: the addend of fc1's dX product), dw2_part fp32 [B, 2*D] (per-sample partial of fc2's
+ *     weight gradient in columns 0..D, zeros after: rows for ovqa_grouped_partial_reduce), db2 fp32 [1] (=|+=, may be NULL;
+ *     the last workgroup to arrive adds the per-sample partials in index order).  `scratch` fp32 [8 + B], private to the
+ *     call; its ticket word is zeroed by the call (a memset node).
+ *
+ * log_softmax + NLLLoss.   replaces: F.log_softmax(output, dim=-1) mcan.py:81; nn.NLLLoss(ignore_index)
+ *                           tasks/classification_task.py:125-127 (and open_ended_task.py:155-157)
+ *   ovqa_log_softmax_fwd: x [M, ld] of `dtype`, the first n columns of every row -> out fp32 [M, n].
+ *   ovqa_log_softmax_bwd: g, logp fp32 [M, n] -> dx [M, ld] of `dtype`: g - exp(logp) * rowsum(g); columns n..ld-1 are
+ *     written as zeros (the padded columns of a ragged classifier).
+ *   ovqa_nll_loss: logp fp32 [M, n], target int64 [M] -> *loss (=|+=) -sum_{target != ignore_index} logp[r][target[r]] / count
+ *     (mean reduction; may be NULL) and, if dlogp != NULL, the dense gradient fp32 [M, n] (-(*gscale or 1) / count at the
+ *     targets).  One workgroup, fixed summation order.
+ * ------------------------------------------------------------------------- */
+int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
+                      int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
+                      void* stream);
+int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
+                       int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
+                       int accumulate, void* stream);
+int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_dropout* drop, void* stream);
+int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
+                  void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const ovqa_dropout* drop, void* stream);
+int ovqa_pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
+                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B,
+                  int64_t N, int64_t D, int accumulate_db2, const ovqa_dropout* drop, void* stream);
+int ovqa_log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, void* stream);
+int ovqa_log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n,
+                         void* stream);
+int ovqa_nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M,
+                  int64_t n, int64_t ignore_index, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

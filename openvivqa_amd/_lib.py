@@ -127,6 +127,15 @@ SIGNATURES = {
     "ovqa_dropout_keep_mask": [_DP, c_vp, c_i64, c_vp],
     "ovqa_grouped_row_gather": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "ovqa_embed_gather": [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "ovqa_embed_scatter": [c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
+    "ovqa_dropout_apply": [c_int, c_vp, c_vp, c_i64, _DP, c_vp],
+    "ovqa_pool_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, _DP, c_vp],
+    "ovqa_pool_bwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
+                      _DP, c_vp],
+    "ovqa_log_softmax_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp],
+    "ovqa_log_softmax_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp],
+    "ovqa_nll_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp],
     "ovqa_lstm_saved_bytes": [c_i64, c_i64, c_i64],
     "ovqa_lstm_scratch_bytes": [c_i64, c_i64, c_i64],
     "ovqa_lstm_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],

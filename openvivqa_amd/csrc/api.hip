@@ -729,4 +729,84 @@ int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh
   return ovqa::lstm_bwd(dtype, persistent, dy, w_hh, w_hh_t, ldwt, saved, dgates, scratch, B, T, H, as_stream(stream));
 }
 
+int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
+                      int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
+                      void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "embed_gather: bad dtype");
+  OVQA_REQUIRE(tokens && table && out, OVQA_ERR_BAD_ARG, "embed_gather: null pointer");
+  OVQA_REQUIRE(B >= 1 && T >= 1 && vocab >= 1 && width >= 1 && ld_table >= width && ld_out >= width && B * T < (1ll << 31),
+               OVQA_ERR_BAD_ARG, "embed_gather: bad size");
+  g_dispatch = "stream";
+  return ovqa::embed_gather(dtype, tokens, table, ld_table, vocab, out, ld_out, B, T, width, time_major, mask, padding_idx,
+                            as_stream(stream));
+}
+
+int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
+                       int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
+                       int accumulate, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "embed_scatter: bad dtype");
+  OVQA_REQUIRE(tokens && drows && dtable, OVQA_ERR_BAD_ARG, "embed_scatter: null pointer");
+  OVQA_REQUIRE(B >= 1 && T >= 1 && rows_table >= 1 && width >= 1 && ld_table >= width && ld_rows >= width &&
+                   B * T < (1ll << 31) && rows_table < (1ll << 31),
+               OVQA_ERR_BAD_ARG, "embed_scatter: bad size");
+  g_dispatch = "stream";
+  return ovqa::embed_scatter(dtype, tokens, drows, ld_rows, dtable, ld_table, rows_table, B, T, width, time_major,
+                             padding_idx, accumulate, as_stream(stream));
+}
+
+int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "dropout_apply: bad dtype");
+  OVQA_REQUIRE(x && y && n >= 0 && n < (1ll << 32), OVQA_ERR_BAD_ARG, "dropout_apply: bad argument");
+  if (n == 0) return OVQA_OK;
+  g_dispatch = "stream";
+  return ovqa::dropout_apply(dtype, x, y, n, make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
+                  void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(feat_dtype), OVQA_ERR_BAD_ARG, "pool_fwd: bad dtype");
+  OVQA_REQUIRE(feat && hpre && w2 && att && pooled && B >= 1 && B * N * D < (1ll << 32), OVQA_ERR_BAD_ARG,
+               "pool_fwd: bad argument");
+  g_dispatch = "stream";
+  return ovqa::pool_fwd(feat_dtype, dtype, feat, hpre, w2, b2, att, pooled, pooled32, B, N, D, make_drop_args(drop),
+                        as_stream(stream));
+}
+
+int ovqa_pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
+                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B,
+                  int64_t N, int64_t D, int accumulate_db2, const ovqa_dropout* drop, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(feat_dtype), OVQA_ERR_BAD_ARG, "pool_bwd: bad dtype");
+  OVQA_REQUIRE(feat && hpre && w2 && att && dpooled && dh && dfeat && dw2_part && scratch && B >= 1 &&
+                   B * N * D < (1ll << 32),
+               OVQA_ERR_BAD_ARG, "pool_bwd: bad argument");
+  g_dispatch = "stream";
+  return ovqa::pool_bwd(feat_dtype, dtype, feat, hpre, w2, att, dpooled, dh, dfeat, dw2_part, db2, scratch, B, N, D,
+                        accumulate_db2, make_drop_args(drop), as_stream(stream));
+}
+
+int ovqa_log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && x && out && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
+               "log_softmax_fwd: bad argument");
+  if (M == 0) return OVQA_OK;
+  g_dispatch = "stream";
+  return ovqa::log_softmax_fwd(dtype, x, ld, out, M, n, as_stream(stream));
+}
+
+int ovqa_log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n,
+                         void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && g && logp && dx && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
+               "log_softmax_bwd: bad argument");
+  if (M == 0) return OVQA_OK;
+  g_dispatch = "stream";
+  return ovqa::log_softmax_bwd(dtype, g, logp, dx, ld, M, n, as_stream(stream));
+}
+
+int ovqa_nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M,
+                  int64_t n, int64_t ignore_index, int accumulate, void* stream) {
+  OVQA_REQUIRE(logp && target && (loss || dlogp) && M >= 1 && n >= 1 && M * n < (1ll << 31), OVQA_ERR_BAD_ARG,
+               "nll_loss: bad argument");
+  g_dispatch = "stream";
+  return ovqa::nll_loss(logp, target, loss, dlogp, gscale, M, n, ignore_index, accumulate, as_stream(stream));
+}
+
 }  // extern "C"

@@ -152,6 +152,24 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
 int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt,
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st);
 
+// ---- model_ends.hip: embedding rows, dropout, attention pooling, log_softmax + NLL ---------------------------------------
+int embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
+                 int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
+                 hipStream_t st);
+int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
+                  int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
+                  int accumulate, hipStream_t st);
+int dropout_apply(int dtype, const void* x, void* y, int64_t n, const DropArgs& da, hipStream_t st);
+int pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
+             void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const DropArgs& da, hipStream_t st);
+int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
+             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B, int64_t N,
+             int64_t D, int accumulate_db2, const DropArgs& da, hipStream_t st);
+int log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, hipStream_t st);
+int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n, hipStream_t st);
+int nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M, int64_t n,
+             int64_t ignore_index, int accumulate, hipStream_t st);
+
 // ---- gather.hip -----------------------------------------------------------------
 int grouped_row_gather(const ovqa_gather_problem* probs, int n_problems, const int32_t* sel, int b_s, int cur, int beam,
                        hipStream_t st);

@@ -1,0 +1,511 @@
+// The two ends of the model around the encoder stacks: token-embedding gather / scatter,
+// elementwise dropout, the attention-pooling head of MCAN / CrossModalityTransformer (models/mcan.py:12-25,70-76) and
+// log_softmax + NLLLoss (mcan.py:81, tasks/classification_task.py:125-127).  Small, HBM / latency-bound kernels: each
+// replaces a chain of 3-8 stock elementwise / reduction launches (and their autograd twins) by one launch.
+#include "common.h"
+#include "kernels.h"
+
+namespace ovqa {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- embedding rows ----------------------------------------------------------------------------------------------------
+// out[r][0 .. width) = table[tokens(r)][0 .. width), r = t * B + b (time-major) or b * T + t; `width` includes the zero
+// padding of a ragged table (runtime._footprint), so the rows come out 16-byte aligned and zero-padded.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ table,
+                                                           int64_t ld_table, int64_t vocab, T* __restrict__ out,
+                                                           int64_t ld_out, int B, int Tn, int width, int time_major,
+                                                           float* __restrict__ mask, int64_t padding_idx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (r >= B * Tn) return;
+  const int b = time_major ? r % B : r / Tn, t = time_major ? r / B : r % Tn;
+  int64_t tok = tokens[(int64_t)b * Tn + t];
+  // generate_padding_mask on token ids (models/utils.py:44-58): (tok == pad) * -10e4, i.e. -1e5 or -0.0, fp32 [B,1,1,T]
+  if (mask != nullptr && l == 0) mask[(int64_t)b * Tn + t] = tok == padding_idx ? -100000.f : -0.f;
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // (torch raises on an out-of-range index; never read outside)
+  constexpr int V = 16 / (int)sizeof(T);
+  const T* src = table + tok * ld_table;
+  T* dst = out + (int64_t)r * ld_out;
+  for (int c = l * V; c < width; c += 64 * V) *reinterpret_cast<u32x4*>(dst + c) = *reinterpret_cast<const u32x4*>(src + c);
+}
+
+// dtable[v][0 .. width) (=|+=) sum over the rows r with tokens(r) == v of drows[r][0 .. width), in increasing r: a fixed
+// order, no atomics (torch's embedding_dense_backward adds atomically).  One wave per table row INCLUDING the rows no token
+// names: they are stored as zeros, so the gradient buffer needs no memset; row `padding_idx` gets none (nn.Embedding).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ drows,
+                                                            int64_t ld_rows, float* __restrict__ dtable, int64_t ld_table,
+                                                            int64_t rows_table, int B, int Tn, int width, int time_major,
+                                                            int64_t padding_idx, int accumulate) {
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (v >= rows_table) return;
+  constexpr int MAXC = 16;  // columns per lane: width <= 1024
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; j++) acc[j] = 0.f;
+  const int R = B * Tn;
+  if (v != padding_idx) {
+    for (int r0 = 0; r0 < R; r0 += 64) {
+      const int r = r0 + l;
+      bool hit = false;
+      if (r < R) {
+        const int b = time_major ? r % B : r / Tn, t = time_major ? r / B : r % Tn;
+        hit = tokens[(int64_t)b * Tn + t] == v;
+      }
+      uint64_t m = __ballot(hit);
+      while (m) {
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const T* src = drows + (int64_t)(r0 + k) * ld_rows;
+#pragma unroll
+        for (int j = 0; j < MAXC; j++) {
+          const int c = l + 64 * j;
+          if (c < width) acc[j] += to_f32<T>(src[c]);
+        }
+      }
+    }
+  }
+  float* dst = dtable + v * ld_table;
+#pragma unroll
+  for (int j = 0; j < MAXC; j++) {
+    const int c = l + 64 * j;
+    if (c < width) dst[c] = accumulate ? dst[c] + acc[j] : acc[j];
+  }
+}
+
+// y[i] = x[i] * keep(i) / (1 - p), flat element index i (forward and backward of an nn.Dropout call site)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n,
+                                                            DropArgs da) {
+  const DropState ds = drop_init(da);
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * V < n; i += stride) {
+    if (i * V + V <= n) {
+      alignas(16) T xv[V], yv[V];
+      *reinterpret_cast<u32x4*>(xv) = *reinterpret_cast<const u32x4*>(x + i * V);
+#pragma unroll
+      for (int e = 0; e < V; e++) yv[e] = from_f32<T>(to_f32<T>(xv[e]) * drop_mul(ds, (uint32_t)(i * V + e)));
+      *reinterpret_cast<u32x4*>(y + i * V) = *reinterpret_cast<const u32x4*>(yv);
+    } else {
+      for (int64_t e = i * V; e < n; e++) y[e] = from_f32<T>(to_f32<T>(x[e]) * drop_mul(ds, (uint32_t)e));
+    }
+  }
+}
+
+// ---- attention pooling (mcan.py:12-25, 70-76) --------------------------------------------------------------------------
+//   logit[b,n] = fc2 . dropout(relu(hpre[b,n,:])) + b2     (hpre = fc1(feat) from the GEMM, bias inside)
+//   att[b,:]   = softmax over the N positions of sample b (padded positions included, as the reference)
+//   pooled[b,:] = sum_n att[b,n] feat[b,n,:]
+// One workgroup (8 waves) per sample; a wave per row for the two row passes, partial pooled sums meet in LDS.
+constexpr int POOL_WAVES = 8;
+constexpr int POOL_MAXN = 1024;  // positions per sample the LDS arrays cover
+constexpr int POOL_MAXD = 1024;
+
+template <typename F>
+__device__ __forceinline__ void load8(const F* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int t = 0; t < 8; t++) v[t] = (float)a[t];
+}
+template <typename F>
+__device__ __forceinline__ void store8t(F* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8t<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8t<bf16>(bf16* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int t = 0; t < 8; t++) o[t] = (bf16)v[t];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+template <typename F, typename T>
+__global__ __launch_bounds__(POOL_WAVES * 64) void pool_fwd_kernel(const F* __restrict__ feat, const T* __restrict__ hpre,
+                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                  float* __restrict__ att, T* __restrict__ pooled,
+                                                                  float* __restrict__ pooled32, int N, int D, DropArgs da) {
+  __shared__ float s_logit[POOL_MAXN];
+  __shared__ float s_part[POOL_WAVES][POOL_MAXD];
+  __shared__ float s_red[POOL_WAVES];
+  const int b = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const DropState ds = drop_init(da);
+  const float bias2 = b2 ? b2[0] : 0.f;
+  // pass 1: logits
+  for (int n = w; n < N; n += POOL_WAVES) {
+    const int64_t row = (int64_t)b * N + n;
+    float s = 0.f;
+    for (int c = l * 8; c < D; c += 512) {
+      float h[8], wv[8], dm[8];
+      load8<T>(hpre + row * D + c, h);
+      load8<float>(w2 + c, wv);
+      drop_mul8(ds, (uint32_t)(row * D + c), dm);
+#pragma unroll
+      for (int t = 0; t < 8; t++) s = fmaf(fmaxf(h[t], 0.f) * dm[t], wv[t], s);
+    }
+    s = wave_sum(s);
+    if (l == 0) s_logit[n] = s + bias2;
+  }
+  __syncthreads();
+  // softmax over the N logits (fixed order: every thread walks its stripe, waves meet in LDS)
+  float mx = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) mx = fmaxf(mx, s_logit[n]);
+  mx = wave_max(mx);
+  if (l == 0) s_red[w] = mx;
+  __syncthreads();
+  mx = s_red[0];
+#pragma unroll
+  for (int i = 1; i < POOL_WAVES; i++) mx = fmaxf(mx, s_red[i]);
+  __syncthreads();
+  float sm = 0.f;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) {
+    const float e = __expf(s_logit[n] - mx);
+    s_logit[n] = e;
+    sm += e;
+  }
+  sm = wave_sum(sm);
+  if (l == 0) s_red[w] = sm;
+  __syncthreads();
+  sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < POOL_WAVES; i++) sm += s_red[i];
+  const float inv = 1.f / sm;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) {
+    const float a = s_logit[n] * inv;
+    s_logit[n] = a;
+    att[(int64_t)b * N + n] = a;
+  }
+  __syncthreads();
+  // pass 2: pooled = sum_n att[n] feat[n]: wave w takes rows w, w + 8, ...; lane l owns columns l*8 + 512*j
+  for (int c0 = 0; c0 < D; c0 += 512) {
+    const int c = c0 + l * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      for (int n = w; n < N; n += POOL_WAVES) {
+        float f[8];
+        load8<F>(feat + ((int64_t)b * N + n) * D + c, f);
+        const float a = s_logit[n];
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[t] = fmaf(a, f[t], acc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; t++) s_part[w][c + t] = acc[t];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += POOL_WAVES * 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < POOL_WAVES; i++) s += s_part[i][c];
+    pooled[(int64_t)b * D + c] = from_f32<T>(s);
+    if (pooled32) pooled32[(int64_t)b * D + c] = s;
+  }
+}
+
+// Backward of the pooling of one sample, given dpooled[b,:] (fp32):
+//   dfeat_direct[b,n,:] = att[b,n] dpooled[b,:]                    (the addend of fc1's dX product)
+//   datt[n] = feat[b,n,:] . dpooled[b,:];  dlogit[n] = att[n] (datt[n] - sum_m att[m] datt[m])
+//   dh[b,n,:] = dlogit[n] w2[:] relu'(hpre) keep/(1-p)              (gradient w.r.t. fc1's output)
+//   dw2 partial[b][:] = sum_n dlogit[n] dropout(relu(hpre[b,n,:]))   ([B][2*D] rows: the deferred grouped reduce sums them)
+//   db2 partial[b] = sum_n dlogit[n]  (analytically 0: softmax shift invariance); the LAST workgroup to arrive adds the B
+//   partials in index order and stores db2 -- deterministic, the ticket lives in the caller's scratch (zeroed by the call).
+template <typename F, typename T>
+__global__ __launch_bounds__(POOL_WAVES * 64) void pool_bwd_kernel(const F* __restrict__ feat, const T* __restrict__ hpre,
+                                                                  const float* __restrict__ w2, const float* __restrict__ att,
+                                                                  const T* __restrict__ dpooled, T* __restrict__ dh,
+                                                                  T* __restrict__ dfeat, float* __restrict__ dw2_part,
+                                                                  float* __restrict__ db2, float* __restrict__ scratch, int B,
+                                                                  int N, int D, int accumulate_db2, DropArgs da) {
+  __shared__ float s_a[POOL_MAXN];   // att, then dlogit
+  __shared__ float s_d[POOL_MAXN];   // datt
+  __shared__ float s_part[POOL_WAVES][POOL_MAXD];
+  __shared__ float s_red[POOL_WAVES];
+  __shared__ bool s_last;
+  const int b = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const DropState ds = drop_init(da);
+  const T* dp = dpooled + (int64_t)b * D;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) s_a[n] = att[(int64_t)b * N + n];
+  __syncthreads();
+  // pass 1: datt[n] and the direct gradient of the features
+  for (int n = w; n < N; n += POOL_WAVES) {
+    const int64_t row = (int64_t)b * N + n;
+    const float a = s_a[n];
+    float s = 0.f;
+    for (int c = l * 8; c < D; c += 512) {
+      float f[8], g[8], o[8];
+      load8<F>(feat + row * D + c, f);
+      load8<T>(dp + c, g);
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        s = fmaf(f[t], g[t], s);
+        o[t] = a * g[t];
+      }
+      store8t<T>(dfeat + row * D + c, o);
+    }
+    s = wave_sum(s);
+    if (l == 0) s_d[n] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) dot += s_a[n] * s_d[n];
+  dot = wave_sum(dot);
+  if (l == 0) s_red[w] = dot;
+  __syncthreads();
+  dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < POOL_WAVES; i++) dot += s_red[i];
+  __syncthreads();
+  float sdl = 0.f;
+  for (int n = threadIdx.x; n < N; n += POOL_WAVES * 64) {
+    const float dl = s_a[n] * (s_d[n] - dot);
+    s_a[n] = dl;
+    sdl += dl;
+  }
+  sdl = wave_sum(sdl);
+  if (l == 0) s_red[w] = sdl;
+  __syncthreads();
+  // pass 2: dh rows and this sample's dw2 partial
+  for (int c0 = 0; c0 < D; c0 += 512) {
+    const int c = c0 + l * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      float wv[8];
+      load8<float>(w2 + c, wv);
+      for (int n = w; n < N; n += POOL_WAVES) {
+        const int64_t row = (int64_t)b * N + n;
+        float h[8], dm[8], o[8];
+        load8<T>(hpre + row * D + c, h);
+        drop_mul8(ds, (uint32_t)(row * D + c), dm);
+        const float dl = s_a[n];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          const float act = fmaxf(h[t], 0.f) * dm[t];
+          acc[t] = fmaf(dl, act, acc[t]);
+          o[t] = h[t] > 0.f ? dl * wv[t] * dm[t] : 0.f;
+        }
+        store8t<T>(dh + row * D + c, o);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; t++) s_part[w][c + t] = acc[t];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += POOL_WAVES * 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < POOL_WAVES; i++) s += s_part[i][c];
+    dw2_part[(int64_t)b * 2 * D + c] = s;
+    dw2_part[(int64_t)b * 2 * D + D + c] = 0.f;  // (second half of the reduce row: unused)
+  }
+  // db2: per-sample partial through device-scope atomics, the last arriver sums them in index order
+  if (threadIdx.x == 0) {
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < POOL_WAVES; i++) mine += s_red[i];
+    const float before = atomicExch(&scratch[8 + b], mine);
+    unsigned one = 1u;
+    asm volatile("; the ticket waits for the returned value of the exchange" : "+v"(one) : "v"(before));
+    s_last = atomicAdd(reinterpret_cast<unsigned*>(scratch), one) == (unsigned)(B - 1);
+  }
+  __syncthreads();
+  if (!s_last || db2 == nullptr) return;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < B; i++) t += atomicAdd(&scratch[8 + i], 0.f);
+    db2[0] = accumulate_db2 ? db2[0] + t : t;
+  }
+}
+
+// ---- log_softmax over the first n columns of every row ([M, ld] input) -> fp32 [M, n]; one wave per row -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
+                                                              int M, int n) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (r >= M) return;
+  const T* p = x + (int64_t)r * ld;
+  float mx = -INFINITY;
+  for (int c = l; c < n; c += 64) mx = fmaxf(mx, to_f32<T>(p[c]));
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = l; c < n; c += 64) s += __expf(to_f32<T>(p[c]) - mx);
+  s = wave_sum(s);
+  const float lse = mx + __logf(s);
+  for (int c = l; c < n; c += 64) out[(int64_t)r * n + c] = to_f32<T>(p[c]) - lse;
+}
+
+// dlogits[r][c] = g[r][c] - exp(logp[r][c]) sum_c g[r][c] for c < n, 0 for n <= c < ld (the padded columns of a ragged
+// classifier); g, logp fp32 [M, n]
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ logp,
+                                                              T* __restrict__ dx, int64_t ld, int M, int n) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (r >= M) return;
+  const float* gp = g + (int64_t)r * n;
+  const float* lp = logp + (int64_t)r * n;
+  float s = 0.f;
+  for (int c = l; c < n; c += 64) s += gp[c];
+  s = wave_sum(s);
+  T* d = dx + (int64_t)r * ld;
+  for (int c = l; c < (int)ld; c += 64) d[c] = from_f32<T>(c < n ? gp[c] - __expf(lp[c]) * s : 0.f);
+}
+
+// NLLLoss(reduction = mean, ignore_index) on log-probabilities fp32 [M, n]: loss = -sum_{t_r != ignore} logp[r][t_r] / cnt
+// and (optionally) its gradient dlogp (dense, -scale / cnt at the targets).  ONE workgroup: fixed summation order.
+__global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
+                                                        float* __restrict__ loss, float* __restrict__ dlogp,
+                                                        const float* __restrict__ gscale, int M, int n, int64_t ignore_index,
+                                                        int accumulate) {
+  __shared__ float s_sum[16];
+  __shared__ float s_cnt[16];
+  float s = 0.f, cnt = 0.f;
+  for (int r = threadIdx.x; r < M; r += 1024) {
+    const int64_t t = target[r];
+    if (t != ignore_index && t >= 0 && t < n) {
+      s -= logp[(int64_t)r * n + t];
+      cnt += 1.f;
+    }
+  }
+  s = wave_sum(s);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = s; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  float ts = 0.f, tc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { ts += s_sum[i]; tc += s_cnt[i]; }
+  const float inv = tc > 0.f ? 1.f / tc : 0.f;  // (torch returns nan for an all-ignored batch; the gradient is 0 either way)
+  if (threadIdx.x == 0 && loss) {
+    const float v = tc > 0.f ? ts * inv : __int_as_float(0x7fc00000);
+    *loss = accumulate ? *loss + v : v;
+  }
+  if (dlogp == nullptr) return;
+  const float sc = (gscale ? gscale[0] : 1.f) * inv;
+  for (int64_t i = threadIdx.x; i < (int64_t)M * n; i += 1024) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    const int64_t t = target[r];
+    dlogp[i] = (t == c && t != ignore_index) ? -sc : 0.f;
+  }
+}
+
+}  // namespace
+
+int embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
+                 int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
+                 hipStream_t st) {
+  const int es = dtype == OVQA_BF16 ? 2 : 4;
+  OVQA_REQUIRE(width * es % 16 == 0 && ld_table * es % 16 == 0 && ld_out * es % 16 == 0 && (uintptr_t)table % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0,
+               OVQA_ERR_BAD_ARG, "embed_gather: rows must be 16-byte aligned and a multiple of 16 bytes wide");
+  const unsigned grid = (unsigned)((B * T + 3) / 4);
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(embed_gather_kernel<bf16>, dim3(grid), dim3(256), 0, st, tokens, (const bf16*)table, ld_table, vocab,
+                       (bf16*)out, ld_out, (int)B, (int)T, (int)width, time_major, mask, padding_idx);
+  else
+    hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(grid), dim3(256), 0, st, tokens, (const float*)table, ld_table, vocab,
+                       (float*)out, ld_out, (int)B, (int)T, (int)width, time_major, mask, padding_idx);
+  return ovqa_check_launch("embed_gather");
+}
+
+int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
+                  int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
+                  int accumulate, hipStream_t st) {
+  OVQA_REQUIRE(width <= 1024, OVQA_ERR_UNSUPPORTED, "embed_scatter: rows wider than 1024 elements");
+  const unsigned grid = (unsigned)((rows_table + 3) / 4);
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(embed_scatter_kernel<bf16>, dim3(grid), dim3(256), 0, st, tokens, (const bf16*)drows, ld_rows, dtable,
+                       ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);
+  else
+    hipLaunchKernelGGL(embed_scatter_kernel<float>, dim3(grid), dim3(256), 0, st, tokens, (const float*)drows, ld_rows,
+                       dtable, ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);
+  return ovqa_check_launch("embed_scatter");
+}
+
+int dropout_apply(int dtype, const void* x, void* y, int64_t n, const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, OVQA_ERR_BAD_ARG, "dropout_apply: 16-byte alignment");
+  const int V = dtype == OVQA_BF16 ? 8 : 4;
+  int64_t blocks = ((n + V - 1) / V + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(dropout_apply_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, da);
+  else
+    hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, n,
+                       da);
+  return ovqa_check_launch("dropout_apply");
+}
+
+static bool pool_shape_ok(int64_t N, int64_t D) { return N >= 1 && N <= POOL_MAXN && D >= 8 && D <= POOL_MAXD && D % 8 == 0; }
+
+int pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
+             void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(pool_shape_ok(N, D), OVQA_ERR_UNSUPPORTED, "pool_fwd: N <= 1024, D <= 1024 and D %% 8 == 0 required");
+  OVQA_REQUIRE((uintptr_t)feat % 16 == 0 && (uintptr_t)hpre % 16 == 0 && (uintptr_t)w2 % 16 == 0, OVQA_ERR_BAD_ARG,
+               "pool_fwd: 16-byte alignment");
+  const dim3 grid((unsigned)B), block(POOL_WAVES * 64);
+#define OVQA_POOL_FWD(F, T)                                                                                             \
+  hipLaunchKernelGGL((pool_fwd_kernel<F, T>), grid, block, 0, st, (const F*)feat, (const T*)hpre, w2, b2, att, (T*)pooled, \
+                     pooled32, (int)N, (int)D, da)
+  if (dtype == OVQA_BF16 && feat_dtype == OVQA_BF16) OVQA_POOL_FWD(bf16, bf16);
+  else if (dtype == OVQA_BF16) OVQA_POOL_FWD(float, bf16);
+  else if (feat_dtype == OVQA_F32) OVQA_POOL_FWD(float, float);
+  else { ovqa_set_error("pool_fwd: bf16 features with fp32 hidden activations"); return OVQA_ERR_UNSUPPORTED; }
+#undef OVQA_POOL_FWD
+  return ovqa_check_launch("pool_fwd");
+}
+
+int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
+             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B, int64_t N,
+             int64_t D, int accumulate_db2, const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(pool_shape_ok(N, D) && B <= 4096, OVQA_ERR_UNSUPPORTED, "pool_bwd: N <= 1024, D <= 1024, D %% 8 == 0, B <= 4096");
+  hipError_t e = hipMemsetAsync(scratch, 0, 32, st);  // the arrival ticket (the partials are overwritten before they are read)
+  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "pool_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+  const dim3 grid((unsigned)B), block(POOL_WAVES * 64);
+#define OVQA_POOL_BWD(F, T)                                                                                              \
+  hipLaunchKernelGGL((pool_bwd_kernel<F, T>), grid, block, 0, st, (const F*)feat, (const T*)hpre, w2, att, (const T*)dpooled, (T*)dh, \
+                     (T*)dfeat, dw2_part, db2, scratch, (int)B, (int)N, (int)D, accumulate_db2, da)
+  if (dtype == OVQA_BF16 && feat_dtype == OVQA_BF16) OVQA_POOL_BWD(bf16, bf16);
+  else if (dtype == OVQA_BF16) OVQA_POOL_BWD(float, bf16);
+  else if (feat_dtype == OVQA_F32) OVQA_POOL_BWD(float, float);
+  else { ovqa_set_error("pool_bwd: bf16 features with fp32 hidden activations"); return OVQA_ERR_UNSUPPORTED; }
+#undef OVQA_POOL_BWD
+  return ovqa_check_launch("pool_bwd");
+}
+
+int log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, hipStream_t st) {
+  const unsigned grid = (unsigned)((M + 3) / 4);
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(log_softmax_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, ld, out, (int)M, (int)n);
+  else
+    hipLaunchKernelGGL(log_softmax_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, ld, out, (int)M, (int)n);
+  return ovqa_check_launch("log_softmax_fwd");
+}
+
+int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n, hipStream_t st) {
+  const unsigned grid = (unsigned)((M + 3) / 4);
+  if (dtype == OVQA_BF16)
+    hipLaunchKernelGGL(log_softmax_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, g, logp, (bf16*)dx, ld, (int)M, (int)n);
+  else
+    hipLaunchKernelGGL(log_softmax_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, g, logp, (float*)dx, ld, (int)M, (int)n);
+  return ovqa_check_launch("log_softmax_bwd");
+}
+
+int nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M, int64_t n,
+             int64_t ignore_index, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(1024), 0, st, logp, target, loss, dlogp, gscale, (int)M, (int)n,
+                     ignore_index, accumulate);
+  return ovqa_check_launch("nll_loss");
+}
+
+}  // namespace ovqa

@@ -76,7 +76,20 @@ def _dx(arena, dy, ps, **kw):
     wt = arena.transposed(ps)
     if wt is not None and ops.linear_bwd_data_wt_ok(dy, wt):
         return ops.linear_bwd_data_wt(dy, wt, **kw)
-    return ops.linear_bwd_data(dy, arena.packed(ps) if len(ps) > 1 else arena.compute(ps[0]), **kw)
+    return ops.linear_bwd_data(dy, arena.packed(ps), **kw)
+
+
+def _pad_cols(x, n):
+    """``x`` with its feature dimension zero-padded to ``n`` columns (a ragged layer's padded footprint in the arena:
+    runtime._footprint); the common case -- nothing to pad -- returns x itself."""
+    return x if x.shape[-1] == n else torch.nn.functional.pad(x, (0, n - x.shape[-1]))
+
+
+def _lin_operands(arena, lin):
+    """(weight [N_p, K_p], fp32 bias [N_p] or None) of an nn.Linear as the kernels see it: the zero-padded footprint."""
+    w = arena.packed([lin.weight])
+    b = arena.packed([lin.bias], "master") if lin.bias is not None else None
+    return w, b
 
 
 def _armed_queue():
@@ -529,21 +542,27 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, st, *params):
         arena, lin = st["arena"], st["lin"]
-        x = _c(x)
-        bias = arena.master_of(lin.bias) if lin.bias is not None else None
-        y = ops.linear_fwd(x, arena.compute(lin.weight), bias)
+        w, bias = _lin_operands(arena, lin)
+        ctx.k_in = x.shape[-1]  # (the caller may hand rows that carry the footprint's zero padding already)
+        x = _pad_cols(_c(x), w.shape[1])
+        y = ops.linear_fwd(x, w, bias)
         ctx.st = st
         ctx.save_for_backward(x)
-        return y
+        N = lin.weight.shape[0]
+        return y if y.shape[-1] == N else y[..., :N].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         st = ctx.st
         arena, lin = st["arena"], st["lin"]
         (x,) = ctx.saved_tensors
-        dy = _c(dy)
+        dy = _pad_cols(_c(dy), arena.foot[id(lin.weight)][0])
         _wgrad(arena, dy, x, [lin.weight], [lin.bias] if lin.bias is not None else [])
-        dx = _dx(arena, dy, [lin.weight]) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx(arena, dy, [lin.weight])
+            if dx.shape[-1] != ctx.k_in:
+                dx = dx[..., :ctx.k_in].contiguous()
         return dx, None, *([None] * len(st["params"]))
 
 
@@ -554,21 +573,28 @@ class _LinearGeluDrop(Function):
     @staticmethod
     def forward(ctx, x, st, *params):
         arena, lin = st["arena"], st["lin"]
-        x = _c(x)
-        y, u = ops.linear_fwd(x, arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_GELU,
-                              want_preact=True, drop=st["drop"])
+        w, bias = _lin_operands(arena, lin)
+        x = _pad_cols(_c(x), w.shape[1])
+        y, u = ops.linear_fwd(x, w, bias, EPI_BIAS_GELU, want_preact=True, drop=st["drop"])
         ctx.st = st
         ctx.save_for_backward(x, u)
-        return y
+        N = lin.weight.shape[0]
+        return y if y.shape[-1] == N else y[..., :N].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         st = ctx.st
         arena, lin = st["arena"], st["lin"]
         x, u = ctx.saved_tensors
-        du = ops.gelu_bwd(_c(dy).reshape(u.shape), u, drop=st["drop"])
+        dy = _pad_cols(_c(dy), u.shape[-1])
+        du = ops.gelu_bwd(dy.reshape(u.shape), u, drop=st["drop"])
         _wgrad(arena, du, x.reshape(-1, x.shape[-1]), [lin.weight], [lin.bias])
-        dx = _dx(arena, du, [lin.weight]).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx(arena, du, [lin.weight]).reshape(x.shape)
+            K = lin.weight.shape[1]
+            if dx.shape[-1] != K:
+                dx = dx[..., :K].contiguous()
         return dx, None, *([None] * len(st["params"]))
 
 
@@ -577,7 +603,9 @@ def linear_gelu_dropout(x, lin, arena, drop):
     st = dict(arena=arena, lin=lin, params=params, drop=drop)
     if torch.is_grad_enabled():
         return _LinearGeluDrop.apply(x, st, *params)
-    return ops.linear_fwd(_c(x), arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_GELU, drop=drop)
+    w, bias = _lin_operands(arena, lin)
+    y = ops.linear_fwd(_pad_cols(_c(x), w.shape[1]), w, bias, EPI_BIAS_GELU, drop=drop)
+    return y if y.shape[-1] == lin.weight.shape[0] else y[..., :lin.weight.shape[0]].contiguous()
 
 
 def linear(x, lin, arena):
@@ -586,8 +614,9 @@ def linear(x, lin, arena):
     st = dict(arena=arena, lin=lin, params=params)
     if torch.is_grad_enabled():
         return _Linear.apply(x, st, *params)
-    bias = arena.master_of(lin.bias) if lin.bias is not None else None
-    return ops.linear_fwd(_c(x), arena.compute(lin.weight), bias)
+    w, bias = _lin_operands(arena, lin)
+    y = ops.linear_fwd(_pad_cols(_c(x), w.shape[1]), w, bias)
+    return y if y.shape[-1] == lin.weight.shape[0] else y[..., :lin.weight.shape[0]].contiguous()
 
 
 # ------------------------------------------------------------------ attention core on projected tensors
@@ -731,3 +760,212 @@ def lstm(x_tb, mod, arena, B, T):
         return _LSTM.apply(x_tb, st, *params)
     return ops.lstm_fwd(_c(x_tb), arena.compute(mod.weight_ih_l0), arena.compute(mod.weight_hh_l0),
                         arena.master_of(mod.bias_ih_l0), arena.master_of(mod.bias_hh_l0), B, T)[0]
+
+
+# ------------------------------------------------------------------ the two ends of the model (csrc/model_ends.hip)
+def _defer_queue(t):
+    """The deferred grouped-reduce queue for a bf16 GPU backward pass, else None (as _ln_bwd)."""
+    if t.dtype == torch.bfloat16 and t.is_cuda and os.environ.get("OVQA_DEFER_WGRAD", "1") != "0":
+        return _armed_queue()
+    return None
+
+
+class _EmbedRows(Function):
+    """rows = table[tokens] (nn.Embedding lookup, text_embeddings.py:71-80,240) in the table's arena dtype, with the zero
+    padding of a ragged table included; backward: a deterministic per-token sum straight into the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, tokens, st, weight):
+        arena = st["arena"]
+        table = arena.padded(weight, st["buf"])
+        out = ops.embed_gather(tokens, table, st["time_major"], st["want_mask"], st["padding_idx"])
+        rows, st["_mask"] = out if st["want_mask"] else (out, None)
+        ctx.st = st
+        ctx.save_for_backward(tokens)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        st = ctx.st
+        (tokens,) = ctx.saved_tensors
+        gw, acc = st["arena"].grad_views([st["weight"]])
+        ops.embed_scatter(tokens, _c(drows), gw, st["time_major"], st["padding_idx"], accumulate=acc)
+        return None, None, None
+
+
+def embed_rows(tokens, emb, arena, time_major=False, master=False, want_mask=False):
+    """Rows of ``emb`` (an nn.Embedding) for int64 ``tokens`` [B, T] -> [B*T, W] (W = the table's padded width), from the
+    compute-dtype shadow or (``master``) the fp32 masters; with ``want_mask`` also the (B,1,1,T) padding mask of the ids."""
+    pad = emb.padding_idx if emb.padding_idx is not None else -1
+    st = dict(arena=arena, weight=emb.weight, time_major=time_major, buf="master" if master else "compute",
+              want_mask=want_mask, padding_idx=pad)
+    tokens = _c(tokens)
+    if torch.is_grad_enabled() and emb.weight.requires_grad:
+        rows = _EmbedRows.apply(tokens, st, emb.weight)
+        return (rows, st["_mask"]) if want_mask else rows
+    return ops.embed_gather(tokens, arena.padded(emb.weight, st["buf"]), time_major, want_mask, pad)
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return ops.dropout_apply(_c(x), drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout_apply(_c(dy), ctx.drop), None
+
+
+def dropout(x, drop):
+    """nn.Dropout on the HIP path (counter-hash mask, regenerated in backward); identity when ``drop`` is None."""
+    if drop is None or drop.p <= 0.0:
+        return x
+    return _Dropout.apply(x, drop) if torch.is_grad_enabled() and x.requires_grad else ops.dropout_apply(_c(x), drop)
+
+
+class _LinearResidual(Function):
+    """res + lin(x) (bias + residual epilogue of the GEMM): the sum of the two pooled projections (mcan.py:78)."""
+
+    @staticmethod
+    def forward(ctx, x, res, st, *params):
+        arena, lin = st["arena"], st["lin"]
+        x = _c(x)
+        y = ops.linear_fwd(x, arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_RESIDUAL, residual=_c(res))
+        ctx.st = st
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st = ctx.st
+        arena, lin = st["arena"], st["lin"]
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        _wgrad(arena, dy, x, [lin.weight], [lin.bias])
+        dx = _dx(arena, dy, [lin.weight]) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, *([None] * len(st["params"]))
+
+
+def linear_residual(x, res, lin, arena):
+    params = [lin.weight, lin.bias]
+    st = dict(arena=arena, lin=lin, params=params)
+    if torch.is_grad_enabled():
+        return _LinearResidual.apply(x, res, st, *params)
+    return ops.linear_fwd(_c(x), arena.compute(lin.weight), arena.master_of(lin.bias), EPI_BIAS_RESIDUAL, residual=_c(res))
+
+
+class _AttentionPool(Function):
+    """pooled[b] = sum_n softmax_n(fc2(dropout(relu(fc1 x[b,n]))))[n] x[b,n]   (mcan.py:12-25, 70-76): the fc1 GEMM, then ONE
+    launch for relu + dropout + the D -> 1 product + softmax over the positions + the weighted sum; backward: one launch for
+    the softmax / fc2 / relu chain, fc1's products through the library's GEMMs (the direct gradient of the features is the
+    dX product's addend), fc2's weight gradient through the deferred grouped reduce."""
+
+    @staticmethod
+    def forward(ctx, feat, st, *params):
+        arena, mlp = st["arena"], st["mlp"]
+        T = arena.compute_dtype
+        feat = _c(feat)
+        x = feat if feat.dtype == T else feat.to(T)
+        B, N, D = feat.shape
+        hpre = ops.linear_fwd(x.reshape(B * N, D), arena.compute(mlp.fc1.weight), arena.master_of(mlp.fc1.bias))
+        att, pooled = ops.pool_fwd(feat, hpre, arena.master_of(mlp.fc2.weight).reshape(-1), arena.master_of(mlp.fc2.bias),
+                                   st["drop"])
+        ctx.st = st
+        ctx.save_for_backward(feat, x, hpre, att)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        st = ctx.st
+        arena, mlp = st["arena"], st["mlp"]
+        feat, x, hpre, att = ctx.saved_tensors
+        B, N, D = feat.shape
+        gb2, acc_b2 = arena.grad_views([mlp.fc2.bias])
+        dh, dfeat, part = ops.pool_bwd(feat, hpre, arena.master_of(mlp.fc2.weight).reshape(-1), att,
+                                       _c(dpooled.to(hpre.dtype)), st["drop"], db2=gb2, accumulate_db2=acc_b2)
+        gw2, acc_w2 = arena.grad_views([mlp.fc2.weight])
+        gw2 = gw2.reshape(-1)[:D]  # (row 0 of the [8, D] footprint of the 1 x D matrix)
+        q = _defer_queue(dh)
+        if q is not None:
+            q.add_reduce(part, B, D, gw2, None, acc_w2)
+        elif acc_w2:
+            gw2.add_(part[:, :D].sum(0))
+        else:
+            gw2.copy_(part[:, :D].sum(0))
+        _wgrad(arena, dh, x.reshape(B * N, D), [mlp.fc1.weight], [mlp.fc1.bias])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx(arena, dh, [mlp.fc1.weight], addend=dfeat).reshape(B, N, D)
+        return dx, None, *([None] * len(st["params"]))
+
+
+def attention_pool(feat, mlp, arena, drop):
+    """``mlp``: the MCAN ``MLP`` module (fc1, fc2).  feat [B, N, D] (fp32 or the compute dtype) -> pooled [B, D] (compute dtype)."""
+    params = [mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias]
+    st = dict(arena=arena, mlp=mlp, params=params, drop=drop)
+    if torch.is_grad_enabled():
+        return _AttentionPool.apply(feat, st, *params)
+    T = arena.compute_dtype
+    feat = _c(feat)
+    B, N, D = feat.shape
+    hpre = ops.linear_fwd(feat.to(T).reshape(B * N, D), arena.compute(mlp.fc1.weight), arena.master_of(mlp.fc1.bias))
+    return ops.pool_fwd(feat, hpre, arena.master_of(mlp.fc2.weight).reshape(-1), arena.master_of(mlp.fc2.bias), drop)[1]
+
+
+class _ClassifyLogSoftmax(Function):
+    """log_softmax(lin(x)) (mcan.py:79-81) for a classifier whose class count need not be a multiple of 8: the GEMM runs
+    on the zero-padded footprint of the weights, log_softmax reads only the real classes."""
+
+    @staticmethod
+    def forward(ctx, x, st, *params):
+        arena, lin = st["arena"], st["lin"]
+        w, bias = _lin_operands(arena, lin)
+        x = _c(x)
+        y = ops.linear_fwd(x, w, bias)
+        logp = ops.log_softmax_fwd(y, lin.weight.shape[0])
+        ctx.st = st
+        ctx.save_for_backward(x, logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.st
+        arena, lin = st["arena"], st["lin"]
+        x, logp = ctx.saved_tensors
+        dy = ops.log_softmax_bwd(_c(g.float()), logp, arena.foot[id(lin.weight)][0], x.dtype)
+        _wgrad(arena, dy, x, [lin.weight], [lin.bias])
+        dx = _dx(arena, dy, [lin.weight]) if ctx.needs_input_grad[0] else None
+        return dx, None, *([None] * len(st["params"]))
+
+
+def classify_log_softmax(x, lin, arena):
+    params = [lin.weight, lin.bias]
+    st = dict(arena=arena, lin=lin, params=params)
+    if torch.is_grad_enabled():
+        return _ClassifyLogSoftmax.apply(x, st, *params)
+    w, bias = _lin_operands(arena, lin)
+    return ops.log_softmax_fwd(ops.linear_fwd(_c(x), w, bias), lin.weight.shape[0])
+
+
+class _NLL(Function):
+    """nn.NLLLoss(ignore_index) on fp32 log-probabilities (classification_task.py:125-127): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, logp, target, ignore_index):
+        logp = _c(logp.float())
+        loss = torch.empty(1, dtype=torch.float32, device=logp.device)
+        ops.nll_loss(logp, target, ignore_index, loss=loss)
+        ctx.ignore_index = ignore_index
+        ctx.save_for_backward(logp, target)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logp, target = ctx.saved_tensors
+        d = ops.nll_loss(logp, target, ctx.ignore_index, want_grad=True, gscale=_c(g.float()).reshape(1))
+        return d, None, None
+
+
+def nll_loss(logp, target, ignore_index=-100):
+    return _NLL.apply(logp, _c(target), ignore_index)

@@ -48,10 +48,8 @@ class CrossModalityTransformer(nn.Module):
         text, (text_mask, _) = self.text_embedding(input_features.question_tokens)
         vision, text = self.encoder(vision_features=vision, vision_padding_mask=vision_mask,
                                     language_features=text, language_padding_mask=text_mask)
-        av = torch.softmax(self.vision_attr_reduce(vision), dim=1)
-        at = torch.softmax(self.text_attr_reduce(text), dim=1)
-        wv = (vision.float() * av).sum(dim=1)
-        wt = (text.float() * at).sum(dim=1)
-        fused = Fn.linear(wv.to(T), self.vision_proj, arena).float() + Fn.linear(wt.to(T), self.text_proj, arena).float()
+        wv = self.vision_attr_reduce.pool(vision, arena)
+        wt = self.text_attr_reduce.pool(text, arena)
+        fused = Fn.linear_residual(wt, Fn.linear(wv, self.vision_proj, arena), self.text_proj, arena)
         out = Fn.prologue(fused, self.layer_norm, None, arena, T)
         return Fn.linear(out, self.classify, arena).float()

@@ -3,8 +3,10 @@
 Same constructor ``(config, vocab)``, attribute names and ``state_dict`` keys as the reference, so
 ``build_model`` + the reference's ``configs/mcan.yaml`` resolve to it and checkpoints interchange.
 The two encoder stacks (97 % of the FLOPs) are the fused HIP blocks; the embedding projection is the fused
-GEMM+GELU(+dropout) epilogue; the attention-pooling head runs its 512x512 projections through the HIP GEMM
-and its softmax pooling (one scalar per position) in plain torch.
+GEMM+GELU(+dropout) epilogue; the attention-pooling head is the fc1 GEMM + ONE kernel per modality (relu, dropout, the
+D -> 1 product, softmax over the positions, weighted sum: csrc/model_ends.hip), the two pooled projections are summed in the
+second GEMM's residual epilogue, and the classifier + log_softmax run on the zero-padded footprint of the (ragged, 353-way)
+classifier weights.
 """
 from __future__ import annotations
 
@@ -28,13 +30,20 @@ class MLP(nn.Module):
         self.relu = nn.ReLU()
         self.dropout = nn.Dropout(config.DROPOUT)
         self.fc2 = nn.Linear(config.D_MODEL, 1)
+        self._site = rt.new_dropout_site()
 
     def forward(self, features: torch.Tensor):
+        """The logits themselves (the reference's MLP.forward); the models below call ``pool`` instead."""
         arena = rt.ensure_arena(self)
         h = Fn.linear(features.to(arena.compute_dtype), self.fc1, arena)
         h = self.dropout(self.relu(h))
         # D -> 1: a matrix-vector product; fp32 torch op on the arena's master weights
         return torch.nn.functional.linear(h.float(), self.fc2.weight, self.fc2.bias)
+
+    def pool(self, features: torch.Tensor, arena):
+        """sum_n softmax_n(self(features))[n] * features[:, n]  (mcan.py:70-76), [B, D] in the compute dtype."""
+        drop = rt.dropout_spec(self.dropout.p, self._site, self.training, features.device)
+        return Fn.attention_pool(features, self, arena, drop)
 
 
 @META_ARCHITECTURE.register()
@@ -69,11 +78,8 @@ class MCAN(nn.Module):
                                      language_features=text, language_padding_mask=text_mask)
         # attention pooling over each sequence (softmax over dim=1, padded positions included as in the
         # reference, mcan.py:70-76)
-        av = torch.softmax(self.vision_attr_reduce(vision), dim=1)
-        at = torch.softmax(self.text_attr_reduce(text), dim=1)
-        wv = (vision.float() * av).sum(dim=1)
-        wt = (text.float() * at).sum(dim=1)
-        fused = Fn.linear(wv.to(T), self.vision_proj, arena).float() + Fn.linear(wt.to(T), self.text_proj, arena).float()
+        wv = self.vision_attr_reduce.pool(vision, arena)
+        wt = self.text_attr_reduce.pool(text, arena)
+        fused = Fn.linear_residual(wt, Fn.linear(wv, self.vision_proj, arena), self.text_proj, arena)
         out = Fn.prologue(fused, self.layer_norm, None, arena, T)
-        logits = Fn.linear(out, self.classify, arena)
-        return torch.log_softmax(logits.float(), dim=-1)
+        return Fn.classify_log_softmax(out, self.classify, arena)

@@ -18,6 +18,19 @@ from ..builders.vision_embedding_builder import META_VISION_EMBEDDING
 from ..utils import generate_padding_mask, generate_sequential_mask
 
 
+_seq_masks = {}
+
+
+def _sequential_mask(n, device):
+    """generate_sequential_mask (models/utils.py:60-66) is a constant of the sequence length: built once per device."""
+    key = (int(n), str(device))
+    m = _seq_masks.get(key)
+    if m is None:
+        m = generate_sequential_mask(n, device=device)
+        _seq_masks[key] = m
+    return m
+
+
 @META_VISION_EMBEDDING.register()
 class FeatureEmbedding(nn.Module):
     def __init__(self, config):
@@ -50,9 +63,17 @@ class UsualEmbedding(nn.Module):
         self.components = nn.Embedding(len(vocab), config.D_MODEL, vocab.padding_idx)
 
     def forward(self, tokens):
-        padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
-        sequential_masks = generate_sequential_mask(tokens.shape[-1], device=tokens.device)
-        return self.components(tokens), (padding_masks, sequential_masks)
+        sequential_masks = _sequential_mask(tokens.shape[-1], tokens.device)
+        if not tokens.is_cuda or tokens.dim() != 2:  # (shapes the gather kernel does not take: the stock lookup)
+            padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
+            return self.components(tokens), (padding_masks, sequential_masks)
+        arena = rt.ensure_arena(self)
+        B, T = tokens.shape
+        # fp32 rows out of the fp32 master table (what the stock lookup returns), padding mask from the same pass
+        rows, padding_masks = Fn.embed_rows(tokens, self.components, arena, master=True, want_mask=True)
+        D = self.components.weight.shape[1]
+        rows = rows if rows.shape[1] == D else rows[:, :D].contiguous()
+        return rows.view(B, T, D), (padding_masks, sequential_masks)
 
 
 class LSTM(nn.Module):
@@ -88,13 +109,15 @@ class LSTMTextEmbedding(nn.Module):
         self.proj = nn.Linear(config.D_EMBEDDING, config.D_MODEL)
         self.dropout = nn.Dropout(config.DROPOUT)
         self.lstm = LSTM(config.D_MODEL, config.D_MODEL)
+        self._site = rt.new_dropout_site()
 
     def forward(self, tokens):
-        padding_masks = generate_padding_mask(tokens, padding_idx=self.padding_idx).to(tokens.device)
-        sequential_masks = generate_sequential_mask(tokens.shape[-1], device=tokens.device)
         arena = rt.ensure_arena(self)
         B, T = tokens.shape
-        x = self.embedding(tokens.t()).to(arena.compute_dtype)          # [T, B, E]: time-major rows
-        x = self.dropout(Fn.linear(x, self.proj, arena)).reshape(T * B, -1)
-        y = Fn.lstm(x, self.lstm, arena, B, T)                            # fp32 [B, T, D]
+        sequential_masks = _sequential_mask(T, tokens.device)
+        # token rows (time-major, zero-padded to the projection's 16-byte row width) and the padding mask in one pass
+        x, padding_masks = Fn.embed_rows(tokens, self.embedding, arena, time_major=True, want_mask=True)
+        x = Fn.linear(x, self.proj, arena)                                                  # [T*B, D]
+        x = Fn.dropout(x, rt.dropout_spec(self.dropout.p, self._site, self.training, x.device))
+        y = Fn.lstm(x, self.lstm, arena, B, T)                                              # fp32 [B, T, D]
         return y, (padding_masks, sequential_masks)

@@ -360,7 +360,7 @@ class WgradQueue:
         return False
 
     def add_reduce(self, partial, blocks, D, out0, out1, accumulate=False):
-        assert out0.dtype == torch.float32 and out1.dtype == torch.float32 and partial.dtype == torch.float32
+        assert out0.dtype == torch.float32 and (out1 is None or out1.dtype == torch.float32) and partial.dtype == torch.float32
         self._note_producer(partial)
         self.reduces.append((partial, blocks, D, out0, out1, bool(accumulate)))
 
@@ -374,7 +374,7 @@ class WgradQueue:
         # order, and add to what the earlier one stored.
         waves = []
         for item in red:
-            key = (item[3].data_ptr(), item[4].data_ptr())
+            key = (item[3].data_ptr(), item[4].data_ptr() if item[4] is not None else 0)
             for w in waves:
                 if key not in w[0]:
                     w[0].add(key)
@@ -1038,3 +1038,104 @@ def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
     _lib.check(lib.ovqa_lstm_bwd(_dt(w_hh), _p(dy), _p(w_hh), _p(w_hh_t), ldwt, _p(saved), _p(dgates), _p(scratch), B, T,
                                  I, H, _stream()), "lstm_bwd")
     return dgates, scratch
+
+
+# ---------------------------------------------------------------------------
+# The two ends of the model (csrc/model_ends.hip)
+def embed_gather(tokens, table, time_major=False, want_mask=False, padding_idx=-1):
+    """rows [B*T, W] = table[tokens] in the table's dtype (W = table.shape[1], zero padding of a ragged table included); row
+    r = t*B + b (time_major) or b*T + t.  ``want_mask``: also the (B, 1, 1, T) additive padding mask of the token ids."""
+    _dev(table)
+    assert tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.is_contiguous() and tokens.is_cuda
+    assert table.dim() == 2 and table.stride(1) == 1
+    B, T = tokens.shape
+    rows = torch.empty(B * T, table.shape[1], dtype=table.dtype, device=table.device)
+    mask = torch.empty(B, 1, 1, T, dtype=torch.float32, device=table.device) if want_mask else None
+    _lib.check(_lib.load().ovqa_embed_gather(_dt(table), _p(tokens), _p(table), table.stride(0), table.shape[0], _p(rows),
+                                             rows.stride(0), B, T, table.shape[1], int(time_major), _p(mask), int(padding_idx),
+                                             _stream()), "embed_gather")
+    return (rows, mask) if want_mask else rows
+
+
+def embed_scatter(tokens, drows, dtable, time_major=False, padding_idx=-1, accumulate=False):
+    """dtable (fp32 [V, W], every row) (=|+=) the sum of drows [B*T, W] per token, in row order (deterministic)."""
+    _dev(drows)
+    B, T = tokens.shape
+    assert drows.dim() == 2 and drows.shape[0] == B * T and drows.stride(1) == 1 and dtable.dtype == torch.float32
+    assert dtable.dim() == 2 and dtable.stride(1) == 1 and dtable.shape[1] == drows.shape[1] and tokens.is_contiguous()
+    _lib.check(_lib.load().ovqa_embed_scatter(_dt(drows), _p(tokens), _p(drows), drows.stride(0), _p(dtable),
+                                              dtable.stride(0), dtable.shape[0], B, T, drows.shape[1], int(time_major),
+                                              int(padding_idx), int(bool(accumulate)), _stream()), "embed_scatter")
+
+
+def dropout_apply(x, drop):
+    """x * keep / (1 - p) with the counter-hash mask of ``drop`` (flat element index); x itself when dropout is off."""
+    if drop is None or drop.p <= 0.0:
+        return x
+    _dev(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().ovqa_dropout_apply(_dt(x), _p(x), _p(y), x.numel(), _drop(drop), _stream()), "dropout_apply")
+    return y
+
+
+def pool_fwd(feat, hpre, w2, b2, drop=None):
+    """Attention pooling forward (``ovqa_pool_fwd``): feat [B, N, D] (fp32 or the compute dtype), hpre [B*N, D] = fc1(feat);
+    w2 fp32 [D], b2 fp32 [1] or None -> (att fp32 [B, N], pooled [B, D] in hpre's dtype)."""
+    _dev(feat)
+    B, N, D = feat.shape
+    assert feat.is_contiguous() and hpre.is_contiguous() and hpre.numel() == B * N * D
+    assert w2.dtype == torch.float32 and w2.numel() == D and w2.is_contiguous()
+    att = torch.empty(B, N, dtype=torch.float32, device=feat.device)
+    pooled = torch.empty(B, D, dtype=hpre.dtype, device=feat.device)
+    _lib.check(_lib.load().ovqa_pool_fwd(_dt(feat), _dt(hpre), _p(feat), _p(hpre), _p(w2), _p(b2), _p(att), _p(pooled), None,
+                                         B, N, D, _drop(drop), _stream()), "pool_fwd")
+    return att, pooled
+
+
+def pool_bwd(feat, hpre, w2, att, dpooled, drop=None, db2=None, accumulate_db2=False):
+    """-> (dh [B*N, D], dfeat [B*N, D] (= att * dpooled), dw2_part fp32 [B, 2*D]); db2 fp32 [>=1] (=|+=) in place if given."""
+    _dev(feat)
+    B, N, D = feat.shape
+    assert dpooled.is_contiguous() and dpooled.dtype == hpre.dtype and dpooled.numel() == B * D
+    dh = torch.empty(B * N, D, dtype=hpre.dtype, device=feat.device)
+    dfeat = torch.empty(B * N, D, dtype=hpre.dtype, device=feat.device)
+    part = torch.empty(B, 2 * D, dtype=torch.float32, device=feat.device)
+    scratch = torch.empty(8 + B, dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().ovqa_pool_bwd(_dt(feat), _dt(hpre), _p(feat), _p(hpre), _p(w2), _p(att), _p(dpooled), _p(dh),
+                                         _p(dfeat), _p(part), _p(db2), _p(scratch), B, N, D, int(bool(accumulate_db2)),
+                                         _drop(drop), _stream()), "pool_bwd")
+    return dh, dfeat, part
+
+
+def log_softmax_fwd(x, n=None):
+    """fp32 [M, n] = log_softmax over the first n columns of every row of x [M, ld]."""
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    n = x.shape[1] if n is None else n
+    out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ovqa_log_softmax_fwd(_dt(x), _p(x), x.stride(0), _p(out), x.shape[0], n, _stream()),
+               "log_softmax_fwd")
+    return out
+
+
+def log_softmax_bwd(g, logp, ld, dtype):
+    """dx [M, ld] of ``dtype`` = g - exp(logp) * rowsum(g) in the first n columns, zeros in the padded ones."""
+    _dev(g)
+    assert g.dtype == torch.float32 and logp.dtype == torch.float32 and g.is_contiguous() and logp.is_contiguous()
+    M, n = logp.shape
+    dx = torch.empty(M, ld, dtype=dtype, device=g.device)
+    _lib.check(_lib.load().ovqa_log_softmax_bwd(_DT[dtype], _p(g), _p(logp), _p(dx), ld, M, n, _stream()), "log_softmax_bwd")
+    return dx
+
+
+def nll_loss(logp, target, ignore_index=-100, loss=None, want_grad=False, gscale=None, accumulate=False):
+    """NLLLoss (mean over the rows whose target != ignore_index) of fp32 log-probabilities [M, n]: writes ``loss`` (fp32
+    device scalar, (=|+=)) if given and returns the dense gradient [M, n] (scaled by the device scalar ``gscale``) if asked."""
+    _dev(logp)
+    assert logp.dtype == torch.float32 and logp.dim() == 2 and logp.is_contiguous()
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.numel() == logp.shape[0]
+    dlogp = torch.empty_like(logp) if want_grad else None
+    _lib.check(_lib.load().ovqa_nll_loss(_p(logp), _p(target), _p(loss), _p(dlogp), _p(gscale), logp.shape[0], logp.shape[1],
+                                         int(ignore_index), int(bool(accumulate)), _stream()), "nll_loss")
+    return dlogp

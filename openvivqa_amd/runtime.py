@@ -26,6 +26,19 @@ _site_counter = itertools.count(1)
 _step_tensors: Dict[int, torch.Tensor] = {}
 
 ALIGN = 64  # elements; keeps every group start 256-byte aligned in fp32 and 128-byte in bf16
+PAD = 8     # ragged parameters are laid out with rows / columns (or length) rounded up to this: 16-byte bf16 rows
+
+
+def _footprint(p) -> tuple:
+    """Shape a parameter occupies in the arena: a matrix whose rows or columns are not multiples of 8 (a 353-way
+    classifier, a 300-wide word embedding: mcan.yaml) gets zero padding up to the next multiple, so that the MFMA GEMMs,
+    the direct-to-LDS weight gradients and the tiled Adam see 16-byte aligned rows; ``p.data`` is the [:rows, :cols] view
+    (same name and shape for state_dict), the padding holds zeros for ever (zero gradient, zero Adam update)."""
+    if p.dim() == 2:
+        return ((p.shape[0] + PAD - 1) // PAD * PAD, (p.shape[1] + PAD - 1) // PAD * PAD)
+    if p.dim() == 1:
+        return ((p.shape[0] + PAD - 1) // PAD * PAD,)
+    return tuple(p.shape)
 
 
 def set_compute_dtype(dtype: torch.dtype) -> None:
@@ -121,22 +134,29 @@ class ParamArena:
         self.small_lo = None
         self._group_of: Dict[int, tuple] = {}  # id(param) -> (group offset, first row, group rows, cols) for 2-D groups
         self._groups2d: List[tuple] = []
+        self.foot: Dict[int, tuple] = {}  # id(param) -> padded shape in the arena (== p.shape unless ragged)
         for g in groups:
             off = (off + ALIGN - 1) // ALIGN * ALIGN
             if g[0].dim() < 2 and self.small_lo is None:
                 self.small_lo = off
-            if g[0].dim() == 2 and all(p.dim() == 2 and p.shape[1] == g[0].shape[1] for p in g):
-                rows, r0 = sum(p.shape[0] for p in g), 0
-                for p in g:
-                    self._group_of[id(p)] = (off, r0, rows, g[0].shape[1])
-                    r0 += p.shape[0]
-                self._groups2d.append((off, rows, g[0].shape[1]))
-            for p in g:
+            # only a group of its own is padded: members of an adjacency group ([fc_q | fc_k | fc_v]) must stay dense
+            foots = [_footprint(p) if len(g) == 1 else tuple(p.shape) for p in g]
+            if g[0].dim() == 2 and all(p.dim() == 2 and f[1] == foots[0][1] for p, f in zip(g, foots)):
+                rows, r0 = sum(f[0] for f in foots), 0
+                for p, f in zip(g, foots):
+                    self._group_of[id(p)] = (off, r0, rows, foots[0][1])
+                    r0 += f[0]
+                self._groups2d.append((off, rows, foots[0][1]))
+            for p, f in zip(g, foots):
                 if id(p) in self.offsets:
                     raise RuntimeError("parameter appears twice in an arena")
                 self.offsets[id(p)] = off
+                self.foot[id(p)] = f
                 self.params.append(p)
-                off += p.numel()
+                n = 1
+                for d in f:
+                    n *= d
+                off += n
         self.numel = (off + ALIGN - 1) // ALIGN * ALIGN
         if self.small_lo is None:
             self.small_lo = self.numel
@@ -154,8 +174,7 @@ class ParamArena:
         self._written_pass = set()    # harness mode: ids written so far in the CURRENT backward pass
         with torch.no_grad():
             for p in self.params:
-                o = self.offsets[id(p)]
-                view = self.master[o:o + p.numel()].view(p.shape)
+                view = self._slice(self.master, p)
                 view.copy_(p.data.to(device=device, dtype=torch.float32))
                 p.data = view
                 p._ovqa_arena = self
@@ -170,9 +189,31 @@ class ParamArena:
                 for i, p in enumerate(self.params)]
 
     # -- views -------------------------------------------------------------
+    def span(self, p) -> int:
+        """Elements ``p`` occupies in the arena (its padded footprint)."""
+        n = 1
+        for d in self.foot[id(p)]:
+            n *= d
+        return n
+
     def _slice(self, buf, p):
+        """View of ``buf`` with p's shape: dense, or the [:rows, :cols] corner of the padded footprint."""
+        o, f = self.offsets[id(p)], self.foot[id(p)]
+        if f == tuple(p.shape):
+            return buf[o:o + p.numel()].view(p.shape)
+        full = buf[o:o + self.span(p)].view(f)
+        return full[:p.shape[0], :p.shape[1]] if p.dim() == 2 else full[:p.shape[0]]
+
+    def is_padded(self, p) -> bool:
+        return self.foot[id(p)] != tuple(p.shape)
+
+    def padded(self, p, buf: str = "compute") -> torch.Tensor:
+        """The WHOLE footprint of ``p`` (contiguous [rows_p, cols_p] or [n_p], zeros beyond p's own shape): what the GEMM
+        kernels take as the weight / bias of a ragged layer."""
+        base = {"compute": self.shadow if self.shadow is not None else self.master, "master": self.master,
+                "grad": self.grad}[buf]
         o = self.offsets[id(p)]
-        return buf[o:o + p.numel()].view(p.shape)
+        return base[o:o + self.span(p)].view(self.foot[id(p)])
 
     def compute(self, p) -> torch.Tensor:
         """Weight in the compute dtype (bf16 shadow or the fp32 master itself)."""
@@ -186,10 +227,12 @@ class ParamArena:
 
     def packed(self, ps: Sequence[nn.Parameter], buf: str = "compute") -> torch.Tensor:
         """One [sum(rows), cols] (or [sum(n)]) view over adjacent parameters."""
+        if len(ps) == 1:
+            return self.padded(ps[0], buf)  # (a ragged parameter: its whole zero-padded footprint)
         o0 = self.offsets[id(ps[0])]
         n, o = 0, o0
         for p in ps:
-            if self.offsets[id(p)] != o:
+            if self.offsets[id(p)] != o or self.is_padded(p):
                 raise RuntimeError("parameters are not adjacent in the arena")
             o += p.numel()
             n += p.numel()
@@ -304,7 +347,7 @@ class ParamArena:
         for p, i in zip(ps, info):
             if i[1] != r:
                 return None
-            r += p.shape[0]
+            r += self.foot[id(p)][0]
         return self.shadow_t[off:off + rows * cols].view(cols, rows)[:, r0:r]
 
     def sync_if_stale(self) -> None:
@@ -320,7 +363,7 @@ class ParamArena:
         last backward: parameters that live in plain torch modules (autograd accumulates into their
         ``.grad``) or that receive no gradient at all (dead cross-attention).  The training
         harness zeroes exactly these before each backward; everything else is overwritten."""
-        spans = sorted((self.offsets[id(p)], self.offsets[id(p)] + p.numel()) for p in self.params
+        spans = sorted((self.offsets[id(p)], self.offsets[id(p)] + self.span(p)) for p in self.params
                        if id(p) not in self.kernel_written)
         merged = []
         for s, e in spans:

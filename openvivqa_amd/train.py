@@ -150,9 +150,8 @@ class FlatAdam:
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise RuntimeError(f"FlatAdam.load_state_dict: moment shape {tuple(st['exp_avg'].shape)} != parameter "
                                    f"shape {tuple(p.shape)} at position {index[k]}")
-            o = a.offsets[id(p)]
-            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            a._slice(self.exp_avg, p).copy_(st["exp_avg"])       # (a ragged parameter: the corner of its padded footprint)
+            a._slice(self.exp_avg_sq, p).copy_(st["exp_avg_sq"])
             steps.add(int(st["step"].item() if torch.is_tensor(st["step"]) else st["step"]))
         if len(steps) > 1:
             raise RuntimeError("FlatAdam.load_state_dict: per-parameter step counts differ (FlatAdam keeps one)")
@@ -180,9 +179,8 @@ class FlatAdam:
             for i, p in enumerate(params):
                 if not p.requires_grad:  # torch.optim.Adam never creates state for a frozen parameter (a decoder's
                     continue             # pos_emb, from_pretrained(freeze=True)): keep the reference's checkpoint layout
-                o = a.offsets[id(p)]
-                state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
-                            "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+                state[i] = {"step": torch.tensor(step), "exp_avg": a._slice(self.exp_avg, p).clone(),
+                            "exp_avg_sq": a._slice(self.exp_avg_sq, p).clone()}
         group = {"lr": self.lr * self.lr_scale, "betas": tuple(self.betas), "eps": self.eps,
                  "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
                  "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,

@@ -341,3 +341,91 @@ def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
                             -1).to(w_hh.dtype)
         out[t] = dg_next
     return torch.cat(out, 0), None
+
+
+def _rc(B, T, time_major):
+    r = torch.arange(B * T)
+    return (r % B, r // B) if time_major else (r // T, r % T)
+
+
+def embed_gather(tokens, table, time_major=False, want_mask=False, padding_idx=-1):
+    B, T = tokens.shape
+    b, t = _rc(B, T, time_major)
+    rows = table[tokens[b, t]].clone()
+    if want_mask:
+        return rows, ((tokens == padding_idx).float() * -10e4).reshape(B, 1, 1, T)
+    return rows
+
+
+def embed_scatter(tokens, drows, dtable, time_major=False, padding_idx=-1, accumulate=False):
+    B, T = tokens.shape
+    b, t = _rc(B, T, time_major)
+    tok = tokens[b, t]
+    g = torch.zeros_like(dtable)
+    keep = tok != padding_idx
+    g.index_add_(0, tok[keep], drows.float()[keep])
+    if accumulate:
+        dtable.add_(g)
+    else:
+        dtable.copy_(g)
+
+
+def dropout_apply(x, drop):
+    assert drop is None or drop.p == 0
+    return x
+
+
+def pool_fwd(feat, hpre, w2, b2, drop=None):
+    assert drop is None or drop.p == 0
+    B, N, D = feat.shape
+    logit = torch.relu(hpre.float()).reshape(B, N, D) @ w2.float() + (b2.float()[0] if b2 is not None else 0.0)
+    att = torch.softmax(logit, dim=1)
+    return att, (feat.float() * att[..., None]).sum(1).to(hpre.dtype)
+
+
+def pool_bwd(feat, hpre, w2, att, dpooled, drop=None, db2=None, accumulate_db2=False):
+    assert drop is None or drop.p == 0
+    B, N, D = feat.shape
+    dp = dpooled.float()
+    datt = (feat.float() * dp[:, None, :]).sum(-1)
+    dl = att * (datt - (att * datt).sum(1, keepdim=True))
+    h = hpre.float().reshape(B, N, D)
+    dh = (dl[..., None] * w2.float() * (h > 0)).reshape(B * N, D).to(hpre.dtype)
+    dfeat = (att[..., None] * dp[:, None, :]).reshape(B * N, D).to(hpre.dtype)
+    part = torch.zeros(B, 2 * D)
+    part[:, :D] = (dl[..., None] * torch.relu(h)).sum(1)
+    if db2 is not None:
+        if accumulate_db2:
+            db2[0] += dl.sum()
+        else:
+            db2[0] = dl.sum()
+    return dh, dfeat, part
+
+
+def log_softmax_fwd(x, n=None):
+    n = x.shape[1] if n is None else n
+    return torch.log_softmax(x[:, :n].float(), dim=-1)
+
+
+def log_softmax_bwd(g, logp, ld, dtype):
+    M, n = logp.shape
+    dx = torch.zeros(M, ld, dtype=dtype)
+    dx[:, :n] = (g - torch.exp(logp) * g.sum(-1, keepdim=True)).to(dtype)
+    return dx
+
+
+def nll_loss(logp, target, ignore_index=-100, loss=None, want_grad=False, gscale=None, accumulate=False):
+    valid = target != ignore_index
+    cnt = valid.sum().clamp(min=1).float()
+    if loss is not None:
+        v = -(logp[valid, target[valid]]).sum() / cnt
+        if accumulate:
+            loss.add_(v)
+        else:
+            loss.fill_(float(v))
+    if not want_grad:
+        return None
+    d = torch.zeros_like(logp)
+    sc = (gscale.float().reshape(-1)[0] if gscale is not None else 1.0) / cnt
+    d[valid, target[valid]] = -sc
+    return d

@@ -1166,3 +1166,119 @@ def test_lstm_persistent_equals_per_step_kernels_and_fence_form(monkeypatch):
         pass
     assert nerr(ref[0], out["y"]) < 2e-3
     assert rel_l2(ref[2].float(), out["dg"].float()) < 6e-3
+
+
+# ---------------------------------------------------------------- the two ends of the model (csrc/model_ends.hip)
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,T,V,W,time_major", [(3, 6, 11, 16, True), (64, 20, 4000, 304, True), (5, 7, 50, 512, False)])
+def test_embed_gather_scatter(dtype, B, T, V, W, time_major):
+    o = ops()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    table = torch.randn(V, W, generator=g).to(DEV, dtype)
+    tokens = torch.randint(0, V, (B, T), generator=g)
+    tokens[0, -2:] = 0  # padding tokens (index 0)
+    tokens[-1] = tokens[0]  # repeated tokens: several rows add into one table row
+    tok = tokens.to(DEV)
+    rows, mask = o.embed_gather(tok, table, time_major, want_mask=True, padding_idx=0)
+    order = tokens.t().reshape(-1) if time_major else tokens.reshape(-1)
+    assert torch.equal(rows.cpu(), table.cpu()[order])
+    assert torch.equal(mask.cpu(), ((tokens == 0).float() * -10e4).reshape(B, 1, 1, T))
+    drows = torch.randn(B * T, W, generator=g).to(DEV, dtype)
+    dt = torch.full((V, W), 7.0, device=DEV)  # every row is overwritten: no memset needed
+    o.embed_scatter(tok, drows, dt, time_major, padding_idx=0)
+    ref = torch.zeros(V, W, dtype=torch.float64)
+    keep = order != 0
+    ref.index_add_(0, order[keep], drows.double().cpu()[keep])
+    assert nerr(dt, ref) < (1e-5 if dtype == F32 else 1e-5)  # fp32 accumulation of the (bf16) rows: exact up to order
+    dt2 = dt.clone()
+    o.embed_scatter(tok, drows, dt2, time_major, padding_idx=0, accumulate=True)
+    assert nerr(dt2, 2 * ref) < 1e-5
+    a = torch.empty_like(dt)
+    o.embed_scatter(tok, drows, a, time_major, padding_idx=0)
+    assert torch.equal(a, dt), "the scatter is not deterministic"
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dropout_apply_matches_keep_mask(dtype):
+    o = ops()
+    n = 1280 * 512 + 3 * 8
+    x = rnd(n, dtype=dtype)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = o.DropSpec(p=0.1, seed=1234, site=5, step=step)
+    y = o.dropout_apply(x, d)
+    keep = o.dropout_keep_mask(d, n, x.device).bool()
+    ref = torch.where(keep, x.float() / 0.9, torch.zeros_like(x.float()))
+    assert nerr(y, ref) < (1e-6 if dtype == F32 else 4e-3)
+    assert 0.08 < 1 - keep.float().mean().item() < 0.12
+    assert o.dropout_apply(x, None) is x
+
+
+def _pool_ref64(feat, hpre, w2, b2, keep, p, dpooled):
+    f = feat.double().cpu().requires_grad_(True)
+    h = hpre.double().cpu().requires_grad_(True)
+    w = w2.double().cpu().requires_grad_(True)
+    bb = b2.double().cpu().requires_grad_(True)
+    B, N, D = f.shape
+    act = torch.relu(h) * (keep.double().cpu().reshape(B * N, D) / (1 - p))
+    logit = (act @ w + bb).reshape(B, N)
+    att = torch.softmax(logit, 1)
+    pooled = (f * att[..., None]).sum(1)
+    (pooled * dpooled.double().cpu()).sum().backward()
+    return att.detach(), pooled.detach(), f.grad, h.grad, w.grad, bb.grad
+
+
+@pytest.mark.parametrize("fdt,dtype", [(F32, F32), (BF16, BF16), (F32, BF16)])
+@pytest.mark.parametrize("B,N,D,p", [(3, 6, 32, 0.0), (64, 100, 512, 0.1), (64, 20, 512, 0.1), (5, 237, 768, 0.0)])
+def test_attention_pool_fwd_bwd(fdt, dtype, B, N, D, p):
+    o = ops()
+    feat = rnd(B, N, D, dtype=fdt, seed=1)
+    hpre = rnd(B * N, D, dtype=dtype, seed=2)
+    w2, b2 = rnd(D, scale=D ** -0.5, seed=3), rnd(1, seed=4)
+    dpooled = rnd(B, D, dtype=dtype, seed=5)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = o.DropSpec(p=p, seed=99, site=3, step=step) if p > 0 else None
+    keep = o.dropout_keep_mask(d, B * N * D, feat.device) if p > 0 else torch.ones(B * N * D, device=DEV)
+    att, pooled = o.pool_fwd(feat, hpre, w2, b2, d)
+    db2 = torch.full((8,), 3.0, device=DEV)
+    dh, dfeat, part = o.pool_bwd(feat, hpre, w2, att, dpooled, d, db2=db2)
+    att64, pooled64, gf, gh, gw, gb = _pool_ref64(feat, hpre, w2, b2, keep, p, dpooled)
+    t = 1e-5 if dtype == F32 else 1e-2
+    assert nerr(att, att64) < 1e-5 and nerr(pooled, pooled64) < t
+    # dfeat is only the direct path att * dpooled; the path through fc1 is the caller's dX product
+    direct = att64[..., None] * dpooled.double().cpu()[:, None, :]
+    assert nerr(dfeat.view(B, N, D), direct) < t
+    assert nerr(dh, gh) < t and nerr(part[:, :D].sum(0), gw) < 2e-4
+    assert float(part[:, D:].abs().max()) == 0.0
+    assert abs(float(db2[0]) - float(gb)) < 1e-4 and float(db2[1]) == 3.0
+    db3 = db2.clone()
+    o.pool_bwd(feat, hpre, w2, att, dpooled, d, db2=db3, accumulate_db2=True)
+    assert abs(float(db3[0]) - 2 * float(db2[0])) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,n,ld", [(3, 7, 8), (64, 353, 360), (1280, 4000, 4000), (5, 11, 16)])
+def test_log_softmax_and_nll(dtype, M, n, ld):
+    o = ops()
+    g = torch.Generator().manual_seed(M + n)
+    x = (torch.randn(M, ld, generator=g) * 3).to(DEV, dtype)
+    logp = o.log_softmax_fwd(x, n)
+    x64 = x.double().cpu()[:, :n].requires_grad_(True)
+    ref = torch.log_softmax(x64, -1)
+    assert nerr(logp, ref) < 1e-5
+    target = torch.randint(0, n, (M,), generator=g)
+    target[0] = 2
+    target[-1] = 0  # ignored
+    loss = torch.zeros(1, device=DEV)
+    dlogp = o.nll_loss(logp, target.to(DEV), ignore_index=0, loss=loss, want_grad=True)
+    rl = torch.nn.functional.nll_loss(ref, target, ignore_index=0)
+    rl.backward()
+    assert abs(float(loss) - float(rl)) < 1e-5 * max(1.0, abs(float(rl)))
+    dx = o.log_softmax_bwd(dlogp, logp, ld, dtype)
+    assert nerr(dx[:, :n], x64.grad) < (1e-6 if dtype == F32 else 1e-3)
+    assert ld == n or float(dx[:, n:].float().abs().max()) == 0.0
+    sc = torch.full((1,), 0.5, device=DEV)
+    d2 = o.nll_loss(logp, target.to(DEV), ignore_index=0, want_grad=True, gscale=sc)
+    assert nerr(d2, 0.5 * dlogp) < 1e-7
+    loss2 = loss.clone()
+    o.nll_loss(logp, target.to(DEV), ignore_index=0, loss=loss2, accumulate=True)
+    assert abs(float(loss2) - 2 * float(loss)) < 1e-6 * max(1.0, abs(float(loss)))
