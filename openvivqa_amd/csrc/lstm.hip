@@ -118,9 +118,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
   bf16x8 xf[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; kk++) xf[kk] = *reinterpret_cast<const bf16x8*>(xrow + kk * 32);
-  f32x4 accx = bias;
+  // (two accumulators per product: a 16-deep chain on ONE accumulator is 16 dependent 8-pass MFMAs)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 accx = bias, accx1 = zero4;
 #pragma unroll
-  for (int kk = 0; kk < KS; kk++) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk], xf[kk], accx, 0, 0, 0);
+  for (int kk = 0; kk < KS; kk += 2) {
+    accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk], xf[kk], accx, 0, 0, 0);
+    accx1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk + 1], xf[kk + 1], accx1, 0, 0, 0);
+  }
+  accx += accx1;
   if (T > 1) {
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) xf[kk] = *reinterpret_cast<const bf16x8*>(xrow + (int64_t)B * a.ldx + kk * 32);
@@ -140,21 +146,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
       u32x4 hf[KS];
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) hf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff + kk * 64, 0, 16);
+      f32x4 acc1 = zero4;
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++)
+      for (int kk = 0; kk < KS; kk += 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whh[kk], __builtin_bit_cast(bf16x8, hf[kk]), acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whh[kk + 1], __builtin_bit_cast(bf16x8, hf[kk + 1]), acc1, 0, 0, 0);
+      }
+      acc += acc1;
     }
     const float ig = sigmoid_f(acc[0]), fg = sigmoid_f(acc[1]), gg = tanh_f(acc[2]), og = sigmoid_f(acc[3]);
     c = fg * c + ig * gg;
     const float h = og * tanh_f(c);
     tile16[n * 16 + w * 4 + q] = (bf16)h;
     tile32[n * 16 + w * 4 + q] = h;
-    float* sv = a.saved + ((int64_t)t * nwg + blockIdx.x) * 5 * 256 + tid;
-    store_saved(sv, ig);
-    store_saved(sv + 256, fg);
-    store_saved(sv + 512, gg);
-    store_saved(sv + 768, og);
-    store_saved(sv + 1024, c);
     __syncthreads();
     if (w == 0) {
       if (l < 32) {  // lane -> (sample l >> 1, half l & 1): 16 bytes of the row's 32
@@ -168,10 +172,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile32 + (l >> 2) * 16 + (l & 3) * 4);
       *reinterpret_cast<f32x4*>(a.y + ((int64_t)(sg * 16 + (l >> 2)) * T + t) * LH + ub * 16 + (l & 3) * 4) = v;
     }
+    {  // what backward needs, AFTER the publish: the publishing wave's drain does not wait for these stores
+      float* sv = a.saved + ((int64_t)t * nwg + blockIdx.x) * 5 * 256 + tid;
+      store_saved(sv, ig);
+      store_saved(sv + 256, fg);
+      store_saved(sv + 512, gg);
+      store_saved(sv + 768, og);
+      store_saved(sv + 1024, c);
+    }
     if (t + 1 < T) {  // the input half of step t + 1 (its operands were requested a step ago), then request t + 2
       accx = bias;
+      accx1 = zero4;
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk], xf[kk], accx, 0, 0, 0);
+      for (int kk = 0; kk < KS; kk += 2) {
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk], xf[kk], accx, 0, 0, 0);
+        accx1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wih[kk + 1], xf[kk + 1], accx1, 0, 0, 0);
+      }
+      accx += accx1;
       if (t + 2 < T) {
 #pragma unroll
         for (int kk = 0; kk < KS; kk++)
@@ -238,10 +255,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
       u32x4 gf[KS];
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) gf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + kk * 64, 0, 16);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++)
+      for (int kk = 0; kk < KS; kk += 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[kk], __builtin_bit_cast(bf16x8, gf[kk]), acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[kk + 1], __builtin_bit_cast(bf16x8, gf[kk + 1]), acc1, 0, 0, 0);
+      }
+      acc += acc1;
 #pragma unroll
       for (int r = 0; r < 4; r++) part[(w * 4 + r) * 64 + l] = acc[r];
       __syncthreads();

@@ -32,30 +32,36 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 }
 
 // dtable[v][0 .. width) (=|+=) sum over the rows r with tokens(r) == v of drows[r][0 .. width), in increasing r: a fixed
-// order, no atomics (torch's embedding_dense_backward adds atomically).  One wave per table row INCLUDING the rows no token
-// names: they are stored as zeros, so the gradient buffer needs no memset; row `padding_idx` gets none (nn.Embedding).
+// order, no atomics (torch's embedding_dense_backward adds atomically).  A wave owns FOUR consecutive table rows and walks
+// the token list once for all of them (the walk, not the sum, is the cost: 4000 rows x 1280 tokens); rows no token names
+// are stored as zeros, so the gradient buffer needs no memset; row `padding_idx` gets none (nn.Embedding).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ drows,
                                                             int64_t ld_rows, float* __restrict__ dtable, int64_t ld_table,
                                                             int64_t rows_table, int B, int Tn, int width, int time_major,
                                                             int64_t padding_idx, int accumulate) {
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int l = threadIdx.x & 63;
-  if (v >= rows_table) return;
+  constexpr int RPW = 4;    // table rows per wave
   constexpr int MAXC = 16;  // columns per lane: width <= 1024
-  float acc[MAXC];
+  const int64_t v0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  const int l = threadIdx.x & 63;
+  if (v0 >= rows_table) return;
+  float acc[RPW][MAXC];
 #pragma unroll
-  for (int j = 0; j < MAXC; j++) acc[j] = 0.f;
+  for (int i = 0; i < RPW; i++)
+#pragma unroll
+    for (int j = 0; j < MAXC; j++) acc[i][j] = 0.f;
   const int R = B * Tn;
-  if (v != padding_idx) {
-    for (int r0 = 0; r0 < R; r0 += 64) {
-      const int r = r0 + l;
-      bool hit = false;
-      if (r < R) {
-        const int b = time_major ? r % B : r / Tn, t = time_major ? r / B : r % Tn;
-        hit = tokens[(int64_t)b * Tn + t] == v;
-      }
-      uint64_t m = __ballot(hit);
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int r = r0 + l;
+    int64_t tok = -1;
+    if (r < R) {
+      const int b = time_major ? r % B : r / Tn, t = time_major ? r / B : r % Tn;
+      tok = tokens[(int64_t)b * Tn + t];
+    }
+    if (tok == padding_idx) tok = -1;
+#pragma unroll
+    for (int i = 0; i < RPW; i++) {
+      uint64_t m = __ballot(tok == v0 + i);
       while (m) {
         const int k = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -63,16 +69,20 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
           const int c = l + 64 * j;
-          if (c < width) acc[j] += to_f32<T>(src[c]);
+          if (c < width) acc[i][j] += to_f32<T>(src[c]);
         }
       }
     }
   }
-  float* dst = dtable + v * ld_table;
 #pragma unroll
-  for (int j = 0; j < MAXC; j++) {
-    const int c = l + 64 * j;
-    if (c < width) dst[c] = accumulate ? dst[c] + acc[j] : acc[j];
+  for (int i = 0; i < RPW; i++) {
+    if (v0 + i >= rows_table) break;
+    float* dst = dtable + (v0 + i) * ld_table;
+#pragma unroll
+    for (int j = 0; j < MAXC; j++) {
+      const int c = l + 64 * j;
+      if (c < width) dst[c] = accumulate ? dst[c] + acc[i][j] : acc[i][j];
+    }
   }
 }
 
@@ -322,9 +332,12 @@ __global__ __launch_bounds__(POOL_WAVES * 64) void pool_bwd_kernel(const F* __re
   }
   __syncthreads();
   if (!s_last || db2 == nullptr) return;
+  // (every thread fetches its partials in parallel -- a device-scope read each --, thread 0 adds them in index order)
+  for (int i = threadIdx.x; i < B; i += POOL_WAVES * 64) s_part[0][i % POOL_MAXD] = atomicAdd(&scratch[8 + i], 0.f);
+  __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int i = 0; i < B; i++) t += atomicAdd(&scratch[8 + i], 0.f);
+    for (int i = 0; i < B; i++) t += s_part[0][i];
     db2[0] = accumulate_db2 ? db2[0] + t : t;
   }
 }
@@ -422,7 +435,7 @@ int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t l
                   int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                   int accumulate, hipStream_t st) {
   OVQA_REQUIRE(width <= 1024, OVQA_ERR_UNSUPPORTED, "embed_scatter: rows wider than 1024 elements");
-  const unsigned grid = (unsigned)((rows_table + 3) / 4);
+  const unsigned grid = (unsigned)((rows_table + 15) / 16);  // 4 waves x 4 table rows per workgroup
   if (dtype == OVQA_BF16)
     hipLaunchKernelGGL(embed_scatter_kernel<bf16>, dim3(grid), dim3(256), 0, st, tokens, (const bf16*)drows, ld_rows, dtable,
                        ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);
@@ -468,7 +481,7 @@ int pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, cons
 int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
              const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B, int64_t N,
              int64_t D, int accumulate_db2, const DropArgs& da, hipStream_t st) {
-  OVQA_REQUIRE(pool_shape_ok(N, D) && B <= 4096, OVQA_ERR_UNSUPPORTED, "pool_bwd: N <= 1024, D <= 1024, D %% 8 == 0, B <= 4096");
+  OVQA_REQUIRE(pool_shape_ok(N, D) && B <= POOL_MAXD, OVQA_ERR_UNSUPPORTED, "pool_bwd: N <= 1024, D <= 1024, D %% 8 == 0, B <= 1024");
   hipError_t e = hipMemsetAsync(scratch, 0, 32, st);  // the arrival ticket (the partials are overwritten before they are read)
   OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "pool_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
   const dim3 grid((unsigned)B), block(POOL_WAVES * 64);
