@@ -19,8 +19,10 @@
 //     also the operand of the W_hh weight gradient): write-through (sc1) 16-byte stores, every storing wave drains
 //     (s_waitcnt vmcnt(0)), ONE lane adds to the group's step counter; the consumer polls that counter with sc1 loads
 //     from one lane, a workgroup barrier, then sc1 loads of the payload -- cdna_hip_programming.md Guideline 16 in its
-//     counter form, placement-independent.  `OVQA_LSTM_FENCE=1` adds the agent-scope acquire (A/B switch: results are
-//     deterministic, so the two forms must agree bit for bit).
+//     counter form, placement-independent (hand-off form 1).  The DEFAULT is form 2, "the data is the flag" (below): no
+//     counter, no drain, the consumer re-reads the payload until no unit shows the sentinel the buffer was filled with.
+//     OVQA_LSTM_HANDOFF=counter|fence selects form 1 (fence: with the agent-scope acquire); the forms are deterministic
+//     and must agree bit for bit.
 //
 // Backward is the same structure in reverse: workgroup (sg, ub) owns dh for 16 samples x 16 units; dh_{t} needs
 // dgates_{t+1} W_hh over ALL 2048 gate columns of its samples, exchanged through `dgates` itself ([T, B, 2048] bf16,
@@ -70,6 +72,39 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
   }
 }
 
+// ---- hand-off form 2 (default): the data is the flag ------------------------------------------------------------------
+// The exchange buffer is filled with 0xFF bytes by a memset node in front of the launch: 0xFFFF is a bf16 NaN that neither
+// h = o tanh(c) nor a finite gradient can be.  A consumer wave simply re-reads its 16 KB with sc1 loads until no 8-byte
+// unit shows the sentinel (cdna_hip_programming.md Guideline 16, recipe R2: 8-byte granules written by ONE sc1 store are
+// observed untorn; here the tag is "not 0xFFFF" in the unit's first element, so the payload is not doubled).  Against
+// the counter form this drops, per step: the producer's store drain, the atomic, the poll round trip and a workgroup
+// barrier -- two of the four dependent memory round trips (MEASURED, scripts/lstm_bench.py, B = 64, T = 20, memset nodes
+// included: forward 104 -> 77 us, backward 127 -> 81 us; with the acquire fence 120 / 146).  OVQA_LSTM_HANDOFF=counter selects form 1, =fence form 1 with the agent-scope
+// acquire; the three forms are deterministic and must agree bit for bit (tests/test_kernels_gpu.py).
+constexpr int SWEEP_LIMIT = 1 << 17;
+// aux of the hand-off loads: sc1 (bit 4) + LLVM's volatile marker (bit 31, stripped at lowering): two sweeps of the same
+// addresses are two loads, and none is hoisted out of a polling loop
+constexpr int AUX_POLL = (int)(0x80000000u | 16u);
+__device__ __forceinline__ bool unit_ready(const u32x4& v) {  // both 8-byte halves of a 16-byte piece
+  return ((v[0] & 0xFFFFu) != 0xFFFFu) & ((v[2] & 0xFFFFu) != 0xFFFFu);
+}
+template <typename RS>
+__device__ __forceinline__ void sweep_until_ready(const RS& rs, unsigned off, u32x4 (&v)[KS], unsigned* status) {
+  for (int spins = 0;;) {
+    bool ok = true;
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) v[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + kk * 64, 0, AUX_POLL);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) ok &= unit_ready(v[kk]);
+    if (__all(ok)) return;
+    if (++spins > SWEEP_LIMIT) {  // a producer workgroup never ran (or produced the NaN pattern itself): give up loudly
+      __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 struct LstmFwdArgs {
   const bf16* x;        // [T*B][512] time-major (row t*B + b), row stride ldx
   int64_t ldx;
@@ -82,13 +117,26 @@ struct LstmFwdArgs {
   float* saved;         // [T][nwg][5][256]: i, f, g, o (post-activation), c_t of the workgroup's lanes
   unsigned* cnt;        // one counter per sample group, 32 words apart
   unsigned* status;
-  int B, T, fence;
+  int B, T, mode;  // hand-off: 0 = counter, 1 = counter + agent-scope acquire, 2 = sentinel (the data is the flag)
+  unsigned* probe;  // diagnostic (OVQA_LSTM_PROBE=1): 100 MHz stamps of one wave's phases, 8 words per step; else NULL
 };
+#define LSTM_STAMP(slot)                                                                                   \
+  do {                                                                                                     \
+    if (a.probe != nullptr && blockIdx.x == 0 && tid == 128)                                               \
+      a.probe[t * 8 + (slot)] = (unsigned)__builtin_amdgcn_s_memrealtime();                                \
+  } while (0)
 
+// SENTINEL: hand-off form 2 (compile-time: behind a run-time switch the two forms' waits meet at the MFMAs, and the
+// sentinel form would wait there for the sweep it deliberately leaves in flight)
+template <bool SENTINEL>
 __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  bf16* tile16 = reinterpret_cast<bf16*>(lds_raw);           // [16 samples][16 units] bf16: h_t for the exchange
-  float* tile32 = reinterpret_cast<float*>(lds_raw + 512);   // [16 samples][16 units] fp32: h_t for y
+  // h_t tiles, double-buffered by step parity: with the sentinel hand-off ONE barrier per step is left, which orders the
+  // writes of step t + 2 behind the reads of step t, not those of step t + 1
+  bf16* tile16_0 = reinterpret_cast<bf16*>(lds_raw);          // [2][16 samples][16 units] bf16: h_t for the exchange
+  float* tile32_0 = reinterpret_cast<float*>(lds_raw + 1024); // [2][16 samples][16 units] fp32: h_t for y
+  unsigned char* hbuf = lds_raw + 4096;                       // [16 samples][HB_STRIDE bytes]: h_{t-1}, shared by the waves
+  constexpr int HB_STRIDE = 1024 + 16;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, q = l >> 4;
   const int nsg = a.B / 16, nwg = gridDim.x;
   int sg, ub;
@@ -134,52 +182,83 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
   float c = 0.f;
   for (int t = 0; t < T; t++) {
     f32x4 acc = accx;
+    LSTM_STAMP(0);
     if (t > 0) {
-      if (tid == 192) {  // wave 3 polls (wave 0 publishes, wave 1 writes y)
-        wait_counter(cnt, (unsigned)(NUB * t), a.status);
-        if (a.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      if (a.fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       // h_{t-1} of the 16 samples: block t of hseq, sc1 loads straight into the B-operand layout
       const unsigned hoff = (unsigned)((((int64_t)t * B + sg * 16 + n) * LH + q * 8) * 2);
       u32x4 hf[KS];
+      if constexpr (SENTINEL) {
+        // the four waves need the SAME 16 KB: each sweeps a quarter (K steps 4 w .. 4 w + 3) until it is ready and
+        // shares it through LDS -- four full sweeps per CU were bound by the CU's fetch path (64 KB at ~60 GB/s: 1.1 us
+        // per sweep, scripts/lstm_probe.py), a quarter each is a plain round trip
+        // One sweep at a time, issued here.  MEASURED alternatives (scripts/lstm_probe.py, lstm_bench.py; B = 64, T = 20):
+        // two sweeps in flight half a round trip apart, and a first sweep issued right behind this workgroup's own
+        // publish -- both slower (forward 101-111 us against 68): whatever the compiler waits for behind a polling loop
+        // (the input half's operands, requested in front of it) it waits for with vmcnt(0), i.e. also for the sweep
+        // that is deliberately in flight.
+        u32x4 pq[4];
+        for (int spins = 0;;) {
+          bool ok = true;
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) hf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff + kk * 64, 0, 16);
+          for (int j = 0; j < 4; j++) pq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff + (4 * w + j) * 64, 0, AUX_POLL);
+#pragma unroll
+          for (int j = 0; j < 4; j++) ok &= unit_ready(pq[j]);
+          if (__all(ok)) break;
+          if (++spins > SWEEP_LIMIT) {
+            __hip_atomic_store(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(hbuf + n * HB_STRIDE + (4 * w + j) * 64 + q * 16) = pq[j];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) hf[kk] = *reinterpret_cast<const u32x4*>(hbuf + n * HB_STRIDE + kk * 64 + q * 16);
+      } else {
+        if (tid == 192) {  // wave 3 polls (wave 0 publishes, wave 1 writes y)
+          wait_counter(cnt, (unsigned)(NUB * t), a.status);
+          if (a.mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (a.mode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) hf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff + kk * 64, 0, 16);
+      }
       f32x4 acc1 = zero4;
 #pragma unroll
       for (int kk = 0; kk < KS; kk += 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whh[kk], __builtin_bit_cast(bf16x8, hf[kk]), acc, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whh[kk + 1], __builtin_bit_cast(bf16x8, hf[kk + 1]), acc1, 0, 0, 0);
       }
+      LSTM_STAMP(1);
       acc += acc1;
     }
     const float ig = sigmoid_f(acc[0]), fg = sigmoid_f(acc[1]), gg = tanh_f(acc[2]), og = sigmoid_f(acc[3]);
     c = fg * c + ig * gg;
     const float h = og * tanh_f(c);
+    bf16* tile16 = tile16_0 + (t & 1) * 256;
+    float* tile32 = tile32_0 + (t & 1) * 256;
     tile16[n * 16 + w * 4 + q] = (bf16)h;
     tile32[n * 16 + w * 4 + q] = h;
+    LSTM_STAMP(2);
     __syncthreads();
+    LSTM_STAMP(3);
     if (w == 0) {
       if (l < 32) {  // lane -> (sample l >> 1, half l & 1): 16 bytes of the row's 32
         const u32x4 v = *reinterpret_cast<const u32x4*>(tile16 + (l >> 1) * 16 + (l & 1) * 8);
         const unsigned off = (unsigned)((((int64_t)(t + 1) * B + sg * 16 + (l >> 1)) * LH + ub * 16 + (l & 1) * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (l == 0 && t + 1 < T) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (!SENTINEL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0 && t + 1 < T) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else if (w == 1) {  // y[b][t][ub*16 ..]: lane -> (sample l >> 2, 16-byte quarter l & 3)
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile32 + (l >> 2) * 16 + (l & 3) * 4);
       *reinterpret_cast<f32x4*>(a.y + ((int64_t)(sg * 16 + (l >> 2)) * T + t) * LH + ub * 16 + (l & 3) * 4) = v;
     }
-    {  // what backward needs, AFTER the publish: the publishing wave's drain does not wait for these stores
-      float* sv = a.saved + ((int64_t)t * nwg + blockIdx.x) * 5 * 256 + tid;
-      store_saved(sv, ig);
-      store_saved(sv + 256, fg);
-      store_saved(sv + 512, gg);
-      store_saved(sv + 768, og);
-      store_saved(sv + 1024, c);
-    }
+    LSTM_STAMP(4);
     if (t + 1 < T) {  // the input half of step t + 1 (its operands were requested a step ago), then request t + 2
       accx = bias;
       accx1 = zero4;
@@ -195,6 +274,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
           xf[kk] = *reinterpret_cast<const bf16x8*>(xrow + (int64_t)(t + 2) * B * a.ldx + kk * 32);
       }
     }
+    {  // what backward needs, LAST: behind a loop the compiler waits for every outstanding memory operation before the
+      // first use of a loaded register, so these stores drain beside the next step's sweep, not in front of the MFMAs above
+      float* sv = a.saved + ((int64_t)t * nwg + blockIdx.x) * 5 * 256 + tid;
+      store_saved(sv, ig);
+      store_saved(sv + 256, fg);
+      store_saved(sv + 512, gg);
+      store_saved(sv + 768, og);
+      store_saved(sv + 1024, c);
+    }
+    LSTM_STAMP(5);
   }
 }
 
@@ -206,9 +295,10 @@ struct LstmBwdArgs {
   bf16* dgates;         // [T*B][2048] time-major, columns gate*512 + unit: output AND exchange buffer
   unsigned* cnt;
   unsigned* status;
-  int B, T, fence;
+  int B, T, mode;
 };
 
+template <bool SENTINEL>
 __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* part = reinterpret_cast<float*>(lds_raw);              // [4 waves][4 regs][64 lanes] fp32 partial dh tiles
@@ -245,16 +335,30 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   for (int t = T - 1; t >= 0; t--) {
     float dh = dyv;
     if (t < T - 1) {
-      if (tid == 192) {
-        wait_counter(cnt, (unsigned)(NUB * (T - 1 - t)), a.status);
-        if (a.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      if (a.fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       const unsigned goff = (unsigned)((((int64_t)(t + 1) * B + sg * 16 + n) * (4 * LH) + w * LH + q * 8) * 2);
       u32x4 gf[KS];
+      if constexpr (SENTINEL) {
+        // a full sweep is 64 KB per CU (every wave its own gate's columns): 1.1 us on the CU's fetch path, so a sweep that
+        // comes too early is expensive.  Probe first: one 16-byte piece per lane, chosen so that the wave sees a piece of
+        // every one of the 32 producers (lane (n, q) reads K step n: producer 2 n + q / 2), re-read until none shows the
+        // sentinel; the full sweep behind it still validates every unit
+        for (int spins = 0;;) {
+          const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + n * 64, 0, AUX_POLL);
+          if (__all(unit_ready(pv))) break;
+          if (++spins > SWEEP_LIMIT) break;  // (the sweep below reports it)
+          __builtin_amdgcn_s_sleep(1);
+        }
+        sweep_until_ready(rs, goff, gf, a.status);
+      } else {
+        if (tid == 192) {
+          wait_counter(cnt, (unsigned)(NUB * (T - 1 - t)), a.status);
+          if (a.mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (a.mode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) gf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + kk * 64, 0, 16);
+        for (int kk = 0; kk < KS; kk++) gf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + kk * 64, 0, 16);
+      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KS; kk += 2) {
@@ -295,8 +399,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
         const unsigned off = (unsigned)((((int64_t)t * B + sg * 16 + s) * (4 * LH) + g * LH + ub * 16 + hlf * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (l == 0 && t > 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (!SENTINEL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0 && t > 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -375,9 +481,11 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_simple(const float* __restr
   dp[3 * H] = from_f32<T>(dh * tc * og * (1.f - og));
 }
 
-bool lstm_fence() {
-  const char* e = getenv("OVQA_LSTM_FENCE");
-  return e && e[0] == '1';
+int lstm_handoff_mode() {  // read per call (tests flip it): 2 = sentinel (default), 0 = counter, 1 = counter + fence
+  const char* e = getenv("OVQA_LSTM_HANDOFF");
+  if (e && e[0] == 'c') return 0;
+  if (e && e[0] == 'f') return 1;
+  return 2;
 }
 
 constexpr int kSyncBytes = 4096;                 // counters (one 128-byte line per sample group) + status word
@@ -401,17 +509,24 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
              const float* b_ih, const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
              int64_t I, int64_t H, hipStream_t st) {
   if (persistent) {
+    const int mode = lstm_handoff_mode();
     hipError_t e = hipMemsetAsync(scratch, 0, kSyncBytes, st);
+    if (e == hipSuccess && mode == 2) e = hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st);  // the sentinel
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)hseq, (float*)saved,
-                  (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, lstm_fence() ? 1 : 0};
+                  (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, mode,
+                  (getenv("OVQA_LSTM_PROBE") && T * 8 <= 480) ? (unsigned*)scratch + 512 : nullptr};
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kPersistentLds);
+      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kPersistentLds);
       attr_set = true;
     }
-    hipLaunchKernelGGL(lstm_fwd_persistent_kernel, dim3((unsigned)((B / 16) * NUB)), dim3(256), kPersistentLds, st, a);
+    const dim3 grid((unsigned)((B / 16) * NUB));
+    if (mode == 2) hipLaunchKernelGGL(lstm_fwd_persistent_kernel<true>, grid, dim3(256), kPersistentLds, st, a);
+    else hipLaunchKernelGGL(lstm_fwd_persistent_kernel<false>, grid, dim3(256), kPersistentLds, st, a);
     return ovqa_check_launch("lstm_fwd(persistent)");
   }
   float* gates = (float*)saved;
@@ -432,17 +547,23 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
 int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt,
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st) {
   if (persistent) {
+    const int mode = lstm_handoff_mode();
     hipError_t e = hipMemsetAsync(scratch, 0, kSyncBytes, st);
+    if (e == hipSuccess && mode == 2) e = hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st);  // the sentinel
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmBwdArgs a{dy, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
-                  (unsigned*)scratch + 1000, (int)B, (int)T, lstm_fence() ? 1 : 0};
+                  (unsigned*)scratch + 1000, (int)B, (int)T, mode};
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kPersistentLds);
+      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kPersistentLds);
       attr_set = true;
     }
-    hipLaunchKernelGGL(lstm_bwd_persistent_kernel, dim3((unsigned)((B / 16) * NUB)), dim3(256), kPersistentLds, st, a);
+    const dim3 grid((unsigned)((B / 16) * NUB));
+    if (mode == 2) hipLaunchKernelGGL(lstm_bwd_persistent_kernel<true>, grid, dim3(256), kPersistentLds, st, a);
+    else hipLaunchKernelGGL(lstm_bwd_persistent_kernel<false>, grid, dim3(256), kPersistentLds, st, a);
     return ovqa_check_launch("lstm_bwd(persistent)");
   }
   const float* gates = (const float*)saved;

@@ -1115,8 +1115,9 @@ def test_lstm_fwd_bwd(B, T, H, dtype, route):
 @pytest.mark.skipif(FORCED_SIMPLE, reason="compares the persistent route with the per-step one")
 def test_lstm_persistent_equals_per_step_kernels_and_fence_form(monkeypatch):
     """The persistent launches against the one-launch-per-step kernels of the same library on the same bf16 operands
-    (same arithmetic up to summation order), run-to-run bitwise determinism, and the A/B switch that adds the agent-scope
-    acquire to every hand-off: the sc1-only hand-off must give the same bits (a stale read would not)."""
+    (same arithmetic up to summation order), run-to-run bitwise determinism under a busy chip, and the three hand-off
+    forms (sentinel = the data is the flag; counter; counter + agent-scope acquire): all deterministic, so they must give
+    the same bits (a stale or torn read would not)."""
     B, T, H = 64, 20, 512
     g = torch.Generator().manual_seed(77)
     s = H ** -0.5
@@ -1145,11 +1146,17 @@ def test_lstm_persistent_equals_per_step_kernels_and_fence_form(monkeypatch):
         for r, o in zip(ref, got):
             assert torch.equal(r, o), f"iteration {it}: the persistent LSTM is not deterministic"
     torch.cuda.synchronize()
-    monkeypatch.setenv("OVQA_LSTM_FENCE", "1")
-    fenced = run()
-    monkeypatch.delenv("OVQA_LSTM_FENCE")
-    for r, o in zip(ref, fenced):
-        assert torch.equal(r, o), "sc1-only hand-off differs from the fenced form"
+    for form in ("counter", "fence"):  # the default is the sentinel form (the data is the flag)
+        monkeypatch.setenv("OVQA_LSTM_HANDOFF", form)
+        for it in range(3):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    a @ a
+            other = run()
+            for r, o in zip(ref, other):
+                assert torch.equal(r, o), f"hand-off form '{form}' differs from the sentinel form"
+        monkeypatch.delenv("OVQA_LSTM_HANDOFF")
+    torch.cuda.synchronize()
     try:
         import subprocess, sys  # the switch is read once per process: ask a fresh one for the per-step result
         code = ("import torch, json, sys; sys.path.insert(0, %r); from openvivqa_amd import ops\n"
