@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
                     help="thread counts the CPU leg sweeps (one B=16 step each) before timing at the best")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (model, cross_modality, decode beam 1 / 3, m4c_decode) that the default "
+                         "single-GPU run of the headline workload appends under `secondary`")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test (no GPU): start the ranks exactly as a real run would, bring up a gloo "
                          "process group, count the ranks with an all-reduce and print the JSON skeleton with `n_gpus` = "
@@ -451,8 +454,9 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    res = None
     if rank == 0:
-        print(json.dumps({
+        res = ({
             "metric": "SECONDARY: M4C greedy decode samples/sec (12 MMT passes per sample), hidden 768, S=182",
             "value": round(world * B * args.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -461,10 +465,8 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
                        f"20 txt + 100 obj + 50 ocr + 12 dec positions, classifier(5000) || OcrPtrNet(768), B={B}/GPU, "
                        f"{passes} passes per decode, eager launches", "global_batch": world * B,
                        "parallelism": f"dp{world}"},
-            "ms_per_mmt_pass": round(dt / args.steps / passes * 1e3, 3)}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            "ms_per_mmt_pass": round(dt / args.steps / passes * 1e3, 3)})
+    return res
 
 
 def decode_bench(args, device, world, rank, dist, B, seed):
@@ -522,13 +524,14 @@ def decode_bench(args, device, world, rank, dist, B, seed):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    res = None
     if rank == 0:
         per_step = dt / args.steps / T
         es = 2 if args.dtype == "bf16" else 4
         n_w = sum(p.numel() for n, p in dec.named_parameters() if "word_emb" not in n and "pos_emb" not in n)
         # per decoding step: every weight once; self K/V prefix (mean length T/2) per live beam; encoder K/V per sample
         bytes_step = n_w * es + L * (B * beam * (T / 2) * 2 * D * es + B * NE * 2 * D * es)
-        print(json.dumps({
+        res = ({
             "metric": "SECONDARY: autoregressive decode tokens/sec (best beam), Decoder L=3 d=512, 237 encoder positions, T=20",
             "value": round(world * B * T * args.steps / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -540,10 +543,8 @@ def decode_bench(args, device, world, rank, dist, B, seed):
             "us_per_decoding_step": round(per_step * 1e6, 1),
             "roofline_decode": {"bound": "hbm", "bytes_per_decoding_step": int(bytes_step), "peak": 8000.0, "unit": "GB/s",
                                 "achieved": round(bytes_step / per_step / 1e9, 1),
-                                "frac": round(bytes_step / per_step / PEAK_HBM, 4)}}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                                "frac": round(bytes_step / per_step / PEAK_HBM, 4)}})
+    return res
 
 
 def ensure_library(local_rank):
@@ -669,52 +670,98 @@ def main():
         os.close(saved_stdout)
 
     import openvivqa_amd as A
+
+    def teardown():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.workload in ("m4c_decode", "decode"):
+        b = A.get_config(args.config).BENCH
+        A.set_compute_dtype(dtype)
+        A.manual_seed(b.SEED + rank)
+        torch.manual_seed(b.SEED)
+        fn = m4c_decode_bench if args.workload == "m4c_decode" else decode_bench
+        res = fn(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        return teardown()
+
+    out, ts, cfg = train_bench(args, args.workload, device, world, rank, dist, dtype)
+    if rank == 0:
+        b = cfg.BENCH
+        if args.workload == "stack":
+            if not args.no_roofline and args.dtype == "bf16":
+                add_rooflines(out, ts, cfg, device)
+            if world == 1 and not args.no_secondary and not args.rehearse_comm:
+                out["secondary"] = secondary_lines(args, device, dtype)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_threads)
+                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    teardown()
+
+
+# algorithmic matmul FLOPs per sample, forward + backward (= 3 x forward), of the whole models (the encoder figures are
+# SURVEY 8d's; the rest is 2 m n k of every nn.Linear in front of / behind the stacks at the bench shapes)
+MODEL_GFLOP_PER_SAMPLE = {
+    # stacks 16.31 + FeatureEmbedding 1024->512 (100 rows) 0.315 + word projection 300->512 (20 rows) 0.018 + LSTM
+    # 2 x [2048 x 512] (20 rows) 0.252 + pooling MLPs fc1 (120 rows) 0.189 + projections / classifier 0.004
+    "model": 17.09,
+    # CrossModalityEncoder L=6 live work 13.97 (dead cross-attention skipped) + FeatureEmbedding 2048->512
+    # 0.629 + pooling MLPs 0.189 + projections / classifier 0.004
+    "cross_modality": 14.79,
+}
+
+
+def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, warmup=None, repeats=None):
+    """Build the workload (stack = BASELINE's metric; model / cross_modality = whole models through build_model), capture
+    its step, time `steps` steps as the contract says.  Returns (JSON dict on rank 0 else None, TrainStep, config)."""
+    import openvivqa_amd as A
     from openvivqa_amd import ops
     from openvivqa_amd.mcan_stack import MCANEncoderStack, synthetic_batch
     from openvivqa_amd.train import TrainStep, noam_lr_scale
-
-    if args.workload == "cross_modality":
-        args.config = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "cross_modality_bench.yaml")
-    cfg = A.get_config(args.config)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    repeats = args.repeats if repeats is None else repeats
+    config = args.config
+    if workload == "cross_modality":
+        config = os.path.join(ROOT, "configs", "cross_modality_bench.yaml")
+    cfg = A.get_config(config)
     b = cfg.BENCH
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     A.set_compute_dtype(dtype)
     A.manual_seed(b.SEED + rank)
     torch.manual_seed(b.SEED)  # identical initial weights on every rank
-    if args.workload == "m4c_decode":
-        return m4c_decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
-    if args.workload == "decode":
-        return decode_bench(args, device, world, rank, dist, int(b.BATCH_PER_GPU), int(b.SEED))
-    whole_model = args.workload in ("model", "cross_modality")
+    whole_model = workload in ("model", "cross_modality")
     D = cfg.MODEL.D_MODEL
-    model = None if whole_model else MCANEncoderStack(cfg.MODEL).to(device).train()
+    loss_buf = torch.zeros(1, device=device)
     if not whole_model:
+        model = MCANEncoderStack(cfg.MODEL).to(device).train()
         v, vm, t, tm = synthetic_batch(b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, b.MIN_REGIONS, b.MIN_TOKENS,
                                        b.SEED + rank, device, dtype)
-    loss_buf = torch.zeros(1, device=device)
-    # MSE against fixed random targets: mean(out^2) alone is constant for LayerNorm outputs
-    # (degenerate gradient), see DESIGN.md section 6.
-    if not whole_model:
+        # MSE against fixed random targets: mean(out^2) alone is constant for LayerNorm outputs
+        # (degenerate gradient), see DESIGN.md section 6.
         gt = torch.Generator().manual_seed(b.SEED + 7919 * (rank + 1))
         tgt_v = torch.randn(v.shape, generator=gt).to(device=device, dtype=dtype)
         tgt_t = torch.randn(t.shape, generator=gt).to(device=device, dtype=dtype)
 
-    def forward_loss(v_, vm_, t_, tm_):
-        vo, lo = model(v_, vm_, t_, tm_)
-        dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss_buf, accumulate=False, target=tgt_v)
-        dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
-        return (vo, lo), (dvo, dlo)
-
-    if whole_model:
+        def forward_loss(v_, vm_, t_, tm_):
+            vo, lo = model(v_, vm_, t_, tm_)
+            dvo = ops.sq_loss_fwd_bwd(vo.detach(), loss_buf, accumulate=False, target=tgt_v)
+            dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
+            return (vo, lo), (dvo, dlo)
+        batch = (v, vm, t, tm)
+    else:
         from types import SimpleNamespace
         from openvivqa_amd.builders import build_model
+        from openvivqa_amd.losses import NLLLoss, nll_loss_fwd_bwd
 
         class Vocab:
             padding_idx, total_answers = 0, int(b.ANSWERS)
 
             def __len__(self):
                 return int(b.VOCAB)
-        torch.manual_seed(b.SEED)
         model = build_model(cfg.MODEL, Vocab()).train()
         g = torch.Generator().manual_seed(b.SEED + rank)
         feats = torch.randn(b.BATCH_PER_GPU, b.REGIONS, int(b.D_FEATURE), generator=g)
@@ -724,151 +771,177 @@ def main():
         ntok = torch.randint(b.MIN_TOKENS, b.TOKENS + 1, (b.BATCH_PER_GPU,), generator=g)
         toks[torch.arange(b.TOKENS)[None, :] >= ntok[:, None]] = 0
         ans = torch.randint(0, int(b.ANSWERS), (b.BATCH_PER_GPU,), generator=g).to(device)
-        v, vm, t, tm = feats.to(device=device, dtype=dtype), toks.to(device), None, None
-        from openvivqa_amd.losses import NLLLoss, nll_loss_fwd_bwd
         nll = NLLLoss()  # (drop-in for the reference's nn.NLLLoss: classification_task.py:125-127)
 
-        def forward_loss(feats_, toks_):  # noqa: F811
-            out = model(SimpleNamespace(region_features=feats_, question_tokens=toks_))
-            if args.workload == "model":  # MCAN returns log-probabilities: loss and its gradient from ONE launch
-                return [out], [nll_loss_fwd_bwd(out, ans, loss_buf)]
-            return nll(out, ans)  # (CrossModalityTransformer feeds raw logits to NLLLoss, as upstream)
+        def forward_loss(feats_, toks_):
+            out_ = model(SimpleNamespace(region_features=feats_, question_tokens=toks_))
+            if workload == "model":  # MCAN returns log-probabilities: loss and its gradient from ONE launch
+                return [out_], [nll_loss_fwd_bwd(out_, ans, loss_buf)]
+            return nll(out_, ans)  # (CrossModalityTransformer feeds raw logits to NLLLoss, as upstream)
+        batch = (feats.to(device=device, dtype=dtype), toks.to(device))
     comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
-                   lr_lambda=lambda s: noam_lr_scale(s, D, int(b.WARMUP)), use_graph=not args.no_graph,
+                   lr_lambda=lambda s_: noam_lr_scale(s_, D, int(b.WARMUP)), use_graph=not args.no_graph,
                    comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
                    force_comm=args.rehearse_comm)
-    if whole_model:
-        batch, loss_buf = (v, vm), ts.loss
+    if workload == "cross_modality":
+        loss_buf = ts.loss  # (the scalar-loss protocol: TrainStep copies the loss into its own buffer)
     else:
-        batch = (v, vm, t, tm)
         ts.loss = loss_buf
 
     ts.prepare(*batch)  # graph capture happens here, never inside the timed region (even with --warmup 0)
     # the synthetic batch is resident in HBM: hand the step the graph's own input buffers (what a data loader
     # would fill in place) instead of paying four device-to-device copies per step
     batch = tuple(ts.static_inputs)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ts.step(*batch)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.step(*batch)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    # further windows of the same K steps (not part of `value`): spread of the measurement
-    windows = [dt]
-    for _ in range(max(0, args.repeats - 1)):
+
+    def window():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
             ts.step(*batch)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        w = time.perf_counter() - t1
+        w = time.perf_counter() - t0
         if dist is not None:
             tw = torch.tensor([w], device=device, dtype=torch.float64)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             w = tw.item()
-        windows.append(w)
+        return w
+    dt = window()
+    # further windows of the same K steps (not part of `value`): spread of the measurement
+    windows = [dt] + [window() for _ in range(max(0, repeats - 1))]
     final_loss = float(loss_buf.item())
     comm_stats = ts.timed_comm_step(*batch) if (dist is not None) else {}
+    if rank != 0:
+        return None, ts, cfg
+    import statistics
+    ms = dt / steps * 1e3
+    value = world * b.BATCH_PER_GPU * steps / dt
+    flops = FLOPS_PER_SAMPLE_FWD_BWD if not whole_model else MODEL_GFLOP_PER_SAMPLE[workload] * 1e9
+    out = {
+        "metric": "VQA samples/sec fwd+bwd, MCAN d=512 L=6, B=64, 100 regions x 20 tokens",
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "world_size": dist.get_world_size() if (dist is not None and world > 1) else 1,
+        "device_count": torch.cuda.device_count(),
+        "config": {"workload": "configs[1]: MCAN encoder stack (Encoder + GuidedAttentionEncoder) d=512 L=6 H=8 "
+                   "dff=2048, 64 samples/GPU x (100 regions + 20 tokens), padded lengths, dropout 0.1, "
+                   "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
+                   "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
+                   "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if (world > 1 or args.rehearse_comm) else None,
+                   "grad_segments": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
+        "final_loss": round(final_loss, 6),
+        "repeats": len(windows),
+        "ms_per_step_median": round(statistics.median(windows) / steps * 1e3, 3),
+        "ms_per_step_min": round(min(windows) / steps * 1e3, 3),
+        "ms_per_step_max": round(max(windows) / steps * 1e3, 3),
+        "gradient_exchange": comm_stats or None,
+        "step_tflops": round(value * flops / 1e12, 1),
+        "step_frac_of_bf16_peak": round(value * flops / world / PEAK_BF16, 4),
+    }
+    if workload == "model":
+        out["metric"] = "SECONDARY: VQA samples/sec fwd+bwd, whole MCAN model (embeddings + stacks + head), L=6, B=64"
+        out["config"]["workload"] = ("secondary (SURVEY 8d model-level): MCAN via build_model from configs/mcan_bench.yaml (the "
+                                     "reference YAML's MODEL node, L=6): FeatureEmbedding 1024->512, LSTMTextEmbedding |V|=4000 "
+                                     "(embedding rows, 300->512 projection, persistent-kernel LSTM), encoder stacks, "
+                                     "attention-pooling head, 353-way classifier + log_softmax, NLLLoss, Adam + Noam: every "
+                                     "launch of the step is the library's")
+    elif workload == "cross_modality":
+        out["metric"] = ("SECONDARY (BASELINE configs[2]): VQA samples/sec fwd+bwd, CrossModalityTransformer "
+                         "d=512 L=6, 64 samples/GPU")
+        out["config"]["workload"] = ("secondary, BASELINE configs[2]: CrossModalityTransformer via build_model from "
+                                     "configs/cross_modality_bench.yaml (the reference YAML's MODEL node, L=6): "
+                                     "FeatureEmbedding 2048->512, UsualEmbedding |V|=4000, 6 CrossModalityEncoder "
+                                     "layers (4 attention + 2 feed-forward blocks each), pooling head, 353-way "
+                                     "classifier, NLLLoss on the logits as upstream, Adam + Noam; 100 regions x 20 "
+                                     "tokens, data parallel")
+    if whole_model:
+        out["algorithmic_gflop_per_sample_fwd_bwd"] = MODEL_GFLOP_PER_SAMPLE[workload]
+    return out, ts, cfg
 
-    if rank == 0:
-        import statistics
-        ms = dt / args.steps * 1e3
-        value = world * b.BATCH_PER_GPU * args.steps / dt
-        out = {
-            "metric": "VQA samples/sec fwd+bwd, MCAN d=512 L=6, B=64, 100 regions x 20 tokens",
-            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "world_size": dist.get_world_size() if (dist is not None and world > 1) else 1,
-            "device_count": torch.cuda.device_count(),
-            "config": {"workload": "configs[1]: MCAN encoder stack (Encoder + GuidedAttentionEncoder) d=512 L=6 H=8 "
-                       "dff=2048, 64 samples/GPU x (100 regions + 20 tokens), padded lengths, dropout 0.1, "
-                       "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
-                       "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
-                       "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if (world > 1 or args.rehearse_comm) else None,
-                       "grad_segments": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
-            "final_loss": round(final_loss, 6),
-            "repeats": len(windows),
-            "ms_per_step_median": round(statistics.median(windows) / args.steps * 1e3, 3),
-            "ms_per_step_min": round(min(windows) / args.steps * 1e3, 3),
-            "ms_per_step_max": round(max(windows) / args.steps * 1e3, 3),
-            "gradient_exchange": comm_stats or None,
-            "step_tflops": round(value * FLOPS_PER_SAMPLE_FWD_BWD / 1e12, 1),
-            "step_frac_of_bf16_peak": round(value * FLOPS_PER_SAMPLE_FWD_BWD / world / PEAK_BF16, 4),
-        }
-        if whole_model:  # secondary lines: whole models; no roofline / CPU legs
-            if args.workload == "model":
-                out["metric"] = "SECONDARY: VQA samples/sec fwd+bwd, whole MCAN model (embeddings + stacks + head), L=6, B=64"
-                out["config"]["workload"] = ("secondary (SURVEY 8d model-level): MCAN model via build_model: FeatureEmbedding "
-                                             "1024->512, LSTMTextEmbedding |V|=4000 (torch/MIOpen LSTM), encoder stacks on "
-                                             "the HIP path, attention-pooling head, 353-way classifier, NLLLoss, Adam")
-            else:
-                out["metric"] = ("SECONDARY (BASELINE configs[2]): VQA samples/sec fwd+bwd, CrossModalityTransformer "
-                                 "d=512 L=6, 64 samples/GPU")
-                out["config"]["workload"] = ("secondary, BASELINE configs[2]: CrossModalityTransformer via build_model from "
-                                             "configs/cross_modality_bench.yaml (the reference YAML's MODEL node, L=6): "
-                                             "FeatureEmbedding 2048->512, UsualEmbedding |V|=4000, 6 CrossModalityEncoder "
-                                             "layers (4 attention + 2 feed-forward blocks each), pooling head, 353-way "
-                                             "classifier, NLLLoss on the logits as upstream, Adam + Noam; 100 regions x 20 "
-                                             "tokens, data parallel")
-            for k in ("step_tflops", "step_frac_of_bf16_peak"):
-                out.pop(k)
-            print(json.dumps(out), flush=True)
-            if dist is not None:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
-        if not args.no_roofline and args.dtype == "bf16":
-            sa = cfg.MODEL.SELF_ENCODER.SELF_ATTENTION
-            warm = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF,
-                                  cfg.MODEL.SELF_ENCODER.LAYERS)
-            fams = instep_probe(ts)
-            gemm_fams = {k: v for k, v in fams.items() if not k.startswith("attn_")}
-            dom = max(gemm_fams, key=lambda k: gemm_fams[k]["time_s"])
-            f = fams[dom]
-            achieved = f["flops"] / f["time_s"] / 1e12
-            traffic, tfile = pmc_traffic(KERNEL_OF_FAMILY[dom])
-            traffic_src = (f"{tfile}: FETCH_SIZE / WRITE_SIZE PMC passes of this same step under rocprofv3, committed with "
-                           "the round -- read from the file, not collected by this run") if tfile else None
-            out["roofline"] = {
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": KERNEL_OF_FAMILY[dom] + " ...>", "launches_per_step": f["launches"],
-                "avg_launch_us": round(f["time_s"] / f["launches"] * 1e6, 2),
-                "algorithmic_flops_per_launch": round(f["flops"] / f["launches"]),
-                "method": "in-step: every launch of the family inside one eager step of the real workload carries its own "
-                          "start/stop HIP events (hipExtLaunchKernel via ovqa_launch_timing_begin/_end: the dispatch "
-                          "packet's begin/end timestamps on the launch stream; gate kernel first; cold operands); "
-                          "profiles/r04_step_kernel_stats.csv holds the rocprofv3 --kernel-trace --stats averages of "
-                          "the same step",
-                "families_in_step": {k: {"launches": v["launches"], "avg_launch_us": round(v["time_s"] / v["launches"] * 1e6, 2),
-                                         "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in gemm_fams.items()},
-                "families_warm_replay": warm["families"],
-            }
-            # secondary: the attention kernels of the step, each on its rooflines
-            out["roofline_attention"] = attention_rooflines(fams)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_threads)
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def add_rooflines(out, ts, cfg, device):
+    b = cfg.BENCH
+    D = cfg.MODEL.D_MODEL
+    sa = cfg.MODEL.SELF_ENCODER.SELF_ATTENTION
+    warm = roofline_probe(device, b.BATCH_PER_GPU, b.REGIONS, b.TOKENS, D, sa.D_FF, cfg.MODEL.SELF_ENCODER.LAYERS)
+    fams = instep_probe(ts)
+    gemm_fams = {k: v for k, v in fams.items() if not k.startswith("attn_")}
+    dom = max(gemm_fams, key=lambda k: gemm_fams[k]["time_s"])
+    f = fams[dom]
+    achieved = f["flops"] / f["time_s"] / 1e12
+    traffic, tfile = pmc_traffic(KERNEL_OF_FAMILY[dom])
+    traffic_src = (f"{tfile}: FETCH_SIZE / WRITE_SIZE PMC passes of this same step under rocprofv3, committed with "
+                   "the round -- read from the file, not collected by this run") if tfile else None
+    out["roofline"] = {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+        "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": KERNEL_OF_FAMILY[dom] + " ...>", "launches_per_step": f["launches"],
+        "avg_launch_us": round(f["time_s"] / f["launches"] * 1e6, 2),
+        "algorithmic_flops_per_launch": round(f["flops"] / f["launches"]),
+        "method": "in-step: every launch of the family inside one eager step of the real workload carries its own "
+                  "start/stop HIP events (hipExtLaunchKernel via ovqa_launch_timing_begin/_end: the dispatch "
+                  "packet's begin/end timestamps on the launch stream; gate kernel first; cold operands); "
+                  "profiles/ holds the rocprofv3 --kernel-trace averages of the same step (replay window)",
+        "families_in_step": {k: {"launches": v["launches"], "avg_launch_us": round(v["time_s"] / v["launches"] * 1e6, 2),
+                                 "tflops": round(v["flops"] / v["time_s"] / 1e12, 1)} for k, v in gemm_fams.items()},
+        "families_warm_replay": warm["families"],
+    }
+    # secondary: the attention kernels of the step, each on its rooflines
+    out["roofline_attention"] = attention_rooflines(fams)
+
+
+def secondary_lines(args, device, dtype):
+    """The other BASELINE configurations on the same clock as the headline: after the headline window,
+    in this process, each in try / except -- a failure becomes an "error" string, never a non-zero exit of the headline.
+    Short windows (20 steps / 5 decodes) so that the whole default run stays within a couple of minutes."""
+    import copy
+    res = {}
+
+    def compact(line, extra=()):
+        keep = ("value", "unit", "ms_per_step", "steps", "warmup") + tuple(extra)
+        d = {k: line[k] for k in keep if k in line}
+        d["config"] = line["config"]["workload"]
+        return d
+
+    def guarded(name, fn):
+        try:
+            torch.cuda.synchronize()
+            res[name] = fn()
+        except Exception as exc:  # noqa: BLE001
+            res[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        finally:
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+
+    for wl in ("model", "cross_modality"):
+        guarded(wl, lambda wl=wl: compact(train_bench(args, wl, device, 1, 0, None, dtype, steps=20, warmup=3, repeats=1)[0],
+                                          ("step_frac_of_bf16_peak", "algorithmic_gflop_per_sample_fwd_bwd")))
+    a2 = copy.copy(args)
+    a2.steps, a2.warmup = 5, 2
+    import openvivqa_amd as A
+    cfg = A.get_config(args.config)
+    B, seed = int(cfg.BENCH.BATCH_PER_GPU), int(cfg.BENCH.SEED)
+    for beam in (1, 3):
+        a3 = copy.copy(a2)
+        a3.beam = beam
+
+        def run_decode(a3=a3):
+            line = decode_bench(a3, device, 1, 0, None, B, seed)
+            d = compact(line, ("us_per_decoding_step",))
+            d["frac_of_hbm_peak"] = line["roofline_decode"]["frac"]
+            return d
+        guarded(f"decode_beam{beam}", run_decode)
+    guarded("m4c_decode", lambda: compact(m4c_decode_bench(a2, device, 1, 0, None, B, seed), ("ms_per_mmt_pass",)))
+    return res
 
 
 if __name__ == "__main__":
