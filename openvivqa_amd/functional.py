@@ -95,8 +95,12 @@ def _lin_operands(arena, lin):
 def _armed_queue():
     """The deferred-work queue, with its flush registered to run when the current backward pass ends."""
     q = wgrad_queue()
-    if not q.items and not q.inflight and not q.reduces:
+    # armed = a flush callback is registered for the running backward call.  An EMPTY queue re-arms as well: a backward pass
+    # that raised never ran its callback (a second registration is harmless, the flush of an empty queue is a no-op); the
+    # flag alone would not do, a phased backward holds LayerNorm reductions in the queue across its phases.
+    if not getattr(q, "armed", False) or not (q.items or q.inflight or q.reduces):
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+        q.armed = True
     return q
 
 

@@ -306,6 +306,12 @@ class WgradQueue:
         self.defer_uploads = False  # capture mode of a harness: tables are uploaded ONCE after the capture
         self._deferred = []         # (pinned host, device, nbytes) of tables a captured launch reads
         self._producers = set()     # streams (other than the flushing one) whose kernels wrote queued operands
+        # A backward pass differentiated in PHASES (train.TrainStep, N > 1) flushes the weight gradients at the end of
+        # every phase -- its gradient segment goes on the wire -- but the LayerNorm dgamma / dbeta reductions write the 1-D
+        # tail of the arena, which belongs to the LAST segment: held until the last phase they are one launch, not one per
+        # phase (5 x 9.5 us against 15 in the MCAN step)
+        self.hold_reduces = False
+        self.armed = False          # functional._armed_queue: a flush callback is registered for the running backward call
 
     def _note_producer(self, t):
         if t.is_cuda:
@@ -428,8 +434,24 @@ class WgradQueue:
         # group), each XCD has a private L2, and all tiles of one problem stream the same dY / X panels.
         # Whole problems are therefore binned per XCD (longest-processing-time first) and the bins are
         # interleaved; without this every XCD fetches every panel (measured: 2.9 GB of L2 misses per launch).
+        # A problem far above an XCD's fair share is split (whole column blocks of tiles stay together: they share the dY
+        # panel): in the ONE launch of a plain step no problem is (61 problems, 336 tiles per XCD), but a launch per backward
+        # phase (N > 1) can consist of little more than the hoisted K / V projection -- 192 tiles that one XCD then walked
+        # alone while seven idled (73 us for 385 light tiles).  The other operand's panel is fetched once per XCD that
+        # takes a part: M x K x 2 bytes, small beside the idle time it removes.
+        fair = sum(w for w, _, _ in per_problem) / 8.0
+        parts = []
+        for work, M, tl in per_problem:
+            n_parts = min(8, int(work / max(fair, 1.0) + 0.75)) if work > 1.25 * fair else 1
+            if n_parts <= 1:
+                parts.append((work, M, tl))
+                continue
+            per = (len(tl) + n_parts - 1) // n_parts
+            for i in range(0, len(tl), per):
+                chunk = tl[i:i + per]
+                parts.append((work * len(chunk) / len(tl), M, chunk))
         bins = [[0, []] for _ in range(8)]
-        for work, M, tl in sorted(per_problem, key=lambda t: (-t[1], -t[0])):
+        for work, M, tl in sorted(parts, key=lambda t: (-t[1], -t[0])):
             b = min(bins, key=lambda bb: bb[0])
             b[0] += work
             b[1].extend(tl)
@@ -484,10 +506,22 @@ class WgradQueue:
         self._deferred = []
         torch.cuda.synchronize()
 
+    def abandon(self):
+        """Drop everything queued and every table upload deferred by an ABORTED stream capture (nothing of it ran):
+        the next pass starts from an empty queue."""
+        self.items, self.reduces, self.ntiles = [], [], 0
+        self.inflight, self._deferred = [], []
+        self._producers.clear()
+        self.defer_uploads = False
+        self.hold_reduces = False
+        self.armed = False
+
     def finish(self):
         """End of the backward pass: launch the remainder and make the main stream wait for the side stream."""
+        self.armed = False  # (the flush callback of this backward call has run: the next call registers its own)
         self._join_producers()
-        self._flush_reduces()
+        if not self.hold_reduces:
+            self._flush_reduces()
         self.flush()
         if self._used_side:
             for dev, side in self._side.items():

@@ -33,12 +33,22 @@ def main():
         if period is not None:
             break
     if period is None:
-        raise SystemExit("no periodic tail found in the kernel trace")
-    rows, names = rows[:n], names[:n]
-    steps = min(steps, n // period)
-    while steps > 1 and names[n - steps * period:n - (steps - 1) * period] != names[n - period:]:
-        steps -= 1
-    win = rows[n - steps * period:]
+        # kernels of several streams interleave differently from step to step (the data-parallel exchange beside
+        # backward): delimit the steps by a kernel that runs exactly once per step instead
+        delim = next((d for d in ("begin_step_kernel", "adam_tiled_kernel") if sum(d in x for x in names) >= 3), None)
+        if delim is None:
+            raise SystemExit("no periodic tail found in the kernel trace")
+        marks = [i for i, x in enumerate(names) if delim in x]
+        steps = min(steps, len(marks) - 1)
+        lo, hi = marks[-1 - steps], marks[-1]
+        win = rows[lo:hi]
+        period = round(len(win) / steps, 1)
+    else:
+        rows, names = rows[:n], names[:n]
+        steps = min(steps, n // period)
+        while steps > 1 and names[n - steps * period:n - (steps - 1) * period] != names[n - period:]:
+            steps -= 1
+        win = rows[n - steps * period:]
     agg = OrderedDict()
     for r in win:
         a = agg.setdefault(short(r["Kernel_Name"]), [0, 0.0, 1e30, 0.0])

@@ -97,12 +97,17 @@ class WgradQueue:
     def __init__(self):
         self.items = []
         self.inflight = []
+        self.reduces = []
+        self.hold_reduces = False
 
     def finish(self):
         self.flush()
 
     def reserve(self, n):
         pass
+
+    def abandon(self):
+        self.items = []
 
     def add(self, dy, x, dw, accumulate, db=None, accumulate_db=False):
         self.items.append((dy, x, dw, accumulate, db, accumulate_db))

@@ -134,6 +134,41 @@ def test_whole_step_graph_equals_phase_graphs_with_eager_adam(single_rank_group,
     assert int(a.optim.step_t.item()) == 5 == a.optim.host_step and abs(float(a.optim.lr_eff) - 1e-4 * noam_lr_scale(4, 512, 3)) < 1e-12
 
 
+def test_failed_whole_step_capture_falls_back_cleanly(single_rank_group, monkeypatch):
+    """a whole-step capture that dies MID-BODY -- behind the first segments' collectives -- must leave
+    neither work handles of the aborted capture in the reducer (a later ``wait_segment(k)`` would join a dead handle, and
+    Adam would run before segment k's all-reduce) nor queued products / deferred table uploads in the grouped-dW queue.
+    The fallback (one graph per backward phase, exchange and Adam from the host) must then give the bits of a harness that
+    took that route from the start."""
+    from openvivqa_amd import functional as Fn
+    from openvivqa_amd.train import TrainStep, noam_lr_scale
+    kw = dict(lr_lambda=lambda s: noam_lr_scale(s, 512, 3), force_comm=True, overlap_mb=16.0)
+    _, a, batch = _make(2, **kw)
+    real, calls = TrainStep._release, {"n": 0}
+
+    def failing(self, k):
+        real(self, k)
+        calls["n"] += 1
+        if torch.cuda.is_current_stream_capturing() and self.whole is None and k == 1 and calls["n"] < 64:
+            raise RuntimeError("injected: the capture dies behind the second segment's collective")
+    monkeypatch.setattr(TrainStep, "_release", failing)
+    a.prepare(*batch)
+    monkeypatch.setattr(TrainStep, "_release", real)
+    assert a.whole is None and a.graphs is not None and len(a.segments) >= 3
+    assert a.reducer._done == [] and not a.reducer._pending
+    q = Fn.wgrad_queue()
+    assert not q.items and not q.reduces and not q._deferred and not q.defer_uploads
+    monkeypatch.setenv("OVQA_WHOLE_STEP_GRAPH", "0")
+    _, b, _ = _make(2, **kw)
+    b.prepare(*batch)
+    for i in range(4):
+        a.step(*batch)
+        b.step(*batch)
+        torch.cuda.synchronize()
+        assert float(a.loss) == float(b.loss), i
+        assert torch.equal(a.arena.master, b.arena.master), i
+
+
 def test_checkpoint_resume_inside_the_one_graph_step_is_bitwise():
     """Save after 3 steps (model state_dict + TrainStep.state_dict), rebuild everything, load, take 2 more: the weights,
     moments and loss of the uninterrupted 5-step run, bit for bit -- the step is deterministic, and the device-side
