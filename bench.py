@@ -835,7 +835,7 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
                    "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
                    "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
                    "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if (world > 1 or args.rehearse_comm) else None,
-                   "grad_segments": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
+                   "grad_segments": ts.n_exchanges, "backward_phases": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
         "final_loss": round(final_loss, 6),
         "repeats": len(windows),
         "ms_per_step_median": round(statistics.median(windows) / steps * 1e3, 3),

@@ -311,6 +311,7 @@ class WgradQueue:
         # tail of the arena, which belongs to the LAST segment: held until the last phase they are one launch, not one per
         # phase (5 x 9.5 us against 15 in the MCAN step)
         self.hold_reduces = False
+        self.hold_items = False     # the same for the products of a phase that releases no gradient segment
         self.armed = False          # functional._armed_queue: a flush callback is registered for the running backward call
 
     def _note_producer(self, t):
@@ -514,6 +515,7 @@ class WgradQueue:
         self._producers.clear()
         self.defer_uploads = False
         self.hold_reduces = False
+        self.hold_items = False
         self.armed = False
 
     def finish(self):
@@ -522,6 +524,8 @@ class WgradQueue:
         self._join_producers()
         if not self.hold_reduces:
             self._flush_reduces()
+        if self.hold_items:
+            return  # (the queued operands stay referenced; the next phase's flush launches them with its own)
         self.flush()
         if self._used_side:
             for dev, side in self._side.items():

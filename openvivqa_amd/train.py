@@ -583,7 +583,9 @@ class TrainStep:
                         break
             now = [(o, g) for o, g in zip(outs, grads) if id(o) not in srcs]
             self._live = {"cuts": cuts, "outs": outs, "grads": grads, "extra": extra}
-            self._queue().hold_reduces = bool(cuts)  # LayerNorm-parameter reductions: one launch, in the LAST phase
+            q = self._queue()
+            q.hold_reduces = bool(cuts)  # LayerNorm-parameter reductions: one launch, in the LAST phase
+            q.hold_items = bool(cuts) and len(self.segments) == len(cuts) + 1 and not self.segments[0]
             if now:
                 torch.autograd.backward([o for o, _ in now], [g for _, g in now])
             if not cuts:
@@ -601,8 +603,11 @@ class TrainStep:
                 for o, og in live["extra"].get(k, []):
                     roots.append(o)
                     rgrads.append(og)
+                q = self._queue()
+                j = len(live["cuts"]) - k  # this phase's index in backward order
+                q.hold_items = k > 0 and len(self.segments) == len(live["cuts"]) + 1 and not self.segments[j]
                 if k == 0:
-                    self._queue().hold_reduces = False
+                    q.hold_reduces = False
                 if roots:
                     torch.autograd.backward(roots, rgrads)
                 elif k == 0:
@@ -676,15 +681,21 @@ class TrainStep:
             if acc_n >= thresh:
                 active.add(n_all - 1 - j)
                 acc_n = 0
+        release = set(active)  # cuts behind which a segment goes on the wire
         for b in barriers:  # a tensor feeding several sections must be cut if any later section boundary is
             if any(i > b for i in active):
                 active.add(b)
+        # a cut that only the barrier rule asked for ends a PHASE, not a segment: its ranges ride with the next release
+        # (an empty segment: no exchange, and the phase's weight-gradient products stay queued -- one grouped launch fewer)
         segments, acc = [], []
         for j in range(nph - 1):
             acc += per_phase[j]
             if n_all - 1 - j in active:
-                segments.append(_merge(acc))
-                acc = []
+                if n_all - 1 - j in release:
+                    segments.append(_merge(acc))
+                    acc = []
+                else:
+                    segments.append([])
         done = [r for seg in segments for r in seg]
         segments.append(_complement(done, 0, a.numel))  # everything else: final only when backward has ended
         self.segments = segments
@@ -948,6 +959,11 @@ class TrainStep:
                          "exposed_ms": round(max(0.0, last_ready.elapsed_time(done)), 4)})
         return {"segments": segs, "exposed_ms_total": round(max(s["exposed_ms"] for s in segs), 4),
                 "world": self.reducer.world, "comm_dtype": str(self.reducer.comm_dtype).replace("torch.", "")}
+
+    @property
+    def n_exchanges(self) -> int:
+        """Gradient segments that actually go on the wire (phases that only a barrier cut created release nothing)."""
+        return sum(1 for seg in self.segments if seg)
 
     @property
     def graph(self):  # single-graph view kept for callers that replay the captured fwd+bwd themselves

@@ -99,9 +99,11 @@ class WgradQueue:
         self.inflight = []
         self.reduces = []
         self.hold_reduces = False
+        self.hold_items = False
 
     def finish(self):
-        self.flush()
+        if not self.hold_items:
+            self.flush()
 
     def reserve(self, n):
         pass
