@@ -206,3 +206,86 @@ def test_reference_base_transformer_without_containers_alias_is_refused(cpu_ops,
                 C._refuse_foreign_stateful_parent)
     finally:
         _restore(saved)
+
+
+@needs_reference
+def test_reference_iterative_mcan_from_unmodified_yaml(cpu_ops, monkeypatch):
+    """The one shipped model that joins everything on the path: the reference's UNMODIFIED
+    ``models/iterative_mcan.py`` -- MCA stack, ``PositionWiseFeedForward`` used directly (:26), the stateful ``Decoder`` under
+    ``tasks/open_ended_task.py:128-169`` -- built from the unmodified ``configs/iterative_mcan.yaml`` over this package's
+    builders and containers: the teacher-forced forward and ``beam_search(beam_size=3)`` equal the same glue code over the
+    oracle's modules (same weights; the oracle side searches with ``oracle_generate``, its own restated search)."""
+    import oracle as O
+    from openvivqa_amd.config import get_config
+    saved = _reference_tree(monkeypatch, alias_containers=True)
+    try:
+        import models.iterative_mcan as ref_im  # noqa: E402  (the reference's file, unmodified)
+        import openvivqa_amd.modules as M
+        assert ref_im.__file__.startswith(REF)
+        cfg = get_config(os.path.join(REF, "configs", "iterative_mcan.yaml")).MODEL
+        cfg.DEVICE = "cpu"
+
+        class Vocab:
+            max_answer_length, padding_idx, bos_idx, eos_idx = 7, 0, 1, 2
+
+            def __len__(self):
+                return 40
+        vocab = Vocab()
+        torch.manual_seed(21)
+        ours = ref_im.IterativeMCAN(cfg, vocab)
+        assert type(ours).__module__ == "models.iterative_mcan" and isinstance(ours.decoder, M.Decoder)
+        assert isinstance(ours.self_encoder, M.Encoder) and isinstance(ours.guided_encoder, M.GuidedAttentionEncoder)
+        assert type(ours.fusion).__module__ == "models.modules.positionwise_feed_forward"  # the reference's own class (:26)
+        text = {"UsualEmbedding": O.OracleUsualEmbedding, "LSTMTextEmbedding": O.OracleLSTMTextEmbedding}
+        swaps = dict(build_encoder=O.build_oracle_encoder, build_decoder=lambda c, vocab: O.OracleDecoder(c, vocab),
+                     build_text_embedding=lambda c, v: text[c.ARCHITECTURE](c, v),
+                     build_vision_embedding=lambda c: O.OracleFeatureEmbedding(c))
+        kept = {k: getattr(ref_im, k) for k in swaps}
+        try:  # the same glue code over the oracle's modules
+            for k, v in swaps.items():
+                setattr(ref_im, k, v)
+            theirs = ref_im.IterativeMCAN(cfg, vocab)
+        finally:
+            for k, v in kept.items():
+                setattr(ref_im, k, v)
+        missing, unexpected = theirs.load_state_dict(ours.state_dict(), strict=False)
+        assert not unexpected and not [k for k in missing if "running_" not in k and "pos_emb" not in k], (missing, unexpected)
+        with torch.no_grad():  # spread the next-word scores so that no two candidates of the search are close
+            for m in (ours, theirs):
+                m.decoder.fc.weight.mul_(6.0)
+        ours.eval()
+        theirs.eval()
+        g = torch.Generator().manual_seed(4)
+        regions = torch.randn(3, 9, cfg.VISION_EMBEDDING.D_FEATURE, generator=g)
+        regions[1, 7:] = 0
+        question = torch.randint(4, 40, (3, 6), generator=g)
+        question[2, 4:] = 0
+        answer = torch.randint(4, 40, (3, 5), generator=g)
+        answer[:, 0] = vocab.bos_idx
+        answer[0, 3:] = 0
+        inp = SimpleNamespace(region_features=regions, question_tokens=question, answer_tokens=answer)
+        with torch.no_grad():
+            lo, lt = ours(inp), theirs(inp)
+        assert lo.shape == (3, 5, 40) and float((lo - lt).abs().max()) < 2e-5
+        # decode as tasks/open_ended_task.py:134-135 does: model.beam_search under torch.no_grad()
+        seen = {}
+        real_step = ours.step
+
+        def spy(t, prev, **kw):
+            out = real_step(t, prev, **kw)
+            if t == 2:
+                seen["stateful"] = ours.decoder._is_stateful
+                seen["n_states"] = len(list(ours.states()))
+            return out
+        ours.step = spy
+        with torch.no_grad():
+            toks, lp = ours.beam_search(inp, batch_size=3, beam_size=3, out_size=1, return_probs=False)
+            enc_t, mask_t = theirs.encoder_forward(inp)
+            ref_toks, ref_lp = O.oracle_generate(theirs.decoder, enc_t, mask_t, vocab.bos_idx, vocab.eos_idx, 3,
+                                                 max_len=vocab.max_answer_length)
+        assert seen["stateful"] is True and seen["n_states"] == 2 + 2 + 2 * cfg.DECODER.LAYERS
+        assert torch.equal(toks.reshape(ref_toks.shape), ref_toks)
+        assert float((lp.reshape(ref_lp.shape) - ref_lp).abs().max()) < 5e-5
+        assert not ours.decoder._is_stateful
+    finally:
+        _restore(saved)

@@ -813,3 +813,88 @@ def test_baseline_size_padding_and_sample_order_properties():
         for i in torch.nonzero(keep).flatten().tolist():
             n = int(nv[i])
             assert nerr(vo_t[i, :n], vo[i, :n]) < 4e-3, i  # (another tile count: the same math in another summation order)
+
+
+# ---- BASELINE configs[2] at ITS batch: CrossModalityEncoder d = 512, L = 6, B = 64 per GPU ------------
+def _config2_encoder(namespace, seed=31):
+    from openvivqa_amd.config import ConfigNode, attention_config
+    sa = attention_config()
+    cfg = ConfigNode(dict(D_MODEL=512, LAYERS=6, VISION_LANGUAGE_ATTENTION=sa, LANGUAGE_VISION_ATTENTION=sa,
+                          VISION_SELF_ATTENTION=sa, LANGUAGE_SELF_ATTENTION=sa))
+    torch.manual_seed(seed)
+    return namespace.CrossModalityEncoder(cfg)
+
+
+def _config2_batch(B=64):
+    gen = torch.Generator().manual_seed(6)
+    v, l = torch.randn(B, 100, 512, generator=gen), torch.randn(B, 20, 512, generator=gen)
+    nv, nt = torch.randint(80, 101, (B,), generator=gen), torch.randint(8, 21, (B,), generator=gen)
+    for i in range(B):
+        v[i, nv[i]:] = 0
+        l[i, nt[i]:] = 0
+    return v, l
+
+
+def test_config2_forward_at_batch_64_vs_oracle():
+    """configs[2]'s own size (B = 64; the gradient test above runs at B = 16, samples being independent): forward of the
+    bf16 HIP path against the fp32 oracle (north-star 1e-2, normalised max and relative L2) and the bf16-emulating one."""
+    import openvivqa_amd as A
+    import openvivqa_amd.utils as U
+    import oracle as O
+    from conftest import parity_record as rec
+    A.set_compute_dtype(BF16)
+    ref = _config2_encoder(oracle_namespace()).eval()
+    hip = _config2_encoder(hip_namespace())
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV).eval()
+    v, l = _config2_batch()
+    with torch.no_grad():
+        a, b = ref(v, O.padding_mask(v, 0), l, O.padding_mask(l, 0))
+        with O.emulate_bf16():
+            ae, be = ref(v, O.padding_mask(v, 0), l, O.padding_mask(l, 0))
+        vd, ld = v.to(DEV), l.to(DEV)
+        ah, bh = hip(vision_features=vd, vision_padding_mask=U.generate_padding_mask(vd, 0), language_features=ld,
+                     language_padding_mask=U.generate_padding_mask(ld, 0))
+    tag = "config2[B=64]"
+    for what, h, r, e in (("vision", ah, a, ae), ("language", bh, b, be)):
+        assert rec(tag, f"{what} out vs fp32 oracle", nerr(h, r), 1e-2) < 1e-2 and rel_l2(h, r) < 1e-2, what
+        assert rec(tag, f"{what} out vs emulation", nerr(h, e), 8e-3) < 8e-3, what
+
+
+def test_config2_linearity_and_sample_order_properties():
+    """The size-independent properties of the MCAN stacks, on configs[2]'s CrossModalityEncoder at B = 64, L = 6: (1) an
+    upstream gradient scaled by 4 scales both input gradients and every live parameter gradient by exactly 4, bit for bit,
+    and the dead cross-attention parameters (encoders.py:39-66) get none; (2) a permutation of the batch permutes both
+    outputs bit for bit."""
+    import openvivqa_amd as A
+    import openvivqa_amd.utils as U
+    A.set_compute_dtype(BF16)
+    hip = _config2_encoder(hip_namespace()).to(DEV).eval()
+    v, l = _config2_batch()
+    v, l = v.to(DEV), l.to(DEV)
+    vm, lm = U.generate_padding_mask(v, 0), U.generate_padding_mask(l, 0)
+    gen = torch.Generator().manual_seed(3)
+    gv, gl = torch.randn(v.shape, generator=gen).to(DEV, BF16), torch.randn(l.shape, generator=gen).to(DEV, BF16)
+    grads = []
+    for scale in (1.0, 4.0):
+        for p in hip.parameters():
+            p.grad = None
+        vd, ld = v.clone().requires_grad_(), l.clone().requires_grad_()
+        vo, lo = hip(vision_features=vd, vision_padding_mask=vm, language_features=ld, language_padding_mask=lm)
+        torch.autograd.backward([vo, lo], [gv.to(vo.dtype) * scale, gl.to(lo.dtype) * scale])
+        g = {"d vision": vd.grad.clone(), "d language": ld.grad.clone()}
+        g.update({k: (None if p.grad is None else p.grad.detach().clone()) for k, p in hip.named_parameters()})
+        grads.append(g)
+    dead = [k for k, g in grads[0].items() if g is None or float(g.abs().max()) == 0.0]
+    assert len([k for k in dead if "vision_language_mhattn" in k or "language_vision_mhattn" in k]) == 120  # 20 per layer
+    for k, g1 in grads[0].items():
+        if g1 is None:
+            assert grads[1][k] is None
+            continue
+        assert torch.equal(grads[1][k], g1 * 4.0), k
+    with torch.no_grad():
+        vo, lo = hip(vision_features=v, vision_padding_mask=vm, language_features=l, language_padding_mask=lm)
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+        vo_p, lo_p = hip(vision_features=v[perm], vision_padding_mask=vm[perm], language_features=l[perm],
+                         language_padding_mask=lm[perm])
+    assert torch.equal(vo_p, vo[perm]) and torch.equal(lo_p, lo[perm])
