@@ -53,7 +53,12 @@ def parity_record(test, what, value, bar):
     return value
 
 
-ESCAPE_CEILING = 0.15  # no gradient tensor passes further than this from the emulation, whatever the format's own error
+# no gradient tensor passes further than this from the emulation, whatever the format's own error.  Round 5: 0.15 -> 0.12
+# (measured worst at the depth of the deepest shipped stack, 30 chained blocks at fresh weights: 0.110, profiles/
+# r05_parity_report.tsv); the one case that needed 0.15 -- CoAttentionEncoder at L = 6, 48 chained blocks, no shipped
+# config -- no longer goes through the clause at all (tests/test_modules_gpu.py: tensors the bf16 format itself cannot
+# resolve there are counted, not asserted)
+ESCAPE_CEILING = 0.12
 ESCAPES = []           # (test tag, tensor, measured, bar, format error) of every pass through the second arm
 
 

@@ -52,6 +52,9 @@ def mode(request):
 # relative L2 per tensor.  A parameter whose gradient is analytically zero (fc_k.bias: softmax shift invariance) is
 # pure rounding noise on both sides and is skipped.
 EMU_GRAD_BAR = 1.5e-2
+# bf16 gradients against the REFERENCE's fp32 gradients (golden cases; input gradients per tensor, parameter gradients all
+# together), relative L2: 2e-2 since round 5 (3e-2 before; worst measured 9.7e-3, profiles/r05_parity_report.tsv)
+FP32_REF_GRAD_BAR = 2e-2
 # 30 chained blocks (MCAN L=6): a 1-ulp bf16 flip early in the stack is amplified by every later rounding, so the
 # gap to the emulation grows with depth (scripts/parity_depth.py); every gradient tensor of the L=6 stacks is held to this
 G9_EMU_BAR = 2.5e-2
@@ -89,7 +92,7 @@ def test_hip_modules_match_reference_golden(name, mode):
     # and of each input gradient, 3e-2; (2) every tensor against the bf16-emulating oracle, EMU_GRAD_BAR
     _, egin, egw = _emu_case(name)
     for k, ref in case.gin.items():
-        assert rec(tag, f"gin/{k} vs fp32 reference", rel_l2(gin[k], ref), 3e-2) < 3e-2, f"{name} gin/{k}"
+        assert rec(tag, f"gin/{k} vs fp32 reference", rel_l2(gin[k], ref), FP32_REF_GRAD_BAR) < FP32_REF_GRAD_BAR, f"{name} gin/{k}"
         rec(tag, f"gin/{k} vs emulation", rel_l2(gin[k], egin[k]), EMU_GRAD_BAR)
         assert grad_close(rel_l2(gin[k], egin[k]), rel_l2(egin[k], ref), EMU_GRAD_BAR, tag, f"gin/{k}"), \
             f"{name} gin/{k} vs emulation: {rel_l2(gin[k], egin[k]):.3e}"
@@ -99,7 +102,7 @@ def test_hip_modules_match_reference_golden(name, mode):
     if keys:
         allh = torch.cat([gw[k].detach().double().cpu().flatten() for k in keys])
         allr = torch.cat([case.gw[k].double().flatten() for k in keys])
-        assert rec(tag, "gw/* together vs fp32 reference", rel_l2(allh, allr), 3e-2) < 3e-2, f"{name} gw"
+        assert rec(tag, "gw/* together vs fp32 reference", rel_l2(allh, allr), FP32_REF_GRAD_BAR) < FP32_REF_GRAD_BAR, f"{name} gw"
     for k in keys:
         e, fmt = rel_l2(gw[k], egw[k]), rel_l2(egw[k], case.gw[k])
         rec(tag, f"gw/{k} vs emulation", e, EMU_GRAD_BAR)
@@ -202,7 +205,7 @@ def test_fullsize_mcan_against_reference_checksum(mode):
     if mode == BF16:
         assert rel_l2(vo[:, ::17, ::61], c.out["vision_sample"]) < 1e-2
         assert rel_l2(lo[:, ::3, ::61], c.out["language_sample"]) < 1e-2
-    gtol = 1e-3 if mode == F32 else 3e-2
+    gtol = 1e-3 if mode == F32 else FP32_REF_GRAD_BAR
     assert rel_l2(v.grad[:, ::17, ::61], c.out["gin_vision_sample"]) < gtol
     assert rel_l2(l.grad[:, ::3, ::61], c.out["gin_language_sample"]) < gtol
     names = c.meta["grad_norm_names"]
@@ -471,6 +474,14 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
         if not grad_close(e, fmt, gbar, tag, what):
             bad.append((what, e, fmt))
     gref = dict(ref.named_parameters())
+    # CoAttentionEncoder at L = 6 chains 48 blocks (the deepest shipped stack: 30) and no shipped config builds it: its
+    # late fc_q / fc_k gradients are cancellations the bf16 FORMAT cannot resolve (emulation vs fp32 oracle up to 0.10, no
+    # kernel involved).  Round 5: such tensors no longer pass through grad_close's escape clause here (it needed a ceiling
+    # of 0.15 for this case alone); a tensor is asserted when the format resolves it (its own error <= half the bar: the
+    # HIP path sits at ~sqrt(2) x the format's error, two realisations of the same rounding noise), the others are counted
+    # and recorded.  Every other case keeps the clause, under the lower ceiling.
+    no_escape = arch == "CoAttentionEncoder" and layers == 6
+    unresolved = 0
     for k, p in hip.named_parameters():
         if gref[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
@@ -478,9 +489,14 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
         if k.endswith("fc_k.bias"):
             continue
         e, fmt = rec(tag, f"gw/{k} vs emulation", rel_l2(p.grad, gref[k].grad), gbar), rel_l2(gref[k].grad, g32[k])
-        if not grad_close(e, fmt, gbar, tag, "gw/" + k):
+        if no_escape and fmt > 0.5 * gbar:
+            unresolved += 1
+            rec(tag, f"[not asserted: the format's own error is {fmt:.3e}] gw/{k}", e, gbar)
+            continue
+        if not grad_close(e, fmt, gbar, tag, "gw/" + k, allow_escape=not no_escape):
             bad.append((k, e, fmt))
     assert not bad, bad
+    assert unresolved <= 120, unresolved  # (of 576 tensors)
 
 
 def test_crossmodality_dead_branch_and_unused_grads(mode):
