@@ -117,8 +117,8 @@ KERNEL_OF_FAMILY = {
 }
 
 
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
-PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+PMC_FILES = ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
 
 
 def pmc_traffic(kernel_prefix):
