@@ -548,9 +548,9 @@ int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh
  *     whose rows are padded to 16 bytes.  Rows 16-byte aligned.  `mask` (may be NULL): fp32 [B, T] = the additive padding
  *     mask of the token ids, (tokens == padding_idx) * -10e4 (generate_padding_mask, models/utils.py:44-58), from the
  *     same pass.
- *   ovqa_embed_scatter: dtable[v][0..width) (=|+=) sum of drows[r][0..width) over the rows r with token v, in increasing r (a
- *     fixed order; no atomics), for EVERY v < rows_table: rows no token names are stored as zeros (no memset needed), row
- *     padding_idx gets zeros (nn.Embedding's padding_idx).  dtable fp32.
+ *   ovqa_embed_scatter: dtable[v][0..width) (=|+=) sum of drows[r][0..width) over the rows r with token v, in a fixed order (the
+ *     order the tokens lie in memory; no atomics), for EVERY v < rows_table: rows no token names are stored as zeros (no
+ *     memset needed), row padding_idx gets zeros (nn.Embedding's padding_idx).  dtable fp32.
  * ovqa_dropout_apply: y[i] = x[i] * keep(i) / (1 - p), flat index i -- forward and backward of an nn.Dropout call site whose
  *   producer has no fused epilogue (text_embeddings.py:241).
  *

@@ -31,58 +31,57 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
   for (int c = l * V; c < width; c += 64 * V) *reinterpret_cast<u32x4*>(dst + c) = *reinterpret_cast<const u32x4*>(src + c);
 }
 
-// dtable[v][0 .. width) (=|+=) sum over the rows r with tokens(r) == v of drows[r][0 .. width), in increasing r: a fixed
-// order, no atomics (torch's embedding_dense_backward adds atomically).  A wave owns FOUR consecutive table rows and walks
-// the token list once for all of them (the walk, not the sum, is the cost: 4000 rows x 1280 tokens); rows no token names
-// are stored as zeros, so the gradient buffer needs no memset; row `padding_idx` gets none (nn.Embedding).
+// dtable[v][0 .. width) (=|+=) sum over the positions with token v of their rows of drows, in a fixed order (the order the
+// tokens lie in memory: ANY fixed order makes the sum deterministic, and this one needs an integer division per MATCH only),
+// no atomics (torch's embedding_dense_backward adds atomically).  One wave per TABLE row, including the rows no token names:
+// they are stored as zeros, so the gradient buffer needs no memset; row `padding_idx` gets zeros (nn.Embedding).  The four
+// waves of a workgroup share the token list through LDS, 2048 positions per round of loads.
+// MEASURED (1280 positions, 4000 x 320 table, in the model step): walking the list from global memory, one dependent load per
+// 64 positions, 13.8 us; four table rows per wave 18.4; a wave per POSITION (owner = first occurrence) + a memset node for
+// the untouched rows 10.6-12.8 + 4.9; this form: profiles/README.md.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ drows,
                                                             int64_t ld_rows, float* __restrict__ dtable, int64_t ld_table,
                                                             int64_t rows_table, int B, int Tn, int width, int time_major,
                                                             int64_t padding_idx, int accumulate) {
-  constexpr int RPW = 4;    // table rows per wave
-  constexpr int MAXC = 16;  // columns per lane: width <= 1024
-  const int64_t v0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-  const int l = threadIdx.x & 63;
-  if (v0 >= rows_table) return;
-  float acc[RPW][MAXC];
-#pragma unroll
-  for (int i = 0; i < RPW; i++)
-#pragma unroll
-    for (int j = 0; j < MAXC; j++) acc[i][j] = 0.f;
+  constexpr int MAXC = 16;    // columns per lane: width <= 1024
+  constexpr int CHUNK = 2048;  // positions staged in LDS per round
+  __shared__ int64_t s_tok[CHUNK];
   const int R = B * Tn;
-  for (int r0 = 0; r0 < R; r0 += 64) {
-    const int r = r0 + l;
-    int64_t tok = -1;
-    if (r < R) {
-      const int b = time_major ? r % B : r / Tn, t = time_major ? r / B : r % Tn;
-      tok = tokens[(int64_t)b * Tn + t];
-    }
-    if (tok == padding_idx) tok = -1;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  const bool live = v < rows_table && v != padding_idx;
+  float acc[MAXC];
 #pragma unroll
-    for (int i = 0; i < RPW; i++) {
-      uint64_t m = __ballot(tok == v0 + i);
-      while (m) {
-        const int k = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const T* src = drows + (int64_t)(r0 + k) * ld_rows;
+  for (int j = 0; j < MAXC; j++) acc[j] = 0.f;
+  for (int base = 0; base < R; base += CHUNK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < CHUNK; i += 256) s_tok[i] = base + i < R ? tokens[base + i] : -1;
+    __syncthreads();
+    if (!live) continue;  // (wave-uniform; every wave reaches the barriers)
+    const int n = min(CHUNK, R - base);
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      uint64_t hits = __ballot(s_tok[i0 + l] == v);
+      while (hits) {
+        const int k = __ffsll((long long)hits) - 1;
+        hits &= hits - 1;
+        const int mm = base + i0 + k;
+        const int r = time_major ? (mm % Tn) * B + mm / Tn : mm;  // the row of drows that position (b, t) owns
+        const T* src = drows + (int64_t)r * ld_rows;
 #pragma unroll
         for (int j = 0; j < MAXC; j++) {
           const int c = l + 64 * j;
-          if (c < width) acc[i][j] += to_f32<T>(src[c]);
+          if (c < width) acc[j] += to_f32<T>(src[c]);
         }
       }
     }
   }
+  if (v >= rows_table) return;
+  float* dst = dtable + v * ld_table;
 #pragma unroll
-  for (int i = 0; i < RPW; i++) {
-    if (v0 + i >= rows_table) break;
-    float* dst = dtable + (v0 + i) * ld_table;
-#pragma unroll
-    for (int j = 0; j < MAXC; j++) {
-      const int c = l + 64 * j;
-      if (c < width) dst[c] = accumulate ? dst[c] + acc[i][j] : acc[i][j];
-    }
+  for (int j = 0; j < MAXC; j++) {
+    const int c = l + 64 * j;
+    if (c < width) dst[c] = accumulate ? dst[c] + acc[j] : acc[j];
   }
 }
 
@@ -435,7 +434,7 @@ int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t l
                   int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                   int accumulate, hipStream_t st) {
   OVQA_REQUIRE(width <= 1024, OVQA_ERR_UNSUPPORTED, "embed_scatter: rows wider than 1024 elements");
-  const unsigned grid = (unsigned)((rows_table + 15) / 16);  // 4 waves x 4 table rows per workgroup
+  const unsigned grid = (unsigned)((rows_table + 3) / 4);  // one wave per table row
   if (dtype == OVQA_BF16)
     hipLaunchKernelGGL(embed_scatter_kernel<bf16>, dim3(grid), dim3(256), 0, st, tokens, (const bf16*)drows, ld_rows, dtable,
                        ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);

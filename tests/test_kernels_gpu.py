@@ -1177,7 +1177,8 @@ def test_lstm_persistent_equals_per_step_kernels_and_fence_form(monkeypatch):
 
 # ---------------------------------------------------------------- the two ends of the model (csrc/model_ends.hip)
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("B,T,V,W,time_major", [(3, 6, 11, 16, True), (64, 20, 4000, 304, True), (5, 7, 50, 512, False)])
+@pytest.mark.parametrize("B,T,V,W,time_major", [(3, 6, 11, 16, True), (64, 20, 4000, 304, True), (5, 7, 50, 512, False),
+                                                 (128, 40, 300, 64, True), (70, 30, 97, 32, False)])
 def test_embed_gather_scatter(dtype, B, T, V, W, time_major):
     o = ops()
     g = torch.Generator().manual_seed(B * 100 + T)
