@@ -562,9 +562,8 @@ int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh
  *        (and pooled32 fp32 [B, D] if not NULL).
  *   ovqa_pool_bwd: dpooled [B, D] of `dtype` -> dh [B*N, D] (gradient w.r.t. fc1's output), dfeat [B*N, D] (= att * dpooled, the
  *     direct gradient of the features: the addend of fc1's dX product), dw2_part fp32 [B, 2*D] (per-sample partial of fc2's
- *     weight gradient in columns 0..D, zeros after: rows for ovqa_grouped_partial_reduce), db2 fp32 [1] (=|+=, may be NULL;
- *     the last workgroup to arrive adds the per-sample partials in index order).  `scratch` fp32 [8 + B], private to the
- *     call; its ticket word is zeroed by the call (a memset node).
+ *     weight gradient in columns 0..D, zeros after) and db2_part fp32 [B, 16] (per-sample partial of fc2's bias gradient in
+ *     column 0, zeros after; may be NULL): rows for ovqa_grouped_partial_reduce (D and 8), which adds them in a fixed order.
  *
  * log_softmax + NLLLoss.   replaces: F.log_softmax(output, dim=-1) mcan.py:81; nn.NLLLoss(ignore_index)
  *                           tasks/classification_task.py:125-127 (and open_ended_task.py:155-157)
@@ -585,8 +584,8 @@ int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_
 int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
                   void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const ovqa_dropout* drop, void* stream);
 int ovqa_pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
-                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B,
-                  int64_t N, int64_t D, int accumulate_db2, const ovqa_dropout* drop, void* stream);
+                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2_part, int64_t B, int64_t N,
+                  int64_t D, const ovqa_dropout* drop, void* stream);
 int ovqa_log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, void* stream);
 int ovqa_log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n,
                          void* stream);

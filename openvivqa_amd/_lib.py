@@ -131,8 +131,7 @@ SIGNATURES = {
     "ovqa_embed_scatter": [c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     "ovqa_dropout_apply": [c_int, c_vp, c_vp, c_i64, _DP, c_vp],
     "ovqa_pool_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, _DP, c_vp],
-    "ovqa_pool_bwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int,
-                      _DP, c_vp],
+    "ovqa_pool_bwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_log_softmax_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp],
     "ovqa_log_softmax_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp],
     "ovqa_nll_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp],

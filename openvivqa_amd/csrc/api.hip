@@ -773,15 +773,14 @@ int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre,
 }
 
 int ovqa_pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
-                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B,
-                  int64_t N, int64_t D, int accumulate_db2, const ovqa_dropout* drop, void* stream) {
+                  const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2_part, int64_t B, int64_t N,
+                  int64_t D, const ovqa_dropout* drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(feat_dtype), OVQA_ERR_BAD_ARG, "pool_bwd: bad dtype");
-  OVQA_REQUIRE(feat && hpre && w2 && att && dpooled && dh && dfeat && dw2_part && scratch && B >= 1 &&
-                   B * N * D < (1ll << 32),
+  OVQA_REQUIRE(feat && hpre && w2 && att && dpooled && dh && dfeat && dw2_part && B >= 1 && B * N * D < (1ll << 32),
                OVQA_ERR_BAD_ARG, "pool_bwd: bad argument");
   g_dispatch = "stream";
-  return ovqa::pool_bwd(feat_dtype, dtype, feat, hpre, w2, att, dpooled, dh, dfeat, dw2_part, db2, scratch, B, N, D,
-                        accumulate_db2, make_drop_args(drop), as_stream(stream));
+  return ovqa::pool_bwd(feat_dtype, dtype, feat, hpre, w2, att, dpooled, dh, dfeat, dw2_part, db2_part, B, N, D,
+                        make_drop_args(drop), as_stream(stream));
 }
 
 int ovqa_log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, void* stream) {

@@ -163,8 +163,8 @@ int dropout_apply(int dtype, const void* x, void* y, int64_t n, const DropArgs& 
 int pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
              void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const DropArgs& da, hipStream_t st);
 int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
-             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B, int64_t N,
-             int64_t D, int accumulate_db2, const DropArgs& da, hipStream_t st);
+             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2_part, int64_t B, int64_t N, int64_t D,
+             const DropArgs& da, hipStream_t st);
 int log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, hipStream_t st);
 int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n, hipStream_t st);
 int nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M, int64_t n,

@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
   int sg, ub;
   wg_role(blockIdx.x, nsg, sg, ub);
   const int B = a.B, T = a.T;
+  if (SENTINEL && blockIdx.x == 0 && tid == 0)  // (a give-up is reported after >= 1e5 sweeps: long after this store)
+    __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- this wave's 16 gate rows of W_ih and W_hh, A-operand layout, resident for the whole launch
   // A row r = l & 15 -> (unit 4 w + (r >> 2), gate r & 3): C row 4 q + reg = (unit 4 w + q, gate reg)
   const int arow = (n & 3) * LH + ub * 16 + w * 4 + (n >> 2);
@@ -308,6 +310,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   int sg, ub;
   wg_role(blockIdx.x, nsg, sg, ub);
   const int B = a.B, T = a.T;
+  if (SENTINEL && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // A operand of the recurrent product dh[u'][n] = sum_col W_hh[col][u'] dgates[n][col]: wave w reduces over gate w's
   // 512 columns; A row = l & 15 -> input unit ub*16 + (l & 15), k = w*512 + kk*32 + q*8 ..
   bf16x8 wt[KS];
@@ -510,8 +514,9 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
              int64_t I, int64_t H, hipStream_t st) {
   if (persistent) {
     const int mode = lstm_handoff_mode();
-    hipError_t e = hipMemsetAsync(scratch, 0, kSyncBytes, st);
-    if (e == hipSuccess && mode == 2) e = hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st);  // the sentinel
+    // form 2: ONE memset node, the sentinel fill (the status word is zeroed by the launch's first workgroup); form 1: the counters
+    hipError_t e = mode == 2 ? hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st)
+                             : hipMemsetAsync(scratch, 0, kSyncBytes, st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)hseq, (float*)saved,
                   (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, mode,
@@ -548,8 +553,8 @@ int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, cons
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st) {
   if (persistent) {
     const int mode = lstm_handoff_mode();
-    hipError_t e = hipMemsetAsync(scratch, 0, kSyncBytes, st);
-    if (e == hipSuccess && mode == 2) e = hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st);  // the sentinel
+    hipError_t e = mode == 2 ? hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st)
+                             : hipMemsetAsync(scratch, 0, kSyncBytes, st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmBwdArgs a{dy, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
                   (unsigned*)scratch + 1000, (int)B, (int)T, mode};

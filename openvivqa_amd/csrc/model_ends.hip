@@ -229,20 +229,18 @@ __global__ __launch_bounds__(POOL_WAVES * 64) void pool_fwd_kernel(const F* __re
 //   datt[n] = feat[b,n,:] . dpooled[b,:];  dlogit[n] = att[n] (datt[n] - sum_m att[m] datt[m])
 //   dh[b,n,:] = dlogit[n] w2[:] relu'(hpre) keep/(1-p)              (gradient w.r.t. fc1's output)
 //   dw2 partial[b][:] = sum_n dlogit[n] dropout(relu(hpre[b,n,:]))   ([B][2*D] rows: the deferred grouped reduce sums them)
-//   db2 partial[b] = sum_n dlogit[n]  (analytically 0: softmax shift invariance); the LAST workgroup to arrive adds the B
-//   partials in index order and stores db2 -- deterministic, the ticket lives in the caller's scratch (zeroed by the call).
+//   db2 partial[b][0] = sum_n dlogit[n]  (analytically 0: softmax shift invariance), one [2 * 8]-float row per sample for the
+//   same deferred reduce (fc2.bias occupies an 8-element footprint in the arena).
 template <typename F, typename T>
 __global__ __launch_bounds__(POOL_WAVES * 64) void pool_bwd_kernel(const F* __restrict__ feat, const T* __restrict__ hpre,
                                                                   const float* __restrict__ w2, const float* __restrict__ att,
                                                                   const T* __restrict__ dpooled, T* __restrict__ dh,
                                                                   T* __restrict__ dfeat, float* __restrict__ dw2_part,
-                                                                  float* __restrict__ db2, float* __restrict__ scratch, int B,
-                                                                  int N, int D, int accumulate_db2, DropArgs da) {
+                                                                  float* __restrict__ db2_part, int N, int D, DropArgs da) {
   __shared__ float s_a[POOL_MAXN];   // att, then dlogit
   __shared__ float s_d[POOL_MAXN];   // datt
   __shared__ float s_part[POOL_WAVES][POOL_MAXD];
   __shared__ float s_red[POOL_WAVES];
-  __shared__ bool s_last;
   const int b = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const DropState ds = drop_init(da);
   const T* dp = dpooled + (int64_t)b * D;
@@ -319,25 +317,13 @@ __global__ __launch_bounds__(POOL_WAVES * 64) void pool_bwd_kernel(const F* __re
     dw2_part[(int64_t)b * 2 * D + c] = s;
     dw2_part[(int64_t)b * 2 * D + D + c] = 0.f;  // (second half of the reduce row: unused)
   }
-  // db2: per-sample partial through device-scope atomics, the last arriver sums them in index order
-  if (threadIdx.x == 0) {
+  // db2: this sample's sum of dlogit as row b of a [B][2 * 8] partial block (column 0; the rest zeros): the deferred grouped
+  // reduce adds the rows in a fixed order into fc2.bias's 8-element footprint in the gradient arena -- no ticket, no memset
+  if (db2_part != nullptr && threadIdx.x < 16) {
     float mine = 0.f;
 #pragma unroll
     for (int i = 0; i < POOL_WAVES; i++) mine += s_red[i];
-    const float before = atomicExch(&scratch[8 + b], mine);
-    unsigned one = 1u;
-    asm volatile("; the ticket waits for the returned value of the exchange" : "+v"(one) : "v"(before));
-    s_last = atomicAdd(reinterpret_cast<unsigned*>(scratch), one) == (unsigned)(B - 1);
-  }
-  __syncthreads();
-  if (!s_last || db2 == nullptr) return;
-  // (every thread fetches its partials in parallel -- a device-scope read each --, thread 0 adds them in index order)
-  for (int i = threadIdx.x; i < B; i += POOL_WAVES * 64) s_part[0][i % POOL_MAXD] = atomicAdd(&scratch[8 + i], 0.f);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int i = 0; i < B; i++) t += s_part[0][i];
-    db2[0] = accumulate_db2 ? db2[0] + t : t;
+    db2_part[(int64_t)b * 16 + threadIdx.x] = threadIdx.x == 0 ? mine : 0.f;
   }
 }
 
@@ -478,15 +464,13 @@ int pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, cons
 }
 
 int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* att,
-             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2, float* scratch, int64_t B, int64_t N,
-             int64_t D, int accumulate_db2, const DropArgs& da, hipStream_t st) {
-  OVQA_REQUIRE(pool_shape_ok(N, D) && B <= POOL_MAXD, OVQA_ERR_UNSUPPORTED, "pool_bwd: N <= 1024, D <= 1024, D %% 8 == 0, B <= 1024");
-  hipError_t e = hipMemsetAsync(scratch, 0, 32, st);  // the arrival ticket (the partials are overwritten before they are read)
-  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "pool_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+             const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2_part, int64_t B, int64_t N, int64_t D,
+             const DropArgs& da, hipStream_t st) {
+  OVQA_REQUIRE(pool_shape_ok(N, D), OVQA_ERR_UNSUPPORTED, "pool_bwd: N <= 1024, D <= 1024, D %% 8 == 0");
   const dim3 grid((unsigned)B), block(POOL_WAVES * 64);
 #define OVQA_POOL_BWD(F, T)                                                                                              \
   hipLaunchKernelGGL((pool_bwd_kernel<F, T>), grid, block, 0, st, (const F*)feat, (const T*)hpre, w2, att, (const T*)dpooled, (T*)dh, \
-                     (T*)dfeat, dw2_part, db2, scratch, (int)B, (int)N, (int)D, accumulate_db2, da)
+                     (T*)dfeat, dw2_part, db2_part, (int)N, (int)D, da)
   if (dtype == OVQA_BF16 && feat_dtype == OVQA_BF16) OVQA_POOL_BWD(bf16, bf16);
   else if (dtype == OVQA_BF16) OVQA_POOL_BWD(float, bf16);
   else if (feat_dtype == OVQA_F32) OVQA_POOL_BWD(float, float);

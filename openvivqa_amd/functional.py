@@ -885,18 +885,21 @@ class _AttentionPool(Function):
         arena, mlp = st["arena"], st["mlp"]
         feat, x, hpre, att = ctx.saved_tensors
         B, N, D = feat.shape
-        gb2, acc_b2 = arena.grad_views([mlp.fc2.bias])
-        dh, dfeat, part = ops.pool_bwd(feat, hpre, arena.master_of(mlp.fc2.weight).reshape(-1), att,
-                                       _c(dpooled.to(hpre.dtype)), st["drop"], db2=gb2, accumulate_db2=acc_b2)
+        dh, dfeat, part, bpart = ops.pool_bwd(feat, hpre, arena.master_of(mlp.fc2.weight).reshape(-1), att,
+                                              _c(dpooled.to(hpre.dtype)), st["drop"])
         gw2, acc_w2 = arena.grad_views([mlp.fc2.weight])
         gw2 = gw2.reshape(-1)[:D]  # (row 0 of the [8, D] footprint of the 1 x D matrix)
+        gb2, acc_b2 = arena.grad_views([mlp.fc2.bias])  # (the 8-element footprint of the 1-element bias)
         q = _defer_queue(dh)
         if q is not None:
             q.add_reduce(part, B, D, gw2, None, acc_w2)
-        elif acc_w2:
-            gw2.add_(part[:, :D].sum(0))
+            q.add_reduce(bpart, B, 8, gb2, None, acc_b2)
         else:
-            gw2.copy_(part[:, :D].sum(0))
+            for g, acc, src in ((gw2, acc_w2, part[:, :D].sum(0)), (gb2[:1], acc_b2, bpart[:, :1].sum(0))):
+                if acc:
+                    g.add_(src)
+                else:
+                    g.copy_(src)
         _wgrad(arena, dh, x.reshape(B * N, D), [mlp.fc1.weight], [mlp.fc1.bias])
         dx = None
         if ctx.needs_input_grad[0]:

@@ -1131,19 +1131,19 @@ def pool_fwd(feat, hpre, w2, b2, drop=None):
     return att, pooled
 
 
-def pool_bwd(feat, hpre, w2, att, dpooled, drop=None, db2=None, accumulate_db2=False):
-    """-> (dh [B*N, D], dfeat [B*N, D] (= att * dpooled), dw2_part fp32 [B, 2*D]); db2 fp32 [>=1] (=|+=) in place if given."""
+def pool_bwd(feat, hpre, w2, att, dpooled, drop=None):
+    """-> (dh [B*N, D], dfeat [B*N, D] (= att * dpooled), dw2_part fp32 [B, 2*D], db2_part fp32 [B, 16]): the two partial
+    blocks are rows for the grouped partial reduce (fc2's weight gradient in columns 0..D, its bias gradient in column 0)."""
     _dev(feat)
     B, N, D = feat.shape
     assert dpooled.is_contiguous() and dpooled.dtype == hpre.dtype and dpooled.numel() == B * D
     dh = torch.empty(B * N, D, dtype=hpre.dtype, device=feat.device)
     dfeat = torch.empty(B * N, D, dtype=hpre.dtype, device=feat.device)
     part = torch.empty(B, 2 * D, dtype=torch.float32, device=feat.device)
-    scratch = torch.empty(8 + B, dtype=torch.float32, device=feat.device)
+    bpart = torch.empty(B, 16, dtype=torch.float32, device=feat.device)
     _lib.check(_lib.load().ovqa_pool_bwd(_dt(feat), _dt(hpre), _p(feat), _p(hpre), _p(w2), _p(att), _p(dpooled), _p(dh),
-                                         _p(dfeat), _p(part), _p(db2), _p(scratch), B, N, D, int(bool(accumulate_db2)),
-                                         _drop(drop), _stream()), "pool_bwd")
-    return dh, dfeat, part
+                                         _p(dfeat), _p(part), _p(bpart), B, N, D, _drop(drop), _stream()), "pool_bwd")
+    return dh, dfeat, part, bpart
 
 
 def log_softmax_fwd(x, n=None):

@@ -390,7 +390,7 @@ def pool_fwd(feat, hpre, w2, b2, drop=None):
     return att, (feat.float() * att[..., None]).sum(1).to(hpre.dtype)
 
 
-def pool_bwd(feat, hpre, w2, att, dpooled, drop=None, db2=None, accumulate_db2=False):
+def pool_bwd(feat, hpre, w2, att, dpooled, drop=None):
     assert drop is None or drop.p == 0
     B, N, D = feat.shape
     dp = dpooled.float()
@@ -401,12 +401,9 @@ def pool_bwd(feat, hpre, w2, att, dpooled, drop=None, db2=None, accumulate_db2=F
     dfeat = (att[..., None] * dp[:, None, :]).reshape(B * N, D).to(hpre.dtype)
     part = torch.zeros(B, 2 * D)
     part[:, :D] = (dl[..., None] * torch.relu(h)).sum(1)
-    if db2 is not None:
-        if accumulate_db2:
-            db2[0] += dl.sum()
-        else:
-            db2[0] = dl.sum()
-    return dh, dfeat, part
+    bpart = torch.zeros(B, 16)
+    bpart[:, 0] = dl.sum(1)
+    return dh, dfeat, part, bpart
 
 
 def log_softmax_fwd(x, n=None):

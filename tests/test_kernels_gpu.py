@@ -1247,8 +1247,7 @@ def test_attention_pool_fwd_bwd(fdt, dtype, B, N, D, p):
     d = o.DropSpec(p=p, seed=99, site=3, step=step) if p > 0 else None
     keep = o.dropout_keep_mask(d, B * N * D, feat.device) if p > 0 else torch.ones(B * N * D, device=DEV)
     att, pooled = o.pool_fwd(feat, hpre, w2, b2, d)
-    db2 = torch.full((8,), 3.0, device=DEV)
-    dh, dfeat, part = o.pool_bwd(feat, hpre, w2, att, dpooled, d, db2=db2)
+    dh, dfeat, part, bpart = o.pool_bwd(feat, hpre, w2, att, dpooled, d)
     att64, pooled64, gf, gh, gw, gb = _pool_ref64(feat, hpre, w2, b2, keep, p, dpooled)
     t = 1e-5 if dtype == F32 else 1e-2
     assert nerr(att, att64) < 1e-5 and nerr(pooled, pooled64) < t
@@ -1256,11 +1255,8 @@ def test_attention_pool_fwd_bwd(fdt, dtype, B, N, D, p):
     direct = att64[..., None] * dpooled.double().cpu()[:, None, :]
     assert nerr(dfeat.view(B, N, D), direct) < t
     assert nerr(dh, gh) < t and nerr(part[:, :D].sum(0), gw) < 2e-4
-    assert float(part[:, D:].abs().max()) == 0.0
-    assert abs(float(db2[0]) - float(gb)) < 1e-4 and float(db2[1]) == 3.0
-    db3 = db2.clone()
-    o.pool_bwd(feat, hpre, w2, att, dpooled, d, db2=db3, accumulate_db2=True)
-    assert abs(float(db3[0]) - 2 * float(db2[0])) < 1e-5
+    assert float(part[:, D:].abs().max()) == 0.0 and float(bpart[:, 1:].abs().max()) == 0.0
+    assert abs(float(bpart[:, 0].sum()) - float(gb)) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
