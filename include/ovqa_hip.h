@@ -515,10 +515,11 @@ int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx,
  *             models/modules/text_embeddings.py:236,243   (one layer, zero initial state, gate order i, f, g, o;
  *             padded positions are ordinary time steps: the reference does not pack the sequence)
  *   Forward: x [T*B, I] TIME-MAJOR rows (row t*B + b; ldx), w_ih [4H, I], w_hh [4H, H] of `dtype`, b_ih / b_hh fp32 [4H]
- *     -> y fp32 [B, T, H] (batch-major, what the module returns),
+ *     -> y fp32 [B, T, H] (batch-major, what the module returns), y_lp (may be NULL): the same values in `dtype`, for a
+ *        consumer that takes the compute dtype (the operand of the stack behind it) without a cast launch,
  *        hseq `dtype` [(T+1)*B, H] time-major: block 0 = zeros, block t+1 = h_t  (the operand of the w_hh gradient:
  *        dW_hh = dgates^T hseq[0 : T*B]), and `saved` (opaque, ovqa_lstm_saved_bytes; handed to ovqa_lstm_bwd).
- *   Backward: dy fp32 [B, T, H] -> dgates `dtype` [T*B, 4H] time-major, columns gate*H + unit (gradient w.r.t. the
+ *   Backward: dy [B, T, H] of dy_dtype (fp32, or bf16 from a bf16 LayerNorm backward) -> dgates `dtype` [T*B, 4H] time-major, columns gate*H + unit (gradient w.r.t. the
  *     pre-activations).  The caller finishes with the library's GEMMs: dx = dgates w_ih, dW_ih = dgates^T x,
  *     dW_hh = dgates^T hseq[0 : T*B], db_ih = db_hh = column sums of dgates.  `w_hh_t` [H, 4H] (row stride ldwt) is the
  *     transposed copy of w_hh the bf16 persistent kernel reads (NULL in fp32 mode).
@@ -533,10 +534,10 @@ int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx,
 int64_t ovqa_lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
 int64_t ovqa_lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
 int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const void* w_hh, const float* b_ih,
-                  const float* b_hh, float* y, void* hseq, void* saved, void* scratch,
+                  const float* b_hh, float* y, void* y_lp, void* hseq, void* saved, void* scratch,
                   int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
-int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt, const void* saved,
-                  void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
+int ovqa_lstm_bwd(int dtype, const void* dy, int dy_dtype, const void* w_hh, const void* w_hh_t, int64_t ldwt,
+                  const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream);
 
 /* ---------------------------------------------------------------------------
  * The two ends of the model around the encoder stacks (ABI 8; "next" rows 2 and 4): csrc/model_ends.hip

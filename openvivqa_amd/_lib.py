@@ -137,8 +137,8 @@ SIGNATURES = {
     "ovqa_nll_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp],
     "ovqa_lstm_saved_bytes": [c_i64, c_i64, c_i64],
     "ovqa_lstm_scratch_bytes": [c_i64, c_i64, c_i64],
-    "ovqa_lstm_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
-    "ovqa_lstm_bwd": [c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
+    "ovqa_lstm_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
+    "ovqa_lstm_bwd": [c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
 }
 _RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_last_dispatch": C.c_char_p, "ovqa_workspace_bytes": C.c_int64,
             "ovqa_lstm_saved_bytes": C.c_int64, "ovqa_lstm_scratch_bytes": C.c_int64}

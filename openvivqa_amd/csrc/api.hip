@@ -694,8 +694,8 @@ static bool lstm_route_persistent(int dtype, int64_t B, int64_t T, int64_t I, in
 }
 
 int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const void* w_hh, const float* b_ih,
-                  const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T, int64_t I,
-                  int64_t H, void* stream) {
+                  const float* b_hh, float* y, void* y_lp, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
+                  int64_t I, int64_t H, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "lstm_fwd: bad dtype");
   OVQA_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y && hseq && saved && scratch, OVQA_ERR_BAD_ARG,
                "lstm_fwd: null pointer");
@@ -711,13 +711,14 @@ int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const
     return OVQA_ERR_UNSUPPORTED;
   }
   g_dispatch = persistent ? "mfma" : "simple";
-  return ovqa::lstm_fwd(dtype, persistent, x, ldx, w_ih, w_hh, b_ih, b_hh, y, hseq, saved, scratch, B, T, I, H,
+  OVQA_REQUIRE(y_lp == nullptr || (uintptr_t)y_lp % 16 == 0, OVQA_ERR_BAD_ARG, "lstm_fwd: y_lp must be 16-byte aligned");
+  return ovqa::lstm_fwd(dtype, persistent, x, ldx, w_ih, w_hh, b_ih, b_hh, y, y_lp, hseq, saved, scratch, B, T, I, H,
                         as_stream(stream));
 }
 
-int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt, const void* saved,
-                  void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream) {
-  OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "lstm_bwd: bad dtype");
+int ovqa_lstm_bwd(int dtype, const void* dy, int dy_dtype, const void* w_hh, const void* w_hh_t, int64_t ldwt,
+                  const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream) {
+  OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(dy_dtype), OVQA_ERR_BAD_ARG, "lstm_bwd: bad dtype");
   OVQA_REQUIRE(dy && w_hh && saved && dgates && scratch, OVQA_ERR_BAD_ARG, "lstm_bwd: null pointer");
   OVQA_REQUIRE(B >= 1 && T >= 1 && H >= 1 && B * H < (1ll << 31), OVQA_ERR_BAD_ARG, "lstm_bwd: bad size");
   const bool persistent = lstm_route_persistent(dtype, B, T, I, H);
@@ -726,7 +727,8 @@ int ovqa_lstm_bwd(int dtype, const float* dy, const void* w_hh, const void* w_hh
                      (uintptr_t)scratch % 16 == 0,
                  OVQA_ERR_BAD_ARG, "lstm_bwd(bf16, H = 512): needs the transposed w_hh copy (16-byte aligned rows)");
   g_dispatch = persistent ? "mfma" : "simple";
-  return ovqa::lstm_bwd(dtype, persistent, dy, w_hh, w_hh_t, ldwt, saved, dgates, scratch, B, T, H, as_stream(stream));
+  return ovqa::lstm_bwd(dtype, persistent, dy, dy_dtype == OVQA_BF16 ? 1 : 0, w_hh, w_hh_t, ldwt, saved, dgates, scratch, B, T,
+                        H, as_stream(stream));
 }
 
 int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,

@@ -147,9 +147,9 @@ bool lstm_persistent_supported(int dtype, int64_t B, int64_t T, int64_t I, int64
 int64_t lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
 int64_t lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
 int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void* w_ih, const void* w_hh,
-             const float* b_ih, const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
-             int64_t I, int64_t H, hipStream_t st);
-int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt,
+             const float* b_ih, const float* b_hh, float* y, void* y16, void* hseq, void* saved, void* scratch, int64_t B,
+             int64_t T, int64_t I, int64_t H, hipStream_t st);
+int lstm_bwd(int dtype, bool persistent, const void* dy, int dy_bf16, const void* w_hh, const void* w_hh_t, int64_t ldwt,
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st);
 
 // ---- model_ends.hip: embedding rows, dropout, attention pooling, log_softmax + NLL ---------------------------------------

@@ -113,6 +113,7 @@ struct LstmFwdArgs {
   const float* b_ih;    // [2048]
   const float* b_hh;    // [2048]
   float* y;             // [B][T][512] fp32
+  bf16* y16;            // the same in bf16 (the GEMM / LayerNorm operand of the stack behind it), or NULL
   bf16* hseq;           // [(T+1)*B][512] time-major: block 0 = zeros, block t+1 = h_t
   float* saved;         // [T][nwg][5][256]: i, f, g, o (post-activation), c_t of the workgroup's lanes
   unsigned* cnt;        // one counter per sample group, 32 words apart
@@ -259,6 +260,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
     } else if (w == 1) {  // y[b][t][ub*16 ..]: lane -> (sample l >> 2, 16-byte quarter l & 3)
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile32 + (l >> 2) * 16 + (l & 3) * 4);
       *reinterpret_cast<f32x4*>(a.y + ((int64_t)(sg * 16 + (l >> 2)) * T + t) * LH + ub * 16 + (l & 3) * 4) = v;
+    } else if (w == 2 && a.y16 != nullptr && l < 32) {  // the bf16 twin of y, batch-major like y
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tile16 + (l >> 1) * 16 + (l & 1) * 8);
+      *reinterpret_cast<u32x4*>(a.y16 + ((int64_t)(sg * 16 + (l >> 1)) * T + t) * LH + ub * 16 + (l & 1) * 8) = v;
     }
     LSTM_STAMP(4);
     if (t + 1 < T) {  // the input half of step t + 1 (its operands were requested a step ago), then request t + 2
@@ -290,7 +294,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
 }
 
 struct LstmBwdArgs {
-  const float* dy;      // [B][T][512] fp32
+  const void* dy;       // [B][T][512] fp32, or bf16 when dy_bf16 (the gradient arrives from a bf16 LayerNorm backward)
+  int dy_bf16;
   const bf16* whh_t;    // transposed W_hh: row u' (input unit), 2048 gate columns, row stride ldwt
   int64_t ldwt;
   const float* saved;   // as written by the forward kernel
@@ -326,7 +331,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   const int ftid = q * 64 + w * 16 + n;
   const float* sv0 = a.saved + (int64_t)blockIdx.x * 5 * 256 + ftid;
   const int64_t sv_step = (int64_t)nwg * 5 * 256;
-  const float* dyp = a.dy + (int64_t)(sg * 16 + n) * T * LH + ub * 16 + unit_in;
+  const int64_t dy0 = (int64_t)(sg * 16 + n) * T * LH + ub * 16 + unit_in;
+  auto dy_at = [&](int t) {
+    return a.dy_bf16 ? (float)((const bf16*)a.dy)[dy0 + (int64_t)t * LH] : ((const float*)a.dy)[dy0 + (int64_t)t * LH];
+  };
   float dc_carry = 0.f;  // dc_{t+1} * f_{t+1}
   // operands of step t that do not depend on the recurrence are requested one step ahead
   float ig, fg, gg, og, ct, cprev, dyv;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
     const float* sv = sv0 + (int64_t)(T - 1) * sv_step;
     ig = sv[0]; fg = sv[256]; gg = sv[512]; og = sv[768]; ct = sv[1024];
     cprev = T > 1 ? (sv - sv_step)[1024] : 0.f;
-    dyv = dyp[(int64_t)(T - 1) * LH];
+    dyv = dy_at(T - 1);
   }
   for (int t = T - 1; t >= 0; t--) {
     float dh = dyv;
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
       const float* sv = sv0 + (int64_t)(t - 1) * sv_step;
       ig = sv[0]; fg = sv[256]; gg = sv[512]; og = sv[768]; ct = sv[1024];
       cprev = t > 1 ? (sv - sv_step)[1024] : 0.f;
-      dyv = dyp[(int64_t)(t - 1) * LH];
+      dyv = dy_at(t - 1);
     }
     __syncthreads();
     if (w == 0) {  // 16 samples x 4 gates x 32 bytes: two 16-byte stores per lane
@@ -419,7 +427,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lstm_step_fwd_simple(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w_ih,
                                                             const float* __restrict__ b_ih, const T* __restrict__ w_hh,
                                                             const float* __restrict__ b_hh, T* __restrict__ hseq,
-                                                            float* __restrict__ y, float* __restrict__ gates,
+                                                            float* __restrict__ y, T* __restrict__ y16, float* __restrict__ gates,
                                                             float* __restrict__ cs, int B, int Tn, int I, int H, int t) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * H) return;
@@ -453,17 +461,20 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_simple(const T* __restrict_
   cs[((int64_t)t * B + b) * H + u] = c;
   hseq[((int64_t)(t + 1) * B + b) * H + u] = from_f32<T>(h);
   y[((int64_t)b * Tn + t) * H + u] = h;
+  if (y16) y16[((int64_t)b * Tn + t) * H + u] = from_f32<T>(h);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void lstm_step_bwd_simple(const float* __restrict__ dy, const T* __restrict__ w_hh,
+__global__ __launch_bounds__(256) void lstm_step_bwd_simple(const void* __restrict__ dy_, int dy_bf16,
+                                                            const T* __restrict__ w_hh,
                                                             const float* __restrict__ gates, const float* __restrict__ cs,
                                                             T* __restrict__ dgates, float* __restrict__ dc_carry, int B,
                                                             int Tn, int H, int t) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * H) return;
   const int b = idx / H, u = idx % H;
-  float dh = dy[((int64_t)b * Tn + t) * H + u];
+  const int64_t di = ((int64_t)b * Tn + t) * H + u;
+  float dh = dy_bf16 ? (float)((const bf16*)dy_)[di] : ((const float*)dy_)[di];
   if (t < Tn - 1) {
     const T* gp = dgates + ((int64_t)(t + 1) * B + b) * 4 * H;
     float s = 0.f;
@@ -510,7 +521,7 @@ int64_t lstm_scratch_bytes(int64_t B, int64_t T, int64_t H) {
 }
 
 int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void* w_ih, const void* w_hh,
-             const float* b_ih, const float* b_hh, float* y, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
+             const float* b_ih, const float* b_hh, float* y, void* y16, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
              int64_t I, int64_t H, hipStream_t st) {
   if (persistent) {
     const int mode = lstm_handoff_mode();
@@ -518,7 +529,7 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
     hipError_t e = mode == 2 ? hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st)
                              : hipMemsetAsync(scratch, 0, kSyncBytes, st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)hseq, (float*)saved,
+    LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)y16, (bf16*)hseq, (float*)saved,
                   (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, mode,
                   (getenv("OVQA_LSTM_PROBE") && T * 8 <= 480) ? (unsigned*)scratch + 512 : nullptr};
     static bool attr_set = false;
@@ -540,23 +551,23 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
   for (int t = 0; t < T; t++) {
     if (dtype == OVQA_BF16)
       hipLaunchKernelGGL(lstm_step_fwd_simple<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)w_ih,
-                         b_ih, (const bf16*)w_hh, b_hh, (bf16*)hseq, y, gates, cs, (int)B, (int)T, (int)I, (int)H, t);
+                         b_ih, (const bf16*)w_hh, b_hh, (bf16*)hseq, y, (bf16*)y16, gates, cs, (int)B, (int)T, (int)I, (int)H, t);
     else
       hipLaunchKernelGGL(lstm_step_fwd_simple<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, ldx,
-                         (const float*)w_ih, b_ih, (const float*)w_hh, b_hh, (float*)hseq, y, gates, cs, (int)B, (int)T,
-                         (int)I, (int)H, t);
+                         (const float*)w_ih, b_ih, (const float*)w_hh, b_hh, (float*)hseq, y, (float*)y16, gates, cs, (int)B,
+                         (int)T, (int)I, (int)H, t);
   }
   return ovqa_check_launch("lstm_fwd(simple)");
 }
 
-int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, const void* w_hh_t, int64_t ldwt,
+int lstm_bwd(int dtype, bool persistent, const void* dy, int dy_bf16, const void* w_hh, const void* w_hh_t, int64_t ldwt,
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st) {
   if (persistent) {
     const int mode = lstm_handoff_mode();
     hipError_t e = mode == 2 ? hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st)
                              : hipMemsetAsync(scratch, 0, kSyncBytes, st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    LstmBwdArgs a{dy, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
+    LstmBwdArgs a{dy, dy_bf16, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
                   (unsigned*)scratch + 1000, (int)B, (int)T, mode};
     static bool attr_set = false;
     if (!attr_set) {
@@ -577,10 +588,10 @@ int lstm_bwd(int dtype, bool persistent, const float* dy, const void* w_hh, cons
   const int blocks = (int)((B * H + 255) / 256);
   for (int t = (int)T - 1; t >= 0; t--) {
     if (dtype == OVQA_BF16)
-      hipLaunchKernelGGL(lstm_step_bwd_simple<bf16>, dim3(blocks), dim3(256), 0, st, dy, (const bf16*)w_hh, gates, cs,
+      hipLaunchKernelGGL(lstm_step_bwd_simple<bf16>, dim3(blocks), dim3(256), 0, st, dy, dy_bf16, (const bf16*)w_hh, gates, cs,
                          (bf16*)dgates, carry, (int)B, (int)T, (int)H, t);
     else
-      hipLaunchKernelGGL(lstm_step_bwd_simple<float>, dim3(blocks), dim3(256), 0, st, dy, (const float*)w_hh, gates, cs,
+      hipLaunchKernelGGL(lstm_step_bwd_simple<float>, dim3(blocks), dim3(256), 0, st, dy, dy_bf16, (const float*)w_hh, gates, cs,
                          (float*)dgates, carry, (int)B, (int)T, (int)H, t);
   }
   return ovqa_check_launch("lstm_bwd(simple)");

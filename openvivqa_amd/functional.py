@@ -208,6 +208,10 @@ class _Prologue(Function):
     def forward(ctx, x, gamma, beta, st):
         arena, T = st["arena"], st["dtype"]
         x = _c(x)
+        ctx.dx_dtype = x.dtype
+        x32 = st.pop("x32", None)
+        if x32 is not None:  # the unrounded values of a bf16 input (its fp32 twin): the LayerNorm reads those
+            x = _c(x32)
         if T == torch.bfloat16:
             y, y32, mean, rstd = ops.layernorm_fwd(x, arena.master_of(gamma), arena.master_of(beta), st["eps"],
                                                    out_dtype=T, pos=st["pos"], want_f32=True)
@@ -225,12 +229,15 @@ class _Prologue(Function):
         arena = st["arena"]
         x, mean, rstd = ctx.saved_tensors
         gamma, beta = st["gamma"], st["beta"]
-        dx, _ = _ln_bwd(arena, _c(dy), x, gamma, beta, mean, rstd, dx_dtype=x.dtype)
+        dx, _ = _ln_bwd(arena, _c(dy), x, gamma, beta, mean, rstd, dx_dtype=ctx.dx_dtype)
         return dx if ctx.needs_input_grad[0] else None, None, None, None
 
 
 def prologue(x, layer_norm, pos, arena, dtype):
     st = dict(arena=arena, dtype=dtype, eps=layer_norm.eps, pos=pos, gamma=layer_norm.weight, beta=layer_norm.bias)
+    tw = _twin(x)
+    if isinstance(tw, torch.Tensor) and tw.dtype == torch.float32 and tw.shape == x.shape and x.dtype == torch.bfloat16:
+        st["x32"] = tw
     return _attach(_Prologue.apply(x, layer_norm.weight, layer_norm.bias, st), st)
 
 
@@ -730,26 +737,39 @@ def pointer_score(q, k, scale, add_mask=None, key_fill=None, query_fill=None):
 
 # ------------------------------------------------------------------ LSTM recurrence
 class _LSTM(Function):
-    """y = LSTM(x) (text_embeddings.py:236,243) on TIME-MAJOR input rows x_tb [T*B, I]; y fp32 [B, T, H].  One persistent
-    launch each way in bf16 mode; the weight / bias gradients and dx are the library's GEMMs on ``dgates``."""
+    """y = LSTM(x) (text_embeddings.py:236,243) on TIME-MAJOR input rows x_tb [T*B, I]; y fp32 [B, T, H] and, in bf16 mode, its
+    bf16 twin (second output: what a stack of this package takes as its operand without a cast launch; a gradient may
+    arrive through either).  One persistent launch each way in bf16 mode; the weight / bias gradients and dx are the
+    library's GEMMs on ``dgates``."""
 
     @staticmethod
     def forward(ctx, x_tb, st, *params):
         arena, m = st["arena"], st["mod"]
         x_tb = _c(x_tb)
-        y, hseq, saved, _ = ops.lstm_fwd(x_tb, arena.compute(m.weight_ih_l0), arena.compute(m.weight_hh_l0),
-                                         arena.master_of(m.bias_ih_l0), arena.master_of(m.bias_hh_l0), st["B"], st["T"])
+        want_lp = x_tb.dtype != torch.float32
+        res = ops.lstm_fwd(x_tb, arena.compute(m.weight_ih_l0), arena.compute(m.weight_hh_l0),
+                           arena.master_of(m.bias_ih_l0), arena.master_of(m.bias_hh_l0), st["B"], st["T"], want_lp=want_lp)
+        y, hseq, saved = res[0], res[1], res[2]
         ctx.st = st
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x_tb, hseq, saved)
-        return y
+        return (y, res[4]) if want_lp else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_lp=None):
         st = ctx.st
         arena, m, B, T = st["arena"], st["mod"], st["B"], st["T"]
         x_tb, hseq, saved = ctx.saved_tensors
         w_ih, w_hh = m.weight_ih_l0, m.weight_hh_l0
-        dgates, _ = ops.lstm_bwd(_c(dy.float()), arena.compute(w_hh), arena.transposed([w_hh]), saved, B, T, w_ih.shape[1])
+        if dy is None and dy_lp is None:
+            return (None,) * (2 + len(st["params"]))
+        if dy is None:
+            g = _c(dy_lp)                       # bf16, read as it is by the kernel
+        elif dy_lp is None:
+            g = _c(dy.float())
+        else:
+            g = _c(dy.float() + dy_lp.float())  # (both outputs were used)
+        dgates, _ = ops.lstm_bwd(g, arena.compute(w_hh), arena.transposed([w_hh]), saved, B, T, w_ih.shape[1])
         _wgrad(arena, dgates, x_tb, [w_ih], [m.bias_ih_l0])
         _wgrad(arena, dgates, hseq[:T * B], [w_hh], [m.bias_hh_l0])
         dx = _dx(arena, dgates, [w_ih]) if ctx.needs_input_grad[0] else None
@@ -757,13 +777,31 @@ class _LSTM(Function):
 
 
 def lstm(x_tb, mod, arena, B, T):
-    """``mod`` holds weight_ih_l0 / weight_hh_l0 / bias_ih_l0 / bias_hh_l0 (torch.nn.LSTM's parameter names)."""
+    """``mod`` holds weight_ih_l0 / weight_hh_l0 / bias_ih_l0 / bias_hh_l0 (torch.nn.LSTM's parameter names).  Returns y fp32
+    [B, T, H]; in bf16 mode its bf16 twin rides along as plumbing (``compute_twin(y)``), the fp32 values as ITS residual twin."""
     params = [mod.weight_ih_l0, mod.weight_hh_l0, mod.bias_ih_l0, mod.bias_hh_l0]
     st = dict(arena=arena, mod=mod, params=params, B=B, T=T)
     if torch.is_grad_enabled():
-        return _LSTM.apply(x_tb, st, *params)
+        out = _LSTM.apply(x_tb, st, *params)
+        if isinstance(out, tuple):
+            y, y_lp = out
+            attach_residual(y_lp, y.detach())
+            y._ovqa_compute = y_lp
+            y._ovqa_compute_tag = (y._version, y.data_ptr(), tuple(y.shape))
+            return y
+        return out
     return ops.lstm_fwd(_c(x_tb), arena.compute(mod.weight_ih_l0), arena.compute(mod.weight_hh_l0),
                         arena.master_of(mod.bias_ih_l0), arena.master_of(mod.bias_hh_l0), B, T)[0]
+
+
+def compute_twin(x, dtype):
+    """The tensor a producer of this package made NEXT TO ``x`` in the compute dtype (same values, its own autograd edge):
+    handing it to the next stack instead of ``x`` saves the cast launches both ways and the fp32 round trip of the stack's
+    output.  ``x`` itself when there is none (or x was modified since)."""
+    tw = getattr(x, "_ovqa_compute", None)
+    if tw is None or tw.dtype != dtype or getattr(x, "_ovqa_compute_tag", None) != (x._version, x.data_ptr(), tuple(x.shape)):
+        return x
+    return tw
 
 
 # ------------------------------------------------------------------ the two ends of the model (csrc/model_ends.hip)

@@ -73,7 +73,9 @@ class MCAN(nn.Module):
         T = arena.compute_dtype
         vision, vision_mask = self.vision_embedding(input_features.region_features)
         text, (text_mask, _) = self.text_embedding(input_features.question_tokens)
-        text = self.self_encoder(features=text, padding_mask=text_mask)
+        # (the LSTM embedding makes its output in the compute dtype too: the question stack takes that twin -- and hands its
+        # own output over in the compute dtype -- instead of casting the fp32 tensor back and forth)
+        text = self.self_encoder(features=Fn.compute_twin(text, T), padding_mask=text_mask)
         vision = self.guided_encoder(vision_features=vision, vision_padding_mask=vision_mask,
                                      language_features=text, language_padding_mask=text_mask)
         # attention pooling over each sequence (softmax over dim=1, padded positions included as in the

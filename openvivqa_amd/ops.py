@@ -1040,9 +1040,10 @@ def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False, target=None):
 
 # ---------------------------------------------------------------------------
 # LSTM recurrence (ovqa_lstm_fwd / ovqa_lstm_bwd)
-def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T):
+def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
     """x_tb [T*B, I] TIME-MAJOR rows (row t*B + b) -> (y fp32 [B, T, H], hseq [(T+1)*B, H] time-major with block 0 = 0 and
-    block t+1 = h_t, saved (opaque bytes for ``lstm_bwd``)).  Gate order i, f, g, o; zero initial state."""
+    block t+1 = h_t, saved (opaque bytes for ``lstm_bwd``), scratch[, y_lp = y in x's dtype with ``want_lp``]).  Gate order
+    i, f, g, o; zero initial state."""
     _dev(x_tb)
     lib = _lib.load()
     H4, I = w_ih.shape
@@ -1052,28 +1053,29 @@ def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T):
     assert b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.numel() == H4 == b_hh.numel()
     dev = x_tb.device
     y = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+    y_lp = torch.empty(B, T, H, dtype=x_tb.dtype, device=dev) if want_lp else None
     hseq = torch.empty((T + 1) * B, H, dtype=x_tb.dtype, device=dev)
     saved = torch.empty(lib.ovqa_lstm_saved_bytes(B, T, H), dtype=torch.uint8, device=dev)
     scratch = torch.empty(lib.ovqa_lstm_scratch_bytes(B, T, H), dtype=torch.uint8, device=dev)
     _lib.check(lib.ovqa_lstm_fwd(_dt(x_tb), _p(x_tb), x_tb.stride(0), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(y),
-                                 _p(hseq), _p(saved), _p(scratch), B, T, I, H, _stream()), "lstm_fwd")
-    return y, hseq, saved, scratch
+                                 _p(y_lp), _p(hseq), _p(saved), _p(scratch), B, T, I, H, _stream()), "lstm_fwd")
+    return (y, hseq, saved, scratch, y_lp) if want_lp else (y, hseq, saved, scratch)
 
 
 def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
-    """dy fp32 [B, T, H] -> dgates [T*B, 4H] (time-major rows, columns gate*H + unit) in w_hh's dtype; ``w_hh_t`` = the
-    transposed bf16 copy [H, 4H] (rows may be strided) or None in fp32 mode."""
+    """dy [B, T, H] (fp32 or bf16) -> dgates [T*B, 4H] (time-major rows, columns gate*H + unit) in w_hh's dtype; ``w_hh_t`` =
+    the transposed bf16 copy [H, 4H] (rows may be strided) or None in fp32 mode."""
     _dev(dy)
     lib = _lib.load()
     H4, H = w_hh.shape
-    assert dy.dtype == torch.float32 and dy.is_contiguous() and dy.shape == (B, T, H) and w_hh.is_contiguous()
+    assert dy.is_contiguous() and dy.shape == (B, T, H) and w_hh.is_contiguous()
     ldwt = 0
     if w_hh_t is not None:
         assert w_hh_t.shape == (H, H4) and w_hh_t.stride(1) == 1 and w_hh_t.dtype == w_hh.dtype
         ldwt = w_hh_t.stride(0)
     dgates = torch.empty(T * B, H4, dtype=w_hh.dtype, device=dy.device)
     scratch = torch.empty(lib.ovqa_lstm_scratch_bytes(B, T, H), dtype=torch.uint8, device=dy.device)
-    _lib.check(lib.ovqa_lstm_bwd(_dt(w_hh), _p(dy), _p(w_hh), _p(w_hh_t), ldwt, _p(saved), _p(dgates), _p(scratch), B, T,
+    _lib.check(lib.ovqa_lstm_bwd(_dt(w_hh), _p(dy), _dt(dy), _p(w_hh), _p(w_hh_t), ldwt, _p(saved), _p(dgates), _p(scratch), B, T,
                                  I, H, _stream()), "lstm_bwd")
     return dgates, scratch
 

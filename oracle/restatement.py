@@ -845,8 +845,9 @@ class OracleMCAN(nn.Module):
                                 language_padding_mask=tmask)
         av = torch.softmax(self.vision_attr_reduce(v), dim=1)
         at = torch.softmax(self.text_attr_reduce(t), dim=1)
-        # (HIP path: the image stack hands its output over in bf16 -- its input was bf16 --, the question stack in fp32)
-        wv, wt = (_r(v) * av).sum(dim=1), (t * at).sum(dim=1)
+        # (HIP path: both stacks hand their outputs over in bf16 -- the image stack's input was bf16, the question stack takes
+        # the LSTM's bf16 twin --, so the pooled sums are taken over bf16 features)
+        wv, wt = (_r(v) * av).sum(dim=1), (_r(t) * at).sum(dim=1)
         # (HIP path: the two projections and the classifier are bf16 GEMMs with bf16 outputs; the second projection adds
         # the first in its epilogue, so the SUM is what is stored in bf16; LayerNorm statistics in fp32)
         out = self.layer_norm(_r(_r(_lin(self.vision_proj, wv)) + _lin(self.text_proj, wt)))

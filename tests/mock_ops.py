@@ -311,7 +311,7 @@ def row_padding_mask(x, pad_value=0.0):
     return ((x.float().sum(-1) == pad_value * D).float() * -10e4).reshape(B, 1, 1, N)
 
 
-def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T):
+def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
     H = w_hh.shape[1]
     xg = (x_tb.float() @ w_ih.float().t() + b_ih).view(T, B, 4 * H)
     h = torch.zeros(B, H)
@@ -328,7 +328,8 @@ def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T):
         ys.append(h)
         hseq.append(h.to(x_tb.dtype))
     saved = torch.cat([torch.stack(gates), torch.stack(cs)], -1)  # [T, B, 5H]
-    return torch.stack(ys, 1).contiguous(), torch.cat(hseq, 0), saved, None
+    y = torch.stack(ys, 1).contiguous()
+    return (y, torch.cat(hseq, 0), saved, None, y.to(x_tb.dtype)) if want_lp else (y, torch.cat(hseq, 0), saved, None)
 
 
 def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
