@@ -505,7 +505,11 @@ int ovqa_dropout_keep_mask(const ovqa_dropout* drop, uint8_t* out, int64_t n, vo
 
 /* Mean-squared-error loss of the stack-level bench harness (fused forward+backward):
  * loss (+)= sum((x-target)^2)/n (fp32 device scalar), dx = 2*(x-target)/n.
- * target (dtype, may be NULL = 0).  NB a NULL target on LayerNorm outputs is a constant. */
+ * target (dtype, may be NULL = 0).  NB a NULL target on LayerNorm outputs is a constant.
+ * The cross-workgroup sum goes through a process-global scratch slot chosen by the STREAM handle (16 slots): launches of
+ * one stream are ordered; launches on different streams are independent unless their handles hash to the same slot --
+ * do not run two of these concurrently on more streams than that.  A launch that is aborted mid-way leaves its slot's
+ * arrival ticket non-zero (later losses of that slot would be wrong): reload the library. */
 int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, float* loss, int64_t n,
                          int accumulate_loss, void* stream);
 

@@ -266,13 +266,17 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(DropArgs da, uint8_t* __
 // XCD's whole L2 (the 6.5 MB of dx just stored included) and made the first version of this kernel 23 us instead of 8.
 // The scratch is per device and process; launches that share it are ordered by the stream they run on.
 constexpr int kLossBlocks = 256;
-__device__ float g_loss_partial[kLossBlocks];
-__device__ unsigned int g_loss_ticket;
+//  one scratch slot per STREAM the launches come from (hashed to kLossSlots slots): two launches on different
+// streams no longer interleave tickets unless their stream handles collide in the hash -- launches of ONE stream are
+// ordered anyway.  The last arriver resets its slot's ticket; an aborted launch would leave it non-zero (include/ovqa_hip.h).
+constexpr int kLossSlots = 16;
+__device__ float g_loss_partial[kLossSlots][kLossBlocks];
+__device__ unsigned int g_loss_ticket[kLossSlots];
 
 template <typename T>
 __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, const T* __restrict__ tgt,
                                                       T* __restrict__ dx, float* __restrict__ loss, int64_t n, int vec,
-                                                      int accumulate) {
+                                                      int accumulate, int slot) {
   __shared__ float red[4];
   __shared__ bool last;
   const float inv_n = 1.f / (float)n;
@@ -304,16 +308,16 @@ __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, c
   if (threadIdx.x == 0) {
     const float mine = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
     // the exchange RETURNS (so it has been performed) before the ticket is taken: the ticket's increment depends on it
-    const float before = atomicExch(&g_loss_partial[blockIdx.x], mine);
+    const float before = atomicExch(&g_loss_partial[slot][blockIdx.x], mine);
     unsigned int one = 1u;
     asm volatile("; the ticket waits for the returned value of the exchange" : "+v"(one) : "v"(before));
-    last = atomicAdd(&g_loss_ticket, one) == gridDim.x - 1;
+    last = atomicAdd(&g_loss_ticket[slot], one) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
   float t = 0.f;
   for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)  // thread k: partial k (at most one: <= 256 workgroups)
-    t += atomicAdd(&g_loss_partial[b], 0.f);               // (a device-scope read of what the other XCDs published)
+    t += atomicAdd(&g_loss_partial[slot][b], 0.f);               // (a device-scope read of what the other XCDs published)
   t = wave_sum(t);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void sq_loss_kernel(const T* __restrict__ x, c
   if (threadIdx.x == 0) {
     const float total = (red[0] + red[1]) + (red[2] + red[3]);
     *loss = accumulate ? *loss + total : total;
-    atomicExch(&g_loss_ticket, 0u);
+    atomicExch(&g_loss_ticket[slot], 0u);
   }
 }
 
@@ -450,12 +454,13 @@ int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, floa
   int blocks = blocks_for((n + per - 1) / per);
   if (blocks > kLossBlocks) blocks = kLossBlocks;  // one partial per workgroup, summed in index order by the last one
   dim3 grid(blocks), block(256);
+  const int slot = (int)((((uintptr_t)st) >> 6) % kLossSlots);
   if (dtype == OVQA_F32)
     hipLaunchKernelGGL(sq_loss_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)target, (float*)dx,
-                       loss, n, vec, accumulate_loss);
+                       loss, n, vec, accumulate_loss, slot);
   else
     hipLaunchKernelGGL(sq_loss_kernel<bf16>, grid, block, 0, st, (const bf16*)x, (const bf16*)target, (bf16*)dx, loss,
-                       n, vec, accumulate_loss);
+                       n, vec, accumulate_loss, slot);
   return ovqa_check_launch("sq_loss");
 }
 

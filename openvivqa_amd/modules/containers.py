@@ -151,3 +151,19 @@ def _refuse_foreign_stateful_parent(parent, name, child):
 
 
 _hook_handle = torch.nn.modules.module.register_module_module_registration_hook(_refuse_foreign_stateful_parent)
+
+
+def remove_foreign_parent_guard() -> None:
+    """Opt out of the guard above: a host that adopts this package's stateful modules into its own stateful
+    containers for TRAINING only -- teacher-forced forward, no statefulness() / beam search -- may remove the hook; decoding
+    through such a container would be stateless without an error, which is why it is on by default."""
+    global _hook_handle
+    if _hook_handle is not None:
+        _hook_handle.remove()
+        _hook_handle = None
+
+
+def install_foreign_parent_guard() -> None:
+    global _hook_handle
+    if _hook_handle is None:
+        _hook_handle = torch.nn.modules.module.register_module_module_registration_hook(_refuse_foreign_stateful_parent)

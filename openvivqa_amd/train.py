@@ -90,6 +90,9 @@ class FlatAdam:
         if self.lr_table is None:
             self.lr_table = torch.empty(self.LR_TABLE, dtype=torch.float32, device=dev)
             self.lr_eff = torch.zeros(1, dtype=torch.float32, device=dev)
+        if dev.type == "cuda" and int(self.step_t.item()) != self.host_step:
+            raise RuntimeError(f"FlatAdam.device_schedule: host step {self.host_step} != device step "
+                               f"{int(self.step_t.item())}: the table is indexed by the device counter (call resync())")
         self._table_from = self.host_step
         self._fill_table(self.host_step, self.host_step + self.LR_TABLE)
 
@@ -160,6 +163,11 @@ class FlatAdam:
         # LambdaLR keeps the un-scaled rate in `initial_lr`; `lr` is initial_lr * lambda(last_epoch)
         self.lr = float(g0.get("initial_lr", g0["lr"]))
         self.betas, self.eps, self.weight_decay = tuple(g0["betas"]), float(g0["eps"]), float(g0["weight_decay"])
+        self._resync_schedule()
+
+    def resync(self) -> None:
+        """Call after changing ``lr``, ``lr_lambda`` or the step count by hand once the device-side schedule is live (ADVICE
+        r4): the table is rebuilt from the DEVICE step counter, which the host counter is set to."""
         self._resync_schedule()
 
     def _resync_schedule(self) -> None:

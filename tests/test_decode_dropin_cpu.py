@@ -196,14 +196,13 @@ def test_reference_base_transformer_without_containers_alias_is_refused(cpu_ops,
         with pytest.raises(TypeError, match="models.modules.containers"):
             _generation_model(ref_bt, ref_db.build_decoder)(cfg, vocab)
         # what would happen without the guard (the round-3 behaviour), documented: the decoder never becomes stateful
-        C._hook_handle.remove()
+        C.remove_foreign_parent_guard()
         try:
             model = _generation_model(ref_bt, ref_db.build_decoder)(cfg, vocab)
             with model.statefulness(2):
                 assert model.decoder._is_stateful is False and len(list(model.states())) == 2
         finally:
-            C._hook_handle = torch.nn.modules.module.register_module_module_registration_hook(
-                C._refuse_foreign_stateful_parent)
+            C.install_foreign_parent_guard()
     finally:
         _restore(saved)
 
