@@ -1307,6 +1307,9 @@ __global__ __launch_bounds__(512 * NH, NH == 1 ? 4 : 4) void attn_bwd_do_smallk_
         for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
     }
   }
+  // (round 5 measured the requests IN FRONT of the projection loop, as attn_bwd_do_smallk1_mfma_kernel has them: 18.4 -> 19.4 us
+  // per launch in the step -- nine register loads per thread of two co-resident workgroups queue ahead of the ring's first
+  // tiles on the same fetch path; the role-split form showed the same)
   // ---- everything else the backward needs is requested now (one round of loads, as in the plain kernel); per head 512
   // threads: the first 256 take Q (4 chunks) and K, the other 256 O / o_lo (4 chunks each), V, lse; the mask row by 32
   const int hs = tid >> 9, t5 = tid & 511;   // staging head and thread within its 512
@@ -1420,6 +1423,7 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
   const int wr = wave;  // feature slab of 32: head wr >> 1
   const int h0 = blockIdx.y * G, b = blockIdx.x, nq = a.nq, nk = a.nk;
 
+  OVQA_PROBE(0);
   f32x4 acc[NJ][NI];
 #pragma unroll
   for (int j = 0; j < NJ; j++)
@@ -1446,6 +1450,30 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
     for (int i = 0; i < PER; i++)
       __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + NW * i) * 1024), 16, 0, 0);
   };
+  // ---- one round of loads for both heads: every thread owns chunk (row tid >> 3, 16 bytes tid & 7) of every image
+  const int ch = tid & 7, row = tid >> 3;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  // (unconditional loads at clamped rows, nothing computed from them here: see attn_bwd_roles_mfma_kernel)
+  const bool has_mask = a.mask != nullptr, has_lo = a.o_lo != nullptr;
+  uint4 vq[G], vo[G], vl[G], vk[G], vv[G];
+  float lse_r[G];
+  const int rq = min(row, nq - 1), rk = min(row, nk - 1);
+  const int mkey = min(tid & (k_rows - 1), nk - 1), mhead = h0 + ((tid / k_rows) & (G - 1));
+  const float* mp = has_mask ? a.mask + (int64_t)b * a.msb + (int64_t)mhead * a.msh + mkey : a.lse + ((int64_t)b * a.H + h0) * nq;
+  float mval = *mp;
+#pragma unroll
+  for (int gi = 0; gi < G; gi++) {
+    const int hh = h0 + gi;
+    const bf16* ob = (const bf16*)a.o + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8;
+    vq[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.q + ((int64_t)b * nq + rq) * a.ldq + hh * 64 + ch * 8);
+    vo[gi] = *reinterpret_cast<const uint4*>(ob);
+    vl[gi] = *reinterpret_cast<const uint4*>(has_lo ? (const bf16*)a.o_lo + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8 : ob);
+    lse_r[gi] = a.lse[((int64_t)b * a.H + hh) * nq + rq];
+    vk[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + rk) * a.ldk + hh * 64 + ch * 8);
+    vv[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + rk) * a.ldv + hh * 64 + ch * 8);
+  }
+  // (requested BEFORE the projection loop, round 5: Q, K, V, O arrive under it instead of in a round trip of their own
+  // behind it -- 1.1 us per workgroup by the phase probe, 3.1 from cold caches)
   const int nkt = g.Dm / BKF;
 #pragma unroll
   for (int p = 0; p < NBUF - 1; p++)
@@ -1475,28 +1503,8 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
         for (int i = 0; i < NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
     }
   }
-  // ---- one round of loads for both heads: every thread owns chunk (row tid >> 3, 16 bytes tid & 7) of every image
-  const int ch = tid & 7, row = tid >> 3;
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  // (unconditional loads at clamped rows, nothing computed from them here: see attn_bwd_roles_mfma_kernel)
-  const bool has_mask = a.mask != nullptr, has_lo = a.o_lo != nullptr;
-  uint4 vq[G], vo[G], vl[G], vk[G], vv[G];
-  float lse_r[G];
-  const int rq = min(row, nq - 1), rk = min(row, nk - 1);
-  const int mkey = min(tid & (k_rows - 1), nk - 1), mhead = h0 + ((tid / k_rows) & (G - 1));
-  const float* mp = has_mask ? a.mask + (int64_t)b * a.msb + (int64_t)mhead * a.msh + mkey : a.lse + ((int64_t)b * a.H + h0) * nq;
-  float mval = *mp;
-#pragma unroll
-  for (int gi = 0; gi < G; gi++) {
-    const int hh = h0 + gi;
-    const bf16* ob = (const bf16*)a.o + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8;
-    vq[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.q + ((int64_t)b * nq + rq) * a.ldq + hh * 64 + ch * 8);
-    vo[gi] = *reinterpret_cast<const uint4*>(ob);
-    vl[gi] = *reinterpret_cast<const uint4*>(has_lo ? (const bf16*)a.o_lo + ((int64_t)b * nq + rq) * a.ldo + hh * 64 + ch * 8 : ob);
-    lse_r[gi] = a.lse[((int64_t)b * a.H + hh) * nq + rq];
-    vk[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.k + ((int64_t)b * nk + rk) * a.ldk + hh * 64 + ch * 8);
-    vv[gi] = *reinterpret_cast<const uint4*>((const bf16*)a.v + ((int64_t)b * nk + rk) * a.ldv + hh * 64 + ch * 8);
-  }
+  OVQA_PROBE(1);
+  OVQA_PROBE(2);
   __syncthreads();  // every wave is done with the staging ring: it becomes the images
 
   // ---- dO image [32][64] (bf16) of the wave's head from the accumulators; rows beyond nq are zero
@@ -1545,6 +1553,7 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
     reinterpret_cast<float*>(smem + (tid / k_rows) * prob_bytes + img_bytes)[tid % k_rows] =
         tid % k_rows < nk ? (has_mask ? mval * LOG2E : 0.f) : -INFINITY;
   __syncthreads();
+  OVQA_PROBE(3);
   smallk_bwd_compute<true, 1, G>(a, smem, b * a.H + h0, wave, lane, false);
 }
 
@@ -1561,15 +1570,25 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
 #ifndef OVQA_ROLES_WAVES_PER_EU
 #define OVQA_ROLES_WAVES_PER_EU 4
 #endif
-template <int NQT_T, int NKT_T, bool ROWMASK>
-__global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1) void attn_bwd_roles_mfma_kernel(ovqa::AttnBwdArgs a, int nqt_rt, int nkt_rt) {
+// FUSE_NBUF > 0 (round 5; needs NQT_T = NKT_T = 4): the fc_o dX product inside, the form attn_bwd_do_smallk_mfma_kernel
+// has for the guided attention -- dO of the head = dY [128 rows, d_model] x 64 rows of the transposed fc_o weights, with
+// that kernel's projection loop (ring of FUSE_NBUF K steps of 64: 24 KB each, aliased with the images), rounded to bf16
+// straight into the dO image; grid (B, H), so that the 8 heads of a sample -- which all stream the sample's dY rows --
+// share an XCD.  dO never travels through HBM and the 6400 x 512 <- 512 dX launch in front of this kernel is gone.
+template <int NQT_T, int NKT_T, bool ROWMASK, int FUSE_NBUF = 0>
+__global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1) void attn_bwd_roles_mfma_kernel(DoBwdArgs g, int nqt_rt, int nkt_rt) {
+  constexpr bool FUSE = FUSE_NBUF > 0, EARLY = FUSE_NBUF >= 10;
+  constexpr int RING = FUSE ? FUSE_NBUF % 10 : 1;  // (1: never used, keeps the un-fused instantiations free of a % 0)
+  static_assert(!FUSE || (NQT_T == 4 && NKT_T == 4), "the fused form is built for 4 x 4 tiles");
+  const ovqa::AttnBwdArgs& a = g.att;
   const int nqt = NQT_T ? NQT_T : nqt_rt, nkt = NKT_T ? NKT_T : nkt_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nk = a.nk, nq = a.nq;
   const int q_rows = nqt * 32, k_rows = nkt * 32;
-  const int pid = (int)blockIdx.x;
-  const int b = pid / a.H, h = pid - b * a.H;
+  const int b = FUSE ? (int)blockIdx.x : (int)blockIdx.x / a.H;
+  const int h = FUSE ? (int)blockIdx.y : (int)blockIdx.x - b * a.H;
+  const int pid = b * a.H + h;
   char* Qs = smem;
   char* Gs = Qs + q_rows * 128;
   char* Ks = Gs + q_rows * 128;
@@ -1580,6 +1599,75 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
   float* lse_s = mlds + k_rows;
   float* del_s = lse_s + q_rows;
   OVQA_PROBE(0);
+  // ---- (fused form) dO of the head into accumulators: acc[j][i] = 16 rows (wc * 32 + i * 16 ..) x 16 features
+  // (wr * 32 + j * 16 ..) per wave, the staging ring over the (not yet written) images
+  constexpr int PJ_NI = 2, PJ_NJ = 2;
+  f32x4 acc[PJ_NJ][PJ_NI];
+  const int wc = wave >> 1, wr = wave & 1;
+  // the projection loop of the fused form; EARLY (FUSE_NBUF >= 10): it runs BEHIND the staging requests below, so that Q, K, V,
+  // O arrive under it.  MEASURED (phase probe, round 5): slower -- the 14 register loads per thread of two co-resident
+  // workgroups take 3.4 us just to issue (8-9 from cold caches: the CU's fetch path is the bottleneck either way) and the
+  // ring's first tiles queue behind them: 19.9 against 17.6-18.8 us per workgroup warm, 27.4 against 26.4 cold.
+  auto project = [&]() {
+    constexpr int BKF = 64, NW = 8, PROWS = 8, CHR = 8, WCH = 64 / PROWS, XCH = 128 / PROWS, PER = (WCH + XCH) / NW;
+    constexpr int STAGE = (WCH + XCH) * 1024;
+#pragma unroll
+    for (int j = 0; j < PJ_NJ; j++)
+#pragma unroll
+      for (int i = 0; i < PJ_NI; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto off32 = [&](int row, int ch) { return row * (BKF * 2) + ((ch ^ (row & 7)) << 4); };
+    const bf16* src[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int ci = wave + NW * i;
+      const int prow = lane / CHR, pch = lane % CHR;
+      if (ci < WCH) {
+        const int row = ci * PROWS + prow;
+        src[i] = g.wt + (int64_t)(h * 64 + perm32(row)) * g.ldwt + ((pch ^ (row & 7)) << 3);
+      } else {
+        const int row = (ci - WCH) * PROWS + prow;
+        const int r = row < nq ? row : nq - 1;
+        src[i] = g.dy + ((int64_t)b * nq + r) * g.lddy + ((pch ^ (row & 7)) << 3);
+      }
+    }
+    auto issue = [&](int kt) {
+      char* buf = smem + (kt % RING) * STAGE;
+#pragma unroll
+      for (int i = 0; i < PER; i++)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src[i] + kt * BKF), (lds_void*)(buf + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+    const int nkt_p = g.Dm / BKF;
+#pragma unroll
+    for (int p = 0; p < RING - 1; p++)
+      if (p < nkt_p) issue(p);
+    for (int kt = 0; kt < nkt_p; kt++) {
+      if (kt + RING - 2 >= nkt_p) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (RING - 2)) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kt + RING - 1 < nkt_p) issue(kt + RING - 1);
+      const char* Ws = smem + (kt % RING) * STAGE;
+      const char* Xs = Ws + WCH * 1024;
+#pragma unroll
+      for (int ks = 0; ks < BKF / 32; ks++) {
+        bf16x8 pf[PJ_NJ], qf[PJ_NI];
+#pragma unroll
+        for (int j = 0; j < PJ_NJ; j++)
+          pf[j] = *reinterpret_cast<const bf16x8*>(Ws + off32(wr * 32 + j * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+        for (int i = 0; i < PJ_NI; i++)
+          qf[i] = *reinterpret_cast<const bf16x8*>(Xs + off32(wc * 32 + i * 16 + (lane & 15), ks * 4 + (lane >> 4)));
+#pragma unroll
+        for (int j = 0; j < PJ_NJ; j++)
+#pragma unroll
+          for (int i = 0; i < PJ_NI; i++) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
+      }
+    }
+    OVQA_PROBE(6);
+  };
+  if constexpr (FUSE && !EARLY) project();
   // ---- staging: one round of global loads (all issued before the first LDS store): a thread owns chunk `ch` of rows
   // r0 and r0 + 64 of each of Q, dO, K, V -- and of O, so that delta = dO . O falls out of the staging (8 consecutive
   // lanes hold a row) instead of a second, dependent pass over dO and O.
@@ -1609,7 +1697,7 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
       const int row = r0 + 64 * i;
       const int rq = min(row, nq - 1), rk = min(row, nk - 1);
       vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)rq * a.ldq);
-      vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)rq * a.lddo);
+      if constexpr (!FUSE) vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)rq * a.lddo);
       vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)rq * a.ldo);
       vl[i] = *reinterpret_cast<const uint4*>(lob2 + (int64_t)rq * a.ldo);
       lse_r[i] = lb[rq];
@@ -1617,11 +1705,30 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
       vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)rk * a.ldv);
     }
     OVQA_PROBE(1);
+    if constexpr (FUSE && EARLY) project();
+    if constexpr (FUSE) {
+      __syncthreads();  // every wave is done with the staging ring: it becomes the images
+      // dO image [128][64] (bf16) from the accumulators; rows beyond nq are zero
+#pragma unroll
+      for (int i = 0; i < PJ_NI; i++) {
+        const int r = wc * 32 + i * 16 + (lane & 15);
+        const int col = wr * 32 + (lane >> 4) * 8;
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          o8[e] = r < nq ? (bf16)acc[0][i][e] : (bf16)0.f;
+          o8[4 + e] = r < nq ? (bf16)acc[1][i][e] : (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(Gs + img_off(r, col >> 3)) = o8;
+      }
+      __syncthreads();  // the dO image is complete: delta reads it
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
       const bool qv = row < nq, kv = row < nk;
       if (!has_lo) vl[i] = zero4;
+      if constexpr (FUSE) vd[i] = *reinterpret_cast<const uint4*>(Gs + img_off(min(row, q_rows - 1), ch));  // (zero beyond nq)
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[i]);
       const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
       const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
@@ -1635,7 +1742,7 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
       if (!kv) { vk[i] = zero4; vv[i] = zero4; }
       if (row < q_rows) {
         *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = vq[i];
-        *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
+        if constexpr (!FUSE) *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
         if (ch == 0) {
           lse_s[row] = qv ? lse_r[i] * LOG2E : INFINITY;
           del_s[row] = qv ? dl : 0.f;
@@ -1925,11 +2032,12 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (merged && a.nk > 32 && a.nk <= 128 && a.nq <= 128 && merged != 2) {  // one launch, role-split waves
     const int nqt = (a.nq + 31) / 32, nkt = (a.nk + 31) / 32;
     const size_t lds = (size_t)(2 * nqt * 32 + 2 * nkt * 32) * 128 + (size_t)(nkt * 32 + 2 * nqt * 32) * 4;
+    const DoBwdArgs g0{nullptr, 0, nullptr, 0, a, 0};
 #define OVQA_ROLES(NQ, NK, RM)                                                                                        \
   {                                                                                                                   \
     int rc = ensure_lds(attn_bwd_roles_mfma_kernel<NQ, NK, RM>, lds, "attention_bwd(mfma,roles)");                    \
     if (rc != OVQA_OK) return rc;                                                                                     \
-    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, a, nqt, nkt); \
+    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, g0, nqt, nkt); \
   }
     if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
       if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
@@ -2026,7 +2134,21 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
   const bool k64 = Dm % 64 == 0;
   // short sequences: 4 samples per workgroup, or 2 when 4 would leave CUs without a workgroup (64 samples x 8 heads:
   // 128 -> 256 workgroups, 3.455 -> 3.442 ms per MCAN step; K steps of 64 made no difference here)
-  if (a.nq <= 32 && (int64_t)((a.B + 3) / 4) * a.H < 256) OVQA_QKV(32, 2, 32, 4)
+  // (OVQA_QKV_TEXT_FORM, round 5: bytes in flight per CU of the two-sample form -- 0: K steps of 32 in a ring of 4 (48 KB in
+  // flight; rounds 2-4), 1: K steps of 64 in a ring of 3 (64 KB), 2 (default): K steps of 64 in a ring of 4 (96 KB), 3: K
+  // steps of 32 in a ring of 6 (80 KB).  In the MCAN step, same box: 10.7-11.0 / 10.25 / 10.09 us per launch; the K loop is
+  // 5.7 of the kernel's 7.9 us per workgroup (phase probe) at 45 GB/s per CU, one workgroup per CU)
+  static int tform = -1;
+  if (tform < 0) {
+    const char* e = getenv("OVQA_QKV_TEXT_FORM");
+    tform = e ? atoi(e) : 2;
+  }
+  if (a.nq <= 32 && (int64_t)((a.B + 3) / 4) * a.H < 256) {
+    if (tform == 1 && k64) OVQA_QKV(32, 2, 64, 3)
+    else if (tform == 2 && k64) OVQA_QKV(32, 2, 64, 4)
+    else if (tform == 3) OVQA_QKV(32, 2, 32, 6)
+    else OVQA_QKV(32, 2, 32, 4)
+  }
   else if (a.nq <= 32) OVQA_QKV(32, 4, 32, 4)
   else if (a.nq <= 64) OVQA_QKV(64, 4, 32, 4)
   // 65-128 positions (100 regions): one sample per workgroup, K steps of 64, two workgroups per CU: 3.408 -> 3.382 ms
@@ -2084,11 +2206,22 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
   return ovqa_check_launch("attention_q_fwd(mfma)");
 }
 
+// OVQA_DOBWD_ROLES: the 100 x 100 self-attention backward with the fc_o dX product inside (ring depth 2 or 3; 0 = off)
+static int dobwd_roles() {
+  static const int v = [] {
+    const char* e = getenv("OVQA_DOBWD_ROLES");
+    return e ? atoi(e) : 3;
+  }();
+  return v;
+}
+
 bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t lddy, int64_t ldwt, const void* dy,
                                      const void* wt) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   const bool guided = a.nq > 64 && a.nq <= 128, single = a.nq >= 1 && a.nq <= 32 && a.H % 2 == 0;
-  return a.dk == 64 && a.dv == 64 && (guided || single) && a.nk >= 1 && a.nk <= 32 && a.msq == 0 &&
+  // (round 5) 97-128 queries x 97-128 keys, the image self-attention: the role-split backward with the projection inside
+  const bool roles = dobwd_roles() && a.nq > 96 && a.nq <= 128 && a.nk > 96 && a.nk <= 128;
+  return a.dk == 64 && a.dv == 64 && (roles || ((guided || single) && a.nk >= 1 && a.nk <= 32)) && a.msq == 0 &&
          a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && Dm % 64 == 0 && Dm >= 64 && lddy % 8 == 0 &&
          ldwt % 8 == 0 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.lddq % 4 == 0 &&
          a.lddk % 4 == 0 && a.lddv % 4 == 0 && al(dy) && al(wt) && al(a.q) && al(a.k) && al(a.v) && al(a.o) &&
@@ -2106,13 +2239,44 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
     const char* e = getenv("OVQA_DOBWD_PAIR");
     pair = e ? atoi(e) : 0;
   }
+  if (a.nk > 32) {  // the role-split form (image self-attention)
+    const size_t img = (size_t)(2 * 128 + 2 * 128) * 128 + (size_t)(128 + 2 * 128) * 4;
+    const size_t stage = (size_t)(64 + 128) * 64 * 2;
+    const int form = dobwd_roles();  // ring depth 2 | 3, + 10: staging requests in front of the projection loop
+    const int nbuf = form % 10 == 2 ? 2 : 3;
+    const size_t lds = nbuf * stage > img ? nbuf * stage : img;
+#define OVQA_DOROLES(F)                                                                                              \
+  {                                                                                                                  \
+    int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, F>, lds, "attention_bwd_do(roles)");                  \
+    if (rc != OVQA_OK) return rc;                                                                                    \
+    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, F>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4); \
+  }
+    if (form == 2) OVQA_DOROLES(2) else if (form == 12) OVQA_DOROLES(12) else if (form == 13) OVQA_DOROLES(13) else OVQA_DOROLES(3)
+#undef OVQA_DOROLES
+    return ovqa_check_launch("attention_bwd_do(mfma,roles)");
+  }
   if (a.nq <= 32) {  // single query tile (20 x 20): two heads per 4-wave workgroup
     const size_t stage1 = (size_t)(128 + 32) * 64 * 2;
     const size_t prob1 = (size_t)(2 * 32 + 2 * 32) * 128 + 32 * 4 + 2 * 32 * 4 + 4096 * 4;
     const size_t lds1 = 3 * stage1 > 2 * prob1 ? 3 * stage1 : 2 * prob1;
-    int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<3>, lds1, "attention_bwd_do");
-    if (rc != OVQA_OK) return rc;
-    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk1_mfma_kernel<3>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), lds1, st, g);
+    // OVQA_DOBWD1_NBUF: ring depth of the projection loop (3, 4 or 5 K steps of 20 KB; in the MCAN step 10.35-10.54 / 9.9 us
+    // per launch with 3 / 4, round 5)
+    static int nb1 = -1;
+    if (nb1 < 0) {
+      const char* e = getenv("OVQA_DOBWD1_NBUF");
+      nb1 = e ? atoi(e) : 4;
+      if (nb1 != 3 && nb1 != 5) nb1 = 4;
+    }
+    const size_t ldsn = (size_t)nb1 * stage1 > 2 * prob1 ? (size_t)nb1 * stage1 : 2 * prob1;
+#define OVQA_DO1(NB)                                                                                                   \
+  {                                                                                                                    \
+    int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<NB>, ldsn, "attention_bwd_do");                                \
+    if (rc != OVQA_OK) return rc;                                                                                      \
+    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk1_mfma_kernel<NB>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), ldsn, st, g); \
+  }
+    if (nb1 == 4) OVQA_DO1(4) else if (nb1 == 5) OVQA_DO1(5) else OVQA_DO1(3)
+#undef OVQA_DO1
+    (void)lds1;
     return ovqa_check_launch("attention_bwd_do(mfma)");
   }
   const size_t prob = (size_t)(2 * 128 + 2 * 32) * 128 + 32 * 4 + 2 * 128 * 4 + 4096 * 4;

@@ -64,79 +64,101 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[VEC]) {
 }
 
 // ---------------------------------------------------------------- forward
-template <typename TIN, typename TOUT, int CHUNKS>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+// R rows per wave (all R rows' loads are in flight before the first reduction), NW waves per workgroup.
+template <typename TIN, typename TOUT, int CHUNKS, int R = 1, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ pos,
                                                      int pos_rows, TOUT* __restrict__ y, float* __restrict__ y32,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      int D, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const TIN* xr = x + (int64_t)row * D;
-  // One round of loads: the row, gamma, beta (and the positional row) are all requested here, unconditionally at clamped
-  // columns -- gamma / beta used to be asked for after the two reductions, a second dependent round trip per wave.
-  Raw8<TIN> xraw[CHUNKS];
-  Raw8<float> graw[CHUNKS], braw[CHUNKS], praw[CHUNKS];
-  const float* pr = pos ? pos + (int64_t)(row % pos_rows) * D : nullptr;
+  const int row0 = (xcd_contiguous_block(blockIdx.x, gridDim.x) * NW + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
+  // One round of loads: the rows, gamma, beta (and the positional rows) are all requested here, unconditionally at clamped
+  // positions -- gamma / beta used to be asked for after the two reductions, a second dependent round trip per wave.
+  Raw8<TIN> xraw[R][CHUNKS];
+  Raw8<float> graw[CHUNKS], braw[CHUNKS], praw[R][CHUNKS];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int row = min(row0 + r, M - 1);
+    const float* pr = pos ? pos + (int64_t)(row % pos_rows) * D : nullptr;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = min((c * 64 + lane) * VEC, D - VEC);
+      xraw[r][c].load(x + (int64_t)row * D + col);
+      if (pr) praw[r][c].load(pr + col);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     const int col = min((c * 64 + lane) * VEC, D - VEC);
-    xraw[c].load(xr + col);
     graw[c].load(gamma + col);
     braw[c].load(beta + col);
-    if (pr) praw[c].load(pr + col);
   }
-  float v[CHUNKS][VEC];
-  float s = 0.f;
+  float v[R][CHUNKS][VEC];
+  float s[R], sq[R], mean[R], rstd[R];
 #pragma unroll
-  for (int c = 0; c < CHUNKS; c++) {
-    const int col = (c * 64 + lane) * VEC;
-    xraw[c].get(v[c]);
-    if (col < D) {
+  for (int r = 0; r < R; r++) {
+    s[r] = 0.f;
 #pragma unroll
-      for (int i = 0; i < VEC; i++) s += v[c][i];
-    } else {
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      xraw[r][c].get(v[r][c]);
+      if (col < D) {
 #pragma unroll
-      for (int i = 0; i < VEC; i++) v[c][i] = 0.f;
-    }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float sq = 0.f;
+        for (int i = 0; i < VEC; i++) s[r] += v[r][c][i];
+      } else {
 #pragma unroll
-  for (int c = 0; c < CHUNKS; c++) {
-    const int col = (c * 64 + lane) * VEC;
-    if (col < D) {
-#pragma unroll
-      for (int i = 0; i < VEC; i++) {
-        const float d = v[c][i] - mean;
-        sq += d * d;
+        for (int i = 0; i < VEC; i++) v[r][c][i] = 0.f;
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
-  }
-  TOUT* yr = y + (int64_t)row * D;
 #pragma unroll
-  for (int c = 0; c < CHUNKS; c++) {
-    const int col = (c * 64 + lane) * VEC;
-    if (col < D) {
-      float g[VEC], b[VEC], o[VEC];
-      graw[c].get(g);
-      braw[c].get(b);
+  for (int r = 0; r < R; r++) mean[r] = wave_sum(s[r]) / (float)D;
 #pragma unroll
-      for (int i = 0; i < VEC; i++) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
-      if (pr) {
-        float p[VEC];
-        praw[c].get(p);
+  for (int r = 0; r < R; r++) {
+    sq[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; i++) o[i] += p[i];
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          const float d = v[r][c][i] - mean[r];
+          sq[r] += d * d;
+        }
       }
-      store8<TOUT>(yr + col, o);
-      if (y32) store8<float>(y32 + (int64_t)row * D + col, o);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) rstd[r] = rsqrtf(wave_sum(sq[r]) / (float)D + eps);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean[r];
+      if (rstd_out) rstd_out[row] = rstd[r];
+    }
+    TOUT* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      const int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        float g[VEC], b[VEC], o[VEC];
+        graw[c].get(g);
+        braw[c].get(b);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = (v[r][c][i] - mean[r]) * rstd[r] * g[i] + b[i];
+        if (pos) {
+          float p[VEC];
+          praw[r][c].get(p);
+#pragma unroll
+          for (int i = 0; i < VEC; i++) o[i] += p[i];
+        }
+        store8<TOUT>(yr + col, o);
+        if (y32) store8<float>(y32 + (int64_t)row * D + col, o);
+      }
     }
   }
 }
@@ -333,20 +355,40 @@ __global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const ovqa_reduce_pr
   base[0] = t.x; base[1] = t.y; base[2] = t.z; base[3] = t.w;
 }
 
+// rows per wave x waves per workgroup of the forward (OVQA_LN_FWD_FORM = 10 * rows + log2(waves): 12 = the 1 x 4 default)
+static int ln_fwd_form() {
+  static const int v = [] {
+    const char* e = getenv("OVQA_LN_FWD_FORM");
+    return e ? atoi(e) : 12;
+  }();
+  return v;
+}
+
 template <typename TIN, typename TOUT>
 int fwd_dispatch(const void* x, const float* gamma, const float* beta, const float* pos, int64_t pos_rows, void* y,
                  float* y32, float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
-  dim3 grid((unsigned)((M + 3) / 4)), block(256);
-#define LN_FWD(C)                                                                                              \
-  hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, C>), grid, block, 0, st, (const TIN*)x, gamma, beta, pos,      \
-                     (int)(pos ? pos_rows : 1), (TOUT*)y, y32, mean, rstd, (int)M, (int)D, eps)
+  const int form = chunks == 1 ? ln_fwd_form() : 12;
+#define LN_FWD_RW(C, R, NW)                                                                                          \
+  hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, C, R, NW>), dim3((unsigned)((M + R * NW - 1) / (R * NW))),            \
+                     dim3(NW * 64), 0, st, (const TIN*)x, gamma, beta, pos, (int)(pos ? pos_rows : 1), (TOUT*)y, y32, \
+                     mean, rstd, (int)M, (int)D, eps)
   switch (chunks) {
-    case 1: LN_FWD(1); break;
-    case 2: LN_FWD(2); break;
-    default: LN_FWD(4); break;
+    case 1:
+      switch (form) {
+        case 11: LN_FWD_RW(1, 1, 2); break;
+        case 13: LN_FWD_RW(1, 1, 8); break;
+        case 21: LN_FWD_RW(1, 2, 2); break;
+        case 22: LN_FWD_RW(1, 2, 4); break;
+        case 23: LN_FWD_RW(1, 2, 8); break;
+        case 42: LN_FWD_RW(1, 4, 4); break;
+        default: LN_FWD_RW(1, 1, 4); break;
+      }
+      break;
+    case 2: LN_FWD_RW(2, 1, 4); break;
+    default: LN_FWD_RW(4, 1, 4); break;
   }
-#undef LN_FWD
+#undef LN_FWD_RW
   return ovqa_check_launch("layernorm_fwd");
 }
 
@@ -356,23 +398,27 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
                  const DropArgs& da, void* ws, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
   const int nblocks = ovqa::layernorm_bwd_blocks(M, D);
-  const bool wide = ovqa::layernorm_bwd_waves(M, D) == 8;
+  const int nw = ovqa::layernorm_bwd_waves(M, D);
   OVQA_REQUIRE((int64_t)nblocks * 2 * D * 4 <= ovqa::kWorkspaceBytes, OVQA_ERR_WORKSPACE, "layernorm_bwd: ws too small");
   float* partial = (float*)ws;
-  const size_t smem = (size_t)(wide ? 7 : 3) * 2 * D * sizeof(float);
-#define LN_BWD(C)                                                                                                  \
-  if (wide)                                                                                                        \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, 8>), dim3(nblocks), dim3(512), smem, st, (const TDY*)dy,    \
-                       (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da);  \
-  else                                                                                                             \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, 4>), dim3(nblocks), dim3(256), smem, st, (const TDY*)dy,    \
-                       (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
+  const size_t smem = (size_t)(nw - 1) * 2 * D * sizeof(float);
+#define LN_BWD_W(C, W)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, W>), dim3(nblocks), dim3(W * 64), smem, st, (const TDY*)dy,    \
+                     (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
+#define LN_BWD(C)                                                                                                   \
+  switch (nw) {                                                                                                     \
+    case 8: LN_BWD_W(C, 8); break;                                                                                  \
+    case 13: LN_BWD_W(C, 13); break;                                                                                \
+    case 16: LN_BWD_W(C, 16); break;                                                                                \
+    default: LN_BWD_W(C, 4); break;                                                                                 \
+  }
   switch (chunks) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
     default: LN_BWD(4); break;
   }
 #undef LN_BWD
+#undef LN_BWD_W
   int rc = ovqa_check_launch("layernorm_bwd");
   if (rc != OVQA_OK) return rc;
   if (dgamma == nullptr && dbeta == nullptr) return OVQA_OK;  // partials stay in ws (deferred grouped reduce)
@@ -401,14 +447,28 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
   return OVQA_ERR_UNSUPPORTED;
 }
 
-// 8 waves per workgroup for the long activations, while its 7 * 2 * D floats of dynamic LDS stay inside the 64 KiB a
-// launch gets without hipFuncSetAttribute (D <= 1168); wider rows keep the 4-wave form (3 * 2 * D floats: 48 KiB at 2048)
-int layernorm_bwd_waves(int64_t M, int64_t D) { return (M >= 4096 && 7 * 2 * D * 4 <= 64 * 1024) ? 8 : 4; }
+// Waves per workgroup of the backward: 8 for the long activations, while its 7 * 2 * D floats of dynamic LDS stay inside
+// the 64 KiB a launch gets without hipFuncSetAttribute (D <= 1168); wider rows keep the 4-wave form (3 * 2 * D floats:
+// 48 KiB at 2048).  OVQA_LN_BWD_WAVES = 13 | 16: more waves per workgroup at the same 512 workgroups, so that a wave of a
+// 6400-row launch owns ONE row (13 x 512 >= 6400) instead of one or two.
+static int ln_bwd_waves_env() {
+  static const int v = [] {
+    const char* e = getenv("OVQA_LN_BWD_WAVES");
+    const int w = e ? atoi(e) : 8;
+    return (w == 13 || w == 16) ? w : 8;
+  }();
+  return v;
+}
+int layernorm_bwd_waves(int64_t M, int64_t D) {
+  if (M < 4096 || 7 * 2 * D * 4 > 64 * 1024) return 4;
+  const int w = ln_bwd_waves_env();
+  return (int64_t)(w - 1) * 2 * D * 4 <= 64 * 1024 ? w : 8;
+}
 int layernorm_bwd_blocks(int64_t M, int64_t D) {
   const int nw = layernorm_bwd_waves(M, D);
   // (measured in the MCAN step, 6400 rows: 512 workgroups 3.19 ms; 800 / 1024 -- one row per wave -- 3.23 / 3.24: the
   // partial rows the deferred reduce streams grow with the workgroup count; 384 / 256: 3.20-3.24 / 3.22)
-  const int64_t cap = nw == 8 ? 512 : 1024;
+  const int64_t cap = nw >= 8 ? 512 : 1024;
   int64_t nb = (M + nw - 1) / nw;
   return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }

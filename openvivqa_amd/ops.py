@@ -850,13 +850,16 @@ def attention_bwd(d_o, q, k, v, o, lse, mask, H, scale=None, dq=None, dk=None, d
 
 def attention_bwd_do_ok(dy, wt, q, k, mask, H):
     """Shapes the fused form of ``attention_bwd_do`` covers (``ovqa_attention_bwd_do``): bf16, d = 64, <= 32 keys, 65-128
-    queries (guided attention) or <= 32 queries with an even head count (the 20 x 20 question self-attention), key mask
-    or none."""
+    queries (guided attention) or <= 32 queries with an even head count (the 20 x 20 question self-attention), or 97-128
+    queries x 97-128 keys (the image self-attention, round 5); key mask or none."""
     nq = q.shape[1] if q.dim() == 3 else 0
     if os.environ.get("OVQA_FORCE_SIMPLE", "0") == "1" or os.environ.get("OVQA_NO_FUSED_QKV", "0") == "1":
         return False  # (the library's A/B switches that turn the fused attention forms off)
+    nk = k.shape[1]
+    small_k = (64 < nq <= 128 or (1 <= nq <= 32 and H % 2 == 0)) and nk <= 32
+    roles = 96 < nq <= 128 and 96 < nk <= 128 and os.environ.get("OVQA_DOBWD_ROLES", "3") != "0"  # image self-attention
     return (dy.is_cuda and dy.dtype == torch.bfloat16 and wt is not None and wt.dtype == torch.bfloat16 and q.dim() == 3
-            and q.shape[2] == H * 64 and (64 < nq <= 128 or (1 <= nq <= 32 and H % 2 == 0)) and k.shape[1] <= 32
+            and q.shape[2] == H * 64 and (small_k or roles)
             and dy.shape[-1] % 64 == 0
             and (mask is None or mask.shape[2] == 1) and wt.shape[0] == H * 64 and wt.shape[1] == dy.shape[-1])
 

@@ -115,3 +115,46 @@ for flush in (False, True):
 names = ["start", "images", "delta", "barrier", "dQ waves end", "dK/dV waves end"]
 for flush in (False, True):
     run(100, 100, "image 100x100", flush)
+
+
+def run_do(nq, nk, label, names, flush=False):
+    """ovqa_attention_bwd_do: the fc_o dX product inside the attention backward (20 x 20: two heads per 4-wave workgroup;
+    100 x 100: the role-split kernel)."""
+    Bn, H, D = 64, 8, 512
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(Bn, nq, 3 * D, device="cuda", generator=g).bfloat16()
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    mask = torch.zeros(Bn, 1, 1, nk, device="cuda")
+    mask[:, :, :, nk - 3:] = -1e5
+    lo = []
+    o, lse, _ = ops.attention_fwd(q, k, v, mask, H, lo_out=lo)
+    dy = torch.randn(Bn, nq, D, device="cuda", generator=g).bfloat16()
+    wt = (torch.randn(D, D, device="cuda", generator=g) * D ** -0.5).bfloat16()
+    if not ops.attention_bwd_do_ok(dy, wt, q, k, mask, H):
+        print(label, "not covered by the fused form")
+        return
+    junk = torch.empty(512 * 1024 * 1024 // 4, device="cuda")
+    for it in range(4):
+        if flush:
+            junk.fill_(1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, o_lo=lo[0])
+        e1.record()
+        torch.cuda.synchronize()
+    out = (C.c_ulonglong * 32)()
+    assert lib.ovqa_debug_probe(out) == 0
+    for wg in range(2):
+        ts = [out[wg * 16 + i] for i, _ in names]
+        print(f"{label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
+              "  ".join(f"{n} {((t - ts[0]) / 100.0):.2f}" for (_, n), t in zip(names, ts)) +
+              f"   [events {e0.elapsed_time(e1) * 1e3:.1f} us]")
+
+
+for flush in (False, True):
+    run_do(20, 20, "fused dO backward 20x20",
+           [(0, "start"), (1, "projection loop"), (2, "loads issued"), (3, "images + delta"), (4, "dQ waves"), (7, "end")], flush)
+    run_do(100, 100, "fused dO backward 100x100",
+           [(0, "start"), (6, "projection loop"), (1, "loads issued"), (2, "images + delta"), (3, "barrier"),
+            (4, "dQ waves end"), (5, "dK/dV waves end")], flush)

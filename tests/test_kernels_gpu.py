@@ -996,7 +996,7 @@ def test_attention_q_fwd_equals_projection_plus_attention(dtype, B, nq, nk):
 
 
 @pytest.mark.parametrize("B,nq,nk", [(64, 100, 20), (3, 128, 32), (2, 65, 1), (5, 97, 13), (64, 20, 20), (3, 32, 32), (2, 1, 1),
-                                     (4, 17, 29), (2, 50, 20)])
+                                     (4, 17, 29), (2, 50, 20), (64, 100, 100), (3, 128, 128), (2, 97, 100), (2, 100, 97)])
 def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     """ovqa_attention_bwd_do (the fc_o dX product inside the guided-attention backward kernel, from the transposed weight
     copy) against ovqa_linear_bwd_data_wt + ovqa_attention_bwd: same dq, dk, dv."""
@@ -1015,8 +1015,12 @@ def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     wt = group[:, 3 * Dm:]                                          # fc_o's slice: rows = input features, strided
     dkv1, dkv0 = torch.zeros_like(kv), torch.zeros_like(kv)
     fused_on = not FORCED_SIMPLE and not NO_FUSED_QKV
-    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (fused_on and (nq > 64 or nq <= 32))
-    if 32 < nq <= 64 or not fused_on:
+    # (round 5: 97-128 queries x 97-128 keys -- the image self-attention -- run the role-split backward with the projection
+    # inside; OVQA_DOBWD_ROLES=0 turns that form off)
+    roles_on = os.environ.get("OVQA_DOBWD_ROLES", "3") != "0"
+    covered = ((nq > 64 or nq <= 32) and nk <= 32) or (roles_on and nq > 96 and nk > 96)
+    assert o_.attention_bwd_do_ok(dy, wt, q, k, mask, H) == (fused_on and covered)
+    if not covered or not fused_on:
         return
     dq1, _, _ = o_.attention_bwd_do(dy, wt, q, k, v, o, lse, mask, H, o_lo=lo[0], dk=dkv1[..., 2 * H * d:3 * H * d],
                                     dv=dkv1[..., 3 * H * d:])
