@@ -1575,9 +1575,10 @@ __global__ __launch_bounds__(256) void attn_bwd_do_smallk1_mfma_kernel(DoBwdArgs
 // that kernel's projection loop (ring of FUSE_NBUF K steps of 64: 24 KB each, aliased with the images), rounded to bf16
 // straight into the dO image; grid (B, H), so that the 8 heads of a sample -- which all stream the sample's dY rows --
 // share an XCD.  dO never travels through HBM and the 6400 x 512 <- 512 dX launch in front of this kernel is gone.
-template <int NQT_T, int NKT_T, bool ROWMASK, int FUSE_NBUF = 0>
+template <int NQT_T, int NKT_T, bool ROWMASK, int FUSE_NBUF = 0, bool DMA = false>
 __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1) void attn_bwd_roles_mfma_kernel(DoBwdArgs g, int nqt_rt, int nkt_rt) {
   constexpr bool FUSE = FUSE_NBUF > 0, EARLY = FUSE_NBUF >= 10;
+  static_assert(!DMA || ROWMASK, "clamped rows rely on the key mask row / lse to vanish");
   constexpr int RING = FUSE ? FUSE_NBUF % 10 : 1;  // (1: never used, keeps the un-fused instantiations free of a % 0)
   static_assert(!FUSE || (NQT_T == 4 && NKT_T == 4), "the fused form is built for 4 x 4 tiles");
   const ovqa::AttnBwdArgs& a = g.att;
@@ -1690,24 +1691,50 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
     // (no mask row / no o_lo: the load goes to another valid address and its result is dropped below)
     const bool has_mrow = a.msq == 0 && a.mask != nullptr, has_lo = a.o_lo != nullptr;
     const float* mp = has_mrow ? a.mask + (int64_t)b * a.msb + (int64_t)h * a.msh : lb;
+    // DMA form (round 5): the Q, dO, K, V images are filled by direct-to-LDS loads -- a wave instruction fills 8 image rows
+    // (1 KiB), lane l the 16-byte slot l & 7 of row l >> 3 with the chunk the XOR layout puts there -- instead of travelling
+    // through 12 of this thread's 14 uint4 registers.  Rows beyond nq / nk re-read the last valid row: finite values that
+    // lse = +inf / mask = -inf turn into p = 0 (what the zero fill achieved), their outputs are not stored.
+    auto dma_image = [&](char* img, const bf16* base, int64_t ld, int n, int rows_pad) {
+      const int prow = lane >> 3, slot = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int piece = wave + 8 * i;
+        if (piece * 8 < rows_pad) {  // (wave-uniform)
+          const int row = piece * 8 + prow;
+          const bf16* src = base + (int64_t)min(row, n - 1) * ld + ((slot ^ xs(row)) << 3);
+          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(img + piece * 1024), 16, 0, 0);
+        }
+      }
+    };
+    auto dma_qkv = [&]() {
+      dma_image(Qs, qb - ch * 8, a.ldq, nq, q_rows);
+      if constexpr (!FUSE) dma_image(Gs, gb - ch * 8, a.lddo, nq, q_rows);
+      dma_image(Ks, kb - ch * 8, a.ldk, nk, k_rows);
+      dma_image(Vs, vb - ch * 8, a.ldv, nk, k_rows);
+    };
+    if constexpr (DMA && !FUSE) dma_qkv();
     float mval = mp[min(tid, (has_mrow ? nk : nq) - 1)];
     const bf16* lob2 = has_lo ? lob : ob;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
       const int rq = min(row, nq - 1), rk = min(row, nk - 1);
-      vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)rq * a.ldq);
-      if constexpr (!FUSE) vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)rq * a.lddo);
+      if constexpr (!DMA) vq[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)rq * a.ldq);
+      if constexpr (!DMA && !FUSE) vd[i] = *reinterpret_cast<const uint4*>(gb + (int64_t)rq * a.lddo);
       vo[i] = *reinterpret_cast<const uint4*>(ob + (int64_t)rq * a.ldo);
       vl[i] = *reinterpret_cast<const uint4*>(lob2 + (int64_t)rq * a.ldo);
       lse_r[i] = lb[rq];
-      vk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)rk * a.ldk);
-      vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)rk * a.ldv);
+      if constexpr (!DMA) {
+        vk[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)rk * a.ldk);
+        vv[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)rk * a.ldv);
+      }
     }
     OVQA_PROBE(1);
     if constexpr (FUSE && EARLY) project();
     if constexpr (FUSE) {
       __syncthreads();  // every wave is done with the staging ring: it becomes the images
+      if constexpr (DMA) dma_qkv();
       // dO image [128][64] (bf16) from the accumulators; rows beyond nq are zero
 #pragma unroll
       for (int i = 0; i < PJ_NI; i++) {
@@ -1721,14 +1748,18 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
         }
         *reinterpret_cast<bf16x8*>(Gs + img_off(r, col >> 3)) = o8;
       }
-      __syncthreads();  // the dO image is complete: delta reads it
+      if constexpr (!DMA) __syncthreads();  // the dO image is complete: delta reads it
+    }
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave's pieces have landed (and the dO image of the fused form is written)
     }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = r0 + 64 * i;
       const bool qv = row < nq, kv = row < nk;
       if (!has_lo) vl[i] = zero4;
-      if constexpr (FUSE) vd[i] = *reinterpret_cast<const uint4*>(Gs + img_off(min(row, q_rows - 1), ch));  // (zero beyond nq)
+      if constexpr (FUSE || DMA) vd[i] = *reinterpret_cast<const uint4*>(Gs + img_off(min(row, q_rows - 1), ch));
       const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(&vd[i]);
       const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(&vo[i]);
       const bf16x8 l8 = *reinterpret_cast<const bf16x8*>(&vl[i]);
@@ -1738,20 +1769,24 @@ __global__ __launch_bounds__(512, (NQT_T && NKT_T) ? OVQA_ROLES_WAVES_PER_EU : 1
       dl += __shfl_xor(dl, 1, 64);
       dl += __shfl_xor(dl, 2, 64);
       dl += __shfl_xor(dl, 4, 64);
-      if (!qv) { vq[i] = zero4; vd[i] = zero4; }
-      if (!kv) { vk[i] = zero4; vv[i] = zero4; }
+      if constexpr (!DMA) {
+        if (!qv) { vq[i] = zero4; vd[i] = zero4; }
+        if (!kv) { vk[i] = zero4; vv[i] = zero4; }
+      }
       if (row < q_rows) {
-        *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = vq[i];
-        if constexpr (!FUSE) *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
+        if constexpr (!DMA) *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = vq[i];
+        if constexpr (!DMA && !FUSE) *reinterpret_cast<uint4*>(Gs + img_off(row, ch)) = vd[i];
         if (ch == 0) {
           lse_s[row] = qv ? lse_r[i] * LOG2E : INFINITY;
           del_s[row] = qv ? dl : 0.f;
           if (qv) a.delta[(int64_t)pid * nq + row] = dl;
         }
       }
-      if (row < k_rows) {
-        *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = vk[i];
-        *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vv[i];
+      if constexpr (!DMA) {
+        if (row < k_rows) {
+          *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = vk[i];
+          *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vv[i];
+        }
       }
     }
     if (a.msq == 0 && tid < k_rows) mlds[tid] = tid < nk ? (has_mrow ? mval * LOG2E : 0.f) : -INFINITY;
@@ -2019,6 +2054,17 @@ int launch_bwd_two(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   }
 }
 
+// OVQA_ROLES_DMA: the role-split backward fills its Q / dO / K / V images by direct-to-LDS loads (1, default) or through
+// registers (0).  In the MCAN step, same box: 26.07 -> 25.55 us per launch with the fc_o projection inside, 21.13 -> 21.15
+// without it (round 5: the staging is bound by the CU's fetch path either way).
+static int roles_dma() {
+  static const int v = [] {
+    const char* e = getenv("OVQA_ROLES_DMA");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (a.dk == 96) return launch_bwd_two<96>(a, st);
   if (a.dk == 128) return launch_bwd_two<128>(a, st);
@@ -2040,7 +2086,11 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, g0, nqt, nkt); \
   }
     if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
-      if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
+      if (rowmask && roles_dma()) {
+        int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, 0, true>, lds, "attention_bwd(mfma,roles)");
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, 0, true>), dim3((unsigned)nprob), dim3(512), lds, st, g0, nqt, nkt);
+      } else if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
     } else {
       if (rowmask) OVQA_ROLES(0, 0, true) else OVQA_ROLES(0, 0, false)
     }
@@ -2251,7 +2301,11 @@ int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, co
     if (rc != OVQA_OK) return rc;                                                                                    \
     OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, F>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4); \
   }
-    if (form == 2) OVQA_DOROLES(2) else if (form == 12) OVQA_DOROLES(12) else if (form == 13) OVQA_DOROLES(13) else OVQA_DOROLES(3)
+    if (roles_dma() && form % 10 != 2 && form < 10) {
+      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>, lds, "attention_bwd_do(roles)");
+      if (rc != OVQA_OK) return rc;
+      OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4);
+    } else if (form == 2) OVQA_DOROLES(2) else if (form == 12) OVQA_DOROLES(12) else if (form == 13) OVQA_DOROLES(13) else OVQA_DOROLES(3)
 #undef OVQA_DOROLES
     return ovqa_check_launch("attention_bwd_do(mfma,roles)");
   }

@@ -337,10 +337,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the other one half of its accumulators and finishes the other half.
 template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128, int KSP = 1>
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
-  static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || (BC == 32 && NW == 4 && !Q_KMAJOR),
+  static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || ((BC == 32 || BC == 64) && NW == 4 && !Q_KMAJOR),
                 "unsupported tile");
   static_assert(NW == 4 || NW == 8 || (NW == 16 && BC == 128 && BR == 128 && KSP == 1), "4, 8 or (128 x 128) 16 waves");
-  static_assert(BR == 128 || (BR == 64 && NW == 4 && BC == 32 && !P_KMAJOR), "unsupported tile");
+  static_assert(BR == 128 || (BR == 64 && NW == 4 && (BC == 32 || BC == 64) && !P_KMAJOR), "unsupported tile");
   static_assert(KSP == 1 || (KSP == 2 && NW == 8 && BC >= 64 && BR == 128), "k-split form: 8 waves");
   constexpr int NWT = NW / KSP;  // waves of one tile grid
   constexpr int WC = NWT == 16 ? 4 : (NWT == 8 ? (BC >= 64 ? 4 : BC / 16) : 2);  // wave grid: WC along c x WR along r
@@ -1253,7 +1253,18 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
   const int variant = (K % BK == 0 && (PK || !Epi::kWide || wide_ok)) ? gemm_variant() : 0;
   // few 128x128 tiles (the M = 1280 question stack): halve the c tile -> twice the workgroups
   const bool small_c = !QK && variant >= 10 && g.tiles_r * g.tiles_c <= small_tile_threshold();
-  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold();
+  // OVQA_GEMM_TINY_MAXR (round 5): products with more than this many weight rows leave the tiny tier -- the question
+  // stack's 1280 x 2048 outputs (fc1 forward, fc2 dX) run as 160 tiles of 128 x 128 on 16 waves instead of 1280 tiles of
+  // 64 x 32: 262 KB instead of 5 x 98 KB through a CU's fetch path.  In the MCAN step, same box: GELU forward 11.84 -> 9.89
+  // us, dX 13.6 -> 10.3 us per launch, 31 us per step.  (The 1280 x 512 outputs stay on 320 tiles of 64 x 32: 64 x 64 tiles
+  // -- OVQA_GEMM_MICRO64, 160 workgroups, ring of 4 or 6 -- measured 14.0-14.5 against 13.3 us: ONE workgroup on a CU draws
+  // ~45 GB/s, two co-resident ones ~60 together, so fewer bytes per CU did not pay there.)
+  static int tiny_maxr = -1;
+  if (tiny_maxr < 0) {
+    const char* e = getenv("OVQA_GEMM_TINY_MAXR");
+    tiny_maxr = e ? atoi(e) : 1024;
+  }
+  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold() && R <= tiny_maxr;
   if (small_c) g.tiles_c = (int)((C + (tiny_c ? 31 : 63)) / (tiny_c ? 32 : 64));
   const dim3 grid(g.tiles_r * g.tiles_c);
 #define OVQA_GLDS_K(NBUF, NW, BCV, KSPV)                                                                            \
@@ -1284,6 +1295,30 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of the 128 x 32
     // tier (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step
     // 3.53 -> 3.49 ms; a ring of 3 / 6 and the same idea for the 128 x 64 tier (64 x 64 tiles) measured slower.
+    // (OVQA_GEMM_MICRO64 = ring depth 4 | 6, round 5 A/B: 64 x 64 tiles for the tiny tier -- 160 instead of 320 workgroups
+    // for a 1280 x 512 output, a third fewer bytes per output element through the CUs' fetch paths)
+    static int micro64 = -1;
+    if (micro64 < 0) {
+      const char* e = getenv("OVQA_GEMM_MICRO64");
+      micro64 = e ? atoi(e) : 0;
+    }
+    if (tiny_c && micro_tiles() && micro64) {
+      g.tiles_r = (int)((R + 63) / 64);
+      g.tiles_c = (int)((C + 63) / 64);
+      const dim3 grid2(g.tiles_r * g.tiles_c);
+      if (micro64 == 6) {
+        const size_t lds = (size_t)6 * (64 * BK * 2 + 64 * BK * 2);
+        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 6, 4, 64, 64>, lds);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 6, 4, 64, 64>), grid2, dim3(256), lds, st, g, epi);
+      } else {
+        const size_t lds = (size_t)4 * (64 * BK * 2 + 64 * BK * 2);
+        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 64, 64>, lds);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 64, 64>), grid2, dim3(256), lds, st, g, epi);
+      }
+      return ovqa_check_launch(what);
+    }
     if (tiny_c && micro_tiles()) {
       g.tiles_r = (int)((R + 63) / 64);
       const dim3 grid2(g.tiles_r * g.tiles_c);

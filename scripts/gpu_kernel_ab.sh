@@ -18,7 +18,7 @@ for cfg in "$@"; do
   ) || { echo "run $i ($cfg) failed"; tail -5 $OUT/t$i.log; exit 1; }
   f=$(find $OUT/t$i -name "*kernel_trace.csv" | head -1)
   python3 $R/scripts/replay_window_stats.py $f 10 $OUT/stats_$i.csv > /dev/null || exit 1
-  echo "== $cfg"
-  grep -E "$PAT|# sum|# launches" $OUT/stats_$i.csv | cut -c1-70,71-400 | awk -F, '{n=$1; if (length(n)>64) n=substr(n,1,64); printf "%-64s %s\n", n, $0 ~ /^#/ ? $2" "$3 : $2" x "$4" us = "$3}'
+  ARGS="$ARGS ${cfg// /,}::=$OUT/stats_$i.csv"
   rm -rf $OUT/t$i
 done
+python3 $R/scripts/kernel_ab_table.py "$PAT" $ARGS
