@@ -466,6 +466,13 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
                        f"{passes} passes per decode, eager launches", "global_batch": world * B,
                        "parallelism": f"dp{world}"},
             "ms_per_mmt_pass": round(dt / args.steps / passes * 1e3, 3)})
+        # algorithmic work of one MMT pass (forward only): per position and layer the four 768 x 768 projections and the
+        # two 768 x 3072 FFN products (2 flops per multiply-add) + scores and weighted sum over S = 182 positions; the
+        # classifier / pointer heads on the 12 decoding positions are < 1 % and left out
+        S, Hd, Ff, Lm = 20 + 100 + 50 + 12, 768, 3072, 4
+        gf_pass = B * S * Lm * (2 * (4 * Hd * Hd + 2 * Hd * Ff) + 4 * S * Hd) / 1e9
+        res["algorithmic_gflop_per_mmt_pass"] = round(gf_pass, 1)
+        res["step_frac_of_bf16_peak"] = round(gf_pass * passes * args.steps * world / dt / 1e3 / (world * 2500.0), 4)
     return res
 
 
@@ -940,7 +947,8 @@ def secondary_lines(args, device, dtype):
             d["frac_of_hbm_peak"] = line["roofline_decode"]["frac"]
             return d
         guarded(f"decode_beam{beam}", run_decode)
-    guarded("m4c_decode", lambda: compact(m4c_decode_bench(a2, device, 1, 0, None, B, seed), ("ms_per_mmt_pass",)))
+    guarded("m4c_decode", lambda: compact(m4c_decode_bench(a2, device, 1, 0, None, B, seed),
+                                                 ("ms_per_mmt_pass", "algorithmic_gflop_per_mmt_pass", "step_frac_of_bf16_peak")))
     return res
 
 

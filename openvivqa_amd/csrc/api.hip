@@ -697,10 +697,11 @@ int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const
                   const float* b_hh, float* y, void* y_lp, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
                   int64_t I, int64_t H, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "lstm_fwd: bad dtype");
+  OVQA_REQUIRE(B >= 0 && T >= 0 && I >= 1 && H >= 1 && ldx >= I && B * H < (1ll << 31), OVQA_ERR_BAD_ARG,
+               "lstm_fwd: bad size");
+  if (B == 0 || T == 0) return OVQA_OK;  // an empty batch / sequence: nothing to write (pointers may be null)
   OVQA_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y && hseq && saved && scratch, OVQA_ERR_BAD_ARG,
                "lstm_fwd: null pointer");
-  OVQA_REQUIRE(B >= 1 && T >= 1 && I >= 1 && H >= 1 && ldx >= I && B * H < (1ll << 31), OVQA_ERR_BAD_ARG,
-               "lstm_fwd: bad size");
   const bool persistent = lstm_route_persistent(dtype, B, T, I, H);
   if (persistent)
     OVQA_REQUIRE(ldx % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w_ih % 16 == 0 && (uintptr_t)w_hh % 16 == 0 &&
@@ -719,8 +720,9 @@ int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const
 int ovqa_lstm_bwd(int dtype, const void* dy, int dy_dtype, const void* w_hh, const void* w_hh_t, int64_t ldwt,
                   const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t I, int64_t H, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(dy_dtype), OVQA_ERR_BAD_ARG, "lstm_bwd: bad dtype");
+  OVQA_REQUIRE(B >= 0 && T >= 0 && H >= 1 && B * H < (1ll << 31), OVQA_ERR_BAD_ARG, "lstm_bwd: bad size");
+  if (B == 0 || T == 0) return OVQA_OK;
   OVQA_REQUIRE(dy && w_hh && saved && dgates && scratch, OVQA_ERR_BAD_ARG, "lstm_bwd: null pointer");
-  OVQA_REQUIRE(B >= 1 && T >= 1 && H >= 1 && B * H < (1ll << 31), OVQA_ERR_BAD_ARG, "lstm_bwd: bad size");
   const bool persistent = lstm_route_persistent(dtype, B, T, I, H);
   if (persistent)
     OVQA_REQUIRE(w_hh_t && ldwt >= 4 * H && ldwt % 8 == 0 && (uintptr_t)w_hh_t % 16 == 0 && (uintptr_t)dgates % 16 == 0 &&
@@ -735,9 +737,10 @@ int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64
                       int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
                       void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "embed_gather: bad dtype");
-  OVQA_REQUIRE(tokens && table && out, OVQA_ERR_BAD_ARG, "embed_gather: null pointer");
-  OVQA_REQUIRE(B >= 1 && T >= 1 && vocab >= 1 && width >= 1 && ld_table >= width && ld_out >= width && B * T < (1ll << 31),
+  OVQA_REQUIRE(B >= 0 && T >= 0 && vocab >= 1 && width >= 1 && ld_table >= width && ld_out >= width && B * T < (1ll << 31),
                OVQA_ERR_BAD_ARG, "embed_gather: bad size");
+  if (B == 0 || T == 0) return OVQA_OK;
+  OVQA_REQUIRE(tokens && table && out, OVQA_ERR_BAD_ARG, "embed_gather: null pointer");
   g_dispatch = "stream";
   return ovqa::embed_gather(dtype, tokens, table, ld_table, vocab, out, ld_out, B, T, width, time_major, mask, padding_idx,
                             as_stream(stream));
@@ -747,10 +750,20 @@ int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int6
                        int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                        int accumulate, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "embed_scatter: bad dtype");
-  OVQA_REQUIRE(tokens && drows && dtable, OVQA_ERR_BAD_ARG, "embed_scatter: null pointer");
-  OVQA_REQUIRE(B >= 1 && T >= 1 && rows_table >= 1 && width >= 1 && ld_table >= width && ld_rows >= width &&
+  OVQA_REQUIRE(dtable && (B == 0 || T == 0 || (tokens && drows)), OVQA_ERR_BAD_ARG, "embed_scatter: null pointer");
+  OVQA_REQUIRE(B >= 0 && T >= 0 && rows_table >= 1 && width >= 1 && ld_table >= width && ld_rows >= width &&
                    B * T < (1ll << 31) && rows_table < (1ll << 31),
                OVQA_ERR_BAD_ARG, "embed_scatter: bad size");
+  if (B == 0 || T == 0) {  // no tokens: the gradient of the table is zero (or stays what it was)
+    if (!accumulate) {
+      hipError_t e = hipMemset2DAsync(dtable, (size_t)ld_table * 4, 0, (size_t)width * 4, (size_t)rows_table, as_stream(stream));
+      if (e != hipSuccess) {
+        ovqa_set_error("embed_scatter: hipMemset2DAsync: %s", hipGetErrorString(e));
+        return OVQA_ERR_LAUNCH;
+      }
+    }
+    return OVQA_OK;
+  }
   g_dispatch = "stream";
   return ovqa::embed_scatter(dtype, tokens, drows, ld_rows, dtable, ld_table, rows_table, B, T, width, time_major,
                              padding_idx, accumulate, as_stream(stream));
@@ -758,8 +771,9 @@ int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int6
 
 int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_dropout* drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype), OVQA_ERR_BAD_ARG, "dropout_apply: bad dtype");
-  OVQA_REQUIRE(x && y && n >= 0 && n < (1ll << 32), OVQA_ERR_BAD_ARG, "dropout_apply: bad argument");
+  OVQA_REQUIRE(n >= 0 && n < (1ll << 32), OVQA_ERR_BAD_ARG, "dropout_apply: bad size");
   if (n == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && y, OVQA_ERR_BAD_ARG, "dropout_apply: null pointer");
   g_dispatch = "stream";
   return ovqa::dropout_apply(dtype, x, y, n, make_drop_args(drop), as_stream(stream));
 }
@@ -767,8 +781,9 @@ int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_
 int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
                   void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const ovqa_dropout* drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(feat_dtype), OVQA_ERR_BAD_ARG, "pool_fwd: bad dtype");
-  OVQA_REQUIRE(feat && hpre && w2 && att && pooled && B >= 1 && B * N * D < (1ll << 32), OVQA_ERR_BAD_ARG,
-               "pool_fwd: bad argument");
+  OVQA_REQUIRE(B >= 0 && N >= 1 && D >= 1 && B * N * D < (1ll << 32), OVQA_ERR_BAD_ARG, "pool_fwd: bad size");
+  if (B == 0) return OVQA_OK;
+  OVQA_REQUIRE(feat && hpre && w2 && att && pooled, OVQA_ERR_BAD_ARG, "pool_fwd: null pointer");
   g_dispatch = "stream";
   return ovqa::pool_fwd(feat_dtype, dtype, feat, hpre, w2, b2, att, pooled, pooled32, B, N, D, make_drop_args(drop),
                         as_stream(stream));
@@ -778,26 +793,29 @@ int ovqa_pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre,
                   const void* dpooled, void* dh, void* dfeat, float* dw2_part, float* db2_part, int64_t B, int64_t N,
                   int64_t D, const ovqa_dropout* drop, void* stream) {
   OVQA_REQUIRE(dtype_ok(dtype) && dtype_ok(feat_dtype), OVQA_ERR_BAD_ARG, "pool_bwd: bad dtype");
-  OVQA_REQUIRE(feat && hpre && w2 && att && dpooled && dh && dfeat && dw2_part && B >= 1 && B * N * D < (1ll << 32),
-               OVQA_ERR_BAD_ARG, "pool_bwd: bad argument");
+  OVQA_REQUIRE(B >= 0 && N >= 1 && D >= 1 && B * N * D < (1ll << 32), OVQA_ERR_BAD_ARG, "pool_bwd: bad size");
+  if (B == 0) return OVQA_OK;
+  OVQA_REQUIRE(feat && hpre && w2 && att && dpooled && dh && dfeat && dw2_part, OVQA_ERR_BAD_ARG, "pool_bwd: null pointer");
   g_dispatch = "stream";
   return ovqa::pool_bwd(feat_dtype, dtype, feat, hpre, w2, att, dpooled, dh, dfeat, dw2_part, db2_part, B, N, D,
                         make_drop_args(drop), as_stream(stream));
 }
 
 int ovqa_log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, void* stream) {
-  OVQA_REQUIRE(dtype_ok(dtype) && x && out && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
+  OVQA_REQUIRE(dtype_ok(dtype) && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
                "log_softmax_fwd: bad argument");
   if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(x && out, OVQA_ERR_BAD_ARG, "log_softmax_fwd: null pointer");
   g_dispatch = "stream";
   return ovqa::log_softmax_fwd(dtype, x, ld, out, M, n, as_stream(stream));
 }
 
 int ovqa_log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n,
                          void* stream) {
-  OVQA_REQUIRE(dtype_ok(dtype) && g && logp && dx && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
+  OVQA_REQUIRE(dtype_ok(dtype) && M >= 0 && n >= 1 && ld >= n && M < (1ll << 31), OVQA_ERR_BAD_ARG,
                "log_softmax_bwd: bad argument");
   if (M == 0) return OVQA_OK;
+  OVQA_REQUIRE(g && logp && dx, OVQA_ERR_BAD_ARG, "log_softmax_bwd: null pointer");
   g_dispatch = "stream";
   return ovqa::log_softmax_bwd(dtype, g, logp, dx, ld, M, n, as_stream(stream));
 }

@@ -1034,6 +1034,36 @@ def test_attention_bwd_do_equals_projection_plus_backward(B, nq, nk):
     assert rel(dq1, dq0) < 2e-3 and rel(dkv1, dkv0) < 2e-3, (rel(dq1, dq0), rel(dkv1, dkv0))
 
 
+def test_model_end_entry_points_accept_empty_batches():
+    """Empty inputs (a batch of zero samples, as a ragged last batch can produce) are no-ops of the round-5 entry points, like
+    those of the older ones; a scatter without tokens still leaves a ZERO table gradient (or the old one when accumulating)."""
+    o = ops()
+    H, I, T = 512, 512, 5
+    w_ih, w_hh = rnd(4 * H, I, dtype=BF16, scale=I ** -0.5), rnd(4 * H, H, dtype=BF16, scale=H ** -0.5, seed=1)
+    b0 = torch.zeros(4 * H, device=DEV)
+    y, hseq, saved, scratch = o.lstm_fwd(torch.empty(0, I, dtype=BF16, device=DEV), w_ih, w_hh, b0, b0, 0, T)
+    assert y.shape == (0, T, H)
+    dg, _ = o.lstm_bwd(torch.empty(0, T, H, device=DEV), w_hh, w_hh.t().contiguous(), saved, 0, T, I)
+    assert dg.shape == (0, 4 * H)
+    table = rnd(11, 24)
+    tok = torch.empty(0, T, dtype=torch.int64, device=DEV)
+    rows, mask = o.embed_gather(tok, table, time_major=True, want_mask=True, padding_idx=0)
+    assert rows.shape == (0, 24) and mask.shape == (0, 1, 1, T)
+    dtable = torch.full((11, 24), 7.0, device=DEV)
+    o.embed_scatter(tok, rows, dtable, time_major=True, padding_idx=0, accumulate=True)
+    assert torch.equal(dtable, torch.full_like(dtable, 7.0))
+    o.embed_scatter(tok, rows, dtable, time_major=True, padding_idx=0)
+    assert torch.count_nonzero(dtable).item() == 0
+    feat = torch.empty(0, 20, 64, dtype=BF16, device=DEV)
+    att, pooled = o.pool_fwd(feat, torch.empty(0, 64, dtype=BF16, device=DEV), torch.ones(64, device=DEV), None)
+    assert att.shape == (0, 20) and pooled.shape == (0, 64)
+    dh, dfeat, part, bpart = o.pool_bwd(feat, torch.empty(0, 64, dtype=BF16, device=DEV), torch.ones(64, device=DEV), att, pooled)
+    assert dh.shape == (0, 64) and part.shape == (0, 128)
+    assert o.log_softmax_fwd(torch.empty(0, 360, dtype=BF16, device=DEV), 353).shape == (0, 353)
+    assert o.dropout_apply(torch.empty(0, 8, device=DEV), o.DropSpec(0.1, 1, 2)).numel() == 0
+    torch.cuda.synchronize()
+
+
 def test_stream_helpers_of_the_c_abi():
     """ovqa_stream_create (priority / CU mask) hands back streams that torch can drive: a cast launched on a CU-masked
     stream (the first 64 compute units) and on a high-priority stream gives the values of the default stream."""
