@@ -34,8 +34,9 @@ def meas(pred):
 
 fam = bench.gemm_launch_list(B, NV, NT, D, DFF, L)
 mv, mt = B * NV, B * NT
-# the fc_o dX products that run inside the attention backward kernels (guided + question self-attention) are not GEMM launches
-fused_dx = [(mv, D, D)] * L + [(mt, D, D)] * L
+# the fc_o dX products that run inside the attention backward kernels (guided, question self-attention and -- round 5 -- the
+# image self-attention) are not GEMM launches
+fused_dx = [(mv, D, D)] * (2 * L) + [(mt, D, D)] * L
 dx = list(fam["dx"])
 for sh in fused_dx:
     for i, s in enumerate(dx):
