@@ -2205,6 +2205,8 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
   // per MCAN step (two samples per workgroup with K steps of 64: 3.390)
   else if (form == 1 && k64) OVQA_QKV(128, 1, 64, 2)
   else if (form == 2 && k64) OVQA_QKV(128, 2, 64, 2)
+  // (round 5 measured one sample with K steps of 32 in a ring of 4 / 3 -- 60 / 40 KB in flight per workgroup instead of 40,
+  // still two workgroups per CU: 28.7 / 28.8 against 26.7 us per launch in the step: removed)
   else OVQA_QKV(128, 2, 32, 4)
 #undef OVQA_QKV
   return ovqa_check_launch("attention_qkv_fwd(mfma)");
