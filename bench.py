@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
                     help="thread counts the CPU leg sweeps (one B=16 step each) before timing at the best")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fuse-adam", action="store_true",
+                    help="keep Adam a launch of its own at N = 1 too (default at N = 1: the weight matrices are updated inside "
+                         "the last grouped weight-gradient launch, TrainStep(fuse_adam=True); with N > 1 the gradient exchange "
+                         "stands between gradient and update and Adam is always separate)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workloads (model, cross_modality, decode beam 1 / 3, m4c_decode) that the default "
                          "single-GPU run of the headline workload appends under `secondary`")
@@ -790,7 +794,7 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s_: noam_lr_scale(s_, D, int(b.WARMUP)), use_graph=not args.no_graph,
                    comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
-                   force_comm=args.rehearse_comm)
+                   force_comm=args.rehearse_comm, fuse_adam=not getattr(args, "no_fuse_adam", False) and os.environ.get("OVQA_FUSE_ADAM", "1") != "0")
     if workload == "cross_modality":
         loss_buf = ts.loss  # (the scalar-loss protocol: TrainStep copies the loss into its own buffer)
     else:
@@ -842,7 +846,10 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
                    "fwd+loss+bwd+grad all-reduce+Adam(0.9,0.98)+Noam LR",
                    "global_batch": world * b.BATCH_PER_GPU, "parallelism": f"dp{world}",
                    "hipgraph": not args.no_graph, "comm_dtype": args.comm_dtype if (world > 1 or args.rehearse_comm) else None,
-                   "grad_segments": ts.n_exchanges, "backward_phases": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm)},
+                   "grad_segments": ts.n_exchanges, "backward_phases": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm),
+                   "adam": ("inside the last weight-gradient launch for the weight matrices (TrainStep.fuse_adam: world size 1), "
+                            "one launch for the 1-D parameters" if getattr(ts, "_fused", None) is not None and ts._fused.began
+                            else "separate launch(es) behind backward / the gradient exchange")},
         "final_loss": round(final_loss, 6),
         "repeats": len(windows),
         "ms_per_step_median": round(statistics.median(windows) / steps * 1e3, 3),

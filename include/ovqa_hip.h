@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 8
+#define OVQA_ABI_VERSION 9
 
 typedef enum {
   OVQA_OK = 0,
@@ -196,6 +196,34 @@ typedef struct {
 int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems_dev,
                                    const int32_t* tiles_dev, int64_t n_tiles, int32_t form,
                                    void* stream);
+/* The same launch with the OPTIMISER STEP of a weight inside the epilogue of its last gradient tile (round 5; form 1 only):
+ * for problem i with targets[i].param != NULL the fp32 tile of dW is NOT stored -- the workgroup that finished it applies
+ * Adam to the 128 x 128 tile of the master weights and both moments (same arithmetic as ovqa_adam_step_tiled: the two
+ * kernels share one update function and give the same bits) and writes the tile of the bf16 shadow and of its transposed
+ * copy.  What a training step saves: the gradient's round trip through HBM (8 B per weight) and a second pass over the
+ * optimiser state; valid when this product is the ONLY contribution to the weight's gradient in the step and no exchange
+ * between ranks stands between gradient and update (world size 1).  Such a problem needs accumulate bit 0 clear and
+ * N % 128 == 0, K % 128 == 0; the bias gradient (db) is written as before.  Problems with a NULL target behave like
+ * ovqa_grouped_linear_bwd_weight.
+ *   replaces: loss.backward() of the nn.Linear weights + optim.step() for them (tasks/base_task.py:46,
+ *             classification_task.py:131-133), fused.
+ *   targets_dev: DEVICE array, one entry per problem; transposed[(k) * ld_transposed + n] receives element (n, k). */
+typedef struct {
+  float* param;        /* fp32 master [N,K] (row stride K), or NULL: plain gradient store */
+  float* exp_avg;      /* fp32 [N,K] */
+  float* exp_avg_sq;   /* fp32 [N,K] */
+  void* shadow;        /* bf16 [N,K] */
+  void* transposed;    /* bf16 [K, ld_transposed]: column n of it is row n of the weight */
+  int64_t ld_transposed;
+} ovqa_adam_target;
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay, grad_scale;
+  const float* lr_scale_ptr;   /* device scalar multiplied into lr (ovqa_begin_step's lr_out), or NULL */
+  const uint32_t* step_ptr;    /* device step counter t (bias correction 1 - beta^t), already incremented for this step */
+} ovqa_adam_consts;
+int ovqa_grouped_linear_bwd_weight_adam(int dtype, const ovqa_wgrad_problem* problems_dev, const int32_t* tiles_dev,
+                                        int64_t n_tiles, const ovqa_adam_target* targets_dev,
+                                        const ovqa_adam_consts* consts, void* stream);
 /* db (fp32 [N]) (+)= column sums of dy [M,N] (bias gradient on its own). */
 int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N,
                    int accumulate, void* stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -24,6 +24,20 @@ class WgradProblem(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
                 ("lddy", C.c_int64), ("ldx", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class AdamTarget(C.Structure):
+    """ovqa_adam_target (include/ovqa_hip.h): where the Adam epilogue of the grouped weight-gradient launch finds a problem's
+    master weights, moments and bf16 shadows (param = NULL: plain gradient store)."""
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("shadow", C.c_void_p),
+                ("transposed", C.c_void_p), ("ld_transposed", C.c_int64)]
+
+
+class AdamConsts(C.Structure):
+    """ovqa_adam_consts (include/ovqa_hip.h)."""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("lr_scale_ptr", C.c_void_p),
+                ("step_ptr", C.c_void_p)]
 
 
 class TransposeProblem(C.Structure):
@@ -76,6 +90,7 @@ SIGNATURES = {
                               _DP, c_vp],
     "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_int, c_vp],
+    "ovqa_grouped_linear_bwd_weight_adam": [c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
     "ovqa_bias_grad": [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
     "ovqa_linear_bwd_data_wt": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64,
                                 _DP, c_vp],

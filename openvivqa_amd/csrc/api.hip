@@ -273,6 +273,20 @@ int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems
                                   as_stream(stream));
 }
 
+int ovqa_grouped_linear_bwd_weight_adam(int dtype, const ovqa_wgrad_problem* problems_dev, const int32_t* tiles_dev,
+                                        int64_t n_tiles, const ovqa_adam_target* targets_dev,
+                                        const ovqa_adam_consts* consts, void* stream) {
+  OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight_adam: bf16 only");
+  OVQA_REQUIRE(n_tiles >= 0 && (n_tiles == 0 || (problems_dev && tiles_dev && targets_dev)) && consts, OVQA_ERR_BAD_ARG,
+               "grouped_linear_bwd_weight_adam: bad argument");
+  OVQA_REQUIRE(n_tiles < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight_adam: too many tiles");
+  OVQA_REQUIRE(!force_simple(), OVQA_ERR_UNSUPPORTED,
+               "grouped_linear_bwd_weight_adam: the direct-to-LDS form only (no fallback under OVQA_FORCE_SIMPLE)");
+  if (n_tiles == 0) return OVQA_OK;
+  g_dispatch = "mfma-fused";
+  return ovqa::mfma_grouped_linear_bwd_weight_adam(problems_dev, tiles_dev, n_tiles, targets_dev, *consts, as_stream(stream));
+}
+
 int ovqa_bias_grad(int dtype, const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate,
                    void* stream) {
   OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "bias_grad: bf16 only (fp32 goes through linear_bwd_weight)");

@@ -80,6 +80,32 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nwg) {
 #endif
 }
 
+// ---- Adam ------------------------------------------------------------------
+// One element of torch.optim.Adam's update, written ONCE: the tiled Adam kernel (misc.hip) and the Adam epilogue of the
+// grouped weight-gradient kernel (gemm_mfma.hip) must give the same bits for the same gradient (the same expression tree
+// is contracted into the same fmas).
+struct AdamK {
+  float b1, b2, eps, wd, grad_scale, step_size, inv_sqrt_bc2;
+};
+__device__ __forceinline__ AdamK adam_consts(float lr, const float* lr_scale_ptr, float b1, float b2, float eps, float wd,
+                                             float grad_scale, const uint32_t* step_ptr) {
+  const float t = (float)(step_ptr ? *step_ptr : 1u);
+  const float lr_eff = lr * (lr_scale_ptr ? *lr_scale_ptr : 1.f);
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2 = 1.f - powf(b2, t);
+  return AdamK{b1, b2, eps, wd, grad_scale, lr_eff / bc1, rsqrtf(bc2)};
+}
+// (contraction is OFF inside and every fused multiply-add is written out: left to the compiler, the two kernels contracted
+// `b1 * m + (1 - b1) * g` differently -- equal results while m = 0, different last bits from the second step on)
+__device__ __forceinline__ void adam_update1(const AdamK& k, float g, float& p, float& m, float& v) {
+#pragma clang fp contract(off)
+  const float gk = __builtin_fmaf(k.wd, p, g * k.grad_scale);
+  m = __builtin_fmaf(k.b1, m, (1.f - k.b1) * gk);
+  v = __builtin_fmaf(k.b2, v, ((1.f - k.b2) * gk) * gk);
+  const float denom = __builtin_fmaf(sqrtf(v), k.inv_sqrt_bc2, k.eps);
+  p = p - (k.step_size * m) / denom;
+}
+
 // ---- scalar conversion -----------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

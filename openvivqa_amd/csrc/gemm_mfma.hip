@@ -924,6 +924,100 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
   gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128, KSP>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
+// ---- the optimiser step inside the grouped dW (round 5) -------------------------------------------------------------------
+// For a weight whose gradient is exactly one product of the step (and no exchange between ranks follows), the workgroup
+// that finished a 128 x 128 tile of dW applies Adam to that tile right away: the fp32 tile goes to LDS (the ring is idle
+// after the K loop; 16-byte chunks XOR-swizzled by the row so that the fragment stores -- 16 rows of one chunk column per
+// wave instruction -- and the row-wise reads are both conflict free), every thread then owns 16-byte pieces of whole rows:
+// master, both moments in and out (512-byte row segments per 32 lanes, streaming cache policy like the tiled Adam kernel),
+// the bf16 shadow out, its bf16 values back into LDS, and after a barrier the tile of the TRANSPOSED shadow is gathered
+// from there (8 output features per 16-byte store).  The gradient never reaches HBM (8 B per weight of traffic less) and
+// the optimiser state is streamed while other workgroups' K loops keep the fetch path busy with L2 hits.
+// Same update function as adam_tiled_kernel (common.h): same bits.
+struct MEpiWgradAdam {
+  static constexpr bool kWide = false;
+  float* dw; int64_t ld; int accumulate; float* db; int accumulate_db;
+  float* tile;  // fused: the fp32 tile in LDS; nullptr: the plain gradient store
+  int c0, r0;
+  __device__ __forceinline__ void init() {
+    if (tile) __syncthreads();  // (workgroup-uniform) every wave is done with the last K tile's fragments
+  }
+  __device__ __forceinline__ bool wants_colsum() const { return db != nullptr; }
+  __device__ __forceinline__ void colsum(int n, float v) const { db[n] = accumulate_db ? db[n] + v : v; }
+  __device__ __forceinline__ void operator()(int n, int i, const f32x4& a) const {
+    if (tile) {
+      const int ln = n - c0, li = i - r0;
+      *reinterpret_cast<f32x4*>(tile + ln * 128 + ((((li >> 2) ^ ln) & 31) << 2)) = a;
+      return;
+    }
+    float4* p = reinterpret_cast<float4*>(dw + (int64_t)n * ld + i);
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (accumulate) {
+      const float4 o = *p;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *p = v;
+  }
+};
+
+__global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_adam_kernel(const ovqa_wgrad_problem* __restrict__ probs,
+                                                                              const int4* __restrict__ tiles,
+                                                                              const ovqa_adam_target* __restrict__ targets,
+                                                                              const ovqa_adam_consts kc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int4 t = tiles[blockIdx.x];
+  if (t.x < 0) return;
+  const ovqa_wgrad_problem pr = probs[t.x];
+  const ovqa_adam_target tg = targets[t.x];
+  const bool fused = tg.param != nullptr;  // (workgroup-uniform)
+  const int c0 = t.y * BT, r0 = t.z * BT;
+  float* T = reinterpret_cast<float*>(smem);
+  MEpiWgradAdam epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1, fused ? T : nullptr, c0, r0};
+  GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
+  gemm_tile_glds<true, true, MEpiWgradAdam, true, 2, 8, 128, 128, 1>(g, c0, r0, epi, smem);
+  if (!fused) return;
+  __syncthreads();  // the tile is complete
+  const AdamK ak = adam_consts(kc.lr, kc.lr_scale_ptr, kc.beta1, kc.beta2, kc.eps, kc.weight_decay, kc.grad_scale, kc.step_ptr);
+  const int tid = threadIdx.x, q = tid & 31;
+#pragma unroll 2
+  for (int pass = 0; pass < 8; pass++) {
+    const int ln = pass * 16 + (tid >> 5);
+    float* slot = T + ln * 128 + (((q ^ ln) & 31) << 2);
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(slot);
+    const int64_t e4 = ((int64_t)(c0 + ln) * pr.K + r0 + q * 4) >> 2;  // (K % 128 == 0: 16-byte aligned)
+    f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tg.param) + e4);
+    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tg.exp_avg) + e4);
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tg.exp_avg_sq) + e4);
+    bf16x4 s4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float pk = pp[k], mk = mm[k], vk = vv[k];
+      adam_update1(ak, g4[k], pk, mk, vk);
+      pp[k] = pk; mm[k] = mk; vv[k] = vk;
+      s4[k] = (bf16)pk;
+    }
+    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(tg.param) + e4);
+    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(tg.exp_avg) + e4);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(tg.exp_avg_sq) + e4);
+    reinterpret_cast<bf16x4*>(tg.shadow)[e4] = s4;
+    *reinterpret_cast<bf16x4*>(slot) = s4;  // (this thread's own 16-byte slot: its first 8 bytes now hold the bf16 values)
+  }
+  __syncthreads();
+  bf16* tt = reinterpret_cast<bf16*>(tg.transposed);
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+    const int li = pass * 32 + (tid >> 4);  // input feature = row of the transposed tile
+    const int cn = (tid & 15) * 8;          // 8 consecutive output features
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int ln = cn + e;
+      o[e] = reinterpret_cast<const bf16*>(T + ln * 128 + ((((li >> 2) ^ ln) & 31) << 2))[li & 3];
+    }
+    *reinterpret_cast<bf16x8*>(tt + (int64_t)(r0 + li) * tg.ld_transposed + c0 + cn) = o;
+  }
+}
+
 // ---- 256 x 256 dW tiles: ONE 16-wave workgroup per CU (form 2 of the grouped launch; NOT the default) -------------------
 // Built when the 128 x 128 form (two co-resident workgroups per CU, 32 KB per 64-deep K step each) sat at 32 % matrix-pipe
 // occupancy: a 256 x 256 tile does four times the MFMA work on twice the bytes.
@@ -1689,6 +1783,23 @@ int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles
   hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3((unsigned)n_tiles), dim3(256), 4 * TILE_BYTES, st, probs_dev,
                      reinterpret_cast<const int4*>(tiles_dev));
   return ovqa_check_launch("grouped_linear_bwd_weight(mfma)");
+}
+
+int mfma_grouped_linear_bwd_weight_adam(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles,
+                                        const ovqa_adam_target* targets_dev, const ovqa_adam_consts& consts, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_grouped_wgrad_adam_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (e != hipSuccess) {
+      ovqa_set_error("grouped_linear_bwd_weight_adam: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return OVQA_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_adam_kernel, dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st, probs_dev,
+                     reinterpret_cast<const int4*>(tiles_dev), targets_dev, consts);
+  return ovqa_check_launch("grouped_linear_bwd_weight_adam(mfma,glds)");
 }
 
 int colsum_bf16(const void* dy, int64_t lddy, float* db, int64_t M, int64_t N, int accumulate, hipStream_t st) {

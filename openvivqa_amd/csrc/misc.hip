@@ -17,12 +17,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const float* __restrict__ lr_scale_ptr, float b1, float b2,
                                                    float eps, float wd, float grad_scale,
                                                    const uint32_t* __restrict__ step_ptr) {
-  const float t = (float)(step_ptr ? *step_ptr : 1u);
-  const float lr_eff = lr * (lr_scale_ptr ? *lr_scale_ptr : 1.f);
-  const float bc1 = 1.f - powf(b1, t);
-  const float bc2 = 1.f - powf(b2, t);
-  const float step_size = lr_eff / bc1;
-  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  const AdamK ak = adam_consts(lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -37,13 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float* ma = &mm.x;
     float* va = &vv.x;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float gk = ga[k] * grad_scale + wd * pa[k];
-      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
-      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
-      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
-      pa[k] -= step_size * ma[k] / denom;
-    }
+    for (int k = 0; k < 4; k++) adam_update1(ak, ga[k], pa[k], ma[k], va[k]);
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
@@ -56,12 +45,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   // tail (n not a multiple of 4)
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gk = to_f32<TG>(g[i]) * grad_scale + wd * p[i];
-    const float mk = b1 * m[i] + (1.f - b1) * gk;
-    const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    float pk = p[i], mk = m[i], vk = v[i];
+    adam_update1(ak, to_f32<TG>(g[i]), pk, mk, vk);
     m[i] = mk;
     v[i] = vk;
-    const float pk = p[i] - step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
     p[i] = pk;
     if (shadow) shadow[i] = (bf16)pk;
   }
@@ -85,12 +72,7 @@ __global__ __launch_bounds__(256) void adam_tiled_kernel(float* __restrict__ p, 
                                                          float eps, float wd, float grad_scale,
                                                          const uint32_t* __restrict__ step_ptr) {
   __shared__ bf16 tile[64][64 + 8];
-  const float t = (float)(step_ptr ? *step_ptr : 1u);
-  const float lr_eff = lr * (lr_scale_ptr ? *lr_scale_ptr : 1.f);
-  const float bc1 = 1.f - powf(b1, t);
-  const float bc2 = 1.f - powf(b2, t);
-  const float step_size = lr_eff / bc1;
-  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  const AdamK ak = adam_consts(lr, lr_scale_ptr, b1, b2, eps, wd, grad_scale, step_ptr);
   typedef __attribute__((ext_vector_type(4))) TG g4_t;
   auto update4 = [&](int64_t i4, bf16x4& s) {  // elements 4 * i4 .. 4 * i4 + 3 of the arena
 #if OVQA_NT_ADAM
@@ -111,11 +93,7 @@ __global__ __launch_bounds__(256) void adam_tiled_kernel(float* __restrict__ p, 
     float* va = &vv.x;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const float gk = to_f32<TG>(g4[k]) * grad_scale + wd * pa[k];
-      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
-      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
-      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
-      pa[k] -= step_size * ma[k] / denom;
+      adam_update1(ak, to_f32<TG>(g4[k]), pa[k], ma[k], va[k]);
       s[k] = (bf16)pa[k];
     }
 #if OVQA_NT_ADAM

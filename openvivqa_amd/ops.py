@@ -313,6 +313,10 @@ class WgradQueue:
         self.hold_reduces = False
         self.hold_items = False     # the same for the products of a phase that releases no gradient segment
         self.armed = False          # functional._armed_queue: a flush callback is registered for the running backward call
+        # The optimiser step inside the LAST launch of a pass (ovqa_grouped_linear_bwd_weight_adam; train.TrainStep at
+        # world size 1): an object with ``pre_flush()`` (the step counters / learning rate of this step, launched in front
+        # of the weight-gradient launch), ``targets(items) -> [AdamTarget | None]`` and ``consts() -> AdamConsts``.
+        self.adam = None
 
     def _note_producer(self, t):
         if t.is_cuda:
@@ -411,8 +415,9 @@ class WgradQueue:
         if capturing:
             self.keepalive.append((host, devbuf, red))
 
-    def flush(self):
-        """Launch everything queued so far on the side stream (asynchronously w.r.t. the main stream)."""
+    def flush(self, final=False):
+        """Launch everything queued so far on the side stream (asynchronously w.r.t. the main stream).  ``final``: the last
+        launch of the pass (``finish``): the one that may carry the optimiser step (``self.adam``)."""
         if not self.items:
             return
         import numpy as np
@@ -456,6 +461,8 @@ class WgradQueue:
             b = min(bins, key=lambda bb: bb[0])
             b[0] += work
             b[1].extend(tl)
+        # (round 5, with the optimiser step in the epilogue: interleaving long and short tiles -- 1, 2, 3 or 5 long ones per short
+        # one -- so that the HBM-bound epilogues do not come in rounds measured 614-756 us against 599 longest-first: kept as is)
         depth = max(len(b[1]) for b in bins)
         tile_arr = np.full((depth * 8, 4), -1, dtype=np.int32)  # -1 = padding entry (kernel returns)
         for xcd, b in enumerate(bins):
@@ -466,12 +473,22 @@ class WgradQueue:
         pad = (-prob_bytes.size) % 16  # keep the int4 tile table 16-byte aligned
         if pad:
             prob_bytes = np.concatenate([prob_bytes, np.zeros(pad, dtype=np.uint8)])
-        nbytes = prob_bytes.size + tile_arr.nbytes
+        # the optimiser step inside this launch (the last one of the pass): one target per problem behind the tile table
+        targets = None
+        if final and self.adam is not None and fast and not big and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0"):
+            tl = self.adam.targets(items)
+            if any(t is not None for t in tl):
+                arr = (_lib.AdamTarget * len(items))(*[t if t is not None else _lib.AdamTarget() for t in tl])
+                targets = np.frombuffer(bytes(arr), dtype=np.uint8)
+        tile_bytes = tile_arr.nbytes + ((-tile_arr.nbytes) % 16)
+        nbytes = prob_bytes.size + tile_bytes + (targets.size if targets is not None else 0)
         capturing = torch.cuda.is_current_stream_capturing()
         entry = self._buffers(nbytes, dev, capturing)
         host, devbuf = entry[0], entry[1]
         host[:prob_bytes.size] = torch.from_numpy(prob_bytes.copy())
-        host[prob_bytes.size:nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
+        host[prob_bytes.size:prob_bytes.size + tile_arr.nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
+        if targets is not None:
+            host[prob_bytes.size + tile_bytes:nbytes] = torch.from_numpy(targets.copy())
         main = torch.cuda.current_stream(dev)
         # a side stream only when launches are meant to overlap the rest of backward (FLUSH_TILES set); the default
         # single launch at the end stays on the main stream: a fork/join in a captured graph turns every node
@@ -483,9 +500,16 @@ class WgradQueue:
             side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
         with torch.cuda.stream(side):
             self._upload(host, devbuf, nbytes, capturing)
-            _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
-                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), 2 if big else int(fast),
-                side.cuda_stream), "grouped_linear_bwd_weight")
+            if targets is not None:
+                consts = self.adam.consts()
+                _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight_adam(
+                    OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles),
+                    devbuf.data_ptr() + prob_bytes.size + tile_bytes, C.addressof(consts), side.cuda_stream),
+                    "grouped_linear_bwd_weight_adam")
+            else:
+                _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
+                    OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), 2 if big else int(fast),
+                    side.cuda_stream), "grouped_linear_bwd_weight")
         self._used(entry, side, capturing)
         self._used_side = self._used_side or overlapping
         self.inflight.append(items)
@@ -526,7 +550,9 @@ class WgradQueue:
             self._flush_reduces()
         if self.hold_items:
             return  # (the queued operands stay referenced; the next phase's flush launches them with its own)
-        self.flush()
+        if self.adam is not None and self.items:
+            self.adam.pre_flush()  # this step's counters and learning rate, in front of the launch that applies them
+        self.flush(final=True)
         if self._used_side:
             for dev, side in self._side.items():
                 torch.cuda.current_stream(dev).wait_stream(side)

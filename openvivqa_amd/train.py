@@ -506,6 +506,89 @@ def _complement(spans, lo, hi):
     return out
 
 
+class _FusedAdam:
+    """``ops.WgradQueue.adam`` for a TrainStep at world size 1: the LAST grouped weight-gradient launch of a step applies
+    Adam to every weight matrix whose gradient is exactly one product of that launch (``ovqa_grouped_linear_bwd_weight_adam``:
+    the fp32 gradient tile never reaches HBM; master, moments, bf16 shadow and transposed shadow are updated by the
+    workgroup that finished the tile).  A matrix GROUP of the arena (adjacent fc_q | fc_k | fc_v ...) is taken only when
+    its rows are covered completely by such products; ``self.ranges`` then lists the arena ranges the launch has updated
+    and the optimiser tail leaves out.  Same arithmetic as the tiled Adam kernel: bit-identical weights and moments."""
+
+    def __init__(self, ts):
+        self.ts = ts
+        self.began = False
+        self.ranges = []
+
+    def reset(self):
+        self.began, self.ranges = False, []
+
+    def pre_flush(self):
+        self.ts.optim.begin_step(also=self.ts.drop_step)
+        self.began = True
+
+    def consts(self):
+        from . import _lib
+        o = self.ts.optim
+        lr, ptr = (1.0, o.lr_eff.data_ptr()) if o.lr_table is not None else (o.lr * o.lr_scale, None)
+        return _lib.AdamConsts(lr, o.betas[0], o.betas[1], o.eps, o.weight_decay, 1.0, ptr, o.step_t.data_ptr())
+
+    def targets(self, items):
+        import bisect
+        from collections import Counter
+        from . import _lib
+        a, o = self.ts.arena, self.ts.optim
+        groups = sorted(a._groups2d)
+        starts = [g[0] for g in groups]
+        g0 = a.grad.data_ptr()
+        uses = Counter(it[2].data_ptr() for it in items)
+        cand, cover = {}, Counter()
+        for idx, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
+            if (acc & 1) or uses[dw.data_ptr()] != 1 or N % 128 or K % 128 or not dw.is_contiguous():
+                continue
+            off = (dw.data_ptr() - g0) // 4
+            gi = bisect.bisect_right(starts, off) - 1
+            if off < 0 or gi < 0:
+                continue
+            goff, rows, cols = groups[gi]
+            if cols != K or (off - goff) % K or off + N * K > goff + rows * cols:
+                continue
+            cand[idx] = (gi, off, (off - goff) // K)
+            cover[gi] += N
+        out = [None] * len(items)
+        for idx, (gi, off, r0) in cand.items():
+            goff, rows, cols = groups[gi]
+            if cover[gi] != rows:
+                continue  # (a group whose other rows keep the separate update stays whole: the Adam tile table is per group)
+            N, K = items[idx][6], items[idx][7]
+            out[idx] = _lib.AdamTarget(a.master.data_ptr() + 4 * off, o.exp_avg.data_ptr() + 4 * off,
+                                       o.exp_avg_sq.data_ptr() + 4 * off, a.shadow.data_ptr() + 2 * off,
+                                       a.shadow_t.data_ptr() + 2 * (goff + r0), rows)
+        done = sorted({cand[idx][0] for idx, t in enumerate(out) if t is not None})
+        self.ranges = _merge([(groups[gi][0], groups[gi][0] + groups[gi][1] * groups[gi][2]) for gi in done])
+        return out
+
+    def rest(self):
+        """The arena ranges the launch did NOT update, as runs of whole matrix groups + the 1-D tail: what
+        ``FlatAdam.apply(ranges=...)`` still has to do."""
+        a = self.ts.arena
+        fused = {lo for lo, _ in [(g[0], 0) for g in a._groups2d
+                                  if any(lo <= g[0] and g[0] + g[1] * g[2] <= hi for lo, hi in self.ranges)]}
+        runs, cur = [], None
+        for off, rows, cols in sorted(a._groups2d):
+            if off in fused:
+                if cur is not None:
+                    runs.append(tuple(cur))
+                    cur = None
+                continue
+            end = off + rows * cols
+            cur = [off, end] if cur is None else [cur[0], end]
+        if cur is not None:
+            runs.append(tuple(cur))
+        if a.small_lo < a.numel:
+            runs.append((a.small_lo, a.numel))
+        return runs
+
+
 class TrainStep:
     """forward -> loss -> backward -> all-reduce -> Adam, replayed from ONE hipGraph (round 4: the gradient exchange -- RCCL
     collectives are capturable -- and Adam with its LambdaLR schedule, read from a device table, are inside the graph;
@@ -534,7 +617,7 @@ class TrainStep:
                  lr_lambda: Optional[Callable[[int], float]] = None, use_graph: bool = True,
                  comm_dtype: torch.dtype = torch.float32, bucket_mb: float = 64.0, device=None,
                  compute_dtype: Optional[torch.dtype] = None, overlap_mb: float = 96.0,
-                 force_comm: bool = False):
+                 force_comm: bool = False, fuse_adam: Optional[bool] = None):
         self.model = model
         self.arena = rt.prepare(model, device=device, compute_dtype=compute_dtype)
         self.arena.overwrite_grads = True
@@ -551,6 +634,12 @@ class TrainStep:
         self.drop_step = rt.step_tensor(self.arena.device)
         self._foreign = [(0, self.arena.numel)]  # until the first backward tells which grads the kernels own
         self.overlap_mb = overlap_mb
+        # Adam inside the last weight-gradient launch (``_FusedAdam``): only without a gradient exchange, on the bf16 path
+        # with its transposed shadow; opt-in (``fuse_adam=True`` or OVQA_FUSE_ADAM=1): the weight matrices' entries of
+        # ``arena.grad`` are then NOT written by a step (bench.py turns it on at N = 1)
+        want = (os.environ.get("OVQA_FUSE_ADAM", "0") == "1") if fuse_adam is None else bool(fuse_adam)
+        self._fused = (_FusedAdam(self) if want and not self.reducer.active and self.arena.device.type == "cuda"
+                       and getattr(self.arena, "shadow_t", None) is not None and self.arena.adam_tiles() is not None else None)
         self._cuts = None            # _Cuts sink when backward is phased
         self.segments = [[(0, self.arena.numel)]]  # segments[k] = ranges final after phase k
         self._live = None
@@ -825,14 +914,28 @@ class TrainStep:
         capturable) -- then ovqa_begin_step (counters + this step's learning rate out of the device table) and Adam,
         range by range behind the exchange of that range.  Nothing about a step comes from the host."""
         first, later = self._phase_fns()
-        first()
-        ncut = len(self._live["cuts"])
-        self._release(0)
-        for j, k in enumerate(reversed(range(ncut))):
-            later(k)()
-            self._release(j + 1)
+        self._arm_fused(True)
+        try:
+            first()
+            ncut = len(self._live["cuts"])
+            self._release(0)
+            for j, k in enumerate(reversed(range(ncut))):
+                later(k)()
+                self._release(j + 1)
+        finally:
+            self._arm_fused(False)
         self._live = None
         self._optimiser_tail(host=False)
+
+    def _arm_fused(self, on: bool) -> None:
+        """The optimiser step rides in the last weight-gradient launch of THIS pass (a real step) -- never in the discovery
+        and warm-up passes, whose gradients are computed and discarded."""
+        if self._fused is None:
+            return
+        q = self._queue()
+        if on:
+            self._fused.reset()
+        q.adam = self._fused if on else None
 
     def _optimiser_tail(self, host: bool = True) -> None:
         scale = 1.0 / self.reducer.world
@@ -850,6 +953,10 @@ class TrainStep:
             self.optim.apply(buf, scale, ranges=_merge([r for seg in self.segments[:-1] for r in seg]))
             self.optim.apply(self.reducer.wait_segment(n - 1, self.arena.grad), scale, ranges=self.segments[-1])
             self.reducer.finish(self.arena.grad)
+        elif self._fused is not None and self._fused.began:
+            # the weight matrices were updated inside the last weight-gradient launch: what is left are the groups that launch
+            # did not take and the 1-D parameters (one launch each run; the counters have been advanced in front of it)
+            self.optim.apply(self.arena.grad, scale, ranges=self._fused.rest())
         else:
             self.optim.begin_step(also=self.drop_step)
             self.optim.apply(self.reducer.finish(self.arena.grad), scale)
@@ -934,7 +1041,11 @@ class TrainStep:
                 g.replay()
                 self._release(k)
         else:
-            self._fwd_bwd(on_phase=self._release)
+            self._arm_fused(True)
+            try:
+                self._fwd_bwd(on_phase=self._release)
+            finally:
+                self._arm_fused(False)
         self._optimiser_tail()
         return self.loss
 

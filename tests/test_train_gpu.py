@@ -107,6 +107,33 @@ def test_graph_replay_equals_eager_steps():
         assert float(a.loss) == float(b.loss)
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_adam_inside_the_weight_gradient_launch_equals_separate_adam(use_graph):
+    """Round 5: at world size 1 the last grouped weight-gradient launch of a step applies Adam to the weight matrices itself
+    (ovqa_grouped_linear_bwd_weight_adam: the fp32 gradient tile never reaches HBM).  Against the separate tiled Adam launch,
+    over 4 steps of a schedule that changes every step: bit-identical losses, master weights, moments, bf16 shadows and
+    transposed shadows -- the two kernels share one update function."""
+    from openvivqa_amd.train import noam_lr_scale
+    kw = dict(lr_lambda=lambda s: noam_lr_scale(s, 512, 3), use_graph=use_graph)
+    _, a, batch = _make(2, fuse_adam=True, **kw)
+    _, b, _ = _make(2, fuse_adam=False, **kw)
+    assert a._fused is not None and b._fused is None
+    for i in range(4):
+        a.step(*batch)
+        b.step(*batch)
+        torch.cuda.synchronize()
+        assert float(a.loss) == float(b.loss), i
+        assert torch.equal(a.arena.master, b.arena.master), i
+        assert torch.equal(a.arena.shadow, b.arena.shadow) and torch.equal(a.arena.shadow_t, b.arena.shadow_t), i
+        assert torch.equal(a.optim.exp_avg, b.optim.exp_avg) and torch.equal(a.optim.exp_avg_sq, b.optim.exp_avg_sq), i
+    # the launch took (nearly) every matrix of the stacks, and the 1-D parameters went through the separate launch
+    fused = sum(hi - lo for lo, hi in a._fused.ranges)
+    assert a._fused.began and fused >= 0.95 * a.arena.small_lo, (fused, a.arena.small_lo)
+    assert int(a.optim.step_t.item()) == 4 == a.optim.host_step
+    lo = a.arena.small_lo
+    assert torch.equal(a.arena.grad[lo:], b.arena.grad[lo:])
+
+
 @pytest.mark.parametrize("force", [False, True])
 def test_whole_step_graph_equals_phase_graphs_with_eager_adam(single_rank_group, force, monkeypatch):
     """Round 4: the step is ONE graph -- forward, loss, backward, the gradient exchange of every segment (captured RCCL
