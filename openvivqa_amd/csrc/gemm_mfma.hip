@@ -1358,7 +1358,10 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     const char* e = getenv("OVQA_GEMM_TINY_MAXR");
     tiny_maxr = e ? atoi(e) : 1024;
   }
-  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold() && R <= tiny_maxr;
+  // (only where the 128 x 128 tiling still has >= 128 tiles: a beam-3 decoding step's 192 x 4000 logits are 64 such tiles,
+  // and its decode got 9 % slower -- 296k -> 270k tokens/s -- before this condition)
+  const bool wide_enough = (int64_t)g.tiles_r * ((C + 127) / 128) >= 128;
+  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold() && (R <= tiny_maxr || !wide_enough);
   if (small_c) g.tiles_c = (int)((C + (tiny_c ? 31 : 63)) / (tiny_c ? 32 : 64));
   const dim3 grid(g.tiles_r * g.tiles_c);
 #define OVQA_GLDS_K(NBUF, NW, BCV, KSPV)                                                                            \

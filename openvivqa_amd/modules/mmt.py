@@ -122,13 +122,6 @@ class BertEncoder(nn.Module):
         return (Fn.finalize(hidden_states, dtype),)
 
 
-def _batch_gather(x, inds):
-    """x (B, L, D), inds (B, T) -> (B, T, D)   (mmf_m4c.py:448-459)."""
-    B, L, D = x.shape
-    flat = (torch.arange(B, device=inds.device) * L).unsqueeze(-1) + inds
-    return torch.nn.functional.embedding(flat, x.reshape(B * L, D))
-
-
 class PrevPredEmbeddings(nn.Module):
     """Embeddings of the previous decoding steps' predictions (mmf_m4c.py:399-446): gather from
     [LN(fixed answer table); LN(OCR embeddings)] + LN(position + token-type embedding)."""
