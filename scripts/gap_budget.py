@@ -32,6 +32,7 @@ def meas(pred):
     return tot / n if n else None
 
 
+fused_adam = any("grouped_wgrad_adam" in r[0] for r in rows)
 fam = bench.gemm_launch_list(B, NV, NT, D, DFF, L)
 mv, mt = B * NV, B * NT
 # the fc_o dX products that run inside the attention backward kernels (guided, question self-attention and -- round 5 -- the
@@ -66,13 +67,17 @@ families = [
      sum(gemm_bytes(s, "gelu") for s in fam["gelu"])),
     ("forward GEMMs, fp32 residual epilogue (fc_o, fc2)", lambda k: "MEpiBiasRes32" in k,
      sum(2.0 * s[0] * s[1] * s[2] for s in fam["residual"]), sum(gemm_bytes(s, "residual") for s in fam["residual"])),
-    ("grouped dW (one launch)", lambda k: "grouped_wgrad" in k, 0.348e12,
-     2 * sum(s[0] * (s[1] + s[2]) for f in ("bias", "gelu", "residual") for s in fam[f]) + 4 * 44.1e6),
+    # (round 5, N = 1: Adam of the weight matrices runs in this launch's epilogue -- 28 B per weight instead of the 4 B of a
+    # stored gradient)
+    ("grouped dW + Adam of the weight matrices (one launch)" if fused_adam else "grouped dW (one launch)",
+     lambda k: "grouped_wgrad" in k, 0.348e12,
+     2 * sum(s[0] * (s[1] + s[2]) for f in ("bias", "gelu", "residual") for s in fam[f]) + (28 if fused_adam else 4) * 44.1e6),
     ("attention forward, projections inside", lambda k: "attn_qkv_fwd" in k or "attn_q_fwd" in k, None, None),
     ("attention backward", lambda k: "attn_bwd" in k, None, None),
     ("LayerNorm forward", lambda k: "ln_fwd" in k, 0.0, None),
     ("LayerNorm backward + parameter reduce", lambda k: "ln_bwd" in k, 0.0, None),
-    ("Adam (tiled: master, moments, shadow, transposed shadow)", lambda k: "adam" in k, 0.0, 44.1e6 * 30),
+    ("Adam of the 1-D parameters" if fused_adam else "Adam (tiled: master, moments, shadow, transposed shadow)",
+     lambda k: "adam" in k, 0.0, None if fused_adam else 44.1e6 * 30),
     ("loss, step counter, stray elementwise", lambda k: True, 0.0, None),
 ]
 # the one hoisted K | V projection + the six fused-QKV kernels carry the 'bias' family's flops inside other rows
