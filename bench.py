@@ -309,7 +309,8 @@ def instep_probe(ts, dom_hint=None):
 # family of the in-step probe -> the kernel instantiation the library picks for it (rocprofv3's name, as a prefix)
 ATTN_KERNEL_OF = {"attn_qkv_fwd 100x100": "attn_qkv_fwd_mfma_kernel<128, 1,", "attn_qkv_fwd 20x20": "attn_qkv_fwd_mfma_kernel<32, 2,",
                   "attn_qkv_fwd": "attn_qkv_fwd_mfma_kernel", "attn_q_fwd": "attn_q_fwd_mfma_kernel",
-                  "attn_bwd 100x100": "attn_bwd_roles_mfma_kernel", "attn_bwd_do 100x20": "attn_bwd_do_smallk_mfma_kernel",
+                  "attn_bwd 100x100": "attn_bwd_roles_mfma_kernel", "attn_bwd_do 100x100": "attn_bwd_roles_mfma_kernel",
+                  "attn_bwd_do 100x20": "attn_bwd_do_smallk_mfma_kernel",
                   "attn_bwd_do 20x20": "attn_bwd_do_smallk1_mfma_kernel", "attn_bwd": "attn_bwd_smallk_mfma_kernel",
                   "attn_fwd": "attn_fwd_mfma_kernel"}
 
