@@ -301,6 +301,21 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
                        void* o, int64_t ldo, float* lse, void* att, void* o_lo,
                        int64_t B, int64_t H, int64_t nq, int64_t nk, int64_t dk, int64_t dv,
                        float scale, const ovqa_dropout* att_drop, void* stream);
+/* The same forward for a PREFIX-LM mask given by its structure instead of a dense (B, 1, n, n) tensor (round 5): every query
+ * sees the keys that the key-mask row admits, and among the LAST `causal_tail` positions of the sequence query i does not
+ * see keys j > i.
+ *   replaces: the mask MMT.forward builds for M4C's multimodal transformer -- the padding masks of [txt; obj; ocr] and a
+ *             zero row for the decoding steps, repeated over the queries, with the causal corner of the decoding steps
+ *             written in (mmf_m4c.py:310-340) -- as the attention core of its BertSelfAttention sees it at inference;
+ *             the kernel reads one mask row per (b, h) out of LDS instead of n x n mask values per (b, h) from HBM
+ *             (configs[3]: 126 -> see DESIGN.md us per launch).
+ *   key_mask: fp32 additive row, element (b, h, j) at key_mask[b*msb + h*msh + j], or NULL; self-attention (n queries =
+ *   n keys), bf16 only, inference only (no log-sum-exp consumers beyond `lse`, no dropout, no probabilities).
+ *   Shapes outside the MFMA forward kernel: OVQA_ERR_UNSUPPORTED (callers fall back to the dense mask). */
+int ovqa_attention_fwd_prefix_lm(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                 int64_t ldv, const float* key_mask, int64_t msb, int64_t msh, int64_t causal_tail,
+                                 void* o, int64_t ldo, float* lse, int64_t B, int64_t H, int64_t n, int64_t d,
+                                 float scale, void* stream);
 
 /* Self-attention forward with the Q/K/V projections inside: MultiHeadAttention.forward with queries is keys is
  * values (attentions.py:316-326 -> :49-57; the MCAN SA blocks, encoders.py:46-49, and the M4C MMT layers):

@@ -104,6 +104,8 @@ SIGNATURES = {
     "ovqa_grouped_partial_reduce": [c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_attention_fwd": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
                            c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, _DP, c_vp],
+    "ovqa_attention_fwd_prefix_lm": [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64,
+                                     c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_vp],
     "ovqa_launch_timing_begin": [c_int],
     "ovqa_launch_timing_count": [],
     "ovqa_launch_timing_end": [c_vp, c_int],

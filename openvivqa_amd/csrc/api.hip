@@ -401,6 +401,28 @@ int ovqa_attention_fwd(int dtype, const void* q, int64_t ldq, const void* k, int
   return ovqa::simple_attention_fwd(dtype, a, as_stream(stream));
 }
 
+int ovqa_attention_fwd_prefix_lm(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                 int64_t ldv, const float* key_mask, int64_t msb, int64_t msh, int64_t causal_tail, void* o,
+                                 int64_t ldo, float* lse, int64_t B, int64_t H, int64_t n, int64_t d, float scale,
+                                 void* stream) {
+  OVQA_REQUIRE(dtype == OVQA_BF16, OVQA_ERR_UNSUPPORTED, "attention_fwd_prefix_lm: bf16 only");
+  OVQA_REQUIRE(B >= 0 && H > 0 && n >= 0 && d > 0 && causal_tail >= 0 && causal_tail <= n, OVQA_ERR_BAD_ARG,
+               "attention_fwd_prefix_lm: bad sizes");
+  if (B == 0 || n == 0) return OVQA_OK;
+  OVQA_REQUIRE(q && k && v && o, OVQA_ERR_BAD_ARG, "attention_fwd_prefix_lm: null pointer");
+  OVQA_REQUIRE(ldq >= H * d && ldk >= H * d && ldv >= H * d && ldo >= H * d, OVQA_ERR_BAD_ARG,
+               "attention_fwd_prefix_lm: row stride smaller than H*d");
+  OVQA_REQUIRE(B * H <= 0x7fffffff, OVQA_ERR_UNSUPPORTED, "attention_fwd_prefix_lm: B*H too large");
+  ovqa::AttnArgs a{q, k, v, ldq, ldk, ldv, key_mask, msb, msh, 0, o, ldo, lse, nullptr,
+                   (int)B, (int)H, (int)n, (int)n, (int)d, (int)d, scale, make_drop_args(nullptr)};
+  a.tail = (int)causal_tail;
+  OVQA_REQUIRE(!force_simple() && ovqa::mfma_attention_supported(a), OVQA_ERR_UNSUPPORTED,
+               "attention_fwd_prefix_lm: shape not covered by the MFMA forward kernel (d in {64, 96, 128}, n <= 256 / 192, "
+               "16-byte aligned rows): pass the dense (B, 1, n, n) mask to ovqa_attention_fwd instead");
+  g_dispatch = "mfma";
+  return ovqa::mfma_attention_fwd(a, as_stream(stream));
+}
+
 int ovqa_attention_qkv_fwd(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* qkv,
                            int64_t ldqkv, const float* mask, int64_t msb, int64_t msh, void* o, int64_t ldo, float* lse,
                            void* o_lo, int64_t B, int64_t H, int64_t n, int64_t d_model, int64_t d, float scale,

@@ -182,7 +182,10 @@ __device__ __forceinline__ void attn_fwd_core(const ovqa::AttnArgs& a, int b, in
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const float sv = st[t][4 * g4 + e] * a.scale + mm[e];
+          float sv = st[t][4 * g4 + e] * a.scale + mm[e];
+          // prefix-LM corner (M4C's multimodal transformer, mmf_m4c.py:333-340: the decoding positions are the last `tail`
+          // of the sequence and see each other causally; everything else is the key mask row): computed, not read
+          if (a.tail && key0 + e > q && q >= nq - a.tail) sv = -INFINITY;
           st[t][4 * g4 + e] = sv;
           mx = fmaxf(mx, sv);
         }

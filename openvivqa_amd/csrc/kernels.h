@@ -40,6 +40,7 @@ struct AttnArgs {
   float scale;
   DropArgs drop;  // dropout on the attention probabilities (p == 0: off); element index ((b*H+h)*nq+i)*nk+j
   void* o_lo = nullptr;  // bf16 mode, optional: o_lo = bf16(o_fp32 - float(bf16(o_fp32))), same layout as o (see AttnBwdArgs)
+  int tail = 0;  // prefix-LM form (key-mask rows only): among the LAST `tail` positions, query i does not see keys j > i
 };
 struct AttnBwdArgs {
   const void *d_o, *q, *k, *v, *o, *d_att;

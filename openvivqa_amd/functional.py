@@ -358,6 +358,12 @@ def _project_and_attend(st, queries, keys, values, mask, save_lse=True, lo_out=N
                                         kv[..., nqk:], mask, a.h, save_lse=save_lse, lo_out=lo_out)
         return o, lse, "cross", (q, kv)
     q, k, v, mode, bufs = _project_qkv(st, queries, keys, values)
+    # a dense (B, 1, n, n) mask that its builder has described as "key mask row + causal corner of the last T positions"
+    # (modules/mmt.py, inference): the kernel computes the corner and reads the row out of LDS instead of n x n mask values
+    hint = getattr(mask, "_ovqa_prefix_lm", None)
+    if (hint is not None and not save_lse and lo_out is None and st.get("att_drop") is None and st.get("same") == "all"
+            and not torch.is_grad_enabled() and ops.attention_fwd_prefix_lm_ok(q, a.h)):
+        return ops.attention_fwd_prefix_lm(q, k, v, hint[0], hint[1], a.h), None, mode, bufs
     o, lse, _ = ops.attention_fwd(q, k, v, mask, a.h, save_lse=save_lse, att_drop=st.get("att_drop"), lo_out=lo_out)
     return o, lse, mode, bufs
 

@@ -197,6 +197,10 @@ class MMT(nn.Module):
         S = mask.size(-1)
         ext = mask.repeat(1, 1, S, 1)
         ext[:, :, -steps:, -steps:] = generate_sequential_mask(steps, device=ext.device)
+        # what this tensor IS, for the attention kernel (inference): the key row + a causal corner of `steps` positions --
+        # ovqa_attention_fwd_prefix_lm then reads S mask values per (b, h) instead of S x S (functional._project_and_attend)
+        if mask.shape[1] == 1 and mask.shape[2] == 1:
+            ext._ovqa_prefix_lm = (mask, steps)
         return ext
 
 

@@ -702,6 +702,35 @@ def attention_fwd(q, k, v, mask, H, scale=None, need_att=False, save_lse=True, a
     return o, lse, att
 
 
+def attention_fwd_prefix_lm_ok(q, H):
+    """Shapes ``attention_fwd_prefix_lm`` covers: bf16 on the GPU, heads of 64 / 96 / 128 features, at most 256 (192 for the
+    wider heads) positions, 16-byte aligned rows."""
+    if os.environ.get("OVQA_FORCE_SIMPLE", "0") == "1" or os.environ.get("OVQA_NO_PREFIX_LM", "0") == "1":
+        return False
+    d = q.shape[2] // H
+    return (q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 3 and d in (64, 96, 128)
+            and q.shape[1] <= (256 if d == 64 else 192) and q.data_ptr() % 16 == 0 and _rows(q)[0] % 8 == 0)
+
+
+def attention_fwd_prefix_lm(q, k, v, key_mask, causal_tail, H, scale=None):
+    """Inference-only self-attention under a prefix-LM mask given by its structure (``ovqa_attention_fwd_prefix_lm``): the
+    key-mask row (b|1, h|1, 1, n) or None, and among the last ``causal_tail`` positions query i does not see keys j > i.
+    Returns o [B, n, H*d]."""
+    _dev(q)
+    lib = _lib.load()
+    B, n = q.shape[0], q.shape[1]
+    d = q.shape[2] // H
+    assert k.shape[1] == n and v.shape[1] == n and v.shape[2] == q.shape[2]
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    o = torch.empty(B, n, H * d, dtype=q.dtype, device=q.device)
+    key_mask, sb, sh, sq = _mask_strides(key_mask, B, H, n, n)
+    assert sq == 0, "a key mask: one row per (b, h)"
+    _lib.check(lib.ovqa_attention_fwd_prefix_lm(_dt(q), _p(q), _rows(q)[0], _p(k), _rows(k)[0], _p(v), _rows(v)[0],
+                                                _p(key_mask), sb, sh, int(causal_tail), _p(o), H * d, None, B, H, n, d,
+                                                float(scale), _stream()), "attention_fwd_prefix_lm")
+    return o
+
+
 def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=None):
     """Self-attention forward with the packed projections inside (``ovqa_attention_qkv_fwd``): x [B,n,d_model],
     w [3*H*d, d_model] (fc_q | fc_k | fc_v rows), bias fp32 [3*H*d] -> (qkv [B,n,3*H*d], o [B,n,H*d], lse).

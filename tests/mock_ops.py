@@ -204,6 +204,10 @@ def attention_bwd_do_ok(dy, wt, q, k, mask, H):
     return False  # (the CPU plumbing tests keep the two-kernel form)
 
 
+def attention_fwd_prefix_lm_ok(q, H):
+    return False  # (the dense mask on the CPU)
+
+
 def attention_q_fwd(x, w, bias, k, v, mask, H, scale=None, save_lse=True, lo_out=None):
     q = linear_fwd(x, w, bias)
     o, lse, _ = attention_fwd(q, k, v, mask, H, scale, save_lse=save_lse, lo_out=lo_out)

@@ -1064,6 +1064,28 @@ def test_model_end_entry_points_accept_empty_batches():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,n,tail,d", [(4, 182, 12, 96), (3, 100, 100, 64), (2, 64, 1, 128), (2, 37, 5, 64), (2, 192, 0, 96)])
+def test_attention_fwd_prefix_lm_equals_dense_mask(B, n, tail, d):
+    """ovqa_attention_fwd_prefix_lm (key-mask row + a causal corner of the last `tail` positions, computed in the kernel) against
+    ovqa_attention_fwd on the dense (B, 1, n, n) mask that M4C's MMT.forward builds (mmf_m4c.py:310-340): the same output bits
+    (masked probabilities are exactly zero either way)."""
+    from openvivqa_amd.utils import generate_sequential_mask
+    o_ = ops()
+    H = 8
+    q, k, v = (rnd(B, n, H * d, dtype=BF16, seed=s) for s in (0, 1, 2))
+    row = torch.zeros(B, 1, 1, n, device=DEV)
+    row[0, :, :, 3:7] = -10000.0  # (padded keys in front of the decoding positions)
+    ext = row.repeat(1, 1, n, 1)
+    if tail:
+        ext[:, :, -tail:, -tail:] += generate_sequential_mask(tail, device=DEV)
+    assert o_.attention_fwd_prefix_lm_ok(q, H) == (not FORCED_SIMPLE)
+    if FORCED_SIMPLE:
+        return
+    want, _, _ = o_.attention_fwd(q, k, v, ext, H, save_lse=False)
+    got = o_.attention_fwd_prefix_lm(q, k, v, row, tail, H)
+    assert torch.equal(got, want)
+
+
 def test_stream_helpers_of_the_c_abi():
     """ovqa_stream_create (priority / CU mask) hands back streams that torch can drive: a cast launched on a CU-masked
     stream (the first 64 compute units) and on a high-priority stream gives the values of the default stream."""
