@@ -442,7 +442,11 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
     g = torch.Generator().manual_seed(seed + rank)
     txt, obj, ocr = (torch.randn(B, n, 768, generator=g).to(device) for n in (20, 100, 50))
     z = lambda n: torch.zeros(B, 1, 1, n, device=device)
-    run = lambda: head.greedy_decode(mmt, txt, z(20), obj, z(100), ocr, z(50), 12, 1, -1)
+    from openvivqa_amd.modules.mmt import GraphedGreedyDecode
+    masks = (z(20), z(100), z(50))
+    graphed = GraphedGreedyDecode(head, mmt, 12, 1, -1)
+    use_graph = os.environ.get("OVQA_M4C_GRAPH", "1") != "0"
+    run = lambda: graphed(txt, masks[0], obj, masks[1], ocr, masks[2], use_graph=use_graph)
     for _ in range(max(1, args.warmup)):
         run()
     if dist is not None:
@@ -468,7 +472,8 @@ def m4c_decode_bench(args, device, world, rank, dist, B, seed):
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "secondary, BASELINE configs[3]: MMT 4 layers x 8 heads of 96, intermediate 3072, "
                        f"20 txt + 100 obj + 50 ocr + 12 dec positions, classifier(5000) || OcrPtrNet(768), B={B}/GPU, "
-                       f"{passes} passes per decode, eager launches", "global_batch": world * B,
+                       f"{passes} passes per decode, " + ("every pass replayed from one hipGraph, the early-exit check "
+                       "on the host as upstream" if use_graph else "eager launches"), "global_batch": world * B,
                        "parallelism": f"dp{world}"},
             "ms_per_mmt_pass": round(dt / args.steps / passes * 1e3, 3)})
         # algorithmic work of one MMT pass (forward only): per position and layer the four 768 x 768 projections and the

@@ -136,14 +136,21 @@ class PrevPredEmbeddings(nn.Module):
         self.emb_layer_norm = nn.LayerNorm(hidden, eps=eps)
         self.emb_dropout = nn.Dropout(config.hidden_dropout_prob)
 
-    def forward(self, ans_emb, ocr_emb, prev_inds):
+    def forward(self, ans_emb, ocr_emb, prev_inds, cache=None):
+        """``cache`` (a dict, evaluation only): the two LayerNorm results do not depend on ``prev_inds`` -- the decoding loop
+        computes them on its first pass and keeps them."""
         assert prev_inds.dim() == 2 and prev_inds.dtype == torch.long and ans_emb.dim() == 2
         arena = rt.ensure_arena(self)
         T = arena.compute_dtype
         B, steps = prev_inds.shape
         ans_num = ans_emb.size(0)
-        ans = Fn.prologue(ans_emb.float().unsqueeze(0), self.ans_layer_norm, None, arena, T)[0]
-        ocr = Fn.prologue(ocr_emb.float(), self.ocr_layer_norm, None, arena, T)
+        if cache is not None and "ans" in cache and not torch.is_grad_enabled():
+            ans, ocr = cache["ans"], cache["ocr"]
+        else:
+            ans = Fn.prologue(ans_emb.float().unsqueeze(0), self.ans_layer_norm, None, arena, T)[0]
+            ocr = Fn.prologue(ocr_emb.float(), self.ocr_layer_norm, None, arena, T)
+            if cache is not None and not torch.is_grad_enabled():
+                cache["ans"], cache["ocr"] = ans, ocr
         # the reference concatenates the (expanded) answer table with the OCR embeddings per sample and gathers from that
         # (mmf_m4c.py:425-428): B x (5000 + 50) x 768 values written to pick B x steps rows -- 496 MB and 428 of the 2430 us
         # of a decoding pass at configs[3] size.  The same rows from the two sources directly:
@@ -171,7 +178,7 @@ class MMT(nn.Module):
         embeddings and masks -- only ``prev_inds`` changes.  With a cache the [txt; obj; ocr] rows of the input and the
         whole (B, 1, S, S) mask are written on the first pass and kept; later passes write the decoding rows only (the
         per-pass concatenation of the four blocks, the mask's repeat and its causal corner: ~40 us of stock launches)."""
-        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds)
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, cache=cache)
         steps = dec_emb.size(1)
         if cache is not None and not torch.is_grad_enabled():
             if "x" not in cache:
@@ -251,3 +258,81 @@ class M4CDecodingHead(nn.Module):
             if last_ids.mean() == eos_idx:  # one host sync per pass, as in the reference
                 break
         return scores, prev_inds, passes
+
+
+
+class GraphedGreedyDecode:
+    """``M4CDecodingHead.greedy_decode`` with every PASS of the multimodal transformer replayed from one hipGraph: a pass is
+    ~70 launches of 3-100 us; launched eagerly from Python the GPU waits ~0.3 ms per pass for the host (1.62 ms of kernels in
+    a 1.91 ms pass at configs[3] size).  What is captured: ``MMT.forward`` on static copies of the inputs (prefix rows, mask
+    and the two input LayerNorms kept from the first pass), the output scores, their arg-max and the in-place update of
+    ``prev_inds``.  What stays on the host, as in the reference (mmf_m4c.py:236-256): the early exit -- one check per pass.
+    Inputs must keep their shapes from call to call (they are copied into the static buffers)."""
+
+    def __init__(self, head, mmt, max_iter: int, bos_idx: int, eos_idx: int):
+        self.head, self.mmt, self.max_iter, self.bos, self.eos = head, mmt, max_iter, bos_idx, eos_idx
+        self.graph = None
+
+    def _pass(self):
+        txt, tm, obj, om, ocr, cm = self.static_in
+        res = self.mmt(txt_emb=txt, txt_mask=tm, obj_emb=obj, obj_mask=om, ocr_emb=ocr, ocr_mask=cm,
+                       fixed_ans_emb=self.head.classifier.weight, prev_inds=self.prev, cache=self.cache)
+        scores = self.head.scores(res, cm)
+        am = scores.argmax(dim=-1)
+        self.prev[:, 1:] = am[:, :-1]
+        return scores, am
+
+    @torch.no_grad()
+    def __call__(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, use_graph: bool = True):
+        ins = (txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask)
+        if not use_graph or not txt_emb.is_cuda:
+            return self.head.greedy_decode(self.mmt, *ins, self.max_iter, self.bos, self.eos)
+        B, dev = txt_emb.shape[0], txt_emb.device
+        if self.graph is None:
+            self.static_in = tuple(t.clone() for t in ins)
+            self.prev = torch.zeros((B, self.max_iter), dtype=torch.long, device=dev)
+        else:
+            assert all(a.shape == b.shape for a, b in zip(ins, self.static_in)), "static input shapes"
+            for dst, src in zip(self.static_in, ins):
+                dst.copy_(src, non_blocking=True)
+        self.prev.zero_()
+        self.prev[:, 0] = self.bos
+        self.cache = {}  # (the first pass of every call is eager: it rebuilds prefix rows, mask and input LayerNorms)
+        last_ids = torch.zeros((B,), device=dev)
+        scores, passes = None, 0
+        for ith in range(self.max_iter):
+            if ith == 0:
+                scores, am = self._pass()
+                if self.graph is None:
+                    self._capture()
+                else:  # the graph reads the buffers the cache held at capture time: refresh THEM
+                    for k in ("x", "ext", "ans", "ocr"):
+                        self.cache0[k].copy_(self.cache[k], non_blocking=True)
+                    h0, h1 = (getattr(c["ext"], "_ovqa_prefix_lm", None) for c in (self.cache0, self.cache))
+                    if h0 is not None and h1 is not None:  # (the key row the attention kernel reads instead of `ext`)
+                        h0[0].copy_(h1[0], non_blocking=True)
+                    self.cache = self.cache0
+            else:
+                self.graph.replay()
+                scores, am = self.static_out
+            passes += 1
+            last_ids = torch.where(last_ids == self.eos, last_ids, am[:, ith].to(last_ids.dtype))
+            if last_ids.mean() == self.eos:
+                break
+        return scores, self.prev, passes
+
+    def _capture(self):
+        from .. import runtime as _rt
+        self.cache0 = self.cache
+        keep = self.prev.clone()
+        side = torch.cuda.Stream(device=self.prev.device)
+        side.wait_stream(torch.cuda.current_stream(self.prev.device))
+        with torch.cuda.stream(side):  # warm-up outside the capture
+            self._pass()
+        torch.cuda.current_stream(self.prev.device).wait_stream(side)
+        torch.cuda.synchronize(self.prev.device)
+        self.prev.copy_(keep)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode=_rt.capture_error_mode()):
+            self.static_out = self._pass()
+        self.prev.copy_(keep)  # (capture does not execute, the warm-up pass did)

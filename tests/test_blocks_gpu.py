@@ -318,6 +318,38 @@ def test_mmt_config4_size(mode):
     _compare("mmt", mode, o, h, call, ins, ["txt", "obj", "ocr"])
 
 
+def test_m4c_graphed_greedy_decode_equals_eager():
+    """modules/mmt.GraphedGreedyDecode (every pass of the multimodal transformer replayed from one hipGraph, the early-exit
+    check on the host) against M4CDecodingHead.greedy_decode, bf16, configs[3] shapes, on TWO different batches through
+    the same captured graph (the second call refreshes the graph's static prefix rows, mask row and input LayerNorms): same
+    number of passes, same tokens, bit-identical scores."""
+    from types import SimpleNamespace
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.modules.mmt import GraphedGreedyDecode
+    A.set_compute_dtype(torch.bfloat16)
+    cfg = SimpleNamespace(hidden_size=768, num_hidden_layers=4, num_attention_heads=8, intermediate_size=3072,
+                          layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    num_choices, max_iter, bos, eos = 300, 12, 1, 2
+    torch.manual_seed(21)
+    mmt, head = M.MMT(cfg).to(DEV).eval(), M.M4CDecodingHead(768, num_choices).to(DEV).eval()
+    with torch.no_grad():
+        head.classifier.bias[eos] = 0.3
+    graphed = GraphedGreedyDecode(head, mmt, max_iter, bos, eos)
+    g = torch.Generator().manual_seed(5)
+    B = 8
+    for trial in range(2):
+        txt, obj, ocr = (torch.randn(B, n, 768, generator=g).to(DEV) for n in (20, 100, 50))
+        tm, om, cm = (torch.zeros(B, 1, 1, n, device=DEV) for n in (20, 100, 50))
+        tm[trial, ..., 12:] = -10e4
+        cm[2 + trial, ..., 33:] = -10e4
+        s0, p0, n0 = head.greedy_decode(mmt, txt, tm, obj, om, ocr, cm, max_iter, bos, eos)
+        s1, p1, n1 = graphed(txt, tm, obj, om, ocr, cm)
+        assert n0 == n1 and torch.equal(p0, p1), (trial, n0, n1)
+        assert torch.equal(s0, s1), trial
+    assert graphed.graph is not None
+
+
 def test_m4c_greedy_decode_config4(mode):
     """BASELINE configs[3] (mmf_m4c.yaml: 50 OCR + 100 region tokens + 20 question tokens, hidden 768, 4 layers x 8
     heads, 12 decoding iterations, classifier || OcrPtrNet(768) scores): the product's greedy decoding loop
