@@ -571,8 +571,8 @@ class _FusedAdam:
         """The arena ranges the launch did NOT update, as runs of whole matrix groups + the 1-D tail: what
         ``FlatAdam.apply(ranges=...)`` still has to do."""
         a = self.ts.arena
-        fused = {lo for lo, _ in [(g[0], 0) for g in a._groups2d
-                                  if any(lo <= g[0] and g[0] + g[1] * g[2] <= hi for lo, hi in self.ranges)]}
+        skip = list(self.ranges) + list(getattr(self.ts, "_dead", []))  # updated in the launch / never updated (dead)
+        fused = {g[0] for g in a._groups2d if any(lo <= g[0] and g[0] + g[1] * g[2] <= hi for lo, hi in skip)}
         runs, cur = [], None
         for off, rows, cols in sorted(a._groups2d):
             if off in fused:
@@ -633,6 +633,7 @@ class TrainStep:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.arena.device)
         self.drop_step = rt.step_tensor(self.arena.device)
         self._foreign = [(0, self.arena.numel)]  # until the first backward tells which grads the kernels own
+        self._dead = []              # ranges of parameters that receive no gradient at all (zero for ever)
         self.overlap_mb = overlap_mb
         # Adam inside the last weight-gradient launch (``_FusedAdam``): only without a gradient exchange, on the bf16 path
         # with its transposed shadow; opt-in (``fuse_adam=True`` or OVQA_FUSE_ADAM=1): the weight matrices' entries of
@@ -753,11 +754,31 @@ class TrainStep:
                 if 0 <= lo < a.small_lo:
                     log.append((phase[0], lo, lo + gw.numel()))
             _fn.wgrad_observer = observe
+        # which parameters receive a gradient AT ALL: autograd's hook fires for the plain-torch ones, the kernels register
+        # theirs (arena.kernel_written); the rest -- CrossModalityEncoderLayer's dead cross-attention, SURVEY 3.2 -- are DEAD
+        touched, hooks = set(), []
+        for p_ in a.params:
+            if p_.requires_grad:
+                hooks.append(p_.register_hook(lambda g, _i=id(p_): touched.add(_i)))
         try:
             self._fwd_bwd(on_phase=lambda k: phase.__setitem__(0, k + 1))
         finally:
             _fn.wgrad_observer = None
-        self._foreign = a.foreign_ranges()
+            for h in hooks:
+                h.remove()
+        # Dead parameters: their gradient is zero for ever -- zeroed ONCE here, not in every step (13 fill launches per
+        # CrossModalityTransformer step) -- and, like torch.optim.Adam, which skips a parameter whose .grad is None
+        # (tasks/base_task.py:46), the fused optimiser path leaves them out (10 Adam launches per step; with zero moments the
+        # update of a zero gradient is exactly zero, so the separate whole-arena launch may keep them in)
+        dead = [(a.offsets[id(p_)], a.offsets[id(p_)] + a.span(p_)) for p_ in a.params
+                if id(p_) not in a.kernel_written and id(p_) not in touched]
+        self._dead = _merge(sorted(dead))
+        for s_, e_ in self._dead:
+            a.grad[s_:e_].zero_()
+        dead_set = {lo for lo, _ in dead}
+        live = sorted((a.offsets[id(p_)], a.offsets[id(p_)] + a.span(p_)) for p_ in a.params
+                      if id(p_) not in a.kernel_written and a.offsets[id(p_)] not in dead_set)
+        self._foreign = _merge(live, gap=rt.ALIGN)
         if not plan:
             return
         n_all, barriers = self._cuts.count, list(self._cuts.barriers)
