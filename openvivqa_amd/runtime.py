@@ -312,6 +312,31 @@ class ParamArena:
                     t0 += nt
         return self._adam_tiles or None
 
+    def adam_tiles_of(self, group_offsets):
+        """(device table, number of tiles) of the matrix groups that START at the given arena offsets -- any subset, in one
+        table (the entries are self-describing), cached per subset: what is left for the separate Adam launch when the
+        optimiser step of the other groups ran inside the weight-gradient launch (train._FusedAdam)."""
+        if self.adam_tiles() is None:
+            return None
+        key = tuple(sorted(group_offsets))
+        cache = self.__dict__.setdefault("_adam_subsets", {})
+        if key not in cache:
+            import numpy as np
+            from . import _lib
+            entries = []
+            for off, rows, cols in sorted(self._groups2d):
+                if off in key:
+                    for r0 in range(0, rows, 64):
+                        for c0 in range(0, cols, 64):
+                            entries.append(_lib.AdamTile(off, rows, cols, r0, c0))
+            if entries:
+                arr = (_lib.AdamTile * len(entries))(*entries)
+                raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+            else:
+                raw = torch.empty(0, dtype=torch.uint8, device=self.device)
+            cache[key] = (raw, len(entries))
+        return cache[key]
+
     def adam_tiles_in(self, lo: int, hi: int):
         """The part of ``adam_tiles()`` inside the arena range [lo, hi): (table view, number of tiles, flat_lo, flat_hi),
         or None when a matrix group straddles the range's bounds (or there is no table)."""

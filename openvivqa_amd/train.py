@@ -235,6 +235,21 @@ class FlatAdam:
                           None if a.shadow is None else a.shadow[lo:hi], lr, self.step_t, lr_scale=lr_ptr,
                           betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, grad_scale=grad_scale)
 
+    def apply_subset(self, group_offsets, grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> bool:
+        """Adam update of the matrix groups starting at ``group_offsets`` AND of the 1-D tail, in ONE launch.  False when the
+        arena has no tile table (the caller falls back to ``apply(ranges=...)``)."""
+        a = self.arena
+        sub = a.adam_tiles_of(group_offsets) if hasattr(a, "adam_tiles_of") else None
+        if sub is None or os.environ.get("OVQA_ADAM_TILED", "1") == "0" or a.small_lo % 4 or a.numel % 4:
+            return False
+        g = a.grad if grad is None else grad
+        lr, lr_ptr = (1.0, self.lr_eff) if self.lr_table is not None else (self.lr * self.lr_scale, None)
+        table, n_tiles = sub
+        ops.adam_step_tiled(a.master, g, self.exp_avg, self.exp_avg_sq, a.shadow, a.shadow_t, table, n_tiles, a.small_lo,
+                            a.numel, lr, self.step_t, lr_scale=lr_ptr, betas=self.betas, eps=self.eps,
+                            weight_decay=self.weight_decay, grad_scale=grad_scale)
+        return True
+
     def finish_device(self) -> None:
         """The launches that close a step (capturable): the transposed weight copy after a flat update."""
         if self._transposed_stale:
@@ -518,11 +533,15 @@ class _FusedAdam:
         self.ts = ts
         self.began = False
         self.ranges = []
+        self.dry = False  # a warm-up pass: work out which groups the launch WOULD take (the tile table of the rest is
+        #                   uploaded before the capture), launch the plain form, update nothing
 
     def reset(self):
         self.began, self.ranges = False, []
 
     def pre_flush(self):
+        if self.dry:
+            return
         self.ts.optim.begin_step(also=self.ts.drop_step)
         self.began = True
 
@@ -565,7 +584,14 @@ class _FusedAdam:
                                        a.shadow_t.data_ptr() + 2 * (goff + r0), rows)
         done = sorted({cand[idx][0] for idx, t in enumerate(out) if t is not None})
         self.ranges = _merge([(groups[gi][0], groups[gi][0] + groups[gi][1] * groups[gi][2]) for gi in done])
-        return out
+        return [None] * len(items) if self.dry else out
+
+    def rest_groups(self):
+        """Arena offsets of the matrix groups the launch did not update and that are not dead."""
+        a = self.ts.arena
+        skip = list(self.ranges) + list(getattr(self.ts, "_dead", []))
+        return [g[0] for g in sorted(a._groups2d)
+                if not any(lo <= g[0] and g[0] + g[1] * g[2] <= hi for lo, hi in skip)]
 
     def rest(self):
         """The arena ranges the launch did NOT update, as runs of whole matrix groups + the 1-D tail: what
@@ -872,8 +898,18 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._discover_foreign()
-            for _ in range(2):  # warm-up: allocator pools, lazy arenas, workspace
-                self._fwd_bwd()
+            for i in range(2):  # warm-up: allocator pools, lazy arenas, workspace
+                if i == 1 and self._fused is not None:  # (+ which groups the fused optimiser launch will take)
+                    self._fused.dry = True
+                    self._arm_fused(True)
+                try:
+                    self._fwd_bwd()
+                finally:
+                    if self._fused is not None:
+                        self._arm_fused(False)
+                        self._fused.dry = False
+            if self._fused is not None and hasattr(self.arena, "adam_tiles_of"):
+                self.arena.adam_tiles_of(self._fused.rest_groups())  # its device table: not inside a capture
         from . import functional as _fn
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -977,7 +1013,8 @@ class TrainStep:
         elif self._fused is not None and self._fused.began:
             # the weight matrices were updated inside the last weight-gradient launch: what is left are the groups that launch
             # did not take and the 1-D parameters (one launch each run; the counters have been advanced in front of it)
-            self.optim.apply(self.arena.grad, scale, ranges=self._fused.rest())
+            if not self.optim.apply_subset(self._fused.rest_groups(), self.arena.grad, scale):
+                self.optim.apply(self.arena.grad, scale, ranges=self._fused.rest())
         else:
             self.optim.begin_step(also=self.drop_step)
             self.optim.apply(self.reducer.finish(self.arena.grad), scale)
