@@ -85,7 +85,7 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_launch_list(B, NV, NT, D, DFF, L):
+def gemm_launch_list(B, NV, NT, D, DFF, L, in_step=False):
     """(M, N, K[, flag]) of every MFMA GEMM launch of one step, grouped by kernel family.
     Forward families: y[M,N] = x[M,K] w[N,K]^T (+epilogue).  dX family: dx[M,K] = dy[M,N] w[N,K] (computed
     from the transposed weight copy wt[K,N], as the training step does) with
@@ -110,6 +110,14 @@ def gemm_launch_list(B, NV, NT, D, DFF, L):
     # the guided layers' K/V projections of the question features are hoisted into one GEMM (fwd and dX)
     bias.append((mt, 2 * D * L, D))
     dx.append((mt, 2 * D * L, D, ""))
+    if in_step:
+        # what the step LAUNCHES: the fc_o dX products run inside the attention backward kernels (guided and question
+        # self-attention since round 3, image self-attention since round 5), the self-attention QKV projections inside the
+        # attention forward kernels
+        for sh in [(mv, D, D, "")] * (2 * L) + [(mt, D, D, "")] * L:
+            dx.remove(sh)
+        bias = [sh for sh in bias if sh[1] != 3 * D]
+        bias = [sh for sh in bias if not (sh[0] == mv and sh[1] == D)]  # (the guided query projection: inside attn_q_fwd)
     return {"bias": bias, "gelu": gelu, "residual": resid, "dx": dx}
 
 
@@ -145,7 +153,7 @@ def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):
     """Time every MFMA GEMM kernel family over exactly the launch list of one step (hipGraph replay of the
     list, HIP events on the replay stream) and report the one that takes the most time per step."""
     from openvivqa_amd import ops
-    fam = gemm_launch_list(B, NV, NT, D, DFF, L)
+    fam = gemm_launch_list(B, NV, NT, D, DFF, L, in_step=True)
     results = {}
     for name, shapes in fam.items():
         bufs = {}
