@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_tile256.h"
 #include "kernels.h"
 
 // Phase probe (development only, -DOVQA_PHASE_PROBE; see attention_mfma.hip): wall-clock stamps of thread 0 of the first
@@ -539,6 +540,10 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     OVQA_GPROBE(4);
     return;
   }
+  // (Round 6: every load of the wave's pieces first -- Epi::pre() with clamped addresses -- and then the guarded stores, as
+  // the 256 x 256 tile does it, measured no gain here: 3.025-3.039 against 3.00-3.02 ms per step, three alternations on one
+  // box.  With 2-4 pieces per lane and a second workgroup on the CU the store round trips behind the per-lane branches are
+  // covered; on the 256 x 256 tile, 16 pieces per lane and nothing beside it, they were 5.4 us of 21.)
 #pragma unroll
   for (int i = 0; i < NI; i++) {
     const int c = c0 + wc * (NI * 16) + i * 16 + (lane & 15);
@@ -697,10 +702,27 @@ __device__ __forceinline__ void bias8(const float* bias, int n, const f32x4& lo,
 
 // `wide(m, n, lo, hi)`: 8 consecutive output features n..n+7 of row m (the glds kernels with a row-major P);
 // needs 16-byte aligned rows for every tensor it touches (checked by launch()).
+// (kTwoPhase epilogues also expose pre() = every load of an 8-feature piece and post() = compute + store: the 256 x 256
+// tile, gemm_tile256.h, software-pipelines them so that no store is waited for between pieces)
+struct Bias8 { float4 b0, b1; };
+__device__ __forceinline__ Bias8 load_bias8(const float* bias, int n) {
+  return Bias8{bias4(bias, n), bias4(bias ? bias + 4 : nullptr, n)};
+}
+__device__ __forceinline__ void add_bias8(const Bias8& b, const f32x4& lo, const f32x4& hi, float (&u)[8]) {
+  u[0] = lo[0] + b.b0.x; u[1] = lo[1] + b.b0.y; u[2] = lo[2] + b.b0.z; u[3] = lo[3] + b.b0.w;
+  u[4] = hi[0] + b.b1.x; u[5] = hi[1] + b.b1.y; u[6] = hi[2] + b.b1.z; u[7] = hi[3] + b.b1.w;
+}
 struct MEpiBias {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kTwoPhase = true;
   bf16* y; int64_t ldy; const float* bias;
+  typedef Bias8 Ctx;
   __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ Ctx pre(int m, int n) const { return load_bias8(bias, n); }
+  __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    add_bias8(k, lo, hi, u);
+    store8(y + (int64_t)m * ldy + n, u);
+  }
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
     bias8(bias, n, lo, hi, u);
@@ -714,7 +736,7 @@ struct MEpiBias {
 // y_i = x W_i^T + b_i for three stacked weight matrices [3 F, K], each output with its own base and row stride (a
 // decoding step's q -> a buffer, k and v -> their slots of the in-place caches, in ONE launch)
 struct MEpiBiasSplit3 {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kTwoPhase = false;
   bf16* y0; int64_t ld0; bf16* y1; int64_t ld1; bf16* y2; int64_t ld2; int F; const float* bias;
   __device__ __forceinline__ void init() {}
   __device__ __forceinline__ bf16* dest(int m, int n) const {
@@ -734,12 +756,22 @@ struct MEpiBiasSplit3 {
   }
 };
 struct MEpiBiasGelu {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kTwoPhase = true;
   bf16* y; int64_t ldy; const float* bias; bf16* preact; int N; DropArgs da; DropState ds;
+  typedef Bias8 Ctx;
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ Ctx pre(int m, int n) const { return load_bias8(bias, n); }
+  __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    add_bias8(k, lo, hi, u);
+    finish(m, n, u);
+  }
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
     bias8(bias, n, lo, hi, u);
+    finish(m, n, u);
+  }
+  __device__ __forceinline__ void finish(int m, int n, float (&u)[8]) const {
     if (preact) {
       bf16x8 o_;
 #pragma unroll
@@ -763,13 +795,24 @@ struct MEpiBiasGelu {
   }
 };
 struct MEpiBiasResidual {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kTwoPhase = true;
   bf16* y; int64_t ldy; const float* bias; const bf16* res; int64_t ldres; int N; DropArgs da; DropState ds;
+  struct Ctx { Bias8 b; bf16x8 r; };
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ Ctx pre(int m, int n) const {
+    return Ctx{load_bias8(bias, n), *reinterpret_cast<const bf16x8*>(res + (int64_t)m * ldres + n)};
+  }
+  __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
+    float u[8];
+    add_bias8(k.b, lo, hi, u);
+    finish(m, n, u, k.r);
+  }
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
     bias8(bias, n, lo, hi, u);
-    const bf16x8 r = *reinterpret_cast<const bf16x8*>(res + (int64_t)m * ldres + n);
+    finish(m, n, u, *reinterpret_cast<const bf16x8*>(res + (int64_t)m * ldres + n));
+  }
+  __device__ __forceinline__ void finish(int m, int n, float (&u)[8], const bf16x8& r) const {
     const uint32_t idx = (uint32_t)m * (uint32_t)N + (uint32_t)n;
     float dm[8];
     drop_mul8(ds, idx, dm);
@@ -791,21 +834,36 @@ struct MEpiBiasResidual {
 // here from that sum and its saved row statistics -- (v - mean) * rstd * gamma + beta, the expression ln_fwd_kernel
 // evaluates -- so a block's fp32 output never has to be written to HBM: ln_fwd_kernel stores only the bf16 GEMM operand.
 struct MEpiBiasRes32 {
-  static constexpr bool kWide = true;
-  float* pre; int64_t ldpre; const float* bias; const float* res; int64_t ldres;
+  static constexpr bool kWide = true, kTwoPhase = true;
+  float* pre32; int64_t ldpre; const float* bias; const float* res; int64_t ldres;
   const float* mean; const float* rstd; const float* gamma; const float* beta;
   int N; DropArgs da; DropState ds;
+  struct Ctx { Bias8 b; float4 r0, r1, g0, g1, b0, b1; float mu, rs; };
   __device__ __forceinline__ void init() { ds = drop_init(da); }
-  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+  __device__ __forceinline__ Ctx pre(int m, int n) const {  // (mean: a workgroup-uniform condition)
+    Ctx k{};
+    k.b = load_bias8(bias, n);
+    k.r0 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n);
+    k.r1 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n + 4);
+    if (mean) {
+      k.mu = mean[m]; k.rs = rstd[m];
+      k.g0 = *reinterpret_cast<const float4*>(gamma + n); k.g1 = *reinterpret_cast<const float4*>(gamma + n + 4);
+      k.b0 = *reinterpret_cast<const float4*>(beta + n); k.b1 = *reinterpret_cast<const float4*>(beta + n + 4);
+    }
+    return k;
+  }
+  __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
-    bias8(bias, n, lo, hi, u);
-    const float4 r0 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n);
-    const float4 r1 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n + 4);
+    add_bias8(k.b, lo, hi, u);
+    finish(m, n, u, k);
+  }
+  __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const { post(pre(m, n), m, n, lo, hi); }
+  __device__ __forceinline__ void finish(int m, int n, const float (&u)[8], const Ctx& k) const {
+    const float4 r0 = k.r0, r1 = k.r1;
     float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (mean) {
-      const float mu = mean[m], rs = rstd[m];
-      const float4 g0 = *reinterpret_cast<const float4*>(gamma + n), g1 = *reinterpret_cast<const float4*>(gamma + n + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(beta + n), b1 = *reinterpret_cast<const float4*>(beta + n + 4);
+      const float mu = k.mu, rs = k.rs;
+      const float4 g0 = k.g0, g1 = k.g1, b0 = k.b0, b1 = k.b1;
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       const float nmr = -mu * rs;  // (r - mu) * rs * g + b as two fmas per element
@@ -817,7 +875,7 @@ struct MEpiBiasRes32 {
     drop_mul8(ds, idx, dm);
 #pragma unroll
     for (int t = 0; t < 8; t++) r[t] += u[t] * dm[t];
-    float* o = pre + (int64_t)m * ldpre + n;
+    float* o = pre32 + (int64_t)m * ldpre + n;
     *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
     *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
   }
@@ -837,18 +895,33 @@ struct MEpiBiasRes32 {
     const float u[4] = {a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w};
 #pragma unroll
     for (int t = 0; t < 4; t++) r[t] += u[t] * drop_mul(ds, idx + t);
-    *reinterpret_cast<float4*>(pre + (int64_t)m * ldpre + n) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(pre32 + (int64_t)m * ldpre + n) = make_float4(r[0], r[1], r[2], r[3]);
   }
 };
 // dX = dY W  [* dropmask * gelu'(u)]  (+ dx)
 struct MEpiBwdData {
-  static constexpr bool kWide = true;
+  static constexpr bool kWide = true, kTwoPhase = true;
   bf16* dx; int64_t lddx; const bf16* preact; int Kcols; const bf16* addend; int64_t ldadd; DropArgs da; DropState ds;
+  struct Ctx { bf16x8 u, o; };
   __device__ __forceinline__ void init() { ds = drop_init(da); }
+  __device__ __forceinline__ Ctx pre(int m, int n) const {  // (preact / addend: workgroup-uniform conditions)
+    Ctx k{};
+    if (preact) k.u = *reinterpret_cast<const bf16x8*>(preact + (int64_t)m * Kcols + n);
+    if (addend) k.o = *reinterpret_cast<const bf16x8*>(addend + (int64_t)m * ldadd + n);
+    return k;
+  }
+  __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
+    finish(m, n, lo, hi, k.u, k.o);
+  }
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const {
+    bf16x8 u{}, o{};
+    if (preact) u = *reinterpret_cast<const bf16x8*>(preact + (int64_t)m * Kcols + n);
+    if (addend) o = *reinterpret_cast<const bf16x8*>(addend + (int64_t)m * ldadd + n);
+    finish(m, n, lo, hi, u, o);
+  }
+  __device__ __forceinline__ void finish(int m, int n, const f32x4& lo, const f32x4& hi, const bf16x8& u, const bf16x8& o) const {
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (preact) {
-      const bf16x8 u = *reinterpret_cast<const bf16x8*>(preact + (int64_t)m * Kcols + n);
       const uint32_t idx = (uint32_t)m * (uint32_t)Kcols + (uint32_t)n;
       float dm[8];
       drop_mul8(ds, idx, dm);
@@ -856,7 +929,6 @@ struct MEpiBwdData {
       for (int t = 0; t < 8; t++) v[t] *= dm[t] * gelu_grad_fast((float)u[t]);
     }
     if (addend) {
-      const bf16x8 o = *reinterpret_cast<const bf16x8*>(addend + (int64_t)m * ldadd + n);
 #pragma unroll
       for (int t = 0; t < 8; t++) v[t] += (float)o[t];
     }
@@ -880,7 +952,7 @@ struct MEpiBwdData {
 };
 // dW (fp32) (+)= acc
 struct MEpiWgrad {
-  static constexpr bool kWide = false;
+  static constexpr bool kWide = false, kTwoPhase = false;
   float* dw; int64_t ld; int accumulate; float* db; int accumulate_db;
   __device__ __forceinline__ void init() {}
   __device__ __forceinline__ bool wants_colsum() const { return db != nullptr; }
@@ -935,7 +1007,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
 // the optimiser state is streamed while other workgroups' K loops keep the fetch path busy with L2 hits.
 // Same update function as adam_tiled_kernel (common.h): same bits.
 struct MEpiWgradAdam {
-  static constexpr bool kWide = false;
+  static constexpr bool kWide = false, kTwoPhase = false;
   float* dw; int64_t ld; int accumulate; float* db; int accumulate_db;
   float* tile;  // fused: the fp32 tile in LDS; nullptr: the plain gradient store
   int c0, r0;
@@ -1373,6 +1445,35 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
                       st, g, epi);                                                                                 \
   }
 #define OVQA_GLDS(NBUF, NW, BCV) OVQA_GLDS_K(NBUF, NW, BCV, 1)
+  if constexpr (!QK && !PK && Epi::kWide) {
+    // 256 x 256 tiles on one 8-wave workgroup per CU (gemm_tile256.h, round 6) for long reductions on grids that fill whole
+    // rounds of the chip: 8192 x 4096 x 4096 1290-1357 TFLOP/s against 900-995 on the 128 x 128 tiles (hipBLASLt 1424-1540).
+    // NOT for the step's own K = 512 products: alone, 6400 x 2048 <- 512 takes 19.8-22.2 us against 23.2-26.2 (hipBLASLt
+    // 21.2-22.6), but a tile's epilogue (4-6 us: 128 KB of stores per CU, and for GELU / GELU' ~20 VALU instructions per
+    // element) has nothing to hide behind with one workgroup per CU, where two co-resident 128 x 128 workgroups hide each
+    // other's: in the MCAN step 3.115 ms with fc1 forward + fc2 dX on this form, 3.06-3.08 with fc1 forward only, 3.05-3.06
+    // without (same box, alternated).  OVQA_GEMM_T256=0 switches the form off.
+    static int t256 = -1, cus = 256;
+    if (t256 < 0) {
+      const char* e = getenv("OVQA_GEMM_T256");
+      t256 = e ? atoi(e) : 1;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    }
+    if (t256 && variant >= 10 && K >= 1024 && R % 8 == 0 && ldp < (1 << 22) && ldq < (1 << 22)) {
+      const int tr = (int)((R + 255) / 256), tc = (int)((C + 255) / 256);
+      const int64_t tiles = (int64_t)tr * tc, rounds = (tiles + cus - 1) / cus;
+      if (tiles * 4 >= rounds * cus * 3 && tiles < (1 << 30)) {
+        ovqa_t256::Args a{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K, tr, tc, nullptr,
+                          (tiles >= 2 * cus && tr >= 8 && tc >= 8) ? 4 : 0};
+        int rc = set_max_lds(ovqa_t256::kernel<Epi, 3>, ovqa_t256::LDS_BYTES);
+        if (rc != OVQA_OK) return rc;
+        OVQA_LAUNCH_TIMED((ovqa_t256::kernel<Epi, 3>), dim3((unsigned)tiles), dim3(512), ovqa_t256::LDS_BYTES, st, a, epi);
+        return ovqa_check_launch(what);
+      }
+    }
+  }
   if constexpr (!QK && !PK) {
     // a decoding step's products: few activation rows against a whole weight matrix
     if (variant >= 10 && C <= skinny_max_rows() && K % 32 == 0 && K <= 2048 && R % 4 == 0) {

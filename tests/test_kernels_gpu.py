@@ -165,6 +165,21 @@ def test_linear_fwd_strided_and_3d(dtype):
     assert nerr(y, x.double() @ w.double().t() + b.double()) < tol(dtype)
 
 
+def test_linear_fwd_256_tiles_grouped_raster_and_ragged_edges():
+    """The 256 x 256-tile form (csrc/gemm_tile256.h): a grid large enough for the grouped tile order (>= 512 tiles, >= 8
+    panels each way), and ragged edges in both dimensions (straight-line epilogue inside, guarded one on the edge tiles),
+    every epilogue, against fp32 products of the same bf16 operands."""
+    o = ops()
+    for (M, N, K) in [(8192, 4096, 256), (6001, 2040, 320), (8000, 4104, 64)]:
+        x, w = rnd(M, K, dtype=BF16), rnd(N, K, dtype=BF16, scale=K ** -0.5, seed=1)
+        b, res = rnd(N, seed=2), rnd(M, N, dtype=BF16, seed=3)
+        u = x.float() @ w.float().t() + b
+        assert nerr(o.linear_fwd(x, w, b), u) < 1e-2
+        y, pre = o.linear_fwd(x, w, b, o.EPI_BIAS_GELU, want_preact=True)
+        assert nerr(pre, u) < 1e-2 and nerr(y, gelu(u.double())) < 1e-2
+        assert nerr(o.linear_fwd(x, w, b, o.EPI_BIAS_RESIDUAL, residual=res), u + res.float()) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N,K", [(37, 50, 29), (256, 128, 64), (640, 512, 2048), (1280, 2048, 512)])
 def test_linear_bwd_data(dtype, M, N, K):
