@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OVQA_ABI_VERSION 9
+#define OVQA_ABI_VERSION 10
 
 typedef enum {
   OVQA_OK = 0,
@@ -572,14 +572,22 @@ int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx,
  *     transposed copy of w_hh the bf16 persistent kernel reads (NULL in fp32 mode).
  *   `scratch` (ovqa_lstm_scratch_bytes, uninitialised, private to the call while it runs): the hand-off counters of the
  *     persistent kernels -- zeroed by the call itself with a memset node -- and the per-step kernels' temporaries.
- *   bf16 with H == I == 512, B a multiple of 16 and B/16*32 <= 256: ONE persistent launch each way (weights resident in
- *     registers, h_t / dgates_t handed between workgroups in-launch: csrc/lstm.hip); word 1000 of `scratch` (uint32) is
- *     non-zero afterwards if a hand-off wait gave up (a workgroup of the launch never ran).  Anything else, fp32 and
+ *   bf16 with H == I == 512, B a multiple of 16 and B <= ovqa_lstm_persistent_max_batch() (16 samples per 32 of the
+ *     device's CUs: the 32 workgroups of a sample group must be co-resident): ONE persistent launch each way (weights
+ *     resident in registers, h_t / dgates_t handed between workgroups in-launch: csrc/lstm.hip).  Anything else, fp32 and
  *     OVQA_FORCE_SIMPLE=1: one VALU launch per time step.  Forward and backward of one sequence take the same route
- *     (decided from dtype, B, I, H alone).
+ *     (decided from dtype, B, I, H alone).  A caller with another batch size pads it to whole groups of 16 with zero
+ *     rows and splits it into chunks of at most max_batch samples (the Python host side does: ops.lstm_fwd / lstm_bwd).
+ *   Give-up of a hand-off wait (a workgroup of the launch never ran within ~1e5 polling sweeps): word 1000 of `scratch`
+ *     (uint32) is non-zero afterwards, the same code is OR-ed into a process-lifetime device word that
+ *     ovqa_lstm_status reads -- and clears -- after synchronising `stream` (ABI 10; 0 = every wait so far was served), and
+ *     the outputs of that sample group are NaN from the step of the give-up on (the wave continues with the bf16-NaN
+ *     sentinels it read), so a loss computed from them shows it as well.
  * ------------------------------------------------------------------------- */
 int64_t ovqa_lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
 int64_t ovqa_lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
+int64_t ovqa_lstm_persistent_max_batch(void);
+int ovqa_lstm_status(uint32_t* status, void* stream);
 int ovqa_lstm_fwd(int dtype, const void* x, int64_t ldx, const void* w_ih, const void* w_hh, const float* b_ih,
                   const float* b_hh, float* y, void* y_lp, void* hseq, void* saved, void* scratch,
                   int64_t B, int64_t T, int64_t I, int64_t H, void* stream);

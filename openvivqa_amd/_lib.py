@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libovqa_hip.so")
 
 OVQA_F32, OVQA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_i64, c_int, c_f32, c_vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
@@ -154,11 +154,14 @@ SIGNATURES = {
     "ovqa_nll_loss": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp],
     "ovqa_lstm_saved_bytes": [c_i64, c_i64, c_i64],
     "ovqa_lstm_scratch_bytes": [c_i64, c_i64, c_i64],
+    "ovqa_lstm_persistent_max_batch": [],
+    "ovqa_lstm_status": [c_vp, c_vp],
     "ovqa_lstm_fwd": [c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "ovqa_lstm_bwd": [c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
 }
 _RESTYPE = {"ovqa_last_error": C.c_char_p, "ovqa_last_dispatch": C.c_char_p, "ovqa_workspace_bytes": C.c_int64,
-            "ovqa_lstm_saved_bytes": C.c_int64, "ovqa_lstm_scratch_bytes": C.c_int64}
+            "ovqa_lstm_saved_bytes": C.c_int64, "ovqa_lstm_scratch_bytes": C.c_int64,
+            "ovqa_lstm_persistent_max_batch": C.c_int64}
 
 _lock = threading.Lock()
 _lib = None

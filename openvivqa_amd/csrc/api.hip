@@ -723,6 +723,14 @@ int ovqa_sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx,
 
 int64_t ovqa_lstm_saved_bytes(int64_t B, int64_t T, int64_t H) { return ovqa::lstm_saved_bytes(B, T, H); }
 int64_t ovqa_lstm_scratch_bytes(int64_t B, int64_t T, int64_t H) { return ovqa::lstm_scratch_bytes(B, T, H); }
+int64_t ovqa_lstm_persistent_max_batch(void) { return force_simple() ? 0 : ovqa::lstm_persistent_max_batch(); }
+int ovqa_lstm_status(uint32_t* status, void* stream) {
+  OVQA_REQUIRE(status != nullptr, OVQA_ERR_BAD_ARG, "lstm_status: null pointer");
+  unsigned v = 0;
+  const int rc = ovqa::lstm_status_read_clear(&v, as_stream(stream));
+  *status = v;
+  return rc;
+}
 
 // forward and backward of one sequence must take the same route: the decision uses dtype and sizes only
 static bool lstm_route_persistent(int dtype, int64_t B, int64_t T, int64_t I, int64_t H) {

@@ -145,6 +145,8 @@ int sq_loss_fwd_bwd(int dtype, const void* x, const void* target, void* dx, floa
 
 // ---- lstm.hip ------------------------------------------------------------------
 bool lstm_persistent_supported(int dtype, int64_t B, int64_t T, int64_t I, int64_t H, int64_t ldx);
+int64_t lstm_persistent_max_batch();
+int lstm_status_read_clear(unsigned* out, hipStream_t st);
 int64_t lstm_saved_bytes(int64_t B, int64_t T, int64_t H);
 int64_t lstm_scratch_bytes(int64_t B, int64_t T, int64_t H);
 int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void* w_ih, const void* w_hh,

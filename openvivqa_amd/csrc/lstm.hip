@@ -44,6 +44,16 @@ constexpr int KS = LH / 32;     // K steps of the 16x16x32 MFMA over one 512-lon
 constexpr int NUB = LH / 16;    // workgroups per sample group
 constexpr int SPIN_LIMIT = 1 << 21;
 
+// Process-lifetime status word (round 6): every give-up of a hand-off wait ORs its code in here as well as into the
+// call's own scratch word, so that the host finds it without knowing which call's scratch to look at
+// (ovqa_lstm_status reads and clears it).  A give-up also shows in the data: the wave goes on with the 0xFFFF sentinels
+// it read -- bf16 NaNs -- so h, y and every later step of the sample group are NaN.
+__device__ unsigned g_lstm_status;
+__device__ __forceinline__ void give_up(unsigned* status, unsigned code) {
+  __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_or(&g_lstm_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
 
@@ -66,7 +76,7 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
   while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
     if (++spins > SPIN_LIMIT) {  // a workgroup of the launch never became resident, or died: give up loudly
-      __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      give_up(status, 1u);
       break;
     }
   }
@@ -81,7 +91,7 @@ __device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, uns
 // barrier -- two of the four dependent memory round trips (MEASURED, scripts/lstm_bench.py, B = 64, T = 20, memset nodes
 // included: forward 104 -> 77 us, backward 127 -> 81 us; with the acquire fence 120 / 146).  OVQA_LSTM_HANDOFF=counter selects form 1, =fence form 1 with the agent-scope
 // acquire; the three forms are deterministic and must agree bit for bit (tests/test_kernels_gpu.py).
-constexpr int SWEEP_LIMIT = 1 << 17;
+constexpr int SWEEP_LIMIT = 1 << 17;  // default of the kernels' `sweep_limit` argument (OVQA_LSTM_SWEEP_LIMIT: tests)
 // aux of the hand-off loads: sc1 (bit 4) + LLVM's volatile marker (bit 31, stripped at lowering): two sweeps of the same
 // addresses are two loads, and none is hoisted out of a polling loop
 constexpr int AUX_POLL = (int)(0x80000000u | 16u);
@@ -89,7 +99,7 @@ __device__ __forceinline__ bool unit_ready(const u32x4& v) {  // both 8-byte hal
   return ((v[0] & 0xFFFFu) != 0xFFFFu) & ((v[2] & 0xFFFFu) != 0xFFFFu);
 }
 template <typename RS>
-__device__ __forceinline__ void sweep_until_ready(const RS& rs, unsigned off, u32x4 (&v)[KS], unsigned* status) {
+__device__ __forceinline__ void sweep_until_ready(const RS& rs, unsigned off, u32x4 (&v)[KS], unsigned* status, int limit) {
   for (int spins = 0;;) {
     bool ok = true;
 #pragma unroll
@@ -97,8 +107,8 @@ __device__ __forceinline__ void sweep_until_ready(const RS& rs, unsigned off, u3
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) ok &= unit_ready(v[kk]);
     if (__all(ok)) return;
-    if (++spins > SWEEP_LIMIT) {  // a producer workgroup never ran (or produced the NaN pattern itself): give up loudly
-      __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > limit) {  // a producer workgroup never ran (or produced the NaN pattern itself): give up loudly
+      give_up(status, 2u);
       return;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -119,6 +129,8 @@ struct LstmFwdArgs {
   unsigned* cnt;        // one counter per sample group, 32 words apart
   unsigned* status;
   int B, T, mode;  // hand-off: 0 = counter, 1 = counter + agent-scope acquire, 2 = sentinel (the data is the flag)
+  int sweep_limit;  // sweeps of the sentinel form before a wait gives up
+  int drop_wg;      // tests only (OVQA_LSTM_DEBUG_DROP_WG): workgroup drop_wg - 1 exits at once, as if it never became resident
   unsigned* probe;  // diagnostic (OVQA_LSTM_PROBE=1): 100 MHz stamps of one wave's phases, 8 words per step; else NULL
 };
 #define LSTM_STAMP(slot)                                                                                   \
@@ -145,6 +157,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
   const int B = a.B, T = a.T;
   if (SENTINEL && blockIdx.x == 0 && tid == 0)  // (a give-up is reported after >= 1e5 sweeps: long after this store)
     __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.drop_wg != 0 && (int)blockIdx.x == a.drop_wg - 1) return;  // (workgroup-uniform; tests of the give-up path)
   // ---- this wave's 16 gate rows of W_ih and W_hh, A-operand layout, resident for the whole launch
   // A row r = l & 15 -> (unit 4 w + (r >> 2), gate r & 3): C row 4 q + reg = (unit 4 w + q, gate reg)
   const int arow = (n & 3) * LH + ub * 16 + w * 4 + (n >> 2);
@@ -207,8 +220,8 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
 #pragma unroll
           for (int j = 0; j < 4; j++) ok &= unit_ready(pq[j]);
           if (__all(ok)) break;
-          if (++spins > SWEEP_LIMIT) {
-            __hip_atomic_store(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > a.sweep_limit) {
+            give_up(a.status, 2u);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -303,6 +316,7 @@ struct LstmBwdArgs {
   unsigned* cnt;
   unsigned* status;
   int B, T, mode;
+  int sweep_limit, drop_wg;  // as in LstmFwdArgs
 };
 
 template <bool SENTINEL>
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   const int B = a.B, T = a.T;
   if (SENTINEL && blockIdx.x == 0 && tid == 0)
     __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.drop_wg != 0 && (int)blockIdx.x == a.drop_wg - 1) return;
   // A operand of the recurrent product dh[u'][n] = sum_col W_hh[col][u'] dgates[n][col]: wave w reduces over gate w's
   // 512 columns; A row = l & 15 -> input unit ub*16 + (l & 15), k = w*512 + kk*32 + q*8 ..
   bf16x8 wt[KS];
@@ -357,10 +372,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
         for (int spins = 0;;) {
           const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + n * 64, 0, AUX_POLL);
           if (__all(unit_ready(pv))) break;
-          if (++spins > SWEEP_LIMIT) break;  // (the sweep below reports it)
+          if (++spins > a.sweep_limit) break;  // (the sweep below reports it)
           __builtin_amdgcn_s_sleep(1);
         }
-        sweep_until_ready(rs, goff, gf, a.status);
+        sweep_until_ready(rs, goff, gf, a.status, a.sweep_limit);
       } else {
         if (tid == 192) {
           wait_counter(cnt, (unsigned)(NUB * (T - 1 - t)), a.status);
@@ -503,14 +518,48 @@ int lstm_handoff_mode() {  // read per call (tests flip it): 2 = sentinel (defau
   return 2;
 }
 
+int debug_env(const char* name, int dflt) {  // read per call: tests flip these
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+int device_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 0;  // (unknown: the persistent route is not taken)
+  }
+  return cus;
+}
+
 constexpr int kSyncBytes = 4096;                 // counters (one 128-byte line per sample group) + status word
 constexpr int kPersistentLds = 96 * 1024;        // more than half a CU's LDS: one workgroup per CU
 
 }  // namespace
 
+// The persistent kernels need the 32 workgroups of a sample group co-resident (96 KiB of LDS each: one per CU) -- the grid
+// must fit the device's CUs (a partition or a part with fewer than 256 of them takes fewer samples per launch: the host
+// side, ops.lstm_fwd, splits the batch into sample-group chunks that fit and pads it to whole groups of 16).
+int64_t lstm_persistent_max_batch() { return (int64_t)(device_cus() / NUB) * 16; }
+
 bool lstm_persistent_supported(int dtype, int64_t B, int64_t T, int64_t I, int64_t H, int64_t ldx) {
-  return dtype == OVQA_BF16 && H == LH && I == LH && B >= 16 && B % 16 == 0 && (B / 16) * NUB <= 256 && T >= 1 &&
+  return dtype == OVQA_BF16 && H == LH && I == LH && B >= 16 && B % 16 == 0 && B <= lstm_persistent_max_batch() && T >= 1 &&
          ldx % 8 == 0 && (int64_t)(T + 1) * B * LH * 8 < (1ll << 31);
+}
+
+int lstm_status_read_clear(unsigned* out, hipStream_t st) {
+  unsigned v = 0;
+  hipError_t e = hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_lstm_status), sizeof(v), 0, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && v != 0) {
+    const unsigned zero = 0;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lstm_status), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_status: %s", hipGetErrorString(e));
+  *out = v;
+  return OVQA_OK;
 }
 
 int64_t lstm_saved_bytes(int64_t B, int64_t T, int64_t H) { return 5 * T * B * H * 4; }
@@ -531,6 +580,7 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)y16, (bf16*)hseq, (float*)saved,
                   (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, mode,
+                  debug_env("OVQA_LSTM_SWEEP_LIMIT", SWEEP_LIMIT), debug_env("OVQA_LSTM_DEBUG_DROP_WG", 0),
                   (getenv("OVQA_LSTM_PROBE") && T * 8 <= 480) ? (unsigned*)scratch + 512 : nullptr};
     static bool attr_set = false;
     if (!attr_set) {
@@ -568,7 +618,8 @@ int lstm_bwd(int dtype, bool persistent, const void* dy, int dy_bf16, const void
                              : hipMemsetAsync(scratch, 0, kSyncBytes, st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmBwdArgs a{dy, dy_bf16, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
-                  (unsigned*)scratch + 1000, (int)B, (int)T, mode};
+                  (unsigned*)scratch + 1000, (int)B, (int)T, mode, debug_env("OVQA_LSTM_SWEEP_LIMIT", SWEEP_LIMIT),
+                  debug_env("OVQA_LSTM_DEBUG_DROP_WG", 0)};
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

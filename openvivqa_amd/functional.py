@@ -758,14 +758,21 @@ class _LSTM(Function):
         y, hseq, saved = res[0], res[1], res[2]
         ctx.st = st
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x_tb, hseq, saved)
+        if torch.is_tensor(saved):
+            ctx.save_for_backward(x_tb, hseq, saved)
+        else:  # (a padded / split batch: the chunks' opaque blocks, ops.LstmChunks)
+            ctx.save_for_backward(x_tb, hseq)
+            ctx.lstm_chunks = saved
         return (y, res[4]) if want_lp else y
 
     @staticmethod
     def backward(ctx, dy, dy_lp=None):
         st = ctx.st
         arena, m, B, T = st["arena"], st["mod"], st["B"], st["T"]
-        x_tb, hseq, saved = ctx.saved_tensors
+        if len(ctx.saved_tensors) == 3:
+            x_tb, hseq, saved = ctx.saved_tensors
+        else:
+            (x_tb, hseq), saved = ctx.saved_tensors, ctx.lstm_chunks
         w_ih, w_hh = m.weight_ih_l0, m.weight_hh_l0
         if dy is None and dy_lp is None:
             return (None,) * (2 + len(st["params"]))

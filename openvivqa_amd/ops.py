@@ -1098,17 +1098,52 @@ def sq_loss_fwd_bwd(x, loss, want_grad=True, accumulate=False, target=None):
 
 # ---------------------------------------------------------------------------
 # LSTM recurrence (ovqa_lstm_fwd / ovqa_lstm_bwd)
-def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
-    """x_tb [T*B, I] TIME-MAJOR rows (row t*B + b) -> (y fp32 [B, T, H], hseq [(T+1)*B, H] time-major with block 0 = 0 and
-    block t+1 = h_t, saved (opaque bytes for ``lstm_bwd``), scratch[, y_lp = y in x's dtype with ``want_lp``]).  Gate order
-    i, f, g, o; zero initial state."""
-    _dev(x_tb)
-    lib = _lib.load()
+def lstm_status(raise_on_error: bool = True) -> int:
+    """The process-lifetime status word of the persistent LSTM kernels (ovqa_lstm_status): synchronises the current
+    stream, returns the OR of the give-up codes since the last call (0 = every hand-off wait was served) and clears
+    it.  A non-zero word means a workgroup of a launch never ran beside the others (its sample group's outputs are NaN
+    from that step on): raised as a RuntimeError unless ``raise_on_error`` is False.  Not callable under stream capture."""
+    import ctypes as C
+    st = C.c_uint32(0)
+    _lib.check(_lib.load().ovqa_lstm_status(C.byref(st), _stream()), "lstm_status")
+    if st.value and raise_on_error:
+        raise RuntimeError(f"persistent LSTM kernel: a hand-off wait gave up (status {st.value}: "
+                           f"{'counter wait' if st.value & 1 else ''}{' / ' if st.value == 3 else ''}"
+                           f"{'sentinel sweep' if st.value & 2 else ''}); a workgroup of the launch was not resident "
+                           "beside the others -- the outputs of its sample group are NaN")
+    return int(st.value)
+
+
+def _lstm_check():
+    """Eager calls (no stream capture) read the status word right away: the price is one stream synchronisation per call
+    (OVQA_LSTM_CHECK=0 skips it; TrainStep.check_device_status() covers captured steps)."""
+    if os.environ.get("OVQA_LSTM_CHECK", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        lstm_status()
+
+
+class LstmChunks(list):
+    """``saved`` of a batch that ran as several (padded) sample-group chunks: [(b0, b1, bp, saved bytes)]."""
+
+
+def _lstm_chunks(lib, dtype, B, I, H):
+    """[(b0, b1, bp)] when the batch has to be padded to whole sample groups of 16 and / or split into chunks the persistent
+    kernels can keep co-resident; None = one plain call (fits as it is, or the per-step route anyway)."""
+    if dtype != torch.bfloat16 or H != 512 or I != 512 or B < 1:
+        return None
+    maxb = int(lib.ovqa_lstm_persistent_max_batch())
+    if maxb < 16 or (B % 16 == 0 and B <= maxb):
+        return None
+    out, b0 = [], 0
+    while b0 < B:
+        b1 = min(B, b0 + maxb)
+        out.append((b0, b1, (b1 - b0 + 15) // 16 * 16))
+        b0 = b1
+    return out
+
+
+def _lstm_fwd_call(lib, x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp):
     H4, I = w_ih.shape
     H = H4 // 4
-    assert x_tb.dim() == 2 and x_tb.shape == (T * B, I) and x_tb.stride(1) == 1 and w_hh.shape == (H4, H)
-    assert w_ih.is_contiguous() and w_hh.is_contiguous() and w_ih.dtype == w_hh.dtype == x_tb.dtype
-    assert b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.numel() == H4 == b_hh.numel()
     dev = x_tb.device
     y = torch.empty(B, T, H, dtype=torch.float32, device=dev)
     y_lp = torch.empty(B, T, H, dtype=x_tb.dtype, device=dev) if want_lp else None
@@ -1117,12 +1152,59 @@ def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
     scratch = torch.empty(lib.ovqa_lstm_scratch_bytes(B, T, H), dtype=torch.uint8, device=dev)
     _lib.check(lib.ovqa_lstm_fwd(_dt(x_tb), _p(x_tb), x_tb.stride(0), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), _p(y),
                                  _p(y_lp), _p(hseq), _p(saved), _p(scratch), B, T, I, H, _stream()), "lstm_fwd")
+    return y, hseq, saved, scratch, y_lp
+
+
+def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
+    """x_tb [T*B, I] TIME-MAJOR rows (row t*B + b) -> (y fp32 [B, T, H], hseq [(T+1)*B, H] time-major with block 0 = 0 and
+    block t+1 = h_t, saved (opaque, for ``lstm_bwd``), scratch[, y_lp = y in x's dtype with ``want_lp``]).  Gate order
+    i, f, g, o; zero initial state.  A bf16 batch that is not a multiple of 16 samples, or larger than the persistent
+    kernels can keep co-resident on this device, is padded with zero samples / split into chunks HERE (the padded
+    samples' rows are dropped again; their gradients are zero), so that every batch size takes the MFMA route."""
+    _dev(x_tb)
+    lib = _lib.load()
+    H4, I = w_ih.shape
+    H = H4 // 4
+    assert x_tb.dim() == 2 and x_tb.shape == (T * B, I) and x_tb.stride(1) == 1 and w_hh.shape == (H4, H)
+    assert w_ih.is_contiguous() and w_hh.is_contiguous() and w_ih.dtype == w_hh.dtype == x_tb.dtype
+    assert b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.numel() == H4 == b_hh.numel()
+    chunks = _lstm_chunks(lib, x_tb.dtype, B, I, H)
+    if chunks is None:
+        y, hseq, saved, scratch, y_lp = _lstm_fwd_call(lib, x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp)
+    else:
+        dev = x_tb.device
+        y = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+        y_lp = torch.empty(B, T, H, dtype=x_tb.dtype, device=dev) if want_lp else None
+        hseq = torch.empty((T + 1) * B, H, dtype=x_tb.dtype, device=dev)
+        x3, h3 = x_tb.view(T, B, I) if x_tb.is_contiguous() else x_tb.reshape(T, B, I), hseq.view(T + 1, B, H)
+        saved, scratch = LstmChunks(), None
+        for b0, b1, bp in chunks:
+            nb = b1 - b0
+            xc = torch.zeros(T, bp, I, dtype=x_tb.dtype, device=dev)
+            xc[:, :nb] = x3[:, b0:b1]
+            yc, hc, sc, scratch, ylc = _lstm_fwd_call(lib, xc.view(T * bp, I), w_ih, w_hh, b_ih, b_hh, bp, T, want_lp)
+            y[b0:b1] = yc[:nb]
+            h3[:, b0:b1] = hc.view(T + 1, bp, H)[:, :nb]
+            if want_lp:
+                y_lp[b0:b1] = ylc[:nb]
+            saved.append((b0, b1, bp, sc))
+    _lstm_check()
     return (y, hseq, saved, scratch, y_lp) if want_lp else (y, hseq, saved, scratch)
+
+
+def _lstm_bwd_call(lib, dy, w_hh, w_hh_t, ldwt, saved, B, T, I):
+    H4, H = w_hh.shape
+    dgates = torch.empty(T * B, H4, dtype=w_hh.dtype, device=dy.device)
+    scratch = torch.empty(lib.ovqa_lstm_scratch_bytes(B, T, H), dtype=torch.uint8, device=dy.device)
+    _lib.check(lib.ovqa_lstm_bwd(_dt(w_hh), _p(dy), _dt(dy), _p(w_hh), _p(w_hh_t), ldwt, _p(saved), _p(dgates), _p(scratch), B, T,
+                                 I, H, _stream()), "lstm_bwd")
+    return dgates, scratch
 
 
 def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
     """dy [B, T, H] (fp32 or bf16) -> dgates [T*B, 4H] (time-major rows, columns gate*H + unit) in w_hh's dtype; ``w_hh_t`` =
-    the transposed bf16 copy [H, 4H] (rows may be strided) or None in fp32 mode."""
+    the transposed bf16 copy [H, 4H] (rows may be strided) or None in fp32 mode.  ``saved`` as ``lstm_fwd`` returned it (the
+    chunks of a padded / split batch included)."""
     _dev(dy)
     lib = _lib.load()
     H4, H = w_hh.shape
@@ -1131,11 +1213,20 @@ def lstm_bwd(dy, w_hh, w_hh_t, saved, B, T, I):
     if w_hh_t is not None:
         assert w_hh_t.shape == (H, H4) and w_hh_t.stride(1) == 1 and w_hh_t.dtype == w_hh.dtype
         ldwt = w_hh_t.stride(0)
-    dgates = torch.empty(T * B, H4, dtype=w_hh.dtype, device=dy.device)
-    scratch = torch.empty(lib.ovqa_lstm_scratch_bytes(B, T, H), dtype=torch.uint8, device=dy.device)
-    _lib.check(lib.ovqa_lstm_bwd(_dt(w_hh), _p(dy), _dt(dy), _p(w_hh), _p(w_hh_t), ldwt, _p(saved), _p(dgates), _p(scratch), B, T,
-                                 I, H, _stream()), "lstm_bwd")
-    return dgates, scratch
+    if not isinstance(saved, LstmChunks):
+        out = _lstm_bwd_call(lib, dy, w_hh, w_hh_t, ldwt, saved, B, T, I)
+    else:
+        dgates = torch.empty(T * B, H4, dtype=w_hh.dtype, device=dy.device)
+        g3, scratch = dgates.view(T, B, H4), None
+        for b0, b1, bp, sc in saved:
+            nb = b1 - b0
+            dyc = torch.zeros(bp, T, H, dtype=dy.dtype, device=dy.device)
+            dyc[:nb] = dy[b0:b1]
+            gc, scratch = _lstm_bwd_call(lib, dyc, w_hh, w_hh_t, ldwt, sc, bp, T, I)
+            g3[:, b0:b1] = gc.view(T, bp, H4)[:, :nb]
+        out = (dgates, scratch)
+    _lstm_check()
+    return out
 
 
 # ---------------------------------------------------------------------------

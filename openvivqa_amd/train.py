@@ -942,6 +942,14 @@ class TrainStep:
                 self.reducer.reset()
                 _fn.wgrad_queue().abandon()
                 rt.set_milestone_sink(None)
+                # ... and the fused optimiser may have "begun" in the aborted body (capture errors surface at its end):
+                # the phase graphs below are captured UNARMED (plain weight-gradient launches), so the step must take
+                # the separate Adam over every range -- a stale `began` would leave the matrices of `_fused.ranges`
+                # without an update and the step / dropout counters frozen
+                if self._fused is not None:
+                    self._fused.reset()
+                    self._queue().adam = None
+                    self._fused = None
         if self.use_graph:
             first, later = self._phase_fns()
             graphs = [torch.cuda.CUDAGraph()]
@@ -1057,6 +1065,20 @@ class TrainStep:
         that no timed step pays for the capture."""
         if self.static_inputs is None:
             self._capture(inputs)
+
+    def check_device_status(self) -> None:
+        """Raise if a kernel of a past step reported a failure in its device status word (today: a hand-off wait of the
+        persistent LSTM kernels that gave up, ``ops.lstm_status``).  Synchronises the device: call it where the loop syncs
+        anyway -- next to ``loss.item()`` (tasks/classification_task.py:134 reads the loss every step), at checkpoints."""
+        from . import ops
+        if self.arena.device.type == "cuda":
+            ops.lstm_status()
+
+    def loss_value(self) -> float:
+        """``float(loss)`` of the last step + the device status check: the one host read a training loop makes per step."""
+        v = float(self.loss.item())
+        self.check_device_status()
+        return v
 
     def _param_names(self):
         return {id(p): n for n, p in self.model.named_parameters()}

@@ -1153,7 +1153,9 @@ def _lstm_ref64(x_tb, w_ih, w_hh, b_ih, b_hh, dy, B, T, round_ops):
 @pytest.mark.parametrize("B,T,H,dtype,route", [
     (3, 5, 32, F32, "simple"), (5, 8, 24, F32, "simple"), (4, 6, 32, BF16, "simple"),
     (16, 3, 512, BF16, "mfma"), (64, 20, 512, BF16, "mfma"), (32, 7, 512, BF16, "mfma"), (128, 4, 512, BF16, "mfma"),
-    (24, 4, 512, BF16, "simple"), (64, 20, 512, F32, "simple")])
+    # ragged batches are padded to whole sample groups of 16 by ops.lstm_fwd (the last batch of an epoch), batches larger
+    # than the persistent kernels can keep co-resident run as chunks: both stay on the MFMA route
+    (24, 4, 512, BF16, "mfma"), (5, 3, 512, BF16, "mfma"), (200, 3, 512, BF16, "mfma"), (64, 20, 512, F32, "simple")])
 def test_lstm_fwd_bwd(B, T, H, dtype, route):
     from openvivqa_amd import _lib
     g = torch.Generator().manual_seed(1000 + B * 7 + T)
@@ -1175,12 +1177,43 @@ def test_lstm_fwd_bwd(B, T, H, dtype, route):
     torch.cuda.synchronize()
     if route == "mfma":  # no hand-off wait of the persistent launches gave up
         assert int(scratch.view(torch.int32)[1000]) == 0 and int(scratch_b.view(torch.int32)[1000]) == 0
+        assert o.lstm_status(raise_on_error=False) == 0
     y64, dg64, _ = _lstm_ref64(x, w_ih, w_hh, b_ih, b_hh, dy, B, T, round_ops=dtype == BF16)
     tol = 1e-5 if dtype == F32 else 2e-3  # bf16: a 1-ulp flip of a rounded h_{t-1} moves later steps
     assert nerr(y, y64) < tol, nerr(y, y64)
     assert nerr(hseq[B:].float().view(T, B, H).transpose(0, 1), y64) < (1e-5 if dtype == F32 else 8e-3)
     assert float(hseq[:B].float().abs().max()) == 0.0
     assert rel_l2(dgates.float(), dg64) < (1e-5 if dtype == F32 else 6e-3), rel_l2(dgates.float(), dg64)
+
+
+@pytest.mark.skipif(FORCED_SIMPLE, reason="the give-up path of the persistent kernels")
+def test_lstm_handoff_timeout_reaches_python(monkeypatch):
+    """A workgroup of the persistent launch that never runs (OVQA_LSTM_DEBUG_DROP_WG: it exits at once) makes its sample
+    group's waits give up after `sweep_limit` sweeps: the eager call raises, the outputs of that group are NaN (so a loss
+    would show it), the other sample groups are untouched, and the status word is clear again afterwards."""
+    B, T, H = 32, 4, 512
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T * B, H, generator=g).to(DEV, BF16)
+    w = [(torch.rand(4 * H, H, generator=g) * 2 - 1).mul(H ** -0.5).to(DEV, BF16) for _ in range(2)]
+    b = [(torch.rand(4 * H, generator=g) * 2 - 1).mul(H ** -0.5).to(DEV) for _ in range(2)]
+    o = ops()
+    y_ok = o.lstm_fwd(x, w[0], w[1], b[0], b[1], B, T)[0]
+    assert torch.isfinite(y_ok).all()
+    monkeypatch.setenv("OVQA_LSTM_SWEEP_LIMIT", "2000")
+    monkeypatch.setenv("OVQA_LSTM_DEBUG_DROP_WG", "1")  # workgroup 0: sample group 0 (two groups: blocks b % 8 < 4)
+    with pytest.raises(RuntimeError, match="hand-off wait gave up"):
+        o.lstm_fwd(x, w[0], w[1], b[0], b[1], B, T)
+    assert o.lstm_status(raise_on_error=False) == 0  # read and cleared by the failing call
+    monkeypatch.setenv("OVQA_LSTM_CHECK", "0")
+    y_bad = o.lstm_fwd(x, w[0], w[1], b[0], b[1], B, T)[0]
+    torch.cuda.synchronize()
+    assert torch.isnan(y_bad[:16]).any() and not torch.isnan(y_bad[16:]).any()
+    assert torch.equal(y_bad[16:], y_ok[16:])
+    assert o.lstm_status(raise_on_error=False) == 2
+    monkeypatch.delenv("OVQA_LSTM_DEBUG_DROP_WG")
+    monkeypatch.delenv("OVQA_LSTM_SWEEP_LIMIT")
+    monkeypatch.setenv("OVQA_LSTM_CHECK", "1")
+    assert torch.equal(o.lstm_fwd(x, w[0], w[1], b[0], b[1], B, T)[0], y_ok)
 
 
 @pytest.mark.skipif(FORCED_SIMPLE, reason="compares the persistent route with the per-step one")

@@ -196,6 +196,39 @@ def test_failed_whole_step_capture_falls_back_cleanly(single_rank_group, monkeyp
         assert torch.equal(a.arena.master, b.arena.master), i
 
 
+def test_failed_whole_step_capture_with_adam_in_the_weight_gradient_launch(monkeypatch):
+    """with the optimiser riding in the last weight-gradient launch (world size 1, bench.py's default) a
+    whole-step capture that fails AFTER backward leaves ``_fused.began`` set, while the phase graphs of the fallback are
+    captured unarmed (plain weight-gradient launches).  A stale flag made the optimiser tail skip the matrices the fused
+    launch would have taken and never advance the step / schedule / dropout counters.  The fallback must give the bits of a
+    harness with the separate Adam, and its counters must move."""
+    from openvivqa_amd.train import TrainStep, noam_lr_scale
+    kw = dict(lr_lambda=lambda s: noam_lr_scale(s, 512, 3))
+    _, a, batch = _make(2, fuse_adam=True, **kw)
+    real, fired = TrainStep._optimiser_tail, {"n": 0}
+
+    def failing(self, host=True):
+        if torch.cuda.is_current_stream_capturing() and self.whole is None and fired["n"] == 0:
+            fired["n"] += 1
+            assert self._fused is not None and self._fused.began  # (the state the fallback has to clean up)
+            raise RuntimeError("injected: the capture dies behind backward")
+        return real(self, host)
+    monkeypatch.setattr(TrainStep, "_optimiser_tail", failing)
+    a.prepare(*batch)
+    monkeypatch.setattr(TrainStep, "_optimiser_tail", real)
+    assert fired["n"] == 1 and a.whole is None and a.graphs is not None and a._fused is None
+    _, b, _ = _make(2, fuse_adam=False, **kw)
+    for i in range(4):
+        a.step(*batch)
+        b.step(*batch)
+        torch.cuda.synchronize()
+        assert float(a.loss) == float(b.loss), i
+        assert torch.equal(a.arena.master, b.arena.master), i
+        assert torch.equal(a.arena.shadow, b.arena.shadow) and torch.equal(a.arena.shadow_t, b.arena.shadow_t), i
+    assert torch.equal(a.optim.exp_avg, b.optim.exp_avg) and torch.equal(a.optim.exp_avg_sq, b.optim.exp_avg_sq)
+    assert int(a.optim.step_t.item()) == 4 == a.optim.host_step
+
+
 def test_checkpoint_resume_inside_the_one_graph_step_is_bitwise():
     """Save after 3 steps (model state_dict + TrainStep.state_dict), rebuild everything, load, take 2 more: the weights,
     moments and loss of the uninterrupted 5-step run, bit for bit -- the step is deterministic, and the device-side
