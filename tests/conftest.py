@@ -42,6 +42,31 @@ def _built_library():
     yield
 
 
+# files whose tests run with guard bands around every buffer the C-ABI wrappers allocate (tests/redzone.py); the multi-step
+# training tests are left out (every eager step's allocations would stay alive until the end of the test)
+_RED_ZONE_FILES = ("test_kernels_gpu.py", "test_blocks_gpu.py", "test_modules_gpu.py")
+
+
+@pytest.fixture(autouse=True)
+def _red_zones(request, monkeypatch):
+    """4-KiB bands of 0xFF around the outputs / workspaces ``openvivqa_amd.ops`` allocates and around the inputs a test
+    module's ``rnd()`` makes: an out-of-bounds store of any kernel fails the test that ran it (GPU AddressSanitizer is
+    not available on this pool).  OVQA_TEST_REDZONE=0 switches the bands off."""
+    if (os.path.basename(str(request.node.fspath)) not in _RED_ZONE_FILES or "gpu" not in request.node.keywords
+            or os.environ.get("OVQA_TEST_REDZONE", "1") == "0"):
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    import redzone
+    rz = redzone.install(monkeypatch, request.module)
+    yield
+    torch.cuda.synchronize()
+    rz.check()
+
+
 def parity_record(test, what, value, bar):
     """Measured parity figures: with OVQA_PARITY_REPORT=<file> every compared quantity is appended as a TSV line
     (test, quantity, measured error, bar), so that the bars written in the tests can be checked against the spread

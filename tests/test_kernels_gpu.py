@@ -26,6 +26,26 @@ def ops():
     return o
 
 
+def test_red_zone_harness_sees_a_store_one_byte_out_of_bounds():
+    """The guard bands of tests/redzone.py (conftest.py puts them around every buffer of this file's tests) do catch a
+    store directly behind the last byte and directly in front of the first one."""
+    import redzone
+    rz = redzone.RedZone()
+    t = rz.alloc((5, 7), BF16, DEV)
+    t.zero_()
+    raw = rz.live[0][0]
+    rz.check()  # (a store that stays inside leaves the bands alone)
+    t = rz.alloc((5, 7), BF16, DEV)
+    raw = rz.live[0][0]
+    raw[redzone.BAND + 70] = 0
+    with pytest.raises(AssertionError, match="0 bytes BEHIND"):
+        rz.check()
+    t = rz.alloc((3,), F32, DEV)
+    rz.live[0][0][redzone.BAND - 1] = 0
+    with pytest.raises(AssertionError, match="1 bytes IN FRONT"):
+        rz.check()
+
+
 def nerr(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
