@@ -49,7 +49,7 @@ def parse():
                     help="diagnostic at N=1: run the N>1 code path (phased backward, comm stream, RCCL) on a "
                          "single-rank group")
     ap.add_argument("--beam", type=int, default=1, help="--workload decode: beam size (1 = greedy)")
-    ap.add_argument("--workload", default="stack", choices=["stack", "model", "cross_modality", "m4c_decode", "decode"],
+    ap.add_argument("--workload", default="stack", choices=["stack", "model", "cross_modality", "decoder_train", "m4c_decode", "decode"],
                     help="stack = BASELINE's metric (the two encoder stacks, default); cross_modality = SECONDARY line for "
                          "BASELINE configs[2]: the whole CrossModalityTransformer model (configs/cross_modality_bench.yaml "
                          "= the reference's MODEL node at L=6: FeatureEmbedding 2048->512, UsualEmbedding, 6 "
@@ -73,7 +73,7 @@ def parse():
                          "the last grouped weight-gradient launch, TrainStep(fuse_adam=True); with N > 1 the gradient exchange "
                          "stands between gradient and update and Adam is always separate)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary workloads (model, cross_modality, decode beam 1 / 3, m4c_decode) that the default "
+                    help="skip the secondary workloads (model, cross_modality, decoder_train, decode beam 1 / 3, m4c_decode) that the default "
                          "single-GPU run of the headline workload appends under `secondary`")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test (no GPU): start the ranks exactly as a real run would, bring up a gloo "
@@ -737,6 +737,9 @@ MODEL_GFLOP_PER_SAMPLE = {
     # CrossModalityEncoder L=6 live work 13.97 (dead cross-attention skipped) + FeatureEmbedding 2048->512
     # 0.629 + pooling MLPs 0.189 + projections / classifier 0.004
     "cross_modality": 14.79,
+    # Decoder L=3, T=20 answer positions, 237 encoder positions, |V|=4000: BASELINE.md section 3 (1.218 forward) -- the
+    # K / V projections of the 237 encoder rows, self- and encoder-attention, FFN and the 512 -> 4000 vocabulary product
+    "decoder_train": 3.65,
 }
 
 
@@ -758,7 +761,7 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
     A.set_compute_dtype(dtype)
     A.manual_seed(b.SEED + rank)
     torch.manual_seed(b.SEED)  # identical initial weights on every rank
-    whole_model = workload in ("model", "cross_modality")
+    whole_model = workload in ("model", "cross_modality", "decoder_train")
     D = cfg.MODEL.D_MODEL
     loss_buf = torch.zeros(1, device=device)
     if not whole_model:
@@ -777,6 +780,43 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
             dlo = ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
             return (vo, lo), (dvo, dlo)
         batch = (v, vm, t, tm)
+    elif workload == "decoder_train":
+        # BASELINE configs[4], the TRAINING half (tasks/open_ended_task.py:150-169): the Decoder of
+        # configs/vit_mbert_generation.yaml:68-98 teacher-forced on the right-shifted answer, NLLLoss(ignore_index = pad)
+        # over every answer position, Adam + Noam.  The 237 encoder positions (197 ViT patches + 40 question tokens) are
+        # synthetic features: the ViT / mBERT encoders in front are out of scope.
+        from openvivqa_amd.config import ConfigNode, attention_config
+        from openvivqa_amd.losses import nll_loss_fwd_bwd
+        from openvivqa_amd.utils import generate_padding_mask
+        T_, NE_, V_, L_ = 20, 237, 4000, 3
+
+        class DVocab:
+            max_answer_length, padding_idx, bos_idx, eos_idx = T_, 0, 1, 2
+
+            def __len__(self):
+                return V_
+        dcfg = ConfigNode(dict(
+            ARCHITECTURE="Decoder", D_MODEL=D, LAYERS=L_,
+            ATTENTION=dict(SELF_ATTENTION=attention_config(can_be_stateful=True), ENC_ATTENTION=attention_config()),
+            TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=D, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                                WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+        model = A.build_decoder(dcfg, DVocab()).to(device).train()
+        g = torch.Generator().manual_seed(b.SEED + rank)
+        enc = torch.randn(b.BATCH_PER_GPU, NE_, D, generator=g)
+        ne = torch.randint(200, NE_ + 1, (b.BATCH_PER_GPU,), generator=g)
+        enc[torch.arange(NE_)[None, :] >= ne[:, None]] = 0
+        ans = torch.randint(3, V_, (b.BATCH_PER_GPU, T_ + 1), generator=g)
+        ans[:, 0] = 1
+        na = torch.randint(6, T_ + 1, (b.BATCH_PER_GPU,), generator=g)
+        ans[torch.arange(T_ + 1)[None, :] > na[:, None]] = 0  # <bos> a_1 .. a_n <pad> ...
+        enc = enc.to(device=device, dtype=dtype)
+        emask = generate_padding_mask(enc, 0)
+        tgt = ans[:, 1:].contiguous().to(device)  # shifted_right_answer_tokens (open_ended_task.py:157)
+
+        def forward_loss(tokens_, enc_, emask_):
+            logp = model(tokens_, enc_, emask_)
+            return [logp], [nll_loss_fwd_bwd(logp, tgt, loss_buf, ignore_index=0)]
+        batch = (ans[:, :-1].contiguous().to(device), enc, emask)
     else:
         from types import SimpleNamespace
         from openvivqa_amd.builders import build_model
@@ -889,6 +929,15 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
                                      "layers (4 attention + 2 feed-forward blocks each), pooling head, 353-way "
                                      "classifier, NLLLoss on the logits as upstream, Adam + Noam; 100 regions x 20 "
                                      "tokens, data parallel")
+    elif workload == "decoder_train":
+        out["metric"] = ("SECONDARY (BASELINE configs[4], training half): samples/sec fwd+bwd, teacher-forced Decoder L=3 "
+                         "d=512, T=20, 237 encoder positions, |V|=4000, 64 samples/GPU")
+        out["config"]["workload"] = ("secondary, BASELINE configs[4] training: Decoder (configs/vit_mbert_generation.yaml:68-98: "
+                                     "L=3, d=512, H=8, dff=2048, UsualEmbedding 300 -> 512, |V|=4000) teacher-forced over "
+                                     "T=20 answer positions and 237 synthetic encoder positions, causal + padding masks, "
+                                     "log_softmax + NLLLoss(ignore_index=pad) over every position, dropout 0.1, Adam + Noam "
+                                     "(tasks/open_ended_task.py:150-169)")
+        out["value_tokens_per_s"] = round(value * 20, 1)
     if whole_model:
         out["algorithmic_gflop_per_sample_fwd_bwd"] = MODEL_GFLOP_PER_SAMPLE[workload]
     return out, ts, cfg
@@ -950,7 +999,7 @@ def secondary_lines(args, device, dtype):
             except Exception:  # noqa: BLE001
                 pass
 
-    for wl in ("model", "cross_modality"):
+    for wl in ("model", "cross_modality", "decoder_train"):
         guarded(wl, lambda wl=wl: compact(train_bench(args, wl, device, 1, 0, None, dtype, steps=20, warmup=3, repeats=1)[0],
                                           ("step_frac_of_bf16_peak", "algorithmic_gflop_per_sample_fwd_bwd")))
     a2 = copy.copy(args)

@@ -2,6 +2,8 @@
 // elementwise dropout, the attention-pooling head of MCAN / CrossModalityTransformer (models/mcan.py:12-25,70-76) and
 // log_softmax + NLLLoss (mcan.py:81, tasks/classification_task.py:125-127).  Small, HBM / latency-bound kernels: each
 // replaces a chain of 3-8 stock elementwise / reduction launches (and their autograd twins) by one launch.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -361,11 +363,15 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 }
 
 // NLLLoss(reduction = mean, ignore_index) on log-probabilities fp32 [M, n]: loss = -sum_{t_r != ignore} logp[r][t_r] / cnt
-// and (optionally) its gradient dlogp (dense, -scale / cnt at the targets).  ONE workgroup: fixed summation order.
+// and (optionally) its gradient dlogp (dense, -scale / cnt at the targets).  Every workgroup sums the M targets itself, in the
+// same fixed order (M int64 reads: nothing beside a dense gradient of M x n floats), workgroup 0 stores the loss, and each
+// workgroup writes the gradient rows [blockIdx.x * rows_per_wg, ...): a wave per row, 16-byte stores.  (Round 5 wrote the
+// whole gradient from ONE workgroup with a division per element: 1.2 ms of a 2.6-ms teacher-forced decoder step at
+// 1280 positions x 4000 words, profiles/r06a_decoder_train_kernel_stats_before.csv.)
 __global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                         float* __restrict__ loss, float* __restrict__ dlogp,
                                                         const float* __restrict__ gscale, int M, int n, int64_t ignore_index,
-                                                        int accumulate) {
+                                                        int accumulate, int rows_per_wg) {
   __shared__ float s_sum[16];
   __shared__ float s_cnt[16];
   float s = 0.f, cnt = 0.f;
@@ -384,16 +390,28 @@ __global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < 16; i++) { ts += s_sum[i]; tc += s_cnt[i]; }
   const float inv = tc > 0.f ? 1.f / tc : 0.f;  // (torch returns nan for an all-ignored batch; the gradient is 0 either way)
-  if (threadIdx.x == 0 && loss) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
     const float v = tc > 0.f ? ts * inv : __int_as_float(0x7fc00000);
     *loss = accumulate ? *loss + v : v;
   }
   if (dlogp == nullptr) return;
   const float sc = (gscale ? gscale[0] : 1.f) * inv;
-  for (int64_t i = threadIdx.x; i < (int64_t)M * n; i += 1024) {
-    const int r = (int)(i / n), c = (int)(i % n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r_end = min(M, ((int)blockIdx.x + 1) * rows_per_wg);
+  const bool vec = (n & 3) == 0 && ((uintptr_t)dlogp & 15) == 0;
+  for (int r = (int)blockIdx.x * rows_per_wg + wave; r < r_end; r += 16) {
     const int64_t t = target[r];
-    dlogp[i] = (t == c && t != ignore_index) ? -sc : 0.f;
+    const int hot = (t != ignore_index && t >= 0 && t < n) ? (int)t : -1;
+    float* row = dlogp + (int64_t)r * n;
+    if (vec) {
+      for (int c = lane * 4; c < n; c += 256) {
+        const int d = hot - c;  // (hot = -1: never 0..3 for c >= 0)
+        *reinterpret_cast<float4*>(row + c) =
+            make_float4(d == 0 ? -sc : 0.f, d == 1 ? -sc : 0.f, d == 2 ? -sc : 0.f, d == 3 ? -sc : 0.f);
+      }
+    } else {
+      for (int c = lane; c < n; c += 64) row[c] = c == hot ? -sc : 0.f;
+    }
   }
 }
 
@@ -499,8 +517,12 @@ int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int6
 
 int nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M, int64_t n,
              int64_t ignore_index, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(1024), 0, st, logp, target, loss, dlogp, gscale, (int)M, (int)n,
-                     ignore_index, accumulate);
+  // the gradient rows are dealt to the workgroups 16 at a time (a wave per row), at most 1024 workgroups
+  int rows_per_wg = 16;
+  while ((M + rows_per_wg - 1) / rows_per_wg > 1024) rows_per_wg *= 2;
+  const unsigned grid = dlogp ? (unsigned)std::max<int64_t>(1, (M + rows_per_wg - 1) / rows_per_wg) : 1u;
+  hipLaunchKernelGGL(nll_loss_kernel, dim3(grid), dim3(1024), 0, st, logp, target, loss, dlogp, gscale, (int)M, (int)n,
+                     ignore_index, accumulate, rows_per_wg);
   return ovqa_check_launch("nll_loss");
 }
 

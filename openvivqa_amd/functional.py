@@ -992,13 +992,17 @@ class _ClassifyLogSoftmax(Function):
         arena, lin = st["arena"], st["lin"]
         x, logp = ctx.saved_tensors
         dy = ops.log_softmax_bwd(_c(g.float()), logp, arena.foot[id(lin.weight)][0], x.dtype)
-        _wgrad(arena, dy, x, [lin.weight], [lin.bias])
+        _wgrad(arena, dy, x, [lin.weight], [lin.bias] if lin.bias is not None else [])
         dx = _dx(arena, dy, [lin.weight]) if ctx.needs_input_grad[0] else None
         return dx, None, *([None] * len(st["params"]))
 
 
 def classify_log_softmax(x, lin, arena):
-    params = [lin.weight, lin.bias]
+    """log_softmax(lin(x)) over the last dimension; x [..., K] -> fp32 log-probabilities [..., classes]."""
+    lead = x.shape[:-1]
+    if x.dim() != 2:
+        return classify_log_softmax(x.reshape(-1, x.shape[-1]), lin, arena).view(*lead, -1)
+    params = [lin.weight] + ([lin.bias] if lin.bias is not None else [])
     st = dict(arena=arena, lin=lin, params=params)
     if torch.is_grad_enabled():
         return _ClassifyLogSoftmax.apply(x, st, *params)

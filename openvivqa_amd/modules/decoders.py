@@ -185,5 +185,9 @@ class Decoder(Module):
             out = layer(queries=out, keys=encoder_features, values=encoder_features,
                         self_attention_mask=self_mask, enc_attention_mask=encoder_attention_mask)
         arena = rt.ensure_arena(self.fc)
+        if not return_logits and out.is_cuda:
+            # vocabulary projection + log_softmax on the library's kernels (decoders.py:75-76): the GEMM on the zero-padded
+            # footprint of `fc`, ovqa_log_softmax_fwd / _bwd over the real words
+            return Fn.classify_log_softmax(out.to(arena.compute_dtype), self.fc, arena)
         logits = Fn.linear(out.to(arena.compute_dtype), self.fc, arena)
         return logits if return_logits else F.log_softmax(logits.float(), dim=-1)

@@ -39,7 +39,10 @@ def _footprint(p) -> tuple:
         # a ragged reduction length above one K step goes up to whole 64-deep steps (300 -> 320): the direct-to-LDS
         # GEMM forms take over from the register-staged one (13 + 16 us -> 6 + 9 for the 1280 x 512 x 300 products)
         cpad = 64 if cols % PAD and cols > 64 else PAD
-        return ((rows + PAD - 1) // PAD * PAD, (cols + cpad - 1) // cpad * cpad)
+        # ... and so does a LONG output dimension (a 4000-word vocabulary projection, decoders.py:44: 4000 -> 4032): it is
+        # the reduction length of that layer's dX product (76 -> 12 us at 1280 positions on the direct-to-LDS form)
+        rpad = 64 if rows % 64 and rows > 1024 else PAD
+        return ((rows + rpad - 1) // rpad * rpad, (cols + cpad - 1) // cpad * cpad)
     if p.dim() == 1:
         return ((p.shape[0] + PAD - 1) // PAD * PAD,)
     return tuple(p.shape)

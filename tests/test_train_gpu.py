@@ -375,6 +375,81 @@ def test_mcan_model_two_training_steps_match_oracle(use_graph):
     assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5  # the two-step update as a whole
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_decoder_two_training_steps_match_oracle(use_graph):
+    """BASELINE configs[4], the training half (tasks/open_ended_task.py:150-169): the Decoder (L=3, d=512, 237 encoder
+    positions, T=20) teacher-forced on <bos> a_1 .. a_n, NLLLoss(ignore_index = pad) against the right-shifted answer over
+    every position, trained for two steps by the product's TrainStep in fp32 mode: losses and post-step weights follow the
+    oracle's torch.optim.Adam trajectory (what bench.py times as `secondary.decoder_train`)."""
+    import oracle as O
+    import openvivqa_amd as A
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode, attention_config
+    from openvivqa_amd.losses import NLLLoss
+    from openvivqa_amd.train import TrainStep
+    V, T, NE, B = 1000, 20, 237, 4
+
+    class Vocab:
+        max_answer_length, padding_idx, bos_idx, eos_idx = T, 0, 1, 2
+
+        def __len__(self):
+            return V
+    cfg = ConfigNode(dict(
+        ARCHITECTURE="Decoder", D_MODEL=512, LAYERS=3,
+        ATTENTION=dict(SELF_ATTENTION=attention_config(can_be_stateful=True), ENC_ATTENTION=attention_config()),
+        TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=512, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                            WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+    torch.manual_seed(21)
+    ref = O.OracleDecoder(cfg, Vocab())
+    w0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref.eval()  # dropout off on both sides
+    g = torch.Generator().manual_seed(9)
+    ans = torch.randint(3, V, (B, T + 1), generator=g)
+    ans[:, 0] = 1
+    ans[1, 12:] = 0
+    ans[3, 7:] = 0
+    enc = torch.randn(B, NE, 512, generator=g)
+    enc[2, 210:] = 0
+    emask = O.padding_mask(enc, 0)
+    tin, tgt = ans[:, :-1].contiguous(), ans[:, 1:].contiguous()
+    nll = torch.nn.NLLLoss(ignore_index=0)
+    opt = torch.optim.Adam([p for p in ref.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.98))
+    ref_losses = [O.oracle_train_step(None, lambda: nll(ref(tin, enc, emask).reshape(-1, V), tgt.reshape(-1)), opt)
+                  for _ in range(2)]
+
+    A.set_compute_dtype(torch.float32)
+    try:
+        dev = torch.device("cuda", 0)
+        m = M.Decoder(cfg, Vocab())
+        m.load_state_dict(w0, strict=False)
+        m = m.to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        loss_fn, tg = NLLLoss(ignore_index=0), tgt.to(dev)
+
+        def forward_loss(tokens, enc_, emask_):
+            return loss_fn(m(tokens, enc_, emask_), tg)
+        ts = TrainStep(m, forward_loss, lr=1e-3, betas=(0.9, 0.98), use_graph=use_graph, compute_dtype=torch.float32)
+        batch = (tin.to(dev), enc.to(dev), emask.to(dev))
+        losses = [float(ts.step(*batch)) for _ in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        A.set_compute_dtype(torch.bfloat16)
+    assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-4, (losses, ref_losses)
+    sd = m.state_dict()
+    num = den = 0.0
+    for k, v in ref.state_dict().items():
+        if k.endswith("fc_k.bias") or k == "pos_emb.weight" or k not in sd or v.numel() == 0 or not v.is_floating_point():
+            continue  # analytically zero gradients: Adam turns rounding noise into +-lr steps; frozen table; state buffers
+        d = (sd[k].cpu().double() - v.double()).abs()
+        assert d.max().item() < 1e-3, (k, d.max().item())
+        upd = v.double() - w0[k].double()
+        num += ((sd[k].cpu().double() - w0[k].double()) - upd).pow(2).sum().item()
+        den += upd.pow(2).sum().item()
+    assert den > 0 and (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5  # the two-step update as a whole
+
+
 def test_training_reduces_loss_bf16():
     """30 hipGraph-replayed bf16 steps on one fixed batch (dropout on, lr 2e-4): the regression loss goes down
     monotonically on average and ends well below where it started -- the step is a working optimiser step, not
