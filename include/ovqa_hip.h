@@ -174,16 +174,14 @@ int ovqa_linear_bwd_weight(int dtype, const void* dy, int64_t lddy,
  * individual products have 16..64 output tiles each -- far fewer than 256 CUs --
  * so they are deferred and tiled together instead of being split along M).
  * `problems`/`tiles` are DEVICE arrays written by the host side: tiles[i] =
- * {problem index, tile over N, tile over K, 0} in units of the form's tile edge; an entry with problem index -1 is
+ * {problem index, tile over N, tile over K, 0} in units of 128; an entry with problem index -1 is
  * padding (the workgroup returns). bf16 only.
  * form (the parameter named all_m_mult64 up to ABI 6):
  *   0  register-staged 128 x 128 tiles, any shapes the single-product entry point accepts;
  *   1  direct-to-LDS 128 x 128 tiles (8 waves): the caller promises that every problem's M is a multiple of 64, its
  *      pointers 16-byte aligned, lddy / ldx multiples of 8;
- *   2  (ABI 7) the same promise, tiles of 256 x 256 on one 16-wave workgroup per CU with 128 KB of LDS (half the
- *      operand bytes per flop through the CU's L2 fetch path).  The tile table indexes 256-blocks.  No register-staged
- *      fallback: OVQA_ERR_UNSUPPORTED under OVQA_FORCE_SIMPLE.  Measured slower than form 1 in the MCAN step
- *      (3.231 against 3.195 ms) since form 1 reads its fragments without a compiler-inserted drain of the ring. */
+ *   (ABI 7-9 had a form 2, 256 x 256 tiles on one 16-wave workgroup per CU: measured slower than form 1 in the MCAN step,
+ *   3.231 against 3.195 ms, and removed in ABI 10.) */
 typedef struct {
   const void* dy;   /* [M,N], row stride lddy */
   const void* x;    /* [M,K], row stride ldx  */

@@ -265,12 +265,9 @@ int ovqa_grouped_linear_bwd_weight(int dtype, const ovqa_wgrad_problem* problems
   OVQA_REQUIRE(n_tiles >= 0 && (n_tiles == 0 || (problems_dev && tiles_dev)), OVQA_ERR_BAD_ARG,
                "grouped_linear_bwd_weight: bad argument");
   OVQA_REQUIRE(n_tiles < (1ll << 31), OVQA_ERR_UNSUPPORTED, "grouped_linear_bwd_weight: too many tiles");
-  OVQA_REQUIRE(form >= 0 && form <= 2, OVQA_ERR_BAD_ARG, "grouped_linear_bwd_weight: form must be 0, 1 or 2");
-  OVQA_REQUIRE(form != 2 || !force_simple(), OVQA_ERR_UNSUPPORTED,
-               "grouped_linear_bwd_weight: the 256 x 256 tile form has no register-staged fallback (OVQA_FORCE_SIMPLE)");
+  OVQA_REQUIRE(form == 0 || form == 1, OVQA_ERR_BAD_ARG, "grouped_linear_bwd_weight: form must be 0 or 1");
   g_dispatch = "mfma";
-  return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, form != 0 && !force_simple(), form == 2,
-                                  as_stream(stream));
+  return ovqa::mfma_grouped_wgrad(problems_dev, tiles_dev, n_tiles, form != 0 && !force_simple(), as_stream(stream));
 }
 
 int ovqa_grouped_linear_bwd_weight_adam(int dtype, const ovqa_wgrad_problem* problems_dev, const int32_t* tiles_dev,

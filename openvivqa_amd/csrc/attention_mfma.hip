@@ -2057,28 +2057,15 @@ int launch_bwd_two(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   }
 }
 
-// OVQA_ROLES_DMA: the role-split backward fills its Q / dO / K / V images by direct-to-LDS loads (1, default) or through
-// registers (0).  In the MCAN step, same box: 26.07 -> 25.55 us per launch with the fc_o projection inside, 21.13 -> 21.15
-// without it (round 5: the staging is bound by the CU's fetch path either way).
-static int roles_dma() {
-  static const int v = [] {
-    const char* e = getenv("OVQA_ROLES_DMA");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-
+// (The role-split backward fills its Q / dO / K / V images by direct-to-LDS loads where the mask is a key row; through
+// registers -- OVQA_ROLES_DMA=0 of round 5 -- it measured 26.07 against 25.55 us per launch with the fc_o projection inside,
+// 21.13 against 21.15 without: the staging is bound by the CU's fetch path either way.)
 int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
   if (a.dk == 96) return launch_bwd_two<96>(a, st);
   if (a.dk == 128) return launch_bwd_two<128>(a, st);
   const int64_t nprob = (int64_t)a.B * a.H;
   const bool rowmask = a.msq == 0;
-  static int merged = -1;
-  if (merged < 0) {
-    const char* e = getenv("OVQA_ATTN_BWD_MERGED");
-    merged = e ? atoi(e) : 1;
-  }
-  if (merged && a.nk > 32 && a.nk <= 128 && a.nq <= 128 && merged != 2) {  // one launch, role-split waves
+  if (a.nk > 32 && a.nk <= 128 && a.nq <= 128) {  // one launch, role-split waves
     const int nqt = (a.nq + 31) / 32, nkt = (a.nk + 31) / 32;
     const size_t lds = (size_t)(2 * nqt * 32 + 2 * nkt * 32) * 128 + (size_t)(nkt * 32 + 2 * nqt * 32) * 4;
     const DoBwdArgs g0{nullptr, 0, nullptr, 0, a, 0};
@@ -2089,18 +2076,18 @@ int launch_bwd(const ovqa::AttnBwdArgs& a, hipStream_t st) {
     OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<NQ, NK, RM>), dim3((unsigned)nprob), dim3(512), lds, st, g0, nqt, nkt); \
   }
     if (nqt == 4 && nkt == 4) {  // the 100 x 100 image self-attention: fully unrolled tile loops
-      if (rowmask && roles_dma()) {
+      if (rowmask) {
         int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, 0, true>, lds, "attention_bwd(mfma,roles)");
         if (rc != OVQA_OK) return rc;
         OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, 0, true>), dim3((unsigned)nprob), dim3(512), lds, st, g0, nqt, nkt);
-      } else if (rowmask) OVQA_ROLES(4, 4, true) else OVQA_ROLES(4, 4, false)
+      } else OVQA_ROLES(4, 4, false)
     } else {
       if (rowmask) OVQA_ROLES(0, 0, true) else OVQA_ROLES(0, 0, false)
     }
 #undef OVQA_ROLES
     return ovqa_check_launch("attention_bwd(mfma,roles)");
   }
-  if (merged && a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
+  if (a.nk <= 32 && a.nq <= 128) {  // one launch for dQ, dK and dV
     int W = (a.nq + 31) / 32;
     if (W == 3) W = 4;
     // problems per workgroup (compile-time in the kernel): 4 / W; single-tile problems 2 at a time when 4 at a time
@@ -2179,37 +2166,21 @@ int mfma_attention_qkv_fwd(const AttnArgs& a, const void* x, int64_t ldx, const 
     if (rc != OVQA_OK) return rc;                                                                                  \
     OVQA_LAUNCH_TIMED((attn_qkv_fwd_mfma_kernel<RPV, SV, true, BKV, NBV>), grid, dim3(512), lds, st, g);          \
   }
-  static int form = -1;
-  if (form < 0) {
-    const char* e = getenv("OVQA_QKV_FORM");  // A/B switch for the long-sequence form
-    form = e ? atoi(e) : 1;
-  }
   const bool k64 = Dm % 64 == 0;
   // short sequences: 4 samples per workgroup, or 2 when 4 would leave CUs without a workgroup (64 samples x 8 heads:
-  // 128 -> 256 workgroups, 3.455 -> 3.442 ms per MCAN step; K steps of 64 made no difference here)
-  // (OVQA_QKV_TEXT_FORM, round 5: bytes in flight per CU of the two-sample form -- 0: K steps of 32 in a ring of 4 (48 KB in
-  // flight; rounds 2-4), 1: K steps of 64 in a ring of 3 (64 KB), 2 (default): K steps of 64 in a ring of 4 (96 KB), 3: K
-  // steps of 32 in a ring of 6 (80 KB).  In the MCAN step, same box: 10.7-11.0 / 10.25 / 10.09 us per launch; the K loop is
-  // 5.7 of the kernel's 7.9 us per workgroup (phase probe) at 45 GB/s per CU, one workgroup per CU)
-  static int tform = -1;
-  if (tform < 0) {
-    const char* e = getenv("OVQA_QKV_TEXT_FORM");
-    tform = e ? atoi(e) : 2;
-  }
+  // 128 -> 256 workgroups, 3.455 -> 3.442 ms per MCAN step).  The two-sample form keeps 96 KB in flight per CU: K steps of
+  // 64 in a ring of 4 (round 5, same box: 10.09 us per launch against 10.7-11.0 with K steps of 32 in a ring of 4, 10.25
+  // with 64 / ring of 3, 10.8 with 32 / ring of 6; the K loop is 5.7 of the kernel's 7.9 us per workgroup at 45 GB/s per CU)
   if (a.nq <= 32 && (int64_t)((a.B + 3) / 4) * a.H < 256) {
-    if (tform == 1 && k64) OVQA_QKV(32, 2, 64, 3)
-    else if (tform == 2 && k64) OVQA_QKV(32, 2, 64, 4)
-    else if (tform == 3) OVQA_QKV(32, 2, 32, 6)
+    if (k64) OVQA_QKV(32, 2, 64, 4)
     else OVQA_QKV(32, 2, 32, 4)
   }
   else if (a.nq <= 32) OVQA_QKV(32, 4, 32, 4)
   else if (a.nq <= 64) OVQA_QKV(64, 4, 32, 4)
   // 65-128 positions (100 regions): one sample per workgroup, K steps of 64, two workgroups per CU: 3.408 -> 3.382 ms
-  // per MCAN step (two samples per workgroup with K steps of 64: 3.390)
-  else if (form == 1 && k64) OVQA_QKV(128, 1, 64, 2)
-  else if (form == 2 && k64) OVQA_QKV(128, 2, 64, 2)
-  // (round 5 measured one sample with K steps of 32 in a ring of 4 / 3 -- 60 / 40 KB in flight per workgroup instead of 40,
-  // still two workgroups per CU: 28.7 / 28.8 against 26.7 us per launch in the step: removed)
+  // per MCAN step (two samples per workgroup with K steps of 64: 3.390; one sample with K steps of 32 in a ring of 4 / 3:
+  // 28.7 / 28.8 against 26.7 us per launch)
+  else if (k64) OVQA_QKV(128, 1, 64, 2)
   else OVQA_QKV(128, 2, 32, 4)
 #undef OVQA_QKV
   return ovqa_check_launch("attention_qkv_fwd(mfma)");
@@ -2227,14 +2198,9 @@ bool mfma_attention_q_supported(const AttnArgs& a, int64_t Dm, int64_t ldx, int6
 int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const void* w, const float* bias, void* q,
                          int64_t ldq, int64_t Dm, hipStream_t st) {
   QAttnArgs g{(const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)q, ldq, a, (int)Dm};
-  static int nbuf = -1, pair = -1;
-  if (nbuf < 0) {
-    const char* e = getenv("OVQA_QATT_NBUF");  // ring depth of the projection loop (A/B switch)
-    nbuf = e ? atoi(e) : 3;
-    e = getenv("OVQA_QATT_PAIR");              // two heads per 16-wave workgroup (A/B switch)
-    pair = e ? atoi(e) : 1;
-  }
-  const int NHv = (pair && a.H % 2 == 0) ? 2 : 1;
+  // two heads per 16-wave workgroup where the head count is even, ring of three K steps in the projection loop (a ring of
+  // two and one head per 8-wave workgroup both measured slower in the step, rounds 3-4)
+  const int NHv = a.H % 2 == 0 ? 2 : 1;
   const dim3 grid((unsigned)a.B, (unsigned)(a.H / NHv));
 #define OVQA_QATT_L(NKTV, NBV, NHV)                                                                            \
   {                                                                                                            \
@@ -2245,13 +2211,10 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
     if (rc != OVQA_OK) return rc;                                                                              \
     OVQA_LAUNCH_TIMED((attn_q_fwd_mfma_kernel<NKTV, NBV, NHV>), grid, dim3(512 * NHV), lds, st, g);           \
   }
-#define OVQA_QATT(NKTV)                                                     \
-  {                                                                         \
-    if (NHv == 2) {                                                         \
-      if (nbuf == 3) OVQA_QATT_L(NKTV, 3, 2) else OVQA_QATT_L(NKTV, 2, 2)   \
-    } else {                                                                \
-      if (nbuf == 3) OVQA_QATT_L(NKTV, 3, 1) else OVQA_QATT_L(NKTV, 2, 1)   \
-    }                                                                       \
+#define OVQA_QATT(NKTV)                     \
+  {                                         \
+    if (NHv == 2) OVQA_QATT_L(NKTV, 3, 2)   \
+    else OVQA_QATT_L(NKTV, 3, 1)            \
   }
   if (a.nk <= 32) OVQA_QATT(1)
   else if (a.nk <= 64) OVQA_QATT(2)
@@ -2261,21 +2224,12 @@ int mfma_attention_q_fwd(const AttnArgs& a, const void* x, int64_t ldx, const vo
   return ovqa_check_launch("attention_q_fwd(mfma)");
 }
 
-// OVQA_DOBWD_ROLES: the 100 x 100 self-attention backward with the fc_o dX product inside (ring depth 2 or 3; 0 = off)
-static int dobwd_roles() {
-  static const int v = [] {
-    const char* e = getenv("OVQA_DOBWD_ROLES");
-    return e ? atoi(e) : 3;
-  }();
-  return v;
-}
-
 bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t lddy, int64_t ldwt, const void* dy,
                                      const void* wt) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   const bool guided = a.nq > 64 && a.nq <= 128, single = a.nq >= 1 && a.nq <= 32 && a.H % 2 == 0;
   // (round 5) 97-128 queries x 97-128 keys, the image self-attention: the role-split backward with the projection inside
-  const bool roles = dobwd_roles() && a.nq > 96 && a.nq <= 128 && a.nk > 96 && a.nk <= 128;
+  const bool roles = a.nq > 96 && a.nq <= 128 && a.nk > 96 && a.nk <= 128;
   return a.dk == 64 && a.dv == 64 && (roles || ((guided || single) && a.nk >= 1 && a.nk <= 32)) && a.msq == 0 &&
          a.d_att == nullptr && a.d_lse == nullptr && a.drop.p <= 0.f && Dm % 64 == 0 && Dm >= 64 && lddy % 8 == 0 &&
          ldwt % 8 == 0 && a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0 && a.lddq % 4 == 0 &&
@@ -2286,66 +2240,32 @@ bool mfma_attention_bwd_do_supported(const AttnBwdArgs& a, int64_t Dm, int64_t l
 int mfma_attention_bwd_do(const AttnBwdArgs& a, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, int64_t Dm,
                           hipStream_t st) {
   DoBwdArgs g{(const bf16*)dy, lddy, (const bf16*)wt, ldwt, a, (int)Dm};
-  static int pair = -1;
-  if (pair < 0) {
-    // two heads per 16-wave workgroup (1) or one head per 8-wave workgroup, two workgroups per CU (0, the default since
-    // the staging became one round of loads: 3.241 / 3.239 against 3.265 / 3.256 ms per MCAN step; the forward form keeps
-    // the pair: OVQA_QATT_PAIR=0 there costs what this gains)
-    const char* e = getenv("OVQA_DOBWD_PAIR");
-    pair = e ? atoi(e) : 0;
-  }
   if (a.nk > 32) {  // the role-split form (image self-attention)
     const size_t img = (size_t)(2 * 128 + 2 * 128) * 128 + (size_t)(128 + 2 * 128) * 4;
     const size_t stage = (size_t)(64 + 128) * 64 * 2;
-    const int form = dobwd_roles();  // ring depth 2 | 3, + 10: staging requests in front of the projection loop
-    const int nbuf = form % 10 == 2 ? 2 : 3;
-    const size_t lds = nbuf * stage > img ? nbuf * stage : img;
-#define OVQA_DOROLES(F)                                                                                              \
-  {                                                                                                                  \
-    int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, F>, lds, "attention_bwd_do(roles)");                  \
-    if (rc != OVQA_OK) return rc;                                                                                    \
-    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, F>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4); \
-  }
-    if (roles_dma() && form % 10 != 2 && form < 10) {
-      int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>, lds, "attention_bwd_do(roles)");
-      if (rc != OVQA_OK) return rc;
-      OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4);
-    } else if (form == 2) OVQA_DOROLES(2) else if (form == 12) OVQA_DOROLES(12) else if (form == 13) OVQA_DOROLES(13) else OVQA_DOROLES(3)
-#undef OVQA_DOROLES
+    // ring of three K steps in the projection loop, images filled by direct-to-LDS loads (round 5, same box: 25.6 us per
+    // launch; ring of 2: 28.7; staging requests in front of the projection loop: 27.8; images through registers: 26.1)
+    const size_t lds = 3 * stage > img ? 3 * stage : img;
+    int rc = ensure_lds(attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>, lds, "attention_bwd_do(roles)");
+    if (rc != OVQA_OK) return rc;
+    OVQA_LAUNCH_TIMED((attn_bwd_roles_mfma_kernel<4, 4, true, 3, true>), dim3((unsigned)a.B, (unsigned)a.H), dim3(512), lds, st, g, 4, 4);
     return ovqa_check_launch("attention_bwd_do(mfma,roles)");
   }
   if (a.nq <= 32) {  // single query tile (20 x 20): two heads per 4-wave workgroup
     const size_t stage1 = (size_t)(128 + 32) * 64 * 2;
     const size_t prob1 = (size_t)(2 * 32 + 2 * 32) * 128 + 32 * 4 + 2 * 32 * 4 + 4096 * 4;
-    const size_t lds1 = 3 * stage1 > 2 * prob1 ? 3 * stage1 : 2 * prob1;
-    // OVQA_DOBWD1_NBUF: ring depth of the projection loop (3, 4 or 5 K steps of 20 KB; in the MCAN step 10.35-10.54 / 9.9 us
-    // per launch with 3 / 4, round 5)
-    static int nb1 = -1;
-    if (nb1 < 0) {
-      const char* e = getenv("OVQA_DOBWD1_NBUF");
-      nb1 = e ? atoi(e) : 4;
-      if (nb1 != 3 && nb1 != 5) nb1 = 4;
-    }
-    const size_t ldsn = (size_t)nb1 * stage1 > 2 * prob1 ? (size_t)nb1 * stage1 : 2 * prob1;
-#define OVQA_DO1(NB)                                                                                                   \
-  {                                                                                                                    \
-    int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<NB>, ldsn, "attention_bwd_do");                                \
-    if (rc != OVQA_OK) return rc;                                                                                      \
-    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk1_mfma_kernel<NB>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), ldsn, st, g); \
-  }
-    if (nb1 == 4) OVQA_DO1(4) else if (nb1 == 5) OVQA_DO1(5) else OVQA_DO1(3)
-#undef OVQA_DO1
-    (void)lds1;
+    // ring of four K steps of 20 KB in the projection loop (in the MCAN step 9.9 us per launch against 10.35-10.54 with
+    // three, 10.6 with five: round 5)
+    const size_t ldsn = 4 * stage1 > 2 * prob1 ? 4 * stage1 : 2 * prob1;
+    int rc = ensure_lds(attn_bwd_do_smallk1_mfma_kernel<4>, ldsn, "attention_bwd_do");
+    if (rc != OVQA_OK) return rc;
+    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk1_mfma_kernel<4>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(256), ldsn, st, g);
     return ovqa_check_launch("attention_bwd_do(mfma)");
   }
   const size_t prob = (size_t)(2 * 128 + 2 * 32) * 128 + 32 * 4 + 2 * 128 * 4 + 4096 * 4;
-  if (pair && a.H % 2 == 0) {
-    const size_t stage = (size_t)(128 + 128) * 64 * 2;
-    const size_t lds = 3 * stage > 2 * prob ? 3 * stage : 2 * prob;
-    int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 2>, lds, "attention_bwd_do");
-    if (rc != OVQA_OK) return rc;
-    OVQA_LAUNCH_TIMED((attn_bwd_do_smallk_mfma_kernel<3, 2>), dim3((unsigned)a.B, (unsigned)(a.H / 2)), dim3(1024), lds, st, g);
-  } else {
+  // one head per 8-wave workgroup, two workgroups per CU (two heads per 16-wave workgroup: 3.265 / 3.256 against
+  // 3.241 / 3.239 ms per MCAN step since the staging became one round of loads)
+  {
     const size_t stage = (size_t)(64 + 128) * 64 * 2;
     const size_t lds = 3 * stage > prob ? 3 * stage : prob;
     int rc = ensure_lds(attn_bwd_do_smallk_mfma_kernel<3, 1>, lds, "attention_bwd_do");

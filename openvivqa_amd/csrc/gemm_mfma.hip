@@ -330,20 +330,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // bytes per K-step and CU: the per-CU L2->LDS path, not the matrix pipe, bounds these kernels).
 // BR = rows of the r (P) operand per tile: 128, or 64 with 4 waves and BC = 32 (the M = 1280 products: twice the
 // workgroups again).
-// KSP = 2 (8 waves): the waves form TWO 2 x 2 grids, one per 32-deep half of every K tile (waves 0-3 take ks = 0, waves 4-7
-// ks = 1): a wave's tile is twice as large (64 x 64 / 64 x 32 instead of 64 x 32 / 64 x 16), so the workgroup reads
-// 64 / 48 KB of fragments per K tile instead of 96 / 80 -- the LDS port (DMA writes + fragment reads, ~450 GB/s per CU)
-// is what the main loop of these kernels runs into -- while 8 waves still cover each other's latencies.  The two partial
-// sums of an output element meet once, after the K loop, through the (then idle) ring buffers: each wave of a pair hands
-// the other one half of its accumulators and finishes the other half.
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128, int KSP = 1>
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, bool COLSUM, int NBUF, int NW, int BC = 128, int BR = 128>
 __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0, Epi& epi, char* smem) {
   static_assert(BC == 128 || ((BC == 64 || BC == 32) && NW == 8 && !Q_KMAJOR) || ((BC == 32 || BC == 64) && NW == 4 && !Q_KMAJOR),
                 "unsupported tile");
-  static_assert(NW == 4 || NW == 8 || (NW == 16 && BC == 128 && BR == 128 && KSP == 1), "4, 8 or (128 x 128) 16 waves");
+  static_assert(NW == 4 || NW == 8 || (NW == 16 && BC == 128 && BR == 128), "4, 8 or (128 x 128) 16 waves");
   static_assert(BR == 128 || (BR == 64 && NW == 4 && (BC == 32 || BC == 64) && !P_KMAJOR), "unsupported tile");
-  static_assert(KSP == 1 || (KSP == 2 && NW == 8 && BC >= 64 && BR == 128), "k-split form: 8 waves");
-  constexpr int NWT = NW / KSP;  // waves of one tile grid
+  constexpr int NWT = NW;
   constexpr int WC = NWT == 16 ? 4 : (NWT == 8 ? (BC >= 64 ? 4 : BC / 16) : 2);  // wave grid: WC along c x WR along r
   constexpr int WR = NWT / WC;
   constexpr int NI = BC / (16 * WC);   // 16-wide c sub-tiles per wave
@@ -357,8 +350,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   constexpr bool WIDE = !P_KMAJOR && Epi::kWide;  // 8 consecutive r per lane (see perm32)
   static_assert(!WIDE || NJ % 2 == 0, "wide epilogue pairs the r sub-tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wt = KSP == 1 ? wave : (wave & (NWT - 1)), ksel = KSP == 1 ? 0 : wave / NWT;
-  const int wc = wt / WR, wr = wt % WR;
+  const int wc = wave / WR, wr = wave % WR;
 
   f32x4 acc[NJ][NI];
 #pragma unroll
@@ -381,7 +373,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   // nothing (those LDS rows stay whatever they were: every output row depends on its own c row only, and the epilogue
   // drops the rows past c_hi).
   // (the 8-wave form with a ring of 2 can do the same -- its waits are vmcnt(0) -- but the host never asks it to)
-  constexpr bool CSTEP = !Q_KMAJOR && BC == 128 && KSP == 1 && (NW == 16 || (NW == 8 && NBUF == 2));
+  constexpr bool CSTEP = !Q_KMAJOR && BC == 128 && (NW == 16 || (NW == 8 && NBUF == 2));
   constexpr int QPW = QCH / NW;  // Q pieces per wave (CSTEP: 1 or 2)
   const int c_rows = (CSTEP && g.c_step) ? g.c_step : BC;
   const int c_hi = min(g.C, c0 + c_rows);
@@ -427,8 +419,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     const char* Ps = smem + (kt % NBUF) * STAGE;
     const char* Qs = Ps + PT_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2 / KSP; kk++) {
-      const int ks = KSP == 1 ? kk : ksel;
+    for (int ks = 0; ks < 2; ks++) {
       bf16x8 pf[NJ], qf[NI];
       if constexpr (P_KMAJOR && Q_KMAJOR) {  // (the grouped dW: untracked reads, one hand-placed wait -- see frag_tr_nowait)
         bf16x4 plo[NJ], phi[NJ], qlo[NI], qhi[NI];
@@ -467,7 +458,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
     }
   }
   OVQA_GPROBE(3);
-  if constexpr (COLSUM && KSP == 1) {
+  if constexpr (COLSUM) {
     if (do_colsum && lane < 16) {
 #pragma unroll
       for (int i = 0; i < NI; i++) {
@@ -476,70 +467,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
       }
     }
   }
-  if constexpr (COLSUM && KSP == 2) {
-    // the two k-halves of the column sums meet through LDS first (workgroup-uniform condition around the barriers)
-    if (r0 == 0 && epi.wants_colsum()) {
-      __builtin_amdgcn_s_barrier();  // the last K tile's fragments are consumed
-      float* cx = reinterpret_cast<float*>(smem);
-      if (ksel == 1 && wr == 0 && lane < 16) {
-#pragma unroll
-        for (int i = 0; i < NI; i++) cx[(wc * NI + i) * 16 + lane] = cs[i][0];
-      }
-      __syncthreads();
-      if (ksel == 0 && wr == 0 && lane < 16) {
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-          const int c = c0 + wc * (NI * 16) + i * 16 + lane;
-          if (c < g.C) epi.colsum(c, cs[i][0] + cx[(wc * NI + i) * 16 + lane]);
-        }
-      }
-    }  // (the exchange below opens with a barrier: cx is read before it is overwritten)
-  }
   epi.init();
-  if constexpr (KSP == 2) {
-    // the pair (wave, wave ^ NWT) holds the two k-halves of the same 64 x (NI * 16) outputs: wave `ksel` keeps the c
-    // sub-tiles [ksel * NI/2, ..) and sends the others.  Slot of (sending wave, j, ih): 1 KiB, 16 B per lane.
-    static_assert(KSP == 1 || NI % 2 == 0, "k-split pairs split the c sub-tiles");
-    constexpr int NH = NI / 2;
-    static_assert(KSP == 1 || NW * NJ * NH * 1024 <= NBUF * STAGE, "exchange area fits in the ring");
-    __builtin_amdgcn_s_barrier();  // every wave is done with the last K tile's fragments
-    f32x4* xch = reinterpret_cast<f32x4*>(smem);
-#pragma unroll
-    for (int j = 0; j < NJ; j++)
-#pragma unroll
-      for (int ih = 0; ih < NH; ih++)  // (a select, not a runtime index: the accumulators must stay in registers)
-        xch[((wave * NJ + j) * NH + ih) * 64 + lane] = ksel == 0 ? acc[j][NH + ih] : acc[j][ih];
-    __syncthreads();
-    const int partner = wave ^ NWT;
-    OVQA_GPROBE(5);
-#pragma unroll
-    for (int ih = 0; ih < NH; ih++) {
-      const int c = c0 + wc * (NI * 16) + (ksel * NH + ih) * 16 + (lane & 15);
-      f32x4 sum[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        const f32x4 o = xch[((partner * NJ + j) * NH + ih) * 64 + lane];
-        const f32x4 m = ksel == 0 ? acc[j][ih] : acc[j][NH + ih];
-        sum[j] = f32x4{m[0] + o[0], m[1] + o[1], m[2] + o[2], m[3] + o[3]};
-      }
-      if (c >= c_hi) continue;
-      if constexpr (WIDE) {
-#pragma unroll
-        for (int jp = 0; jp < NJ / 2; jp++) {
-          const int r = r0 + wr * (NJ * 16) + jp * 32 + (lane >> 4) * 8;
-          if (r < g.R) epi.wide(c, r, sum[2 * jp], sum[2 * jp + 1]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          const int r = r0 + wr * (NJ * 16) + j * 16 + (lane >> 4) * 4;
-          if (r < g.R) epi(c, r, sum[j]);
-        }
-      }
-    }
-    OVQA_GPROBE(4);
-    return;
-  }
   // (Round 6: every load of the wave's pieces first -- Epi::pre() with clamped addresses -- and then the guarded stores, as
   // the 256 x 256 tile does it, measured no gain here: 3.025-3.039 against 3.00-3.02 ms per step, three alternations on one
   // box.  With 2-4 pieces per lane and a second workgroup on the CU the store round trips behind the per-lane branches are
@@ -565,7 +493,7 @@ __device__ __forceinline__ void gemm_tile_glds(const GemmArgs& g, int c0, int r0
   OVQA_GPROBE(4);
 }
 
-template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128, int KSP = 1>
+template <bool P_KMAJOR, bool Q_KMAJOR, typename Epi, int NBUF, int NW, int BC = 128, int BR = 128>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = g.tiles_r * g.tiles_c;
@@ -575,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_glds_kernel(GemmArgs g, Epi
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
   const int tc = bid / g.tiles_r, tr = bid % g.tiles_r;
-  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR, KSP>(g, tc * (g.c_step ? g.c_step : BC), tr * BR, epi, smem);
+  gemm_tile_glds<P_KMAJOR, Q_KMAJOR, Epi, false, NBUF, NW, BC, BR>(g, tc * (g.c_step ? g.c_step : BC), tr * BR, epi, smem);
 }
 
 // ---- skinny products (a decoding step: M = batch * beam <= 256 activation rows against a whole weight matrix) ----------
@@ -984,7 +912,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(const ovqa
 }
 
 // The same grouped dW on the direct-to-LDS 8-wave tile (both operands k-major); needs M % 64 == 0 for every problem
-template <int NBUF, int KSP = 1>
+template <int NBUF>
 __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(const ovqa_wgrad_problem* __restrict__ probs,
                                                                               const int4* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -993,7 +921,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_glds_kernel(co
   const ovqa_wgrad_problem pr = probs[t.x];
   MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1};
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
-  gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128, KSP>(g, t.y * BT, t.z * BT, epi, smem);
+  gemm_tile_glds<true, true, MEpiWgrad, true, NBUF, 8, 128, 128>(g, t.y * BT, t.z * BT, epi, smem);
 }
 
 // ---- the optimiser step inside the grouped dW (round 5) -------------------------------------------------------------------
@@ -1046,7 +974,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_adam_kernel(co
   float* T = reinterpret_cast<float*>(smem);
   MEpiWgradAdam epi{pr.dw, pr.K, pr.accumulate & 1, pr.db, (pr.accumulate >> 1) & 1, fused ? T : nullptr, c0, r0};
   GemmArgs g{(const bf16*)pr.x, pr.ldx, (const bf16*)pr.dy, pr.lddy, pr.K, pr.N, pr.M, 0, 0};
-  gemm_tile_glds<true, true, MEpiWgradAdam, true, 2, 8, 128, 128, 1>(g, c0, r0, epi, smem);
+  gemm_tile_glds<true, true, MEpiWgradAdam, true, 2, 8, 128, 128>(g, c0, r0, epi, smem);
   if (!fused) return;
   __syncthreads();  // the tile is complete
   const AdamK ak = adam_consts(kc.lr, kc.lr_scale_ptr, kc.beta1, kc.beta2, kc.eps, kc.weight_decay, kc.grad_scale, kc.step_ptr);
@@ -1090,182 +1018,10 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_grouped_wgrad_adam_kernel(co
   }
 }
 
-// ---- 256 x 256 dW tiles: ONE 16-wave workgroup per CU (form 2 of the grouped launch; NOT the default) -------------------
-// Built when the 128 x 128 form (two co-resident workgroups per CU, 32 KB per 64-deep K step each) sat at 32 % matrix-pipe
-// occupancy: a 256 x 256 tile does four times the MFMA work on twice the bytes.
-//   * 4 x 4 wave grid, 64 x 64 outputs per wave (64 accumulator registers; 16 waves leave 128 VGPRs per lane);
-//   * operands arrive in 32-deep HALF steps -- four half images [32 k][128 columns] of 8 KB: x columns r0.., r0+128.., dy
-//     columns c0.., c0+128.. -- through a ring of 4 half steps (128 KB of the 160), three in flight while the fourth is
-//     consumed.  Same k-major image, swizzle and transposing fragment reads as the 128 x 128 form (a half image is the
-//     first 8 KB of a full one);
-//   * the fragment reads are inline asm with ONE hand-placed lgkmcnt wait tied to their registers: no compiler wait.
-// MEASURED (scripts/dw_bench.py, the MCAN step's 66 products, cold operands; profiles/README.md): 458-493 us against 549
-// for the 128 x 128 form as it was -- whose ring, it turned out while writing this one, was drained in every K step by a
-// compiler-inserted `s_waitcnt vmcnt(0)` in front of the ds_read_b64_tr_b16 builtin.  With untracked reads there too
-// (frag_tr_nowait) the 128 x 128 form takes 480 us and wins in the step (3.195 against 3.231 ms), so this form is opt-in
-// (OVQA_DW_TILE256).  Per 32-deep half step of its critical path (400 of them; 344 if the tiles balanced): fetch alone
-// 0.72 us (44 GB/s per CU = the chip's rate for one third HBM misses, two thirds L2 hits), LDS reads alone 0.39, MFMAs
-// alone 0.57, LDS + MFMA 0.87-0.90: the reads (every wave's 16 land at the end of the workgroup's read burst) and the
-// MFMAs do not overlap.  Tried on top, none faster in the step: counted waits in front of each group of MFMAs (-3 %,
-// LDS + MFMA only); a ring of 5; an 8-wave version with two fragment sets in registers, reads of half step h + 1 between
-// the MFMAs of h, MFMAs as inline asm (LDS + MFMA 0.87 again: with 2 waves per SIMD the b64 reads issue at half the rate,
-// MFMAs alone 0.71); two 8-wave groups in opposite phase (one group's reads beside the other's MFMAs).
-__device__ __forceinline__ void wgrad_tile256(const ovqa_wgrad_problem& pr, int c0, int r0, char* smem) {
-  constexpr int NBUF = 4;
-  constexpr int HIMG = TILE_BYTES / 2;  // 8 KiB: 32 k-rows x 128 columns
-  constexpr int HSTAGE = 4 * HIMG;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave >> 2, wr = wave & 3;
-  const int R = pr.K, C = pr.N;  // r: input features (x columns), c: output features (dy columns)
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias gradient = column sums of dy: the waves of the r0 == 0 tile that hold the first x rows add up the dy fragments
-  // they read anyway (a lane holds 8 k of one column: four VALU partials per lane, the four k-groups meet after the loop;
-  // the all-ones MFMA of gemm_tile would cost 16 more accumulator registers here)
-  const bool do_colsum = r0 == 0 && wr == 0 && pr.db != nullptr;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-
-  // The two 1 KiB chunks this wave brings in per half step: chunk q = 2 * wave + i of 32 -> half image q >> 3 = wave >> 2
-  // (waves 0-3 x columns r0.., 4-7 r0+128.., 8-11 dy columns c0.., 12-15 c0+128..), k-rows 4 (q & 7) .. +3 of it.
-  // Wave-uniform base and LDS slot, a 32-bit lane offset; only the k offset moves over the loop.
-  const bool isP = wave < 8;
-  const int64_t ld = isP ? pr.ldx : pr.lddy;
-  const char* gbase = reinterpret_cast<const char*>(isP ? pr.x : pr.dy);
-  const int cols = isP ? R : C;
-  const int col0 = (isP ? r0 : c0) + ((wave >> 2) & 1) * 128;
-  uint32_t goff[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int ci = (wave * 2 + i) & 7;
-    const int krow = ci * 4 + (lane >> 4), pos = lane & 15;
-    const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-    const int c = ((((pos >> 1) ^ f) << 1) | (pos & 1));
-    int col = col0 + c * 8;
-    col = col <= cols - 8 ? col : cols - 8;
-    goff[i] = (uint32_t)(((int64_t)krow * ld + col) * 2);
-  }
-  const int dst0 = (wave >> 2) * HIMG + ((wave * 2) & 7) * 1024;
-  const int64_t hstep = 64 * ld;  // bytes per 32-deep half step
-  auto issue = [&](int h) {
-    char* buf = smem + (h % NBUF) * HSTAGE + dst0;
-    const char* g = gbase + (int64_t)h * hstep;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      uint32_t o = goff[i];
-      asm volatile("" : "+v"(o));  // opaque: two 32-bit offsets stay live, not two 64-bit induction pointers
-      __builtin_amdgcn_global_load_lds((gbl_void*)(g + o), (lds_void*)(buf + i * 1024), 16, 0, 0);
-    }
-  };
-  // fragment addresses inside a half step (see frag<true>): rows base .. base+15 of the wave's half image
-  uint32_t pa[4], qa[4];
-  {
-    const int kr = 8 * (lane >> 4) + ((lane >> 2) & 3);
-    const int sub = (lane & 1) * 8, chl = (lane & 3) >> 1;
-    const uint32_t s0 = lds_offset(smem);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      pa[j] = s0 + (wr >> 1) * HIMG + km_off(kr, (((wr & 1) * 64 + j * 16) >> 3) + chl) + sub;
-      qa[j] = s0 + (2 + (wc >> 1)) * HIMG + km_off(kr, (((wc & 1) * 64 + j * 16) >> 3) + chl) + sub;
-    }
-  }
-  const int nh = pr.M / 32;
-#pragma unroll
-  for (int p = 0; p < NBUF - 1; p++)
-    if (p < nh) issue(p);
-
-  bf16x4 pl[4], ph[4], ql[4], qh[4];
-  auto reads = [&](int h) {
-    const uint32_t so = (uint32_t)((h % NBUF) * HSTAGE);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      pl[j] = lds_read_tr(pa[j] + so);
-      ph[j] = lds_read_tr_1k(pa[j] + so);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      ql[i] = lds_read_tr(qa[i] + so);
-      qh[i] = lds_read_tr_1k(qa[i] + so);
-    }
-    // the compiler knows nothing of these reads: the wait is tied to their registers, ahead of the first use
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]), "+v"(pl[3]), "+v"(ph[0]), "+v"(ph[1]), "+v"(ph[2]), "+v"(ph[3])
-                 :
-                 : "memory");
-    asm volatile(""
-                 : "+v"(ql[0]), "+v"(ql[1]), "+v"(ql[2]), "+v"(ql[3]), "+v"(qh[0]), "+v"(qh[1]), "+v"(qh[2]), "+v"(qh[3])
-                 :
-                 : "memory");
-  };
-  auto mfmas = [&]() {
-    bf16x8 pf[4], qf[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      pf[j] = bf16x8{pl[j][0], pl[j][1], pl[j][2], pl[j][3], ph[j][0], ph[j][1], ph[j][2], ph[j][3]};
-      qf[j] = bf16x8{ql[j][0], ql[j][1], ql[j][2], ql[j][3], qh[j][0], qh[j][1], qh[j][2], qh[j][3]};
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j], qf[i], acc[j][i], 0, 0, 0);
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const uint4 w = __builtin_bit_cast(uint4, qf[i]);
-        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-        float t = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; e++) t += __uint_as_float(ws[e] << 16) + __uint_as_float(ws[e] & 0xffff0000u);
-        cs[i] += t;
-      }
-    }
-  };
-  for (int h = 0; h < nh; h++) {
-    // half step h has landed: at most the NBUF - 2 younger ones (2 loads each) may still be in flight
-    if (h + NBUF - 2 >= nh) wait_vmcnt<0>();
-    else wait_vmcnt<2 * (NBUF - 2)>();
-    __builtin_amdgcn_s_barrier();  // ... for every wave, and every wave has read half step h - 1 (the slot refilled now)
-    if (h + NBUF - 1 < nh) issue(h + NBUF - 1);
-    reads(h);
-    mfmas();
-  }
-  if (do_colsum) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float v = cs[i];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      const int c = c0 + wc * 64 + i * 16 + lane;
-      if (lane < 16 && c < C) pr.db[c] = (pr.accumulate & 2) ? pr.db[c] + v : v;
-    }
-  }
-  MEpiWgrad epi{pr.dw, pr.K, pr.accumulate & 1, nullptr, 0};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int c = c0 + wc * 64 + i * 16 + (lane & 15);
-    if (c >= C) continue;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int r = r0 + wr * 64 + j * 16 + (lane >> 4) * 4;
-      if (r < R) epi(c, r, acc[j][i]);
-    }
-  }
-}
-
-__global__ __launch_bounds__(1024) void gemm_bf16_grouped_wgrad256_kernel(const ovqa_wgrad_problem* __restrict__ probs,
-                                                                          const int4* __restrict__ tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int4 t = tiles[blockIdx.x];
-  if (t.x < 0) return;
-  const ovqa_wgrad_problem pr = probs[t.x];
-  wgrad_tile256(pr, t.y * 256, t.z * 256, smem);
-}
-
+// (Rounds 4-5 carried a 256 x 256-tile form of the grouped dW here -- one 16-wave workgroup per CU, ring of four 32-deep half
+// steps -- and a 256 x 128 one: 458-493 and 424 us against 480 / 393 for the 128 x 128 form below once that one read its
+// fragments without the compiler's ring-draining wait; the numbers and the per-half-step decomposition are in
+// profiles/README.md.  Removed in round 6 with the other forms that lost.)
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWgrad epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tc = blockIdx.x / g.tiles_r, tr = blockIdx.x % g.tiles_r;
@@ -1274,21 +1030,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_kernel(GemmArgs g, MEpiWg
 
 // Rows of the c operand a 128-row tile should OWN so that the grid fills whole rounds of `per_cu` workgroups per CU (0: keep
 // full tiles): 6400 x 512 on the 16-wave form (one per CU): 4 x 50 tiles on 200 of 256 CUs -> 4 x 64 tiles of 100 rows:
-// step 3.151 / 3.165 -> 3.093 / 3.105 / 3.126 ms on one box, 3.170 -> 3.153 on another.  OVQA_GEMM_CSTEP=0 switches it off.  NOT for the 8-wave form with two
+// step 3.151 / 3.165 -> 3.093 / 3.105 / 3.126 ms on one box, 3.170 -> 3.153 on another.  NOT for the 8-wave form with two
 // workgroups per CU (6400 x 2048: 16 x 50 = 800 tiles = 1.56 rounds -> 16 x 64 = two rounds exactly): measured +0.12 ms
 // per step -- its second, partial round runs with the CUs half empty and therefore fast, which two full rounds of
 // smaller tiles (more weight-tile traffic) do not beat.
-inline int owned_rows(int tiles_r, int tiles_c, int64_t C, int per_cu) {
-  static int cus = -1, on = -1;
+inline int device_cus() {
+  static int cus = -1;
   if (cus < 0) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;
-    const char* e = getenv("OVQA_GEMM_CSTEP");
-    on = e ? atoi(e) : 1;
   }
-  if (!on) return 0;
-  const int slots = cus * per_cu, tiles = tiles_r * tiles_c;
+  return cus;
+}
+
+inline int owned_rows(int tiles_r, int tiles_c, int64_t C, int per_cu) {
+  const int slots = device_cus() * per_cu, tiles = tiles_r * tiles_c;
   if (tiles % slots == 0) return 0;
   const int rounds = (tiles + slots - 1) / slots;
   const int n_c = rounds * slots / tiles_r;  // c tiles that fill `rounds` rounds
@@ -1297,102 +1054,13 @@ inline int owned_rows(int tiles_r, int tiles_c, int64_t C, int per_cu) {
   return (step >= 64 && step < BT) ? step : 0;
 }
 
-inline int small_tile_threshold() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_SMALL_TILES");
-    v = e ? atoi(e) : 320;
-  }
-  return v;
-}
-
-inline int tiny_tile_threshold() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_TINY_TILES");
-    v = e ? atoi(e) : 330;
-  }
-  return v;
-}
-
-// ring depth of the small-tile kernels (latency-bound: few MFMAs per K step, so the round trip of the next
-// tile must be covered by more than one tile in flight).  MEASURED in the MCAN step (operands cold: produced by
-// the previous kernel on other XCDs): (small, tiny) = (2,2) 4.905 ms, (3,3) 4.766, (3,4) 4.721, (4,4) 5.132
-// (BC = 64 with 4 stages leaves one workgroup per CU); an L2-warm microbenchmark prefers 2.
-// the 128 x 32 tier as 64 x 32 tiles with 4 waves (A/B switch; on)
-inline int micro_tiles() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_MICRO_TILES");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-inline int small_nbuf() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_SMALL_NBUF");
-    v = e ? atoi(e) : 3;
-  }
-  return v;
-}
-inline int tiny_nbuf() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_TINY_NBUF");
-    v = e ? atoi(e) : 4;
-  }
-  return v;
-}
-
-// k-split wave grids (gemm_tile_glds, KSP = 2): bit 0 = the 64 x 128 tier, bit 1 = the 128 x 128 tier.
-// MEASURED (round 3): the K loop gets 10-13 % shorter, the exchange adds ~0.6 us per workgroup; 8192 x 4096 x 4096
-// 939 -> 1005 TFLOP/s, 6400 x 512 x 2048 24.9 -> 23.2 us, 6400 x 512 x 512 8.7 -> 9.0 us; in the MCAN step nothing
-// (3.35 / 3.37 / 3.34 / 3.36 ms for gemm / dW k-split off-off / on-off / off-on / on-on, two alternations): the main
-// loops sit at the direct-to-LDS stream's own rate (~100 GB/s per CU), not at the LDS read port.  Default: the
-// 128 x 128 tier for reductions >= OVQA_GEMM_KSPLIT_MINK (no product of the MCAN step qualifies); dW: off.
-inline int ksplit() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_KSPLIT");
-    v = e ? atoi(e) : 2;
-  }
-  return v;
-}
-
-// reductions shorter than this keep the plain wave grid: the exchange after the K loop costs ~0.6 us, the K loop gains
-// ~0.06 us per 64-deep step (scripts/gemm_phase_probe.py: 6400 x 512 <- 512: 5.56 -> 5.72 us per workgroup, <- 2048: 18.5 -> 17.2)
-inline int ksplit_min_k() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_KSPLIT_MINK");
-    v = e ? atoi(e) : 1024;
-  }
-  return v;
-}
-
-// activation rows up to which a row-major x row-major product takes the one-wave-per-tile form (0 = never).
-// MEASURED (bench.py --workload decode, B = 64): 64 rows (greedy) 250 -> 197 us per decoding step; 192 rows (beam 3)
-// 259 -> 258: there the 64 x 32 tiles are as fast (512-wide outputs 5.6 vs 5.0 us, 2048-wide ones 7.9 vs 5.2: 1536
-// one-wave workgroups queue up six deep per CU), so the form stops at 128 rows.
-inline int skinny_max_rows() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_SKINNY_MAXROWS");
-    v = e ? atoi(e) : 128;
-  }
-  return v;
-}
-
-inline int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("OVQA_GEMM_VARIANT");
-    v = e ? atoi(e) : 12;
-  }
-  return v;
-}
+// Tile tiers of the k-contiguous x k-contiguous products (measured in the MCAN step, rounds 2-5; the forms that lost -- rings
+// of other depths, 4-wave 128 x 128 tiles, 64 x 64 tiles, k-split wave grids -- are gone from the source, their numbers
+// are in profiles/README.md):
+constexpr int kSmallTiles = 320;    // at most this many 128 x 128 tiles: 128 x 64 tiles (twice the workgroups) ...
+constexpr int kTinyTiles = 330;     // ... and at most this many of those: 64 x 32 tiles with 4 waves, ring of 4
+constexpr int kTinyMaxRows = 1024;  // products with more weight rows leave the tiny tier for 16-wave 128 x 128 tiles
+constexpr int kSkinnyMaxRows = 128; // activation rows up to which a product takes the one-wave-per-tile form (decoding)
 
 template <typename K>
 inline int set_max_lds(K kernel, size_t bytes) {
@@ -1407,44 +1075,33 @@ inline int set_max_lds(K kernel, size_t bytes) {
   return OVQA_OK;
 }
 
-// variant 0: register-staged (any K % 8 == 0); NBUF = variant % 10 in {2,3}: direct-to-LDS ring (K % 64 == 0);
-// variant >= 10: 8 waves per tile instead of 4.
-// wide_ok: every tensor the epilogue touches has 16-byte aligned rows (the direct-to-LDS kernels with a row-major
-// P use the 8-feature epilogue); otherwise the register-staged kernel (8-byte epilogue accesses) runs.
+// K % 64 == 0 and (for the 8-feature epilogues of a row-major P) 16-byte aligned rows of every tensor the epilogue touches:
+// the direct-to-LDS forms below; anything else: the register-staged kernel (any K % 8 == 0, 8-byte epilogue accesses).
 template <bool PK, bool QK, typename Epi>
 int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, int64_t C, int64_t K, Epi epi,
            hipStream_t st, const char* what, bool wide_ok = true) {
   GemmArgs g{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K,
              (int)((R + BT - 1) / BT), (int)((C + BT - 1) / BT)};
-  const int variant = (K % BK == 0 && (PK || !Epi::kWide || wide_ok)) ? gemm_variant() : 0;
+  const bool glds = K % BK == 0 && (PK || !Epi::kWide || wide_ok);
   // few 128x128 tiles (the M = 1280 question stack): halve the c tile -> twice the workgroups
-  const bool small_c = !QK && variant >= 10 && g.tiles_r * g.tiles_c <= small_tile_threshold();
-  // OVQA_GEMM_TINY_MAXR (round 5): products with more than this many weight rows leave the tiny tier -- the question
-  // stack's 1280 x 2048 outputs (fc1 forward, fc2 dX) run as 160 tiles of 128 x 128 on 16 waves instead of 1280 tiles of
-  // 64 x 32: 262 KB instead of 5 x 98 KB through a CU's fetch path.  In the MCAN step, same box: GELU forward 11.84 -> 9.89
-  // us, dX 13.6 -> 10.3 us per launch, 31 us per step.  (The 1280 x 512 outputs stay on 320 tiles of 64 x 32: 64 x 64 tiles
-  // -- OVQA_GEMM_MICRO64, 160 workgroups, ring of 4 or 6 -- measured 14.0-14.5 against 13.3 us: ONE workgroup on a CU draws
-  // ~45 GB/s, two co-resident ones ~60 together, so fewer bytes per CU did not pay there.)
-  static int tiny_maxr = -1;
-  if (tiny_maxr < 0) {
-    const char* e = getenv("OVQA_GEMM_TINY_MAXR");
-    tiny_maxr = e ? atoi(e) : 1024;
-  }
-  // (only where the 128 x 128 tiling still has >= 128 tiles: a beam-3 decoding step's 192 x 4000 logits are 64 such tiles,
-  // and its decode got 9 % slower -- 296k -> 270k tokens/s -- before this condition)
+  const bool small_c = !QK && glds && g.tiles_r * g.tiles_c <= kSmallTiles;
+  // products with more than kTinyMaxRows weight rows leave the tiny tier -- the question stack's 1280 x 2048 outputs (fc1
+  // forward, fc2 dX) run as 160 tiles of 128 x 128 on 16 waves instead of 1280 tiles of 64 x 32: 262 KB instead of
+  // 5 x 98 KB through a CU's fetch path (GELU forward 11.84 -> 9.89 us, dX 13.6 -> 10.3 us per launch) -- but only where
+  // the 128 x 128 tiling still has >= 128 tiles (a beam-3 decoding step's 192 x 4000 logits are 64 such tiles: 9 % slower)
   const bool wide_enough = (int64_t)g.tiles_r * ((C + 127) / 128) >= 128;
-  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= tiny_tile_threshold() && (R <= tiny_maxr || !wide_enough);
+  const bool tiny_c = small_c && g.tiles_r * (int)((C + 63) / 64) <= kTinyTiles && (R <= kTinyMaxRows || !wide_enough);
   if (small_c) g.tiles_c = (int)((C + (tiny_c ? 31 : 63)) / (tiny_c ? 32 : 64));
   const dim3 grid(g.tiles_r * g.tiles_c);
-#define OVQA_GLDS_K(NBUF, NW, BCV, KSPV)                                                                            \
+#define OVQA_GLDS(NBUF, NW, BCV, BRV, GRID)                                                                         \
   {                                                                                                                \
-    const size_t lds = (size_t)NBUF * (TILE_BYTES + BCV * BK * 2);                                                 \
-    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, 128, KSPV>, lds);                       \
+    const size_t lds = (size_t)NBUF * (BRV * BK * 2 + BCV * BK * 2);                                               \
+    int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, BRV>, lds);                             \
     if (rc != OVQA_OK) return rc;                                                                                  \
-    OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, 128, KSPV>), grid, dim3(NW * 64), lds,    \
-                      st, g, epi);                                                                                 \
+    OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, NBUF, NW, BCV, BRV>), GRID, dim3(NW * 64), lds, st, g,   \
+                      epi);                                                                                        \
+    return ovqa_check_launch(what);                                                                                \
   }
-#define OVQA_GLDS(NBUF, NW, BCV) OVQA_GLDS_K(NBUF, NW, BCV, 1)
   if constexpr (!QK && !PK && Epi::kWide) {
     // 256 x 256 tiles on one 8-wave workgroup per CU (gemm_tile256.h, round 6) for long reductions on grids that fill whole
     // rounds of the chip: 8192 x 4096 x 4096 1290-1357 TFLOP/s against 900-995 on the 128 x 128 tiles (hipBLASLt 1424-1540).
@@ -1453,16 +1110,13 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     // element) has nothing to hide behind with one workgroup per CU, where two co-resident 128 x 128 workgroups hide each
     // other's: in the MCAN step 3.115 ms with fc1 forward + fc2 dX on this form, 3.06-3.08 with fc1 forward only, 3.05-3.06
     // without (same box, alternated).  OVQA_GEMM_T256=0 switches the form off.
-    static int t256 = -1, cus = 256;
+    static int t256 = -1;
     if (t256 < 0) {
       const char* e = getenv("OVQA_GEMM_T256");
       t256 = e ? atoi(e) : 1;
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        cus = 256;
     }
-    if (t256 && variant >= 10 && K >= 1024 && R % 8 == 0 && ldp < (1 << 22) && ldq < (1 << 22)) {
-      const int tr = (int)((R + 255) / 256), tc = (int)((C + 255) / 256);
+    if (t256 && glds && K >= 1024 && R % 8 == 0 && ldp < (1 << 22) && ldq < (1 << 22)) {
+      const int tr = (int)((R + 255) / 256), tc = (int)((C + 255) / 256), cus = device_cus();
       const int64_t tiles = (int64_t)tr * tc, rounds = (tiles + cus - 1) / cus;
       if (tiles * 4 >= rounds * cus * 3 && tiles < (1 << 30)) {
         ovqa_t256::Args a{(const bf16*)P, ldp, (const bf16*)Q, ldq, (int)R, (int)C, (int)K, tr, tc, nullptr,
@@ -1475,8 +1129,10 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     }
   }
   if constexpr (!QK && !PK) {
-    // a decoding step's products: few activation rows against a whole weight matrix
-    if (variant >= 10 && C <= skinny_max_rows() && K % 32 == 0 && K <= 2048 && R % 4 == 0) {
+    // a decoding step's products: few activation rows against a whole weight matrix (MEASURED, bench.py --workload decode,
+    // B = 64: 64 rows (greedy) 250 -> 197 us per decoding step; 192 rows (beam 3) 259 -> 258: there the 64 x 32 tiles are
+    // as fast, so the form stops at 128 rows)
+    if (glds && C <= kSkinnyMaxRows && K % 32 == 0 && K <= 2048 && R % 4 == 0) {
       const dim3 gs((unsigned)((R + 15) / 16), (unsigned)((C + 15) / 16));
       const int nk = (int)(K / 32);
       if (nk <= 16) {
@@ -1488,122 +1144,35 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
       }
       return ovqa_check_launch(what);
     }
-  }
-  if constexpr (!QK && !PK) {
-    // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of the 128 x 32
-    // tier (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step
-    // 3.53 -> 3.49 ms; a ring of 3 / 6 and the same idea for the 128 x 64 tier (64 x 64 tiles) measured slower.
-    // (OVQA_GEMM_MICRO64 = ring depth 4 | 6, round 5 A/B: 64 x 64 tiles for the tiny tier -- 160 instead of 320 workgroups
-    // for a 1280 x 512 output, a third fewer bytes per output element through the CUs' fetch paths)
-    static int micro64 = -1;
-    if (micro64 < 0) {
-      const char* e = getenv("OVQA_GEMM_MICRO64");
-      micro64 = e ? atoi(e) : 0;
-    }
-    if (tiny_c && micro_tiles() && micro64) {
+    // fewest tiles (the M = 1280 question stack): 64 x 32 tiles with 4 waves -- twice the workgroups of a 128 x 32 tier
+    // (320 instead of 160 for 1280 x 512: every CU gets one), 12 KiB per ring stage, ring of 4.  In the step 3.53 -> 3.49 ms;
+    // a ring of 3 / 6 and 64 x 64 tiles (160 workgroups: 14.0-14.5 against 13.3 us) measured slower.
+    if (tiny_c) {
       g.tiles_r = (int)((R + 63) / 64);
-      g.tiles_c = (int)((C + 63) / 64);
-      const dim3 grid2(g.tiles_r * g.tiles_c);
-      if (micro64 == 6) {
-        const size_t lds = (size_t)6 * (64 * BK * 2 + 64 * BK * 2);
-        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 6, 4, 64, 64>, lds);
-        if (rc != OVQA_OK) return rc;
-        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 6, 4, 64, 64>), grid2, dim3(256), lds, st, g, epi);
-      } else {
-        const size_t lds = (size_t)4 * (64 * BK * 2 + 64 * BK * 2);
-        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 64, 64>, lds);
-        if (rc != OVQA_OK) return rc;
-        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 64, 64>), grid2, dim3(256), lds, st, g, epi);
-      }
-      return ovqa_check_launch(what);
+      OVQA_GLDS(4, 4, 32, 64, dim3(g.tiles_r * g.tiles_c))
     }
-    if (tiny_c && micro_tiles()) {
-      g.tiles_r = (int)((R + 63) / 64);
-      const dim3 grid2(g.tiles_r * g.tiles_c);
-      const size_t lds = (size_t)4 * (64 * BK * 2 + 32 * BK * 2);
-      int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>, lds);
-      if (rc != OVQA_OK) return rc;
-      OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 4, 32, 64>), grid2, dim3(256), lds, st, g, epi);
-      return ovqa_check_launch(what);
-    }
-  }
-  if constexpr (!QK && !PK) {
     // ONE 16-wave workgroup (4 x 4 wave grid) on a 128 x 128 tile for the products that would otherwise run two co-resident
     // 8-wave workgroups on 128 x 64 tiles per CU (6400 x 512 outputs: 200 tiles): the 128-row weight tile is staged once per
     // CU instead of twice -- 32 instead of 48 KB per K step through the CU's L2 fetch path, which is what these loops wait
     // for.  MEASURED (scripts/gemm_wg_timeline.py): span 8.2-8.5 -> 7.5-7.7 us (ring of 3; 6.9-7.3 with a ring of 2, which
     // loses in the step, where operands are cold); step 3.407 / 3.389 -> 3.371 / 3.372 ms in two alternations (ring of 4:
-    // 3.412 / 3.365).  OVQA_GEMM_BIG16 = 0 off, 2 / 3 / 4 ring depth.
-    static int big16 = -1;
-    if (big16 < 0) {
-      const char* e = getenv("OVQA_GEMM_BIG16");
-      big16 = e ? atoi(e) : 3;
-    }
-    if (big16 && small_c && !tiny_c) {
+    // 3.412 / 3.365).
+    if (small_c) {
       g.tiles_c = (int)((C + BT - 1) / BT);
       if (const int step = owned_rows(g.tiles_r, g.tiles_c, C, 1)) {
         g.c_step = step;
         g.tiles_c = (int)((C + step - 1) / step);
       }
-      const dim3 grid16(g.tiles_r * g.tiles_c);
-      const int nb = big16 == 2 ? 2 : (big16 == 4 ? 4 : 3);
-      const size_t lds = (size_t)nb * 2 * TILE_BYTES;
-      if (nb == 4) {
-        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 4, 16, 128, 128, 1>, lds);
-        if (rc != OVQA_OK) return rc;
-        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 4, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
-      } else if (nb == 2) {
-        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 2, 16, 128, 128, 1>, lds);
-        if (rc != OVQA_OK) return rc;
-        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 2, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
-      } else {
-        int rc = set_max_lds(gemm_bf16_glds_kernel<PK, QK, Epi, 3, 16, 128, 128, 1>, lds);
-        if (rc != OVQA_OK) return rc;
-        OVQA_LAUNCH_TIMED((gemm_bf16_glds_kernel<PK, QK, Epi, 3, 16, 128, 128, 1>), grid16, dim3(1024), lds, st, g, epi);
-      }
-      return ovqa_check_launch(what);
+      OVQA_GLDS(3, 16, 128, 128, dim3(g.tiles_r * g.tiles_c))
     }
   }
-  if constexpr (!QK) {
-    if (tiny_c) {
-      switch (tiny_nbuf()) {
-        case 3: OVQA_GLDS(3, 8, 32) break;
-        case 4: OVQA_GLDS(4, 8, 32) break;
-        default: OVQA_GLDS(2, 8, 32)
-      }
-      return ovqa_check_launch(what);
-    }
-    if (small_c) {
-      if constexpr (!PK) {
-        if ((ksplit() & 1) && K >= ksplit_min_k()) {
-          OVQA_GLDS_K(3, 8, 64, 2)
-          return ovqa_check_launch(what);
-        }
-      }
-      switch (small_nbuf()) {
-        case 3: OVQA_GLDS(3, 8, 64) break;
-        case 4: OVQA_GLDS(4, 8, 64) break;
-        default: OVQA_GLDS(2, 8, 64)
-      }
-      return ovqa_check_launch(what);
-    }
+  if constexpr (!QK) {  // (a k-major P: the [N, K]-weight form of dX, used where no transposed weight copy exists)
+    if (tiny_c) OVQA_GLDS(4, 8, 32, 128, grid)
+    if (small_c) OVQA_GLDS(3, 8, 64, 128, grid)
   }
-  if constexpr (!PK && !QK) {
-    if (variant == 12 && (ksplit() & 2) && K >= ksplit_min_k()) {
-      OVQA_GLDS_K(2, 8, 128, 2)
-      return ovqa_check_launch(what);
-    }
-  }
-  switch (variant) {
-    case 2: OVQA_GLDS(2, 4, 128) break;
-    case 3: OVQA_GLDS(3, 4, 128) break;
-    case 12: OVQA_GLDS(2, 8, 128) break;
-    case 13: OVQA_GLDS(3, 8, 128) break;
-    default:
-      OVQA_LAUNCH_TIMED((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
-  }
+  if (glds) OVQA_GLDS(2, 8, 128, 128, grid)
 #undef OVQA_GLDS
-#undef OVQA_GLDS_K
+  OVQA_LAUNCH_TIMED((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
   return ovqa_check_launch(what);
 }
 
@@ -1855,33 +1424,11 @@ int mfma_linear_bwd_weight(const void* dy, int64_t lddy, const void* x, int64_t 
 }
 
 int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, bool direct_to_lds,
-                       bool tiles256, hipStream_t st) {
+                       hipStream_t st) {
   if (n_tiles == 0) return OVQA_OK;
-  if (tiles256) {
-    constexpr size_t lds = 4 * 2 * TILE_BYTES;  // ring of 4 half steps x 32 KB
-    int rc = set_max_lds(gemm_bf16_grouped_wgrad256_kernel, lds);
-    if (rc != OVQA_OK) return rc;
-    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad256_kernel, dim3((unsigned)n_tiles), dim3(1024), lds, st, probs_dev,
-                       reinterpret_cast<const int4*>(tiles_dev));
-    return ovqa_check_launch("grouped_linear_bwd_weight(mfma,256)");
-  }
-  static int allow = -1;
-  if (allow < 0) {
-    const char* e = getenv("OVQA_DW_GLDS");
-    allow = e ? atoi(e) : 1;
-  }
-  static int dw_ksplit = -1;
-  if (dw_ksplit < 0) {
-    const char* e = getenv("OVQA_DW_KSPLIT");
-    dw_ksplit = e ? atoi(e) : 0;
-  }
-  if (direct_to_lds && allow) {
-    if (dw_ksplit)
-      hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_glds_kernel<2, 2>), dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES,
-                         st, probs_dev, reinterpret_cast<const int4*>(tiles_dev));
-    else
-      hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_glds_kernel<2, 1>), dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES,
-                         st, probs_dev, reinterpret_cast<const int4*>(tiles_dev));
+  if (direct_to_lds) {  // (every reduction length a multiple of 64)
+    hipLaunchKernelGGL((gemm_bf16_grouped_wgrad_glds_kernel<2>), dim3((unsigned)n_tiles), dim3(512), 4 * TILE_BYTES, st,
+                       probs_dev, reinterpret_cast<const int4*>(tiles_dev));
     return ovqa_check_launch("grouped_linear_bwd_weight(mfma,glds)");
   }
   hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3((unsigned)n_tiles), dim3(256), 4 * TILE_BYTES, st, probs_dev,

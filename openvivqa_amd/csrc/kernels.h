@@ -200,7 +200,7 @@ int mfma_linear_bwd_data_wt(const void* dy, int64_t lddy, const void* wt, int64_
                             const DropArgs& da, hipStream_t st);
 int grouped_transpose_bf16(const ovqa_transpose_problem* probs, int n, int max_tiles, hipStream_t st);
 int mfma_grouped_wgrad(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles, bool direct_to_lds,
-                       bool tiles256, hipStream_t st);
+                       hipStream_t st);
 int mfma_grouped_linear_bwd_weight_adam(const ovqa_wgrad_problem* probs_dev, const int32_t* tiles_dev, int64_t n_tiles,
                                         const ovqa_adam_target* targets_dev, const ovqa_adam_consts& consts, hipStream_t st);
 bool mfma_linear_bwd_weight_supported(int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx);

@@ -254,15 +254,21 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
     mu = mun;
     rs = rsn;
   }
-  // combine the 4 waves of the block
+  // combine the waves of the block through LDS.  A lane's 8 columns are kept as two 16-byte halves D / 2 floats apart
+  // (half h of column group j at h * D/2 + 4 j): consecutive lanes are 16 bytes apart in each half.  (Stored as one 32-byte
+  // run per lane, the ds_read_b128 of the combine hit every bank twice: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 on
+  // every instantiation, profiles/r05_pmc_summary.json.)
+  const int hD = D >> 1;
   if (wave > 0) {
     float* s = smem + (int64_t)(wave - 1) * 2 * D;
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
-      const int col = (c * 64 + lane) * VEC;
-      if (col < D) {
-        store8<float>(s + col, dg[c]);
-        store8<float>(s + D + col, db[c]);
+      const int j4 = (c * 64 + lane) * 4;
+      if (j4 * 2 < D) {
+        *reinterpret_cast<float4*>(s + j4) = make_float4(dg[c][0], dg[c][1], dg[c][2], dg[c][3]);
+        *reinterpret_cast<float4*>(s + hD + j4) = make_float4(dg[c][4], dg[c][5], dg[c][6], dg[c][7]);
+        *reinterpret_cast<float4*>(s + D + j4) = make_float4(db[c][0], db[c][1], db[c][2], db[c][3]);
+        *reinterpret_cast<float4*>(s + D + hD + j4) = make_float4(db[c][4], db[c][5], db[c][6], db[c][7]);
       }
     }
   }
@@ -272,11 +278,14 @@ __global__ __launch_bounds__(NWAVES * 64) void ln_bwd_kernel(const TDY* __restri
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
       const int col = (c * 64 + lane) * VEC;
+      const int j4 = (c * 64 + lane) * 4;
       if (col < D) {
         for (int w = 0; w < NWAVES - 1; w++) {
-          float a[VEC], b[VEC];
-          load8<float>(smem + (int64_t)w * 2 * D + col, a);
-          load8<float>(smem + (int64_t)w * 2 * D + D + col, b);
+          const float* s = smem + (int64_t)w * 2 * D;
+          const float4 a0 = *reinterpret_cast<const float4*>(s + j4), a1 = *reinterpret_cast<const float4*>(s + hD + j4);
+          const float4 b0 = *reinterpret_cast<const float4*>(s + D + j4), b1 = *reinterpret_cast<const float4*>(s + D + hD + j4);
+          const float a[VEC] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const float b[VEC] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
           for (int i = 0; i < VEC; i++) { dg[c][i] += a[i]; db[c][i] += b[i]; }
         }
@@ -355,36 +364,19 @@ __global__ __launch_bounds__(512) void ln_bwd_reduce_kernel(const ovqa_reduce_pr
   base[0] = t.x; base[1] = t.y; base[2] = t.z; base[3] = t.w;
 }
 
-// rows per wave x waves per workgroup of the forward (OVQA_LN_FWD_FORM = 10 * rows + log2(waves): 12 = the 1 x 4 default)
-static int ln_fwd_form() {
-  static const int v = [] {
-    const char* e = getenv("OVQA_LN_FWD_FORM");
-    return e ? atoi(e) : 12;
-  }();
-  return v;
-}
-
+// One row per wave, four waves per workgroup.  (Round 5 swept rows per wave x waves per workgroup -- 1 x 2, 1 x 8, 2 x 2, 2 x 4,
+// 2 x 8, 4 x 4: all equal or slower, profiles/r05_ln_bench_fwd_forms.jsonl: the launch is one latency chain, and a wave per
+// row keeps the most rows in flight.)
 template <typename TIN, typename TOUT>
 int fwd_dispatch(const void* x, const float* gamma, const float* beta, const float* pos, int64_t pos_rows, void* y,
                  float* y32, float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t st) {
   const int chunks = (int)((D + 64 * VEC - 1) / (64 * VEC));
-  const int form = chunks == 1 ? ln_fwd_form() : 12;
 #define LN_FWD_RW(C, R, NW)                                                                                          \
   hipLaunchKernelGGL((ln_fwd_kernel<TIN, TOUT, C, R, NW>), dim3((unsigned)((M + R * NW - 1) / (R * NW))),            \
                      dim3(NW * 64), 0, st, (const TIN*)x, gamma, beta, pos, (int)(pos ? pos_rows : 1), (TOUT*)y, y32, \
                      mean, rstd, (int)M, (int)D, eps)
   switch (chunks) {
-    case 1:
-      switch (form) {
-        case 11: LN_FWD_RW(1, 1, 2); break;
-        case 13: LN_FWD_RW(1, 1, 8); break;
-        case 21: LN_FWD_RW(1, 2, 2); break;
-        case 22: LN_FWD_RW(1, 2, 4); break;
-        case 23: LN_FWD_RW(1, 2, 8); break;
-        case 42: LN_FWD_RW(1, 4, 4); break;
-        default: LN_FWD_RW(1, 1, 4); break;
-      }
-      break;
+    case 1: LN_FWD_RW(1, 1, 4); break;
     case 2: LN_FWD_RW(2, 1, 4); break;
     default: LN_FWD_RW(4, 1, 4); break;
   }
@@ -406,12 +398,8 @@ int bwd_dispatch(const void* dy, const void* x, const float* gamma, const float*
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, C, W>), dim3(nblocks), dim3(W * 64), smem, st, (const TDY*)dy,    \
                      (const TX*)x, gamma, mean, rstd, (TDX*)dx, (TDY*)dx_dropped, partial, (int)M, (int)D, da)
 #define LN_BWD(C)                                                                                                   \
-  switch (nw) {                                                                                                     \
-    case 8: LN_BWD_W(C, 8); break;                                                                                  \
-    case 13: LN_BWD_W(C, 13); break;                                                                                \
-    case 16: LN_BWD_W(C, 16); break;                                                                                \
-    default: LN_BWD_W(C, 4); break;                                                                                 \
-  }
+  if (nw == 8) LN_BWD_W(C, 8);                                                                                      \
+  else LN_BWD_W(C, 4);
   switch (chunks) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -447,22 +435,14 @@ int layernorm_fwd(int dtype, int in_dtype, const void* x, const float* gamma, co
   return OVQA_ERR_UNSUPPORTED;
 }
 
-// Waves per workgroup of the backward: 8 for the long activations, while its 7 * 2 * D floats of dynamic LDS stay inside
-// the 64 KiB a launch gets without hipFuncSetAttribute (D <= 1168); wider rows keep the 4-wave form (3 * 2 * D floats:
-// 48 KiB at 2048).  OVQA_LN_BWD_WAVES = 13 | 16: more waves per workgroup at the same 512 workgroups, so that a wave of a
-// 6400-row launch owns ONE row (13 x 512 >= 6400) instead of one or two.
-static int ln_bwd_waves_env() {
-  static const int v = [] {
-    const char* e = getenv("OVQA_LN_BWD_WAVES");
-    const int w = e ? atoi(e) : 8;
-    return (w == 13 || w == 16) ? w : 8;
-  }();
-  return v;
-}
+// Waves per workgroup of the backward: 8 for the long activations (a wave owns one or two rows of a 6400-row launch), while
+// its 7 * 2 * D floats of dynamic LDS stay inside the 64 KiB a launch gets without hipFuncSetAttribute (D <= 1168); wider
+// rows and short inputs keep the 4-wave form (3 * 2 * D floats: 48 KiB at 2048).
+// (13 waves -- every wave exactly one row -- and 16 measured slower: 12.2 / 11.5 against 9.2-9.4 us cold, round 5: the LDS
+// combine of the column partials and the lower occupancy cost more than the second row.)
 int layernorm_bwd_waves(int64_t M, int64_t D) {
   if (M < 4096 || 7 * 2 * D * 4 > 64 * 1024) return 4;
-  const int w = ln_bwd_waves_env();
-  return (int64_t)(w - 1) * 2 * D * 4 <= 64 * 1024 ? w : 8;
+  return 8;
 }
 int layernorm_bwd_blocks(int64_t M, int64_t D) {
   const int nw = layernorm_bwd_waves(M, D);

@@ -16,21 +16,21 @@
 //   * the input half x_t W_ih^T does not depend on the recurrence: it is computed one step ahead (operands of step
 //     t + 2 in flight), so a step's critical chain is wait -> 16 KB of h_{t-1} -> 16 MFMAs -> gates -> publish;
 //   * h_t travels between the 32 workgroups of a sample group through `hseq` (the [T+1, B, 512] bf16 sequence that is
-//     also the operand of the W_hh weight gradient): write-through (sc1) 16-byte stores, every storing wave drains
-//     (s_waitcnt vmcnt(0)), ONE lane adds to the group's step counter; the consumer polls that counter with sc1 loads
-//     from one lane, a workgroup barrier, then sc1 loads of the payload -- cdna_hip_programming.md Guideline 16 in its
-//     counter form, placement-independent (hand-off form 1).  The DEFAULT is form 2, "the data is the flag" (below): no
-//     counter, no drain, the consumer re-reads the payload until no unit shows the sentinel the buffer was filled with.
-//     OVQA_LSTM_HANDOFF=counter|fence selects form 1 (fence: with the agent-scope acquire); the forms are deterministic
-//     and must agree bit for bit.
+//     also the operand of the W_hh weight gradient): write-through (sc1) 16-byte stores, and "the data is the flag" (below):
+//     no counter, no drain -- the consumer re-reads the payload with sc1 loads until no unit shows the sentinel the buffer
+//     was filled with.  (Rounds 4-5 also carried the counter form of cdna_hip_programming.md Guideline 16 -- drained stores,
+//     one arrival counter per sample group and step, a polling lane, a workgroup barrier -- with and without the agent-scope
+//     acquire: 104 / 127 and 120 / 146 us forward / backward against 77 / 81 for this form, identical bits; removed in
+//     round 6, when the give-up path got a host-visible status word and a test of its own.)
 //
 // Backward is the same structure in reverse: workgroup (sg, ub) owns dh for 16 samples x 16 units; dh_{t} needs
 // dgates_{t+1} W_hh over ALL 2048 gate columns of its samples, exchanged through `dgates` itself ([T, B, 2048] bf16,
 // which the dX / dW GEMMs read afterwards); wave w holds the rows of W_hh^T for gate w (from the arena's transposed
 // shadow) and reduces over that gate's 512 columns; the four partial tiles meet in LDS.
 //
-// Any other shape (hidden size != 512, B not a multiple of 16, more workgroups than CUs) and the fp32 mode run one
-// small VALU launch per step (`lstm_step_*_simple`): same results, no cross-workgroup protocol.
+// Any other hidden size and the fp32 mode run one small VALU launch per step (`lstm_step_*_simple`): same results, no
+// cross-workgroup protocol.  A batch that is not a multiple of 16 samples, or larger than the device's CUs can keep
+// co-resident (16 samples per 32 CUs), is padded / split by the host side (ops.lstm_fwd).
 #include "common.h"
 #include "kernels.h"
 
@@ -70,27 +70,14 @@ __device__ __forceinline__ void wg_role(int b, int nsg, int& sg, int& ub) {
   }
 }
 
-// One lane polls the group's counter (relaxed, agent scope: an sc1 load) until it reaches `target`; bounded.
-__device__ __forceinline__ void wait_counter(unsigned* cnt, unsigned target, unsigned* status) {
-  int spins = 0;
-  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > SPIN_LIMIT) {  // a workgroup of the launch never became resident, or died: give up loudly
-      give_up(status, 1u);
-      break;
-    }
-  }
-}
-
-// ---- hand-off form 2 (default): the data is the flag ------------------------------------------------------------------
+// ---- the hand-off: the data is the flag ------------------------------------------------------------------
 // The exchange buffer is filled with 0xFF bytes by a memset node in front of the launch: 0xFFFF is a bf16 NaN that neither
 // h = o tanh(c) nor a finite gradient can be.  A consumer wave simply re-reads its 16 KB with sc1 loads until no 8-byte
 // unit shows the sentinel (cdna_hip_programming.md Guideline 16, recipe R2: 8-byte granules written by ONE sc1 store are
 // observed untorn; here the tag is "not 0xFFFF" in the unit's first element, so the payload is not doubled).  Against
 // the counter form this drops, per step: the producer's store drain, the atomic, the poll round trip and a workgroup
 // barrier -- two of the four dependent memory round trips (MEASURED, scripts/lstm_bench.py, B = 64, T = 20, memset nodes
-// included: forward 104 -> 77 us, backward 127 -> 81 us; with the acquire fence 120 / 146).  OVQA_LSTM_HANDOFF=counter selects form 1, =fence form 1 with the agent-scope
-// acquire; the three forms are deterministic and must agree bit for bit (tests/test_kernels_gpu.py).
+// included: forward 104 -> 77 us, backward 127 -> 81 us; with the acquire fence 120 / 146).
 constexpr int SWEEP_LIMIT = 1 << 17;  // default of the kernels' `sweep_limit` argument (OVQA_LSTM_SWEEP_LIMIT: tests)
 // aux of the hand-off loads: sc1 (bit 4) + LLVM's volatile marker (bit 31, stripped at lowering): two sweeps of the same
 // addresses are two loads, and none is hoisted out of a polling loop
@@ -126,9 +113,8 @@ struct LstmFwdArgs {
   bf16* y16;            // the same in bf16 (the GEMM / LayerNorm operand of the stack behind it), or NULL
   bf16* hseq;           // [(T+1)*B][512] time-major: block 0 = zeros, block t+1 = h_t
   float* saved;         // [T][nwg][5][256]: i, f, g, o (post-activation), c_t of the workgroup's lanes
-  unsigned* cnt;        // one counter per sample group, 32 words apart
   unsigned* status;
-  int B, T, mode;  // hand-off: 0 = counter, 1 = counter + agent-scope acquire, 2 = sentinel (the data is the flag)
+  int B, T;
   int sweep_limit;  // sweeps of the sentinel form before a wait gives up
   int drop_wg;      // tests only (OVQA_LSTM_DEBUG_DROP_WG): workgroup drop_wg - 1 exits at once, as if it never became resident
   unsigned* probe;  // diagnostic (OVQA_LSTM_PROBE=1): 100 MHz stamps of one wave's phases, 8 words per step; else NULL
@@ -139,9 +125,6 @@ struct LstmFwdArgs {
       a.probe[t * 8 + (slot)] = (unsigned)__builtin_amdgcn_s_memrealtime();                                \
   } while (0)
 
-// SENTINEL: hand-off form 2 (compile-time: behind a run-time switch the two forms' waits meet at the MFMAs, and the
-// sentinel form would wait there for the sweep it deliberately leaves in flight)
-template <bool SENTINEL>
 __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // h_t tiles, double-buffered by step parity: with the sentinel hand-off ONE barrier per step is left, which orders the
@@ -155,7 +138,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
   int sg, ub;
   wg_role(blockIdx.x, nsg, sg, ub);
   const int B = a.B, T = a.T;
-  if (SENTINEL && blockIdx.x == 0 && tid == 0)  // (a give-up is reported after >= 1e5 sweeps: long after this store)
+  if (blockIdx.x == 0 && tid == 0)  // (a give-up is reported after >= 1e5 sweeps: long after this store)
     __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.drop_wg != 0 && (int)blockIdx.x == a.drop_wg - 1) return;  // (workgroup-uniform; tests of the give-up path)
   // ---- this wave's 16 gate rows of W_ih and W_hh, A-operand layout, resident for the whole launch
@@ -176,7 +159,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
     *reinterpret_cast<u32x4*>(a.hseq + (int64_t)(sg * 16 + (l >> 1)) * LH + ub * 16 + (l & 1) * 8) = u32x4{0u, 0u, 0u, 0u};
   // exchange descriptors (wave-uniform): all of hseq
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.hseq, 0, (int)((int64_t)(T + 1) * B * LH * 2), 0x00020000);
-  unsigned* cnt = a.cnt + sg * 32;
   // B operand of the input half: x[t*B + sg*16 + n][kk*32 + q*8 ..]
   const bf16* xrow = a.x + (int64_t)(sg * 16 + n) * a.ldx + q * 8;
   bf16x8 xf[KS];
@@ -203,7 +185,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
       // h_{t-1} of the 16 samples: block t of hseq, sc1 loads straight into the B-operand layout
       const unsigned hoff = (unsigned)((((int64_t)t * B + sg * 16 + n) * LH + q * 8) * 2);
       u32x4 hf[KS];
-      if constexpr (SENTINEL) {
+      {
         // the four waves need the SAME 16 KB: each sweeps a quarter (K steps 4 w .. 4 w + 3) until it is ready and
         // shares it through LDS -- four full sweeps per CU were bound by the CU's fetch path (64 KB at ~60 GB/s: 1.1 us
         // per sweep, scripts/lstm_probe.py), a quarter each is a plain round trip
@@ -231,15 +213,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) hf[kk] = *reinterpret_cast<const u32x4*>(hbuf + n * HB_STRIDE + kk * 64 + q * 16);
-      } else {
-        if (tid == 192) {  // wave 3 polls (wave 0 publishes, wave 1 writes y)
-          wait_counter(cnt, (unsigned)(NUB * t), a.status);
-          if (a.mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        if (a.mode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) hf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, hoff + kk * 64, 0, 16);
       }
       f32x4 acc1 = zero4;
 #pragma unroll
@@ -265,10 +238,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_persistent_kernel(LstmFwdArgs a)
         const u32x4 v = *reinterpret_cast<const u32x4*>(tile16 + (l >> 1) * 16 + (l & 1) * 8);
         const unsigned off = (unsigned)((((int64_t)(t + 1) * B + sg * 16 + (l >> 1)) * LH + ub * 16 + (l & 1) * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
-      }
-      if constexpr (!SENTINEL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0 && t + 1 < T) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (w == 1) {  // y[b][t][ub*16 ..]: lane -> (sample l >> 2, 16-byte quarter l & 3)
       const f32x4 v = *reinterpret_cast<const f32x4*>(tile32 + (l >> 2) * 16 + (l & 3) * 4);
@@ -313,13 +282,11 @@ struct LstmBwdArgs {
   int64_t ldwt;
   const float* saved;   // as written by the forward kernel
   bf16* dgates;         // [T*B][2048] time-major, columns gate*512 + unit: output AND exchange buffer
-  unsigned* cnt;
   unsigned* status;
-  int B, T, mode;
+  int B, T;
   int sweep_limit, drop_wg;  // as in LstmFwdArgs
 };
 
-template <bool SENTINEL>
 __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* part = reinterpret_cast<float*>(lds_raw);              // [4 waves][4 regs][64 lanes] fp32 partial dh tiles
@@ -329,7 +296,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   int sg, ub;
   wg_role(blockIdx.x, nsg, sg, ub);
   const int B = a.B, T = a.T;
-  if (SENTINEL && blockIdx.x == 0 && tid == 0)
+  if (blockIdx.x == 0 && tid == 0)
     __hip_atomic_store(a.status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.drop_wg != 0 && (int)blockIdx.x == a.drop_wg - 1) return;
   // A operand of the recurrent product dh[u'][n] = sum_col W_hh[col][u'] dgates[n][col]: wave w reduces over gate w's
@@ -339,7 +306,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
   for (int kk = 0; kk < KS; kk++)
     wt[kk] = *reinterpret_cast<const bf16x8*>(a.whh_t + (int64_t)(ub * 16 + n) * a.ldwt + w * LH + kk * 32 + q * 8);
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.dgates, 0, (int)((int64_t)T * B * 4 * LH * 2), 0x00020000);
-  unsigned* cnt = a.cnt + sg * 32;
   // elementwise role of this lane: sample n, unit_in = 4 q + w (the rows 4 q + reg of the accumulator tile, reg = w);
   // the forward kernel saved that (sample, unit) from its thread q * 64 + w * 16 + n
   const int unit_in = 4 * q + w;
@@ -364,7 +330,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
     if (t < T - 1) {
       const unsigned goff = (unsigned)((((int64_t)(t + 1) * B + sg * 16 + n) * (4 * LH) + w * LH + q * 8) * 2);
       u32x4 gf[KS];
-      if constexpr (SENTINEL) {
+      {
         // a full sweep is 64 KB per CU (every wave its own gate's columns): 1.1 us on the CU's fetch path, so a sweep that
         // comes too early is expensive.  Probe first: one 16-byte piece per lane, chosen so that the wave sees a piece of
         // every one of the 32 producers (lane (n, q) reads K step n: producer 2 n + q / 2), re-read until none shows the
@@ -376,15 +342,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
           __builtin_amdgcn_s_sleep(1);
         }
         sweep_until_ready(rs, goff, gf, a.status, a.sweep_limit);
-      } else {
-        if (tid == 192) {
-          wait_counter(cnt, (unsigned)(NUB * (T - 1 - t)), a.status);
-          if (a.mode == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        if (a.mode == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) gf[kk] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + kk * 64, 0, 16);
       }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -425,10 +382,6 @@ __global__ __launch_bounds__(256) void lstm_bwd_persistent_kernel(LstmBwdArgs a)
         const u32x4 v = *reinterpret_cast<const u32x4*>(tile + s * 64 + g * 16 + hlf * 8);
         const unsigned off = (unsigned)((((int64_t)t * B + sg * 16 + s) * (4 * LH) + g * LH + ub * 16 + hlf * 8) * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
-      }
-      if constexpr (!SENTINEL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (l == 0 && t > 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -511,13 +464,6 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_simple(const void* __restri
   dp[3 * H] = from_f32<T>(dh * tc * og * (1.f - og));
 }
 
-int lstm_handoff_mode() {  // read per call (tests flip it): 2 = sentinel (default), 0 = counter, 1 = counter + fence
-  const char* e = getenv("OVQA_LSTM_HANDOFF");
-  if (e && e[0] == 'c') return 0;
-  if (e && e[0] == 'f') return 1;
-  return 2;
-}
-
 int debug_env(const char* name, int dflt) {  // read per call: tests flip these
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -573,26 +519,20 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
              const float* b_ih, const float* b_hh, float* y, void* y16, void* hseq, void* saved, void* scratch, int64_t B, int64_t T,
              int64_t I, int64_t H, hipStream_t st) {
   if (persistent) {
-    const int mode = lstm_handoff_mode();
-    // form 2: ONE memset node, the sentinel fill (the status word is zeroed by the launch's first workgroup); form 1: the counters
-    hipError_t e = mode == 2 ? hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st)
-                             : hipMemsetAsync(scratch, 0, kSyncBytes, st);
+    // ONE memset node, the sentinel fill (the status word is zeroed by the launch's first workgroup)
+    hipError_t e = hipMemsetAsync(hseq, 0xFF, (size_t)((T + 1) * B * LH * 2), st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
     LstmFwdArgs a{(const bf16*)x, ldx, (const bf16*)w_ih, (const bf16*)w_hh, b_ih, b_hh, y, (bf16*)y16, (bf16*)hseq, (float*)saved,
-                  (unsigned*)scratch, (unsigned*)scratch + 1000, (int)B, (int)T, mode,
+                  (unsigned*)scratch + 1000, (int)B, (int)T,
                   debug_env("OVQA_LSTM_SWEEP_LIMIT", SWEEP_LIMIT), debug_env("OVQA_LSTM_DEBUG_DROP_WG", 0),
                   (getenv("OVQA_LSTM_PROBE") && T * 8 <= 480) ? (unsigned*)scratch + 512 : nullptr};
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kPersistentLds);
-      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)lstm_fwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kPersistentLds);
       attr_set = true;
     }
-    const dim3 grid((unsigned)((B / 16) * NUB));
-    if (mode == 2) hipLaunchKernelGGL(lstm_fwd_persistent_kernel<true>, grid, dim3(256), kPersistentLds, st, a);
-    else hipLaunchKernelGGL(lstm_fwd_persistent_kernel<false>, grid, dim3(256), kPersistentLds, st, a);
+    hipLaunchKernelGGL(lstm_fwd_persistent_kernel, dim3((unsigned)((B / 16) * NUB)), dim3(256), kPersistentLds, st, a);
     return ovqa_check_launch("lstm_fwd(persistent)");
   }
   float* gates = (float*)saved;
@@ -613,24 +553,18 @@ int lstm_fwd(int dtype, bool persistent, const void* x, int64_t ldx, const void*
 int lstm_bwd(int dtype, bool persistent, const void* dy, int dy_bf16, const void* w_hh, const void* w_hh_t, int64_t ldwt,
              const void* saved, void* dgates, void* scratch, int64_t B, int64_t T, int64_t H, hipStream_t st) {
   if (persistent) {
-    const int mode = lstm_handoff_mode();
-    hipError_t e = mode == 2 ? hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st)
-                             : hipMemsetAsync(scratch, 0, kSyncBytes, st);
+    hipError_t e = hipMemsetAsync(dgates, 0xFF, (size_t)(T * B * 4 * LH * 2), st);
     OVQA_REQUIRE(e == hipSuccess, OVQA_ERR_LAUNCH, "lstm_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    LstmBwdArgs a{dy, dy_bf16, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates, (unsigned*)scratch,
-                  (unsigned*)scratch + 1000, (int)B, (int)T, mode, debug_env("OVQA_LSTM_SWEEP_LIMIT", SWEEP_LIMIT),
+    LstmBwdArgs a{dy, dy_bf16, (const bf16*)w_hh_t, ldwt, (const float*)saved, (bf16*)dgates,
+                  (unsigned*)scratch + 1000, (int)B, (int)T, debug_env("OVQA_LSTM_SWEEP_LIMIT", SWEEP_LIMIT),
                   debug_env("OVQA_LSTM_DEBUG_DROP_WG", 0)};
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kPersistentLds);
-      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)lstm_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kPersistentLds);
       attr_set = true;
     }
-    const dim3 grid((unsigned)((B / 16) * NUB));
-    if (mode == 2) hipLaunchKernelGGL(lstm_bwd_persistent_kernel<true>, grid, dim3(256), kPersistentLds, st, a);
-    else hipLaunchKernelGGL(lstm_bwd_persistent_kernel<false>, grid, dim3(256), kPersistentLds, st, a);
+    hipLaunchKernelGGL(lstm_bwd_persistent_kernel, dim3((unsigned)((B / 16) * NUB)), dim3(256), kPersistentLds, st, a);
     return ovqa_check_launch("lstm_bwd(persistent)");
   }
   const float* gates = (const float*)saved;

@@ -270,39 +270,24 @@ def bias_grad(dy, db, accumulate=False):
 
 
 class WgradQueue:
-    """Deferred weight gradients: (dy, x, dw[, db]) collected during a backward pass and computed by grouped
-    launches (ovqa_grouped_linear_bwd_weight) on a SIDE stream, so the matrix-core-bound dW tiles overlap the
-    latency-bound dX / attention / LayerNorm chain of the layers that are still being differentiated.
-    A launch is issued whenever FLUSH_TILES tiles have accumulated; ``finish()`` (end of the backward pass)
-    launches the rest and joins the side stream back into the main one.  The queued activations are
-    referenced until the join.
+    """Deferred weight gradients: (dy, x, dw[, db]) collected during a backward pass and computed by ONE grouped launch
+    (ovqa_grouped_linear_bwd_weight) at its end, on the main stream; ``finish()`` launches them.  The queued activations
+    are referenced until then.
 
-    MEASURED (MI355X, MCAN L=6 step): overlapping dW with the rest of backward LOSES -- 5.80 / 5.77 / 5.70 ms
-    per step at FLUSH_TILES = 224 / 700 / 1300 against 5.43 ms for one launch at the very end: every kernel of
-    the step is bound by the per-CU L2->LDS load path, so concurrent kernels just steal it from the critical
-    chain.  The default therefore defers everything to the end (OVQA_WGRAD_FLUSH_TILES overrides)."""
+    MEASURED alternatives, removed from the source in round 6 (profiles/README.md has the numbers): launching the tiles
+    early on a side stream so that they overlap the rest of backward LOSES (5.80 / 5.77 / 5.70 ms per step at 224 / 700 /
+    1300 tiles per flush against 5.43 for one launch at the very end, round 2: every kernel of the step is bound by the
+    per-CU L2->LDS path, concurrent kernels steal it from the critical chain); the single launch on a forked side stream:
+    no measurable effect; 256 x 256 tiles on one 16-wave workgroup per CU: 3.231 against 3.195 ms per step."""
 
     TILE = 128
-    # OVQA_DW_TILE256: 256 x 256 tiles on one 16-wave workgroup per CU (half the L2 -> CU bytes per flop) -- 0 (default)
-    # never, 1 for launches with at least BIG_MIN_ROUNDS such tiles per CU, 2 whenever every queued product allows the
-    # direct-to-LDS form.  MEASURED (profiles/README.md): against the 128 x 128 form as it was (its ring drained by a
-    # compiler-inserted wait in every K step) the large tiles won 0.06 ms per step; with that wait gone the 128 x 128
-    # form is the faster one (3.195 against 3.231 ms per step, 480 against 493 us on its own), also for a backward pass
-    # flushed in five gradient segments (N > 1; ~130 large tiles per launch: 3.39 against 3.52).
-    BIG_TILES = os.environ.get("OVQA_DW_TILE256", "0") != "0"
-    BIG_FORCED = os.environ.get("OVQA_DW_TILE256", "0") == "2"
-    BIG_MIN_ROUNDS = 2
-    FLUSH_TILES = int(__import__("os").environ.get("OVQA_WGRAD_FLUSH_TILES", str(1 << 30)))
 
     def __init__(self):
         self.items = []
         self.reduces = []    # deferred LayerNorm dgamma/dbeta reductions: (partial, blocks, D, out0, out1)
-        self.ntiles = 0
-        self.inflight = []   # references the side-stream launches still need
+        self.inflight = []   # the items of launches of this pass (referenced until finish())
         self.keepalive = []  # tables/tensors of captured launches must outlive the graph
         self._cache = []
-        self._side = {}
-        self._used_side = False
         self.defer_uploads = False  # capture mode of a harness: tables are uploaded ONCE after the capture
         self._deferred = []         # (pinned host, device, nbytes) of tables a captured launch reads
         self._producers = set()     # streams (other than the flushing one) whose kernels wrote queued operands
@@ -331,13 +316,6 @@ class WgradQueue:
                 cur.wait_stream(st)
         self._producers.clear()
 
-    def _side_stream(self, dev):
-        st = self._side.get(dev)
-        if st is None:
-            st = torch.cuda.Stream(device=dev)
-            self._side[dev] = st
-        return st
-
     def add(self, dy, x, dw, accumulate, db=None, accumulate_db=False):
         lddy, M = _rows(dy)
         ldx, Mx = _rows(x)
@@ -352,9 +330,6 @@ class WgradQueue:
         N, K = dy.shape[-1], x.shape[-1]
         self._note_producer(dy)
         self.items.append((dy, x, dw, lddy, ldx, M, N, K, flags, db))
-        self.ntiles += ((N + self.TILE - 1) // self.TILE) * ((K + self.TILE - 1) // self.TILE)
-        if self.ntiles >= self.FLUSH_TILES:
-            self.flush()
 
     @staticmethod
     def _span(t):
@@ -416,22 +391,18 @@ class WgradQueue:
             self.keepalive.append((host, devbuf, red))
 
     def flush(self, final=False):
-        """Launch everything queued so far on the side stream (asynchronously w.r.t. the main stream).  ``final``: the last
-        launch of the pass (``finish``): the one that may carry the optimiser step (``self.adam``)."""
+        """Launch everything queued so far.  ``final``: the last launch of the pass (``finish``): the one that may carry the
+        optimiser step (``self.adam``)."""
         if not self.items:
             return
         import numpy as np
-        items, self.items, self.ntiles = self.items, [], 0
+        items, self.items = self.items, []
         dev = items[0][0].device
         probs = (_lib.WgradProblem * len(items))()
         per_problem = []
         fast = all(it[5] % 64 == 0 and it[3] % 8 == 0 and it[4] % 8 == 0 and it[0].data_ptr() % 16 == 0
                    and it[1].data_ptr() % 16 == 0 for it in items)
-        big = fast and self.BIG_TILES and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0")
-        if big and not self.BIG_FORCED:
-            n256 = sum(((it[6] + 255) // 256) * ((it[7] + 255) // 256) for it in items)
-            big = n256 >= self.BIG_MIN_ROUNDS * torch.cuda.get_device_properties(dev).multi_processor_count
-        tile = 256 if big else self.TILE
+        tile = self.TILE
         for i, (dy, x, dw, lddy, ldx, M, N, K, acc, db) in enumerate(items):
             probs[i] = _lib.WgradProblem(_p(dy), _p(x), _p(dw), _p(db), lddy, ldx, M, N, K, acc)
             tn, tk = (N + tile - 1) // tile, (K + tile - 1) // tile
@@ -475,7 +446,7 @@ class WgradQueue:
             prob_bytes = np.concatenate([prob_bytes, np.zeros(pad, dtype=np.uint8)])
         # the optimiser step inside this launch (the last one of the pass): one target per problem behind the tile table
         targets = None
-        if final and self.adam is not None and fast and not big and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0"):
+        if final and self.adam is not None and fast and os.environ.get("OVQA_FORCE_SIMPLE", "0") in ("", "0"):
             tl = self.adam.targets(items)
             if any(t is not None for t in tl):
                 arr = (_lib.AdamTarget * len(items))(*[t if t is not None else _lib.AdamTarget() for t in tl])
@@ -489,29 +460,21 @@ class WgradQueue:
         host[prob_bytes.size:prob_bytes.size + tile_arr.nbytes] = torch.from_numpy(tile_arr.view(np.uint8).reshape(-1).copy())
         if targets is not None:
             host[prob_bytes.size + tile_bytes:nbytes] = torch.from_numpy(targets.copy())
+        # (on the main stream: a fork / join in a captured graph turns every node boundary of the replay into a cross-queue
+        # dependency -- scripts/boundary_bench.py: 1.6 us per dependent launch on one queue)
         main = torch.cuda.current_stream(dev)
-        # a side stream only when launches are meant to overlap the rest of backward (FLUSH_TILES set); the default
-        # single launch at the end stays on the main stream: a fork/join in a captured graph turns every node
-        # boundary of the replay into a cross-queue dependency (scripts/boundary_bench.py: 1.6 us per dependent
-        # launch on one queue)
-        overlapping = self.FLUSH_TILES < (1 << 30) or os.environ.get("OVQA_WGRAD_SIDE", "0") == "1"
-        side = self._side_stream(dev) if overlapping else main
-        if overlapping:
-            side.wait_stream(main)  # every queued dy / x has been produced on the main stream before this point
-        with torch.cuda.stream(side):
-            self._upload(host, devbuf, nbytes, capturing)
-            if targets is not None:
-                consts = self.adam.consts()
-                _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight_adam(
-                    OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles),
-                    devbuf.data_ptr() + prob_bytes.size + tile_bytes, C.addressof(consts), side.cuda_stream),
-                    "grouped_linear_bwd_weight_adam")
-            else:
-                _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
-                    OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), 2 if big else int(fast),
-                    side.cuda_stream), "grouped_linear_bwd_weight")
-        self._used(entry, side, capturing)
-        self._used_side = self._used_side or overlapping
+        self._upload(host, devbuf, nbytes, capturing)
+        if targets is not None:
+            consts = self.adam.consts()
+            _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight_adam(
+                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles),
+                devbuf.data_ptr() + prob_bytes.size + tile_bytes, C.addressof(consts), main.cuda_stream),
+                "grouped_linear_bwd_weight_adam")
+        else:
+            _lib.check(_lib.load().ovqa_grouped_linear_bwd_weight(
+                OVQA_BF16, devbuf.data_ptr(), devbuf.data_ptr() + prob_bytes.size, len(tiles), int(fast),
+                main.cuda_stream), "grouped_linear_bwd_weight")
+        self._used(entry, main, capturing)
         self.inflight.append(items)
         if capturing:
             self.keepalive.append((host, devbuf, items))
@@ -534,7 +497,7 @@ class WgradQueue:
     def abandon(self):
         """Drop everything queued and every table upload deferred by an ABORTED stream capture (nothing of it ran):
         the next pass starts from an empty queue."""
-        self.items, self.reduces, self.ntiles = [], [], 0
+        self.items, self.reduces = [], []
         self.inflight, self._deferred = [], []
         self._producers.clear()
         self.defer_uploads = False
@@ -543,7 +506,7 @@ class WgradQueue:
         self.armed = False
 
     def finish(self):
-        """End of the backward pass: launch the remainder and make the main stream wait for the side stream."""
+        """End of the backward pass: the LayerNorm parameter reductions and the one grouped weight-gradient launch."""
         self.armed = False  # (the flush callback of this backward call has run: the next call registers its own)
         self._join_producers()
         if not self.hold_reduces:
@@ -553,11 +516,7 @@ class WgradQueue:
         if self.adam is not None and self.items:
             self.adam.pre_flush()  # this step's counters and learning rate, in front of the launch that applies them
         self.flush(final=True)
-        if self._used_side:
-            for dev, side in self._side.items():
-                torch.cuda.current_stream(dev).wait_stream(side)
-            self._used_side = False
-        self.inflight = []  # main-stream-ordered frees are safe again after the join
+        self.inflight = []
 
     def _buffers(self, nbytes, dev, capturing):
         """Cache entry [pinned host, device, event, owned-by-a-graph] for a table upload.  Pinned allocations
@@ -912,7 +871,7 @@ def attention_bwd_do_ok(dy, wt, q, k, mask, H):
         return False  # (the library's A/B switches that turn the fused attention forms off)
     nk = k.shape[1]
     small_k = (64 < nq <= 128 or (1 <= nq <= 32 and H % 2 == 0)) and nk <= 32
-    roles = 96 < nq <= 128 and 96 < nk <= 128 and os.environ.get("OVQA_DOBWD_ROLES", "3") != "0"  # image self-attention
+    roles = 96 < nq <= 128 and 96 < nk <= 128  # image self-attention
     return (dy.is_cuda and dy.dtype == torch.bfloat16 and wt is not None and wt.dtype == torch.bfloat16 and q.dim() == 3
             and q.shape[2] == H * 64 and (small_k or roles)
             and dy.shape[-1] % 64 == 0

@@ -218,7 +218,7 @@ class FlatAdam:
         g = a.grad if grad is None else grad
         # device-side schedule: the kernels multiply 1.0 by *lr_eff (this step's rate, written by begin_step)
         lr, lr_ptr = (1.0, self.lr_eff) if self.lr_table is not None else (self.lr * self.lr_scale, None)
-        tiled_ok = hasattr(a, "adam_tiles_in") and os.environ.get("OVQA_ADAM_TILED", "1") != "0"
+        tiled_ok = hasattr(a, "adam_tiles_in")
         for lo, hi in ([(0, a.numel)] if ranges is None else ranges):
             if hi <= lo:
                 continue
@@ -240,7 +240,7 @@ class FlatAdam:
         arena has no tile table (the caller falls back to ``apply(ranges=...)``)."""
         a = self.arena
         sub = a.adam_tiles_of(group_offsets) if hasattr(a, "adam_tiles_of") else None
-        if sub is None or os.environ.get("OVQA_ADAM_TILED", "1") == "0" or a.small_lo % 4 or a.numel % 4:
+        if sub is None or a.small_lo % 4 or a.numel % 4:
             return False
         g = a.grad if grad is None else grad
         lr, lr_ptr = (1.0, self.lr_eff) if self.lr_table is not None else (self.lr * self.lr_scale, None)
@@ -954,7 +954,7 @@ class TrainStep:
             first, later = self._phase_fns()
             graphs = [torch.cuda.CUDAGraph()]
             q = _fn.wgrad_queue()
-            q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graphs
+            q.defer_uploads = True  # no memcpy nodes in the graphs: the tables are uploaded once, behind the capture
             try:
                 mode = self.reducer.capture_mode
                 with torch.cuda.graph(graphs[0], capture_error_mode=mode):
@@ -1043,7 +1043,7 @@ class TrainStep:
         torch.cuda.synchronize()
         # the step is captured at a fixed point of the counters: put them back afterwards (capture does not execute)
         q = _fn.wgrad_queue()
-        q.defer_uploads = os.environ.get("OVQA_GRAPH_MEMCPY", "0") != "1"  # no memcpy nodes in the graph
+        q.defer_uploads = True  # no memcpy nodes in the graph: the tables are uploaded once, behind the capture
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, capture_error_mode=self.reducer.capture_mode):

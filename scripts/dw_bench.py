@@ -1,5 +1,5 @@
 """The grouped dW launch of the MCAN L=6 B=64 step on its own (HIP events over REPS launches, operands cold-ish: the
-problems' operands are 1 GB, four times the Infinity Cache).  Env: OVQA_DW_TILE256."""
+problems' operands are 1 GB, four times the Infinity Cache)."""
 import json
 import os
 import sys

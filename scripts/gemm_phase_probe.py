@@ -1,5 +1,5 @@
 """Development probe: phases inside the direct-to-LDS GEMM tile (library built with -DOVQA_PHASE_PROBE).
-OVQA_GEMM_KSPLIT etc. are read from the environment (one process per setting)."""
+(Rounds 3-5 compared tile forms through environment switches here; the forms that lost are gone from the library.)"""
 import ctypes as C
 import os
 import sys
@@ -37,7 +37,7 @@ def run_gemm(M, N, K, label, flush=False):
     nm = ["start", "prologue issued", "first K tile done", "K loop done", "epilogue done", "exchanged"]
     for wg in range(2):
         ts = [out[wg * 16 + i] for i in range(len(nm))]
-        print(f"ksplit={os.environ.get('OVQA_GEMM_KSPLIT', '0')} {label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
+        print(f"{label} {'cold' if flush else 'warm'} wg{'0' if wg == 0 else 'mid'}: " +
               "  ".join(f"{a} {((t - ts[0]) / 100.0):.2f}" for a, t in zip(nm, ts) if t >= ts[0]) +
               f"   [events {e0.elapsed_time(e1) * 1e3:.1f} us]")
 

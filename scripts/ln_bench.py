@@ -6,8 +6,8 @@ dropout twin), from a replayed hipGraph.
 
 Two cache states per size: `cold` = a graph of NBUF launches over NBUF different buffer sets (> 256 MB together: neither
 the L2s nor the infinity cache hold a launch's operands when its turn comes), `warm` = the same launch NBUF times on one
-buffer set.  The in-step figures of profiles/*_step_kernel_stats.csv lie between the two.  Variants come from the
-environment (OVQA_LN_FWD_FORM, ...), read once per process: run one process per variant."""
+buffer set.  The in-step figures of profiles/*_step_kernel_stats.csv lie between the two.  (Round 5 swept kernel forms through
+environment switches with this script: profiles/r05_ln_bench*.jsonl; the forms that lost are gone from the library.)"""
 import json
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the persistent LSTM launches alone (hipGraph replay of fwd + bwd, HIP events), per hand-off form.
+"""Time the persistent LSTM launches alone (hipGraph replay of fwd + bwd, HIP events), (one hand-off form is left: the data is the flag).
     python scripts/lstm_bench.py [B T]"""
 import os
 import sys
@@ -19,8 +19,7 @@ b0, b1 = torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev)
 dy = torch.randn(B, T, H, generator=g).to(dev)
 wt = w_hh.t().contiguous()
 out = {}
-for form in ("sentinel", "counter", "fence"):
-    os.environ["OVQA_LSTM_HANDOFF"] = form
+for form in ("sentinel",):  # (rounds 4-5 also timed the counter / fence hand-off forms here: profiles/README.md)
     res = {}
     for which in ("fwd", "bwd"):
         y, hseq, saved, _ = ops.lstm_fwd(x, w_ih, w_hh, b0, b1, B, T)

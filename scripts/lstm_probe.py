@@ -13,8 +13,7 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(T * B, H, generator=g).to(dev, torch.bfloat16)
 w = [(torch.rand(4 * H, H, generator=g) * 2 - 1).mul(H ** -0.5).to(dev, torch.bfloat16) for _ in range(2)]
 b = [torch.zeros(4 * H, device=dev) for _ in range(2)]
-for form in ("sentinel", "counter"):
-    os.environ["OVQA_LSTM_HANDOFF"] = form
+for form in ("sentinel",):
     for rep in range(3):
         y, hseq, saved, scratch = ops.lstm_fwd(x, w[0], w[1], b[0], b[1], B, T)
     torch.cuda.synchronize()

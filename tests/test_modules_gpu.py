@@ -302,8 +302,7 @@ def test_baseline_size_vs_oracle_bf16(B):
         lo_h = te(features=ld[:32], padding_mask=lm[:32])
         vo_h = ve(vision_features=vd[:32], vision_padding_mask=vm[:32], language_features=lo_h,
                   language_padding_mask=lm[:32])
-        if "OVQA_GEMM_KSPLIT" not in os.environ:  # (bit-equal under the default tiling: a k-split tier that one batch size
-            assert torch.equal(vo_h, vo[:32]) and torch.equal(lo_h, lo[:32])  # takes and the other does not sums in another order)
+        assert torch.equal(vo_h, vo[:32]) and torch.equal(lo_h, lo[:32])  # (bit-equal: no tile tier changes the summation order)
         assert nerr(vo_h, vo[:32]) < 2e-2 and nerr(lo_h, lo[:32]) < 2e-2
 
 
