@@ -129,7 +129,7 @@ KERNEL_OF_FAMILY = {
 }
 
 
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 PMC_FILES = ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
 
 
@@ -142,11 +142,16 @@ def pmc_traffic(kernel_prefix):
         return None, None
     key = kernel_prefix.replace("(anonymous namespace)::", "")
     tot_bytes, tot_n = 0.0, 0
-    for name, v in json.load(open(path)).items():  # a family = all tile-size instantiations of the kernel
+    table = json.load(open(path))
+    meta = table.pop("_meta", None)  # (round 6 on: commit, box and time of the collection)
+    for name, v in table.items():  # a family = all tile-size instantiations of the kernel
         if key in name.replace("(anonymous namespace)::", ""):
             tot_bytes += v["hbm_bytes_per_launch"] * v["launches"]
             tot_n += v["launches"]
-    return (round(tot_bytes / tot_n) if tot_n else None), "profiles/" + os.path.basename(path)
+    src = "profiles/" + os.path.basename(path)
+    if meta:
+        src += f" (collected at commit {meta.get('commit')} on box {meta.get('box')}, {meta.get('collected_utc')})"
+    return (round(tot_bytes / tot_n) if tot_n else None), src
 
 
 def roofline_probe(device, B, NV, NT, D, DFF, L, reps=20):

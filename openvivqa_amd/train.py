@@ -321,15 +321,20 @@ class GradAllReducer:
         scratch = torch.zeros(n, dtype=self.comm_dtype if self.staging is not None else grad.dtype, device=grad.device)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.group)
+            work = dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        # The process group's watchdog thread polls the events of eagerly issued collectives (every 100 ms) until it has
-        # seen them complete.  Such a poll DURING a stream capture in the default (global) capture mode invalidates the
-        # capture and terminates the process from the watchdog thread: let it retire this one first -- and capture in
-        # thread-local mode (``capture_mode``), where another thread's event query is legal.
+        # The process group's watchdog thread polls the events of eagerly issued collectives until it has seen them
+        # complete.  Such a poll DURING a stream capture in the default (global) capture mode invalidates the capture and
+        # terminates the process from the watchdog thread: the captures of this harness therefore run in thread-local
+        # mode (``capture_mode``), where another thread's event query is legal -- and this collective is finished, through
+        # its own work handle, before anything is captured (rounds 4-5 slept 0.3 s here instead).
+        if work is not None:
+            work.wait()
         torch.cuda.synchronize(self.device)
         import time
-        time.sleep(0.3)
+        t_end = time.monotonic() + 5.0
+        while work is not None and not work.is_completed() and time.monotonic() < t_end:
+            time.sleep(0.001)
 
     def reset(self) -> None:
         """Forget every released segment (after an aborted stream capture: its work handles must not be joined)."""
@@ -798,6 +803,13 @@ class TrainStep:
         # update of a zero gradient is exactly zero, so the separate whole-arena launch may keep them in)
         dead = [(a.offsets[id(p_)], a.offsets[id(p_)] + a.span(p_)) for p_ in a.params
                 if id(p_) not in a.kernel_written and id(p_) not in touched]
+        if not self.use_graph:
+            # Eager steps re-run the Python forward: a parameter this batch did not reach may get a gradient from the next
+            # one (a captured graph freezes the control flow, so there "dead on the discovery batch" is "dead for ever").
+            # Nothing is classified dead then: such parameters stay in the per-step zeroing and in the optimiser's ranges
+            # (a zero gradient on zero moments is a zero update; with weight_decay > 0 they decay, where torch.optim.Adam
+            # would skip a parameter whose .grad is None).
+            dead = []
         self._dead = _merge(sorted(dead))
         for s_, e_ in self._dead:
             a.grad[s_:e_].zero_()

@@ -47,6 +47,13 @@ for k, v in acc.items():
         # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> x2; both are in KB
         traffic[k] = {"launches": len(v["FETCH_SIZE"]), "fetch_kb_avg": f, "write_kb_avg": w,
                       "hbm_bytes_per_launch": (2 * f + w) * 1024}
+# where and on what this was collected (bench.py copies it into roofline.traffic_source): the commit is handed in by the
+# caller (COMMIT=$(git rev-parse --short HEAD): the GPU box has no .git), the box names itself
+import hashlib, os, socket, time
+lib = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "openvivqa_amd", "csrc", "libovqa_hip.so")
+traffic["_meta"] = {"commit": os.environ.get("COMMIT", "unknown"), "box": socket.gethostname(),
+                    "collected_utc": time.strftime("%Y-%m-%dT%H:%MZ", time.gmtime()),
+                    "libovqa_hip_sha256_16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None}
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 # ---- SQ counters per kernel (averages per launch) + durations from the kernel trace of the same pass
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -68,7 +75,7 @@ for k, v in pmc.items():
                 row[c.lower() + "_frac_of_wave_cycles"] = row[c] / row["SQ_WAVE_CYCLES"]
     summary[k] = row
 json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1)
-top = sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]
+top = sorted(((k, v) for k, v in traffic.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]
 for k, v in top:
     s = summary.get(k, {})
     print(f'{k[:78]:78s} n={v["launches"]:4d} hbm={v["hbm_bytes_per_launch"]/1e6:7.1f}MB mfma_busy={s.get("mfma_busy_frac", float("nan")):.3f} '

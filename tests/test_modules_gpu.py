@@ -495,7 +495,7 @@ def test_config3_size_pair_encoders_vs_oracle_bf16(arch, layers):
         if not grad_close(e, fmt, gbar, tag, "gw/" + k, allow_escape=not no_escape):
             bad.append((k, e, fmt))
     assert not bad, bad
-    assert unresolved <= 120, unresolved  # (of 576 tensors)
+    assert unresolved <= 60, unresolved  # (of 576 tensors; measured 50 in round 5: recorded, NOT asserted -- DESIGN.md section 2)
 
 
 def test_crossmodality_dead_branch_and_unused_grads(mode):
