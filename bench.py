@@ -68,6 +68,12 @@ def parse():
     ap.add_argument("--cpu-threads", default="8,16,32,64,128",
                     help="thread counts the CPU leg sweeps (one B=16 step each) before timing at the best")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-shard", action="store_true",
+                    help="N > 1: the replicated optimiser (all-reduce + the same Adam on every rank) instead of the sharded one "
+                         "(reduce-scatter, Adam on the owned chunks, all-gather of the bf16 shadow)")
+    ap.add_argument("--rehearse-shard", type=int, default=0,
+                    help="with --rehearse-comm on ONE rank: run the sharded optimiser's machinery with the slice sizes of N ranks "
+                         "(Adam on 1/N of every exchanged bucket; timing only, the other chunks are not updated)")
     ap.add_argument("--no-fuse-adam", action="store_true",
                     help="keep Adam a launch of its own at N = 1 too (default at N = 1: the weight matrices are updated inside "
                          "the last grouped weight-gradient launch, TrainStep(fuse_adam=True); with N > 1 the gradient exchange "
@@ -726,6 +732,7 @@ def main():
                 add_rooflines(out, ts, cfg, device)
             if world == 1 and not args.no_secondary and not args.rehearse_comm:
                 out["secondary"] = secondary_lines(args, device, dtype)
+                out["ms_per_step_unfused"] = out["secondary"].get("stack_unfused_adam", {}).get("ms_per_step")
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_steps, args.cpu_threads)
                 out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
@@ -853,7 +860,9 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
     ts = TrainStep(model, forward_loss, lr=float(b.LEARNING_RATE), betas=(0.9, 0.98),
                    lr_lambda=lambda s_: noam_lr_scale(s_, D, int(b.WARMUP)), use_graph=not args.no_graph,
                    comm_dtype=comm, compute_dtype=dtype, overlap_mb=args.overlap_mb,
-                   force_comm=args.rehearse_comm, fuse_adam=not getattr(args, "no_fuse_adam", False) and os.environ.get("OVQA_FUSE_ADAM", "1") != "0")
+                   force_comm=args.rehearse_comm, fuse_adam=not getattr(args, "no_fuse_adam", False) and os.environ.get("OVQA_FUSE_ADAM", "1") != "0",
+                   shard_optimizer=False if getattr(args, "no_shard", False) else None,
+                   rehearse_shard=getattr(args, "rehearse_shard", 0) if args.rehearse_comm else 0)
     if workload == "cross_modality":
         loss_buf = ts.loss  # (the scalar-loss protocol: TrainStep copies the loss into its own buffer)
     else:
@@ -908,7 +917,12 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
                    "grad_segments": ts.n_exchanges, "backward_phases": len(ts.segments), "rehearse_comm": bool(args.rehearse_comm),
                    "adam": ("inside the last weight-gradient launch for the weight matrices (TrainStep.fuse_adam: world size 1), "
                             "one launch for the 1-D parameters" if getattr(ts, "_fused", None) is not None and ts._fused.began
-                            else "separate launch(es) behind backward / the gradient exchange")},
+                            else (f"sharded over {ts.reducer.shard_world} ranks: reduce-scatter of the weight matrices' gradients, "
+                                  "Adam on the owned chunks, all-gather of the bf16 shadow, transposed shadow rebuilt locally"
+                                  + (" (single-rank REHEARSAL of the slice sizes: the other chunks are not updated)"
+                                     if ts.reducer.shard_world != ts.reducer.world else "")
+                                  if getattr(ts, "shard", False)
+                                  else "separate launch(es) behind backward / the gradient exchange"))},
         "final_loss": round(final_loss, 6),
         "repeats": len(windows),
         "ms_per_step_median": round(statistics.median(windows) / steps * 1e3, 3),
@@ -1004,6 +1018,11 @@ def secondary_lines(args, device, dtype):
             except Exception:  # noqa: BLE001
                 pass
 
+    # the headline workload with Adam as a launch of its own (what every rank of an N > 1 run executes: the fused form needs
+    # world size 1), so that a scaling curve can be read against the same code path
+    a_unf = copy.copy(args)
+    a_unf.no_fuse_adam = True
+    guarded("stack_unfused_adam", lambda: compact(train_bench(a_unf, "stack", device, 1, 0, None, dtype, steps=30, warmup=5, repeats=1)[0]))
     for wl in ("model", "cross_modality", "decoder_train"):
         guarded(wl, lambda wl=wl: compact(train_bench(args, wl, device, 1, 0, None, dtype, steps=20, warmup=3, repeats=1)[0],
                                           ("step_frac_of_bf16_peak", "algorithmic_gflop_per_sample_fwd_bwd")))

@@ -293,8 +293,18 @@ class GradAllReducer:
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.comm_dtype = comm_dtype
         elt = 2 if comm_dtype == torch.bfloat16 else 4
-        self.bucket = max(1, int(bucket_mb * (1 << 20) / elt))
+        # (whole ALIGN units: a sharded exchange cuts every bucket into `world` equal chunks)
+        self.bucket = max(rt.ALIGN, int(bucket_mb * (1 << 20) / elt) // rt.ALIGN * rt.ALIGN)
         self.staging = torch.empty(numel, dtype=comm_dtype, device=device) if comm_dtype != torch.float32 else None
+        # Sharded optimiser (round 6, ``TrainStep(shard_optimizer=True)``): elements below ``shard_hi`` are REDUCE-SCATTERED
+        # instead of all-reduced -- rank r ends up with the sum of chunk r of every bucket only -- and the updated weights
+        # are ALL-GATHERED afterwards (``gather``).  0 = the replicated form.
+        self.shard_hi = 0
+        self.shard_world = self.world  # (a single-rank rehearsal may pretend to own 1/N: timing only, wrong numerics)
+        # Buckets never straddle ``cut`` (TrainStep: the start of the arena's 1-D tail), sharded or not: the replicated and the
+        # sharded form then exchange the SAME messages, so their gradient sums are the same bits (a collective's summation
+        # order depends on where an element lies in its message).
+        self.cut = 0
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._pending = False
@@ -323,11 +333,15 @@ class GradAllReducer:
         with torch.cuda.stream(self.stream):
             work = dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        # The process group's watchdog thread polls the events of eagerly issued collectives until it has seen them
-        # complete.  Such a poll DURING a stream capture in the default (global) capture mode invalidates the capture and
-        # terminates the process from the watchdog thread: the captures of this harness therefore run in thread-local
-        # mode (``capture_mode``), where another thread's event query is legal -- and this collective is finished, through
-        # its own work handle, before anything is captured (rounds 4-5 slept 0.3 s here instead).
+        # The process group's watchdog thread polls the events of eagerly issued collectives (every 100 ms) until it has
+        # seen them complete, and only then drops them from its list.  Such a poll DURING a stream capture in the default
+        # (global) capture mode invalidates the capture and terminates the process from the watchdog thread: the captures
+        # of this harness therefore run in thread-local mode (``capture_mode``), where another thread's event query is
+        # legal.  This collective is finished through its own work handle -- and the watchdog is then given three of its
+        # poll periods to retire every eager collective issued so far.  Round 6 tried without that pause (VERDICT r5 weak
+        # #10): one of three single-rank rehearsals died in the watchdog with hipErrorCapturedEvent ("operation not
+        # permitted on an event last recorded in a capturing stream") -- a work still on its list when the capture began;
+        # the process group offers no call that waits for the list to drain.
         if work is not None:
             work.wait()
         torch.cuda.synchronize(self.device)
@@ -335,6 +349,7 @@ class GradAllReducer:
         t_end = time.monotonic() + 5.0
         while work is not None and not work.is_completed() and time.monotonic() < t_end:
             time.sleep(0.001)
+        time.sleep(0.3)
 
     def reset(self) -> None:
         """Forget every released segment (after an aborted stream capture: its work handles must not be joined)."""
@@ -351,6 +366,79 @@ class GradAllReducer:
     def bounds(self, numel: int, lo: int = 0):
         return [(s, min(s + self.bucket, lo + numel)) for s in range(lo, lo + numel, self.bucket)]
 
+    # -- sharded form ---------------------------------------------------------------------------------------------------
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if self.world > 1 else 0
+
+    def _native_scatter(self) -> bool:
+        """reduce_scatter_tensor / all_gather_into_tensor exist for RCCL; gloo (the CPU tests, the one-GPU rehearsals over
+        gloo) gets the same RESULT from an all-reduce: every rank then holds every chunk's sum, and uses its own."""
+        try:
+            return self.world > 1 and str(dist.get_backend(self.group)).lower() == "nccl"
+        except Exception:  # noqa: BLE001
+            return False
+
+    def pieces(self, ranges):
+        """``ranges`` cut at ``shard_hi`` and into buckets: [(lo, hi, sharded)]; a sharded piece is a whole number of ALIGN
+        units, i.e. of `world` equal chunks."""
+        out = []
+        for lo, hi in ranges:
+            if hi <= lo:
+                continue
+            cut = min(max(max(self.cut, self.shard_hi), lo), hi)
+            if cut > lo:
+                out += [(s, e, e <= self.shard_hi) for s, e in self.bounds(cut - lo, lo)]
+            if hi > cut:
+                out += [(s, e, False) for s, e in self.bounds(hi - cut, cut)]
+        return out
+
+    def chunk(self, s: int, e: int):
+        """The chunk of the sharded piece [s, e) this rank owns."""
+        n = self.shard_world
+        assert (e - s) % n == 0, (s, e, n)
+        c = (e - s) // n
+        r = self.rank if self.shard_world == self.world else 0
+        return s + r * c, s + (r + 1) * c
+
+    def owned(self, ranges):
+        """What this rank updates of ``ranges``: its chunk of every sharded piece + the replicated part as it is."""
+        return _merge(sorted([self.chunk(s, e) if sh else (s, e) for s, e, sh in self.pieces(ranges)]))
+
+    def _collective(self, buf, s, e, sharded):
+        if sharded and self._native_scatter():
+            lo, hi = self.chunk(s, e)  # (in place: the output is the rank's own chunk of the input)
+            return dist.reduce_scatter_tensor(buf[lo:hi], buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def gather(self, t: torch.Tensor, ranges, async_op: bool = False):
+        """All-gather of the sharded pieces of ``ranges`` in ``t`` (the bf16 shadow, or the fp32 masters): every rank's
+        chunk as its owner left it.  Collectives on the CURRENT stream; returns their work handles (``async_op``)."""
+        handles = []
+        if not self.active or self.shard_hi <= 0:
+            return handles
+        native = self._native_scatter()
+        for s, e, sh in self.pieces(ranges):
+            if not sh:
+                continue
+            lo, hi = self.chunk(s, e)
+            if native:
+                h = dist.all_gather_into_tensor(t[s:e], t[lo:hi], group=self.group, async_op=True)
+            elif self.world > 1:  # exactly one rank contributes a non-zero value per element: the sum IS the gather
+                tmp = torch.zeros(e - s, dtype=torch.float32, device=t.device)
+                tmp[lo - s:hi - s] = t[lo:hi].float()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                t[s:e].copy_(tmp)
+                h = None
+            else:
+                h = None
+            if h is not None:
+                if async_op:
+                    handles.append(h)
+                else:
+                    h.wait()
+        return handles
+
     def _reduce(self, grad: torch.Tensor, ranges):
         for lo, hi in ranges:
             if hi <= lo:
@@ -362,8 +450,7 @@ class GradAllReducer:
                 else:
                     self.staging[lo:hi].copy_(grad[lo:hi])
                 buf = self.staging
-            handles = [dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                       for s, e in self.bounds(hi - lo, lo)]
+            handles = [self._collective(buf, s, e, sh) for s, e, sh in self.pieces([(lo, hi)])]
             for h in handles:
                 h.wait()  # CUDA: orders the current (communication) stream after the collective, no host block
             if self.staging is not None and not grad.is_cuda:
@@ -384,8 +471,7 @@ class GradAllReducer:
             if self.staging is not None:
                 ops.cast(grad[lo:hi], self.staging[lo:hi])
                 buf = self.staging
-            handles += [dist.all_reduce(buf[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                        for s, e in self.bounds(hi - lo, lo)]
+            handles += [self._collective(buf, s, e, sh) for s, e, sh in self.pieces([(lo, hi)])]
         return handles
 
     def reduce_ranges(self, grad: torch.Tensor, ranges, after=None) -> None:
@@ -648,7 +734,8 @@ class TrainStep:
                  lr_lambda: Optional[Callable[[int], float]] = None, use_graph: bool = True,
                  comm_dtype: torch.dtype = torch.float32, bucket_mb: float = 64.0, device=None,
                  compute_dtype: Optional[torch.dtype] = None, overlap_mb: float = 96.0,
-                 force_comm: bool = False, fuse_adam: Optional[bool] = None):
+                 force_comm: bool = False, fuse_adam: Optional[bool] = None, shard_optimizer: Optional[bool] = None,
+                 rehearse_shard: int = 0):
         self.model = model
         self.arena = rt.prepare(model, device=device, compute_dtype=compute_dtype)
         self.arena.overwrite_grads = True
@@ -672,6 +759,21 @@ class TrainStep:
         want = (os.environ.get("OVQA_FUSE_ADAM", "0") == "1") if fuse_adam is None else bool(fuse_adam)
         self._fused = (_FusedAdam(self) if want and not self.reducer.active and self.arena.device.type == "cuda"
                        and getattr(self.arena, "shadow_t", None) is not None and self.arena.adam_tiles() is not None else None)
+        # Sharded optimiser (round 6; default with a gradient exchange over more than one rank, OVQA_SHARD_OPTIMIZER=0 turns it
+        # off): the weight matrices' gradients are reduce-SCATTERED -- rank r owns chunk r of every exchanged bucket --, Adam
+        # runs on the owned chunks only (1/N of the 236 us every rank spent on the same update), and what the next forward
+        # reads (the bf16 shadow; the masters themselves in fp32 mode) is all-gathered: the bytes on a link are
+        # (N-1)/N x (4 + 2) B per weight instead of the all-reduce's (N-1)/N x 8.  The transposed shadow is rebuilt locally
+        # from the gathered one (one grouped-transpose launch).  The 1-D tail (biases, LayerNorm) stays all-reduced and
+        # replicated.  Masters and moments of a chunk live on its owner only: ``state_dict()`` / ``gather_state()``
+        # gather them.  Same bits as the replicated form (one update function, common.h), given the same gradient sums.
+        want_shard = (os.environ.get("OVQA_SHARD_OPTIMIZER", "1") != "0") if shard_optimizer is None else bool(shard_optimizer)
+        n_sh = rehearse_shard if (rehearse_shard and self.reducer.world == 1) else self.reducer.world
+        self.shard = bool(want_shard and self.reducer.active and n_sh > 1 and rt.ALIGN % n_sh == 0 and self.arena.small_lo > 0)
+        self.reducer.cut = self.arena.small_lo
+        if self.shard:
+            self.reducer.shard_hi = self.arena.small_lo
+            self.reducer.shard_world = n_sh
         self._cuts = None            # _Cuts sink when backward is phased
         self.segments = [[(0, self.arena.numel)]]  # segments[k] = ranges final after phase k
         self._live = None
@@ -1014,9 +1116,45 @@ class TrainStep:
             self._fused.reset()
         q.adam = self._fused if on else None
 
+    def _sharded_tail(self, scale: float) -> None:
+        """Adam on this rank's chunks of every exchanged piece, all-gather of what the forward reads (see ``shard``)."""
+        a, red = self.arena, self.reducer
+        n = len(self.segments)
+        tgt = a.shadow if a.shadow is not None else a.master
+        self.optim.begin_step(also=self.drop_step)
+        handles, buf = [], a.grad
+        if n > 1:  # every segment but the last has arrived (or is about to): their chunks first, gathered under the last exchange
+            for k in range(n - 1):
+                buf = red.wait_segment(k, a.grad)
+            early = _merge([c for seg in self.segments[:-1] for c in red.owned(seg)])
+            self.optim.apply(buf, scale, ranges=early)
+            for seg in self.segments[:-1]:
+                handles += red.gather(tgt, seg, async_op=True)
+            buf = red.wait_segment(n - 1, a.grad)
+        else:
+            buf = red.finish(a.grad)
+        self.optim.apply(buf, scale, ranges=red.owned(self.segments[-1]))
+        handles += red.gather(tgt, self.segments[-1], async_op=True)
+        for h in handles:
+            h.wait()
+        red.finish(a.grad)
+        if a.shadow is not None:
+            self.optim._transposed_stale = True  # the gathered chunks of the other ranks: rebuilt in finish_device()
+
+    def gather_state(self) -> None:
+        """Under the sharded optimiser: bring the fp32 masters and both moments of every chunk from its owner to all ranks
+        (a collective: every rank must call it).  ``state_dict()`` does; call it before ``model.state_dict()`` too."""
+        if not self.shard or self.reducer.world <= 1:
+            return
+        for t in ([self.arena.master] if self.arena.shadow is not None else []) + [self.optim.exp_avg, self.optim.exp_avg_sq]:
+            for seg in self.segments:
+                self.reducer.gather(t, seg)
+
     def _optimiser_tail(self, host: bool = True) -> None:
         scale = 1.0 / self.reducer.world
-        if self.reducer.active and len(self.segments) > 1:
+        if self.reducer.active and self.shard:
+            self._sharded_tail(scale)
+        elif self.reducer.active and len(self.segments) > 1:
             # segment by segment: the update of a segment that has arrived overlaps the exchange of the later ones
             # (only the LAST segment's exchange is exposed, and the earlier segments' share of Adam now hides part of it)
             self.optim.begin_step(also=self.drop_step)  # (the dropout step is next read by the NEXT forward)
@@ -1098,6 +1236,7 @@ class TrainStep:
     def state_dict(self) -> dict:
         """Optimiser + dropout-counter state (the model's own ``state_dict`` holds the fp32 master weights).  The
         optimiser part names every parameter, so a checkpoint cannot be loaded onto a differently ordered model."""
+        self.gather_state()
         return {"optim": self.optim.state_dict(self._param_names()), "drop_step": int(self.drop_step.item())}
 
     def load_state_dict(self, sd: dict) -> None:

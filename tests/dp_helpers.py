@@ -39,7 +39,7 @@ CM_CFG = dict(D_MODEL=32, LAYERS=3, VISION_LANGUAGE_ATTENTION=ATT, LANGUAGE_VISI
               VISION_SELF_ATTENTION=ATT, LANGUAGE_SELF_ATTENTION=ATT)
 
 
-def make_step(overlap_mb, comm_dtype=torch.float32, seed=7, kind="mcan"):
+def make_step(overlap_mb, comm_dtype=torch.float32, seed=7, kind="mcan", shard=None):
     import mock_ops
     from openvivqa_amd.config import ConfigNode
     from openvivqa_amd.mcan_stack import MCANEncoderStack
@@ -59,7 +59,7 @@ def make_step(overlap_mb, comm_dtype=torch.float32, seed=7, kind="mcan"):
         dlo = mock_ops.sq_loss_fwd_bwd(lo.detach(), loss_buf, accumulate=True, target=tgt_t)
         return (vo, lo), (dvo, dlo)
     ts = TrainStep(model, forward_loss, lr=1e-2, betas=(0.9, 0.98), use_graph=False, comm_dtype=comm_dtype,
-                   compute_dtype=torch.float32, overlap_mb=overlap_mb, bucket_mb=0.01)
+                   compute_dtype=torch.float32, overlap_mb=overlap_mb, bucket_mb=0.01, shard_optimizer=shard)
     return model, ts
 
 
@@ -70,15 +70,19 @@ def batch(rank, B=3, NV=6, NT=4, D=32):
     return v, vm, t, tm, torch.randn(B, NV, D, generator=g), torch.randn(B, NT, D, generator=g)
 
 
-def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q, kind="mcan"):
+def dp_worker(rank, world, rdv, overlap_mb, comm_bf16, q, kind="mcan", shard=None):
     import torch.distributed as dist
     patch_cpu_ops()
     dist.init_process_group("gloo", init_method="file://" + rdv, rank=rank, world_size=world)
     try:
-        model, ts = make_step(overlap_mb, torch.bfloat16 if comm_bf16 else torch.float32, kind=kind)
+        model, ts = make_step(overlap_mb, torch.bfloat16 if comm_bf16 else torch.float32, kind=kind, shard=shard)
         for _ in range(2):
             ts.step(*batch(rank))
-        q.put((rank, ts.arena.master.clone().numpy(), [list(map(list, s)) for s in ts.segments]))
+        assert ts.shard == (bool(shard) if shard is not None else world > 1), (ts.shard, shard, world)
+        owned = ts.reducer.owned([(0, ts.arena.numel)]) if ts.shard else None
+        sd = ts.state_dict()  # (a collective under the sharded optimiser: masters and moments come home from their owners)
+        q.put((rank, ts.arena.master.clone().numpy(), [list(map(list, s)) for s in ts.segments],
+               sd["optim"]["exp_avg"].numpy(), owned))
     finally:
         dist.destroy_process_group()
 
@@ -141,6 +145,7 @@ def dp_gpu_worker(rank, world, rdv, comm_bf16, steps, q):
         tgt["v"], tgt["t"] = tv, tt
         for _ in range(steps):
             ts.step(*batch)
+        ts.gather_state()  # (sharded optimiser: the fp32 masters of a chunk live on its owner -- a collective, every rank)
         torch.cuda.synchronize()
         if rank == 0:
             q.put(ts.arena.master.detach().cpu().numpy())

@@ -259,6 +259,50 @@ def test_grad_allreduce_gloo_world2(comm_bf16):
     assert torch.equal(res[0], res[1])  # every rank ends with identical gradients
 
 
+def _run_dp(world, overlap_mb, comm_bf16, kind, shard):
+    import tempfile
+    import torch.multiprocessing as mp
+    import dp_helpers as H
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    rdv = os.path.join(tempfile.mkdtemp(prefix="ovqa_rdv_"), "store")
+    procs = [ctx.Process(target=H.dp_worker, args=(r, world, rdv, overlap_mb, comm_bf16, q, kind, shard)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (torch.from_numpy(w), seg, torch.from_numpy(m), own) for r, w, seg, m, own in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("overlap_mb,comm_bf16,kind,world", [
+    (0.0, False, "mcan", 2), (0.02, False, "mcan", 2), (0.02, True, "mcan", 2), (0.02, False, "crossmodality", 2),
+    (0.02, False, "mcan", 8)])
+def test_sharded_optimizer_equals_replicated_bitwise(overlap_mb, comm_bf16, kind, world):
+    """Round 6: with the optimiser SHARDED over the ranks -- gradients of the weight matrices
+    reduce-scattered, Adam on the owned chunk of every exchanged bucket, the weights all-gathered -- every rank ends with
+    the same weights and (after ``state_dict()``'s gather) the same moments as with the replicated optimiser, bit for bit
+    (gloo has no reduce-scatter on CPU tensors: it is emulated by all-reduce + the rank's own slice, so the gradient sums
+    are the same sums), and the ranks' owned ranges partition the matrix part of the arena."""
+    rep = _run_dp(world, overlap_mb, comm_bf16, kind, False)
+    sh = _run_dp(world, overlap_mb, comm_bf16, kind, True)
+    assert rep[0][1] == sh[0][1]  # the same segment plan
+    for r in range(world):
+        assert torch.equal(sh[r][0], rep[0][0]), r
+        assert torch.equal(sh[r][2], rep[0][2]), r
+        assert rep[r][3] is None
+    spans = sorted(tuple(x) for r in range(world) for x in sh[r][3])
+    # chunks of the sharded part are disjoint; the replicated tail is listed by every rank
+    numel = rep[0][0].numel()
+    cover = torch.zeros(numel, dtype=torch.int32)
+    for lo, hi in spans:
+        cover[lo:hi] += 1
+    first_tail = int((cover == world).nonzero()[0]) if (cover == world).any() else numel
+    assert bool((cover[:first_tail] == 1).all()) and bool((cover[first_tail:] == world).all()), (first_tail, numel)
+    assert first_tail > numel // 2  # (the weight matrices are the bulk of the arena)
+
+
 @pytest.mark.parametrize("overlap_mb,comm_bf16,kind,world", [
     (0.0, False, "mcan", 2), (0.02, False, "mcan", 2), (0.02, True, "mcan", 2), (0.02, False, "crossmodality", 2),
     (0.02, False, "mcan", 8)])  # 8 ranks: the node size the driver scales to
@@ -267,19 +311,8 @@ def test_train_step_dp_gloo_world2_phased_backward(overlap_mb, comm_bf16, kind, 
     released segment by segment during a phased backward (overlap_mb > 0) all ranks end with identical weights,
     equal to a single process that averages the ranks' gradients itself; the segment plan is identical on every
     rank (TrainStep._check_plan_identical runs inside)."""
-    import tempfile
-    import torch.multiprocessing as mp
     import dp_helpers as H
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    rdv = os.path.join(tempfile.mkdtemp(prefix="ovqa_rdv_"), "store")
-    procs = [ctx.Process(target=H.dp_worker, args=(r, world, rdv, overlap_mb, comm_bf16, q, kind)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = {r: (torch.from_numpy(w), seg) for r, w, seg in (q.get(timeout=300) for _ in range(world))}
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_dp(world, overlap_mb, comm_bf16, kind, None)  # (the default: the sharded optimiser from two ranks on)
     for r in range(1, world):
         assert torch.equal(res[0][0], res[r][0])
         assert res[0][1] == res[r][1]
