@@ -1035,6 +1035,31 @@ class TrainStep:
             if not self._agree(True):
                 raise _PeerFailed("another rank failed before the gradient exchange was set up")
             self._check_plan_identical()
+            if self.shard and self.reducer.world > 1:
+                # The sharded exchange's own collectives (in-place reduce-scatter / all-gather on slices of the arena), once,
+                # eagerly, on scratch copies of the first piece: if the backend refuses them on ANY rank, every rank falls
+                # back to the replicated form together -- before anything is captured or any weight is touched.
+                ok = True
+                try:
+                    s0, e0, _ = self.reducer.pieces(self.segments[0])[0]
+                    probe_g = self.arena.grad[s0:e0].clone()
+                    tgt = self.arena.shadow if self.arena.shadow is not None else self.arena.master
+                    probe_w = tgt[s0:e0].clone()
+                    lo, hi = self.reducer.chunk(0, e0 - s0)
+                    if self.reducer._native_scatter():
+                        dist.reduce_scatter_tensor(probe_g[lo:hi], probe_g, op=dist.ReduceOp.SUM, group=self.reducer.group)
+                        dist.all_gather_into_tensor(probe_w, probe_w[lo:hi], group=self.reducer.group)
+                    torch.cuda.synchronize()
+                    ok = bool(torch.equal(probe_w, tgt[s0:e0]))  # (the replicas are identical here: the gather is a no-op)
+                except Exception as exc:  # noqa: BLE001
+                    import sys
+                    print(f"openvivqa_amd.TrainStep: sharded exchange refused ({type(exc).__name__}: {exc})", file=sys.stderr)
+                    ok = False
+                if not self._agree(ok):
+                    import sys
+                    print("openvivqa_amd.TrainStep: falling back to the replicated optimiser on every rank", file=sys.stderr)
+                    self.shard = False
+                    self.reducer.shard_hi = 0
             self._fwd_bwd(on_phase=self._release)
             self.reducer.finish(self.arena.grad)
             torch.cuda.synchronize()
