@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel-family gap budget of the headline step (profiles/README.md).
 
-    python scripts/gap_budget.py [profiles/r05_step_kernel_stats.csv profiles/r05_traffic.json]
+    python scripts/gap_budget.py [profiles/r06_step_kernel_stats.csv profiles/r06_traffic.json]
 
 For every family of the replayed step: launches and microseconds per step (rocprofv3 kernel trace, replay window),
 ALGORITHMIC flops and bytes (every operand once, bf16 unless the path stores fp32), measured HBM bytes (separate FETCH_SIZE
@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (gemm_launch_list: the launch list of one step)
 
-stats = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_step_kernel_stats.csv")
-traffic = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r05_traffic.json")
+stats = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_step_kernel_stats.csv")
+traffic = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r06_traffic.json")
 B, NV, NT, D, DFF, L, H = 64, 100, 20, 512, 2048, 6, 8
 rows = [r for r in csv.reader(open(stats)) if r and not r[0].startswith("#") and r[0] != "kernel"]
 tr = json.load(open(traffic))
