@@ -126,21 +126,6 @@ int ovqa_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float
                           float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K,
                           const ovqa_dropout* drop, void* stream);
 
-/* The same product followed by the block's OWN LayerNorm (attentions.py:330-331 / positionwise_feed_forward.py:25-26: the
- * fc_o / fc2 output, dropout, residual add and layer_norm of one block) behind one entry point:
- *     pre[m,:]  = res(m,:) + drop(x W^T + b)[m,:]                       fp32 [M,N], contiguous
- *     y[m,:]    = (pre[m,:] - mean[m]) * rstd[m] * gamma + beta          bf16 [M,N], contiguous
- *     mean[m], rstd[m] = the row statistics of pre (biased variance, eps inside the root), fp32 [M]
- * `ln_in` describes `residual` as in ovqa_linear_fwd_res32 (NULL: a plain fp32 tensor); gamma / beta / eps are THIS
- * block's LayerNorm.  N == 512 with K % 64 == 0 runs as ONE kernel whose workgroups own whole output rows; every other
- * shape as ovqa_linear_fwd_res32 followed by ovqa_layernorm_fwd.  The two forms reduce the row statistics in different
- * orders: results agree to fp32 rounding of the statistics (<= 1 bf16 ulp in y), not bit for bit. */
-int ovqa_linear_fwd_res32_ln(const void* x, int64_t ldx, const void* w, const float* bias,
-                             const float* residual, int64_t ldres, const ovqa_ln_ref* ln_in,
-                             float* pre, const float* gamma, const float* beta, float eps,
-                             void* y, float* mean, float* rstd, int64_t M, int64_t N, int64_t K,
-                             const ovqa_dropout* drop, void* stream);
-
 /* dX = dY W  (autograd of nn.Linear w.r.t. its input).
  *   dy [M,N] (lddy), w [N,K], dx [M,K] (lddx).
  *   If `gelu_preact` != NULL the FFN backward is fused:

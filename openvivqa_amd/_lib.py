@@ -88,8 +88,6 @@ SIGNATURES = {
                         c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_linear_fwd_res32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, C.POINTER(LnRef), c_vp, c_i64, c_i64, c_i64, c_i64,
                               _DP, c_vp],
-    "ovqa_linear_fwd_res32_ln": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, C.POINTER(LnRef), c_vp, c_vp, c_vp, C.c_float,
-                                 c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_linear_bwd_data": [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, _DP, c_vp],
     "ovqa_grouped_linear_bwd_weight": [c_int, c_vp, c_vp, c_i64, c_int, c_vp],
     "ovqa_grouped_linear_bwd_weight_adam": [c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],

@@ -52,12 +52,6 @@ static bool force_simple() {
   return v == 1;
 }
 
-// A/B switch: OVQA_ROWLN=0 runs ovqa_linear_fwd_res32_ln as its two launches at every shape (read per call: tests flip it)
-static bool no_rowln() {
-  const char* e = getenv("OVQA_ROWLN");
-  return e && e[0] == '0';
-}
-
 // A/B switch: run self-attention as the separate projection GEMM + attention kernels (read per call: tests flip it)
 static bool no_fused_qkv() {
   const char* e = getenv("OVQA_NO_FUSED_QKV");
@@ -243,37 +237,6 @@ int ovqa_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float
   OVQA_FALLBACK("linear_fwd_res32");
   return ovqa::simple_linear_fwd_res32(x, ldx, w, bias, residual, ldres, mean, rstd, gamma, beta, pre, ldpre, M, N, K, da,
                                        as_stream(stream));
-}
-
-int ovqa_linear_fwd_res32_ln(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
-                             int64_t ldres, const ovqa_ln_ref* ln_in, float* pre, const float* gamma, const float* beta,
-                             float eps, void* y, float* mean, float* rstd, int64_t M, int64_t N, int64_t K,
-                             const ovqa_dropout* drop, void* stream) {
-  OVQA_REQUIRE(M >= 0 && N > 0 && K > 0, OVQA_ERR_BAD_ARG, "linear_fwd_res32_ln: bad sizes M=%lld N=%lld K=%lld",
-               (long long)M, (long long)N, (long long)K);
-  if (M == 0) return OVQA_OK;
-  OVQA_REQUIRE(x && w && residual && pre && gamma && beta && y && mean && rstd, OVQA_ERR_BAD_ARG,
-               "linear_fwd_res32_ln: null pointer");
-  OVQA_REQUIRE(ldx >= K && ldres >= N, OVQA_ERR_BAD_ARG, "linear_fwd_res32_ln: ld smaller than the row length");
-  OVQA_REQUIRE(!ln_in || (ln_in->mean && ln_in->rstd && ln_in->gamma && ln_in->beta), OVQA_ERR_BAD_ARG,
-               "linear_fwd_res32_ln: incomplete LayerNorm reference");
-  OVQA_REQUIRE(M * (N > K ? N : K) < (1ll << 32), OVQA_ERR_UNSUPPORTED, "linear_fwd_res32_ln: more than 2^32 elements");
-  if (!no_rowln() && !force_simple() && M >= ovqa::kRowLnMinRows &&
-      ovqa::mfma_linear_fwd_res32_ln_supported(M, N, K, ldx, N, ldres, N)) {
-    const DropArgs da = make_drop_args(drop);
-    g_dispatch = "mfma_rowln";
-    return ovqa::mfma_linear_fwd_res32_ln(x, ldx, w, bias, residual, ldres, ln_in ? ln_in->mean : nullptr,
-                                          ln_in ? ln_in->rstd : nullptr, ln_in ? ln_in->gamma : nullptr,
-                                          ln_in ? ln_in->beta : nullptr, pre, N, gamma, beta, eps, y, N, mean, rstd, M, N,
-                                          K, da, as_stream(stream));
-  }
-  // every other shape: the two launches this entry point stands for
-  int rc = ovqa_linear_fwd_res32(x, ldx, w, bias, residual, ldres, ln_in, pre, N, M, N, K, drop, stream);
-  if (rc != OVQA_OK) return rc;
-  const char* d = g_dispatch;
-  rc = ovqa_layernorm_fwd(OVQA_BF16, OVQA_F32, pre, gamma, beta, nullptr, 0, y, nullptr, mean, rstd, M, N, eps, stream);
-  g_dispatch = d;
-  return rc;
 }
 
 int ovqa_linear_bwd_data(int dtype, const void* dy, int64_t lddy, const void* w, void* dx, int64_t lddx,

@@ -30,7 +30,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "gemm_rowln.h"
 #include "gemm_tile256.h"
 #include "kernels.h"
 
@@ -781,39 +780,15 @@ struct MEpiBiasRes32 {
     }
     return k;
   }
-  // the same loads split into the part that depends on the feature only and the part of one row (gemm_rowln.h: a lane holds
-  // 2 feature pieces x 4 rows and keeps the feature part once)
-  struct ColCtx { Bias8 b; float4 g0, g1, b0, b1; };
-  struct RowCtx { float4 r0, r1; float mu, rs; };
-  __device__ __forceinline__ ColCtx pre_cols(int n) const {
-    ColCtx c{};
-    c.b = load_bias8(bias, n);
-    if (mean) {
-      c.g0 = *reinterpret_cast<const float4*>(gamma + n); c.g1 = *reinterpret_cast<const float4*>(gamma + n + 4);
-      c.b0 = *reinterpret_cast<const float4*>(beta + n); c.b1 = *reinterpret_cast<const float4*>(beta + n + 4);
-    }
-    return c;
-  }
-  __device__ __forceinline__ RowCtx pre_rows(int m, int n) const {
-    RowCtx r{};
-    r.r0 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n);
-    r.r1 = *reinterpret_cast<const float4*>(res + (int64_t)m * ldres + n + 4);
-    if (mean) { r.mu = mean[m]; r.rs = rstd[m]; }
-    return r;
-  }
-  static __device__ __forceinline__ Ctx join(const ColCtx& c, const RowCtx& r) {
-    return Ctx{c.b, r.r0, r.r1, c.g0, c.g1, c.b0, c.b1, r.mu, r.rs};
-  }
   __device__ __forceinline__ void post(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi) const {
     float u[8];
     add_bias8(k.b, lo, hi, u);
     finish(m, n, u, k);
   }
   __device__ __forceinline__ void wide(int m, int n, const f32x4& lo, const f32x4& hi) const { post(pre(m, n), m, n, lo, hi); }
-  // the 8 fp32 values of the pre-LN sum (gemm_rowln.h normalises them in registers as well as storing them)
-  __device__ __forceinline__ void sum8(int m, int n, const float (&u)[8], const Ctx& k, float (&r)[8]) const {
+  __device__ __forceinline__ void finish(int m, int n, const float (&u)[8], const Ctx& k) const {
     const float4 r0 = k.r0, r1 = k.r1;
-    r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+    float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     if (mean) {
       const float mu = k.mu, rs = k.rs;
       const float4 g0 = k.g0, g1 = k.g1, b0 = k.b0, b1 = k.b1;
@@ -828,21 +803,9 @@ struct MEpiBiasRes32 {
     drop_mul8(ds, idx, dm);
 #pragma unroll
     for (int t = 0; t < 8; t++) r[t] += u[t] * dm[t];
-  }
-  __device__ __forceinline__ void value(const Ctx& k, int m, int n, const f32x4& lo, const f32x4& hi, float (&r)[8]) const {
-    float u[8];
-    add_bias8(k.b, lo, hi, u);
-    sum8(m, n, u, k, r);
-  }
-  __device__ __forceinline__ void store(int m, int n, const float (&r)[8]) const {
     float* o = pre32 + (int64_t)m * ldpre + n;
     *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
     *reinterpret_cast<float4*>(o + 4) = make_float4(r[4], r[5], r[6], r[7]);
-  }
-  __device__ __forceinline__ void finish(int m, int n, const float (&u)[8], const Ctx& k) const {
-    float r[8];
-    sum8(m, n, u, k, r);
-    store(m, n, r);
   }
   __device__ __forceinline__ void operator()(int m, int n, const f32x4& a) const {
     const float4 bb = bias4(bias, n);
@@ -1367,32 +1330,6 @@ int mfma_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float
   return launch<false, false>(w, K, x, ldx, N, M, K,
                               MEpiBiasRes32{pre, ldpre, bias, residual, ldres, mean, rstd, gamma, beta, (int)N, da, DropState{}},
                               st, "linear_fwd_res32(mfma)", true);
-}
-
-// The same product with the block's own LayerNorm in the epilogue (gemm_rowln.h): N == 512 only -- a workgroup owns whole rows.
-bool mfma_linear_fwd_res32_ln_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldpre, int64_t ldres,
-                                        int64_t ldy) {
-  return N == ovqa_rowln::BR && K % ovqa_rowln::TK == 0 && K >= 2 * ovqa_rowln::TK && ldx % 8 == 0 && ldpre % 4 == 0 &&
-         ldres % 4 == 0 && ldy % 8 == 0 && M >= 1 && M * ldx < (1ll << 31) && N * K < (1ll << 31);
-}
-
-int mfma_linear_fwd_res32_ln(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
-                             int64_t ldres, const float* mean_in, const float* rstd_in, const float* gamma_in,
-                             const float* beta_in, float* pre, int64_t ldpre, const float* gamma, const float* beta,
-                             float eps, void* y, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t N, int64_t K,
-                             const DropArgs& da, hipStream_t st) {
-  OVQA_REQUIRE(aligned16(x) && aligned16(w) && aligned16(pre) && aligned16(residual) && aligned16(y) &&
-                   aligned16(gamma) && aligned16(beta) && (!bias || aligned16(bias)) &&
-                   (!gamma_in || (aligned16(gamma_in) && aligned16(beta_in))),
-               OVQA_ERR_BAD_ARG, "linear_fwd_res32_ln: pointers must be 16-byte aligned");
-  using Epi = MEpiBiasRes32;
-  static int rc_attr = set_max_lds(ovqa_rowln::kernel<Epi>, ovqa_rowln::LDS_BYTES);
-  if (rc_attr != OVQA_OK) return rc_attr;
-  ovqa_rowln::Args a{(const bf16*)w, K, (const bf16*)x, ldx, (int)M, (int)K, gamma, beta, eps, (bf16*)y, ldy, mean, rstd};
-  Epi epi{pre, ldpre, bias, residual, ldres, mean_in, rstd_in, gamma_in, beta_in, (int)N, da, DropState{}};
-  const unsigned grid = (unsigned)((M + ovqa_rowln::BC - 1) / ovqa_rowln::BC);
-  OVQA_LAUNCH_TIMED((ovqa_rowln::kernel<Epi>), dim3(grid), dim3(512), ovqa_rowln::LDS_BYTES, st, a, epi);
-  return ovqa_check_launch("linear_fwd_res32_ln(mfma)");
 }
 
 // dX from a TRANSPOSED weight copy wt[K, N] (row stride ldwt): the forward-type kernel (row-major P tile).

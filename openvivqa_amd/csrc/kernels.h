@@ -216,13 +216,4 @@ int mfma_linear_fwd_res32(const void* x, int64_t ldx, const void* w, const float
                           int64_t ldres, const float* mean, const float* rstd, const float* gamma, const float* beta,
                           float* pre, int64_t ldpre, int64_t M, int64_t N, int64_t K, const DropArgs& da, hipStream_t st);
 
-// activation rows from which ovqa_linear_fwd_res32_ln takes the row-complete kernel (below: GEMM + ln_fwd launches)
-constexpr int64_t kRowLnMinRows = 1;
-bool mfma_linear_fwd_res32_ln_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldpre, int64_t ldres,
-                                        int64_t ldy);
-int mfma_linear_fwd_res32_ln(const void* x, int64_t ldx, const void* w, const float* bias, const float* residual,
-                             int64_t ldres, const float* mean_in, const float* rstd_in, const float* gamma_in,
-                             const float* beta_in, float* pre, int64_t ldpre, const float* gamma, const float* beta,
-                             float eps, void* y, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t N, int64_t K,
-                             const DropArgs& da, hipStream_t st);
 }  // namespace ovqa

@@ -194,15 +194,12 @@ def finalize(out, dtype):
     return out.to(dtype)
 
 
-def _res32_ln(x, lin, ln, arena, st, drop):
-    """The tail of a block in the bf16 mode: pre = res + drop(lin(x)) in fp32 (the residual stream), y = LayerNorm(pre) as the
-    bf16 operand of the next block; leaves the lazy fp32 twin of y in st["_res_out"].  One entry point of the library
-    (one kernel at d_model = 512, gemm_rowln.h)."""
+def _ln_out(pre, ln, arena, st, save_stats=True):
+    """LayerNorm of the fp32 pre-LN sum -> bf16 operand; leaves the lazy fp32 twin in st["_res_out"]."""
     gamma, beta = arena.master_of(ln.weight), arena.master_of(ln.bias)
-    pre, y, mean, rstd = ops.linear_fwd_res32_ln(x, arena.compute(lin.weight), arena.master_of(lin.bias), st.pop("res"),
-                                                 gamma, beta, ln.eps, drop=drop)
+    y, mean, rstd = ops.layernorm_fwd(pre, gamma, beta, ln.eps, out_dtype=arena.compute_dtype)
     st["_res_out"] = ops.LnRef(pre, mean, rstd, gamma, beta, ln.eps)
-    return pre, y, mean, rstd
+    return y, mean, rstd
 
 
 # ------------------------------------------------------------------ prologue
@@ -382,7 +379,9 @@ class _MHABlock(Function):
         o, lse, mode, bufs = _project_and_attend(st, queries, keys, values, mask, lo_out=lo)
         drop = st["drop"]
         if queries.dtype == torch.bfloat16:  # fp32 residual stream: fp32 pre-LN sum, bf16 operand out
-            pre, y, mean, rstd = _res32_ln(o, a.fc_o, ln, arena, st, drop)
+            pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
+                                       drop=drop)
+            y, mean, rstd = _ln_out(pre, ln, arena, st)
         else:
             pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
                                  residual=queries, drop=drop)
@@ -488,7 +487,9 @@ def mha_block(queries, keys, values, mask, st, projected_kv=None):
     queries, keys, values = _canon(queries, keys, values, st["same"])
     o, _, _, _ = _project_and_attend(st, queries, keys, values, mask, save_lse=False)
     if bf16:
-        _, y, _, _ = _res32_ln(o, a.fc_o, ln, arena, st, st["drop"])
+        pre = ops.linear_fwd_res32(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), st.pop("res"),
+                                   drop=st["drop"])
+        y, _, _ = _ln_out(pre, ln, arena, st)
         return _attach(y, st)
     pre = ops.linear_fwd(o, arena.compute(a.fc_o.weight), arena.master_of(a.fc_o.bias), EPI_BIAS_RESIDUAL,
                          residual=queries, drop=st["drop"])
@@ -506,7 +507,9 @@ class _FFNBlock(Function):
                               want_preact=True, drop=st["drop1"])
         ln = m.layer_norm
         if x.dtype == torch.bfloat16:
-            pre, y, mean, rstd = _res32_ln(h, m.fc2, ln, arena, st, st["drop2"])
+            pre = ops.linear_fwd_res32(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), st.pop("res"),
+                                       drop=st["drop2"])
+            y, mean, rstd = _ln_out(pre, ln, arena, st)
         else:
             pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL,
                                  residual=x, drop=st["drop2"])
@@ -541,7 +544,9 @@ def ffn_block(x, st):
     h = ops.linear_fwd(x, arena.compute(m.fc1.weight), arena.master_of(m.fc1.bias), EPI_BIAS_GELU, drop=st["drop1"])
     ln = m.layer_norm
     if bf16:
-        _, y, _, _ = _res32_ln(h, m.fc2, ln, arena, st, st["drop2"])
+        pre = ops.linear_fwd_res32(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), st.pop("res"),
+                                   drop=st["drop2"])
+        y, _, _ = _ln_out(pre, ln, arena, st)
         return _attach(y, st)
     pre = ops.linear_fwd(h, arena.compute(m.fc2.weight), arena.master_of(m.fc2.bias), EPI_BIAS_RESIDUAL, residual=x,
                          drop=st["drop2"])

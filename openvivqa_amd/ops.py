@@ -195,32 +195,6 @@ def linear_fwd_res32(x, w, bias, residual, drop=None):
     return pre
 
 
-def linear_fwd_res32_ln(x, w, bias, residual, gamma, beta, eps, drop=None):
-    """``linear_fwd_res32`` and the block's own LayerNorm behind one entry point (``ovqa_linear_fwd_res32_ln``: one
-    row-complete kernel at N == 512, the two launches otherwise).  Returns (pre32, y bf16, mean, rstd)."""
-    _dev(x)
-    lib = _lib.load()
-    ldx, M = _rows(x)
-    N, K = w.shape
-    assert x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype == torch.bfloat16
-    ln = None
-    if isinstance(residual, LnRef):
-        ln, residual = residual.c(), residual.pre
-    assert residual.dtype == torch.float32 and residual.shape[-1] == N
-    if not residual.is_contiguous() and (residual.stride(-1) != 1 or residual.dim() > 2):
-        residual = residual.contiguous()
-    ldres, mr = _rows(residual)
-    assert mr == M and gamma.dtype == beta.dtype == torch.float32 and gamma.numel() == beta.numel() == N
-    pre = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
-    y = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
-    mean = torch.empty(M, dtype=torch.float32, device=x.device)
-    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    _lib.check(lib.ovqa_linear_fwd_res32_ln(_p(x), ldx, _p(w), _p(bias), _p(residual), ldres, ln, _p(pre), _p(gamma),
-                                            _p(beta), float(eps), _p(y), _p(mean), _p(rstd), M, N, K, _drop(drop),
-                                            _stream()), "linear_fwd_res32_ln")
-    return pre, y, mean, rstd
-
-
 def linear_bwd_data(dy, w, preact=None, drop=None, out=None, addend=None):
     """dx = dy w  [* dropmask * gelu'(preact)]  [+ addend]   (addend may alias out)."""
     _dev(dy)

@@ -127,52 +127,6 @@ def test_linear_fwd_res32(M, N, K, lazy):
     assert nerr(o.linear_fwd_res32(x, w, b, res, drop=d), rres + u * keep) < 2e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 512, 128), (37, 512, 512), (64, 512, 192), (6400, 512, 512), (1283, 512, 2048),
-                                   (300, 256, 512)])
-@pytest.mark.parametrize("lazy", [False, True], ids=["plain-residual", "lazy-layernorm-residual"])
-def test_linear_fwd_res32_ln_one_kernel_equals_the_two_launches(M, N, K, lazy, monkeypatch):
-    """ovqa_linear_fwd_res32_ln (csrc/gemm_rowln.h: fc_o / fc2 + dropout + fp32 residual + the block's LayerNorm in one
-    kernel at N = 512) against the same entry point run as its two launches (OVQA_ROWLN=0) and against fp64: the fp32
-    pre-LN sum bit for bit (same epilogue arithmetic), the row statistics to fp32 rounding (another reduction order),
-    the bf16 operand within one bf16 ulp of the two-launch form's; ragged row counts (guarded last tile), K = 2 .. 32 steps
-    of the ring, dropout on, N != 512 (the composed form behind the same entry point)."""
-    from openvivqa_amd import _lib
-    o = ops()
-    x, w = rnd(M, K, dtype=BF16), rnd(N, K, dtype=BF16, scale=K ** -0.5, seed=1)
-    b = rnd(N, seed=2)
-    g2, b2 = rnd(N, seed=6) * 0.2 + 1.0, rnd(N, seed=7) * 0.1
-    if lazy:
-        prev = rnd(M, N, scale=2.0, seed=3) + 0.3
-        g, be = rnd(N, seed=4) * 0.2 + 1.0, rnd(N, seed=5) * 0.1
-        _, mean, rstd = o.layernorm_fwd(prev, g, be, 1e-5, out_dtype=BF16)
-        res = o.LnRef(prev, mean, rstd, g, be, 1e-5)
-        rres = ln_ref(prev, g, be)[0]
-    else:
-        res = rnd(M, N, scale=2.0, seed=3)
-        rres = res.double()
-    for d in (None, o.DropSpec(p=0.3, seed=9, site=11, step=torch.tensor([3], dtype=torch.int32, device=DEV))):
-        monkeypatch.setenv("OVQA_ROWLN", "1")
-        pre, y, mean, rstd = o.linear_fwd_res32_ln(x, w, b, res, g2, b2, 1e-5, drop=d)
-        if not FORCED_SIMPLE:
-            assert _lib.last_dispatch() == ("mfma_rowln" if N == 512 else "mfma")
-        monkeypatch.setenv("OVQA_ROWLN", "0")
-        pre0, y0, mean0, rstd0 = o.linear_fwd_res32_ln(x, w, b, res, g2, b2, 1e-5, drop=d)
-        assert FORCED_SIMPLE or _lib.last_dispatch() == "mfma"
-        assert torch.equal(pre0, o.linear_fwd_res32(x, w, b, res, drop=d))
-        if N == 512 and not FORCED_SIMPLE:  # K is walked in the same order by both kernels: the same fp32 sums
-            assert torch.equal(pre, pre0)
-        u = x.double() @ w.double().t() + b.double()
-        if d is not None:
-            u = u * (o.dropout_keep_mask(d, M * N, DEV).view(M, N).double() / 0.7)
-        assert nerr(pre, rres + u) < 2e-3
-        ry, rmean, rrstd = ln_ref(pre, g2, b2)
-        assert (mean - rmean.view(-1)).abs().max() < 1e-5 and ((rstd - rrstd.view(-1)).abs() / rrstd.view(-1)).max() < 1e-5
-        assert (mean - mean0).abs().max() < 1e-5
-        assert nerr(y, ry) < 1e-2
-        ulp = (y.float() - y0.float()).abs() / y0.float().abs().clamp_min(2.0 ** -6)
-        assert ulp.max() <= 2.0 ** -7 + 1e-6, ulp.max()
-
-
 def test_layernorm_bwd_fp32_input_bf16_gradient():
     """LayerNorm backward of the residual stream: bf16 dy, fp32 x (the pre-LN sum), bf16 dx (+ dropped branch)."""
     o = ops()
