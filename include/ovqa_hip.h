@@ -605,6 +605,13 @@ int ovqa_lstm_bwd(int dtype, const void* dy, int dy_dtype, const void* w_hh, con
  *   ovqa_embed_scatter: dtable[v][0..width) (=|+=) sum of drows[r][0..width) over the rows r with token v, in a fixed order (the
  *     order the tokens lie in memory; no atomics), for EVERY v < rows_table: rows no token names are stored as zeros (no
  *     memset needed), row padding_idx gets zeros (nn.Embedding's padding_idx).  dtable fp32.
+ * Decoder inputs.   replaces: the padding / causal mask and position arithmetic of a teacher-forced Decoder.forward,
+ *                   models/modules/decoders.py:50-60 and the position add :66 (generate_padding_mask,
+ *                   generate_sequential_mask, generate_self_attention_masks: models/utils.py:44-73)
+ *   ovqa_decoder_inputs: tokens int64 [B, T], emb fp32 [B, T, D] (the word embeddings), pos_table fp32 [pos_rows >= T + 1, D]
+ *     -> out fp32 [B, T, D] = emb + pos_table[seq], seq = 0 at a padding token, t + 1 otherwise (out may alias emb), and
+ *     self_mask fp32 [B, T, T] = (tokens[b][j] == padding_idx || j > t) * -10e4 (-0.0 where unmasked, as the reference's
+ *     long * float product gives).  One launch.
  * ovqa_dropout_apply: y[i] = x[i] * keep(i) / (1 - p), flat index i -- forward and backward of an nn.Dropout call site whose
  *   producer has no fused epilogue (text_embeddings.py:241).
  *
@@ -626,7 +633,7 @@ int ovqa_lstm_bwd(int dtype, const void* dy, int dy_dtype, const void* w_hh, con
  *     written as zeros (the padded columns of a ragged classifier).
  *   ovqa_nll_loss: logp fp32 [M, n], target int64 [M] -> *loss (=|+=) -sum_{target != ignore_index} logp[r][target[r]] / count
  *     (mean reduction; may be NULL) and, if dlogp != NULL, the dense gradient fp32 [M, n] (-(*gscale or 1) / count at the
- *     targets).  One workgroup, fixed summation order.
+ *     targets).  Fixed summation order (every workgroup sums the M targets itself and writes its share of the gradient rows).
  * ------------------------------------------------------------------------- */
 int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
                       int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
@@ -634,6 +641,8 @@ int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64
 int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
                        int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                        int accumulate, void* stream);
+int ovqa_decoder_inputs(const int64_t* tokens, const float* emb, const float* pos_table, int64_t pos_rows, float* out,
+                        float* self_mask, int64_t B, int64_t T, int64_t D, int64_t padding_idx, void* stream);
 int ovqa_dropout_apply(int dtype, const void* x, void* y, int64_t n, const ovqa_dropout* drop, void* stream);
 int ovqa_pool_fwd(int feat_dtype, int dtype, const void* feat, const void* hpre, const float* w2, const float* b2, float* att,
                   void* pooled, float* pooled32, int64_t B, int64_t N, int64_t D, const ovqa_dropout* drop, void* stream);

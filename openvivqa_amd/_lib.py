@@ -145,6 +145,7 @@ SIGNATURES = {
     "ovqa_grouped_row_gather": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "ovqa_sq_loss_fwd_bwd": [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "ovqa_embed_gather": [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "ovqa_decoder_inputs": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp],
     "ovqa_embed_scatter": [c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     "ovqa_dropout_apply": [c_int, c_vp, c_vp, c_i64, _DP, c_vp],
     "ovqa_pool_fwd": [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, _DP, c_vp],

@@ -787,6 +787,17 @@ int ovqa_embed_gather(int dtype, const int64_t* tokens, const void* table, int64
                             as_stream(stream));
 }
 
+int ovqa_decoder_inputs(const int64_t* tokens, const float* emb, const float* pos_table, int64_t pos_rows, float* out,
+                        float* self_mask, int64_t B, int64_t T, int64_t D, int64_t padding_idx, void* stream) {
+  OVQA_REQUIRE(B >= 0 && T >= 0 && D >= 1 && B * T < (1ll << 31), OVQA_ERR_BAD_ARG, "decoder_inputs: bad size");
+  OVQA_REQUIRE(pos_rows >= T + 1, OVQA_ERR_BAD_ARG, "decoder_inputs: the position table has %lld rows, %lld needed",
+               (long long)pos_rows, (long long)T + 1);
+  if (B == 0 || T == 0) return OVQA_OK;
+  OVQA_REQUIRE(tokens && emb && pos_table && out && self_mask, OVQA_ERR_BAD_ARG, "decoder_inputs: null pointer");
+  g_dispatch = "stream";
+  return ovqa::decoder_inputs(tokens, emb, pos_table, out, self_mask, B, T, D, padding_idx, as_stream(stream));
+}
+
 int ovqa_embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
                        int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                        int accumulate, void* stream) {

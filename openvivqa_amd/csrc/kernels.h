@@ -159,6 +159,8 @@ int lstm_bwd(int dtype, bool persistent, const void* dy, int dy_bf16, const void
 int embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld_table, int64_t vocab, void* out,
                  int64_t ld_out, int64_t B, int64_t T, int64_t width, int time_major, float* mask, int64_t padding_idx,
                  hipStream_t st);
+int decoder_inputs(const int64_t* tokens, const float* emb, const float* pos_table, float* out, float* self_mask, int64_t B,
+                   int64_t T, int64_t D, int64_t padding_idx, hipStream_t st);
 int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
                   int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                   int accumulate, hipStream_t st);

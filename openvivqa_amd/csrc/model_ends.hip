@@ -33,6 +33,31 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
   for (int c = l * V; c < width; c += 64 * V) *reinterpret_cast<u32x4*>(dst + c) = *reinterpret_cast<const u32x4*>(src + c);
 }
 
+// The inputs of a teacher-forced decoder pass from the answer tokens (decoders.py:50-60,66), one wave per position (b, t):
+//   out[b][t][:]       = emb[b][t][:] + pos_table[seq][:],   seq = tokens[b][t] == padding_idx ? 0 : t + 1
+//   self_mask[b][t][j] = (tokens[b][j] == padding_idx || j > t) * -10e4      (generate_self_attention_masks of the padding and
+//                        the causal mask, models/utils.py:59-73; "no mask" is -0.0 as there: long 0 * -10e4)
+// -- fourteen stock elementwise / reduce / gather launches of ~5 us in the decoder_train step before (profiles/README.md).
+__global__ __launch_bounds__(256) void decoder_inputs_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ emb,
+                                                             const float* __restrict__ pos_table, float* __restrict__ out,
+                                                             float* __restrict__ self_mask, int R, int Tn, int D,
+                                                             int64_t padding_idx) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (r >= R) return;
+  const int b = r / Tn, t = r % Tn;
+  const int64_t* trow = tokens + (int64_t)b * Tn;
+  const int seq = trow[t] == padding_idx ? 0 : t + 1;
+  const float* e = emb + (int64_t)r * D;
+  const float* p = pos_table + (int64_t)seq * D;
+  float* o = out + (int64_t)r * D;
+  for (int c = l * 4; c < D; c += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(e + c), q = *reinterpret_cast<const float4*>(p + c);
+    *reinterpret_cast<float4*>(o + c) = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+  }
+  float* m = self_mask + (int64_t)r * Tn;
+  for (int j = l; j < Tn; j += 64) m[j] = (trow[j] == padding_idx || j > t) ? -100000.f : -0.f;
+}
+
 // dtable[v][0 .. width) (=|+=) sum over the positions with token v of their rows of drows, in a fixed order (the order the
 // tokens lie in memory: ANY fixed order makes the sum deterministic, and this one needs an integer division per MATCH only),
 // no atomics (torch's embedding_dense_backward adds atomically).  One wave per TABLE row, including the rows no token names:
@@ -41,13 +66,21 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 // MEASURED (1280 positions, 4000 x 320 table, in the model step): walking the list from global memory, one dependent load per
 // 64 positions, 13.8 us; four table rows per wave 18.4; a wave per POSITION (owner = first occurrence) + a memset node for
 // the untouched rows 10.6-12.8 + 4.9; this form: profiles/README.md.
-template <typename T>
+// A token many positions share (<bos> of every sample: 64 hits in decoder_train) is ONE wave's chain of row reads: rows are read
+// 16 bytes per lane (VEC: rows 16-byte aligned, width % (16 / sizeof(T)) == 0) and four hits' loads are issued before the
+// first is added -- in position order, so the sums are those of the one-at-a-time form bit for bit.
+// MEASURED (decoder_train, 1280 positions, 4000 x 512 table, <bos> x 64): 137 us -> see profiles/README.md.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ tokens, const T* __restrict__ drows,
                                                             int64_t ld_rows, float* __restrict__ dtable, int64_t ld_table,
                                                             int64_t rows_table, int B, int Tn, int width, int time_major,
                                                             int64_t padding_idx, int accumulate) {
   constexpr int MAXC = 16;    // columns per lane: width <= 1024
   constexpr int CHUNK = 2048;  // positions staged in LDS per round
+  constexpr int V = VEC ? 16 / (int)sizeof(T) : 1;  // consecutive columns per lane and load
+  constexpr int NL = MAXC / V;                      // loads per row and lane
+  constexpr int HB = 4;                             // hits whose loads are in flight together
+  struct alignas(V * sizeof(T)) Vec { T e[V]; };
   __shared__ int64_t s_tok[CHUNK];
   const int R = B * Tn;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -65,15 +98,32 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
     for (int i0 = 0; i0 < n; i0 += 64) {
       uint64_t hits = __ballot(s_tok[i0 + l] == v);
       while (hits) {
-        const int k = __ffsll((long long)hits) - 1;
-        hits &= hits - 1;
-        const int mm = base + i0 + k;
-        const int r = time_major ? (mm % Tn) * B + mm / Tn : mm;  // the row of drows that position (b, t) owns
-        const T* src = drows + (int64_t)r * ld_rows;
+        Vec val[HB][NL];
+        int nh = 0;
 #pragma unroll
-        for (int j = 0; j < MAXC; j++) {
-          const int c = l + 64 * j;
-          if (c < width) acc[j] += to_f32<T>(src[c]);
+        for (int u = 0; u < HB; u++) {
+          if (!hits) break;  // (wave-uniform: a ballot)
+          const int k = __ffsll((long long)hits) - 1;
+          hits &= hits - 1;
+          const int mm = base + i0 + k;
+          const int r = time_major ? (mm % Tn) * B + mm / Tn : mm;  // the row of drows that position (b, t) owns
+          const T* src = drows + (int64_t)r * ld_rows;
+#pragma unroll
+          for (int j = 0; j < NL; j++) {
+            const int c = (j * 64 + l) * V;
+            if (c < width) val[u][j] = *reinterpret_cast<const Vec*>(src + c);
+          }
+          nh = u + 1;
+        }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+          if (u >= nh) break;
+#pragma unroll
+          for (int j = 0; j < NL; j++)
+            if ((j * 64 + l) * V < width) {
+#pragma unroll
+              for (int t = 0; t < V; t++) acc[j * V + t] += to_f32<T>(val[u][j].e[t]);
+            }
         }
       }
     }
@@ -81,9 +131,11 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
   if (v >= rows_table) return;
   float* dst = dtable + v * ld_table;
 #pragma unroll
-  for (int j = 0; j < MAXC; j++) {
-    const int c = l + 64 * j;
-    if (c < width) dst[c] = accumulate ? dst[c] + acc[j] : acc[j];
+  for (int j = 0; j < NL; j++) {
+    const int c = (j * 64 + l) * V;
+    if (c >= width) continue;
+#pragma unroll
+    for (int t = 0; t < V; t++) dst[c + t] = accumulate ? dst[c + t] + acc[j * V + t] : acc[j * V + t];
   }
 }
 
@@ -362,33 +414,136 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
   for (int c = l; c < (int)ld; c += 64) d[c] = from_f32<T>(c < n ? gp[c] - __expf(lp[c]) * s : 0.f);
 }
 
+// ---- the same two for WIDE rows (a generation vocabulary: 1280 positions x 4000 words in decoder_train): one 256-thread
+// workgroup per row, the row read ONCE in 16-byte pieces and kept in registers over the passes (n <= 8192), 16-byte stores.
+// MEASURED (decoder_train): wave-per-row forms 31.7 (fwd) / 44.1 us (bwd) -> profiles/README.md.
+constexpr int LSM_THREADS = 256, LSM_MAXN = 8192;
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sm) {  // 4 waves; every thread gets the result
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();  // (sm may still be read from the previous reduction)
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(LSM_THREADS) void log_softmax_fwd_row_kernel(const T* __restrict__ x, int64_t ld,
+                                                                          float* __restrict__ out, int n) {
+  constexpr int V = 16 / (int)sizeof(T), NV = LSM_MAXN / (LSM_THREADS * V);
+  struct alignas(16) Vec { T e[V]; };
+  __shared__ float sm[4];
+  const T* p = x + (int64_t)blockIdx.x * ld;
+  float val[NV][V];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (j * LSM_THREADS + (int)threadIdx.x) * V;
+    if (c < n) {
+      const Vec u = *reinterpret_cast<const Vec*>(p + c);
+#pragma unroll
+      for (int t = 0; t < V; t++) { val[j][t] = to_f32<T>(u.e[t]); mx = fmaxf(mx, val[j][t]); }
+    }
+  }
+  mx = block_reduce(mx, true, sm);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++)
+    if ((j * LSM_THREADS + (int)threadIdx.x) * V < n) {
+#pragma unroll
+      for (int t = 0; t < V; t++) s += __expf(val[j][t] - mx);
+    }
+  s = block_reduce(s, false, sm);
+  const float lse = mx + __logf(s);
+  float* o = out + (int64_t)blockIdx.x * n;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (j * LSM_THREADS + (int)threadIdx.x) * V;
+    if (c < n) {
+#pragma unroll
+      for (int t = 0; t < V; t += 4)
+        *reinterpret_cast<float4*>(o + c + t) = make_float4(val[j][t] - lse, val[j][t + 1] - lse, val[j][t + 2] - lse, val[j][t + 3] - lse);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LSM_THREADS) void log_softmax_bwd_row_kernel(const float* __restrict__ g, const float* __restrict__ logp,
+                                                                          T* __restrict__ dx, int64_t ld, int n) {
+  constexpr int V = 16 / (int)sizeof(T), NV = LSM_MAXN / (LSM_THREADS * V);
+  struct alignas(16) Vec { T e[V]; };
+  __shared__ float sm[4];
+  const float* gp = g + (int64_t)blockIdx.x * n;
+  const float* lp = logp + (int64_t)blockIdx.x * n;
+  float gv[NV][V], lv[NV][V];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (j * LSM_THREADS + (int)threadIdx.x) * V;
+    if (c < n) {
+#pragma unroll
+      for (int t = 0; t < V; t += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(gp + c + t), b = *reinterpret_cast<const float4*>(lp + c + t);
+        gv[j][t] = a.x; gv[j][t + 1] = a.y; gv[j][t + 2] = a.z; gv[j][t + 3] = a.w;
+        lv[j][t] = b.x; lv[j][t + 1] = b.y; lv[j][t + 2] = b.z; lv[j][t + 3] = b.w;
+        s += (a.x + a.y) + (a.z + a.w);
+      }
+    }
+  }
+  s = block_reduce(s, false, sm);
+  T* d = dx + (int64_t)blockIdx.x * ld;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (j * LSM_THREADS + (int)threadIdx.x) * V;
+    if (c < (int)ld) {  // (n <= c < ld: the padded columns of a ragged classifier get zeros)
+      Vec u;
+#pragma unroll
+      for (int t = 0; t < V; t++) u.e[t] = from_f32<T>(c < n ? gv[j][t] - __expf(lv[j][t]) * s : 0.f);
+      *reinterpret_cast<Vec*>(d + c) = u;
+    }
+  }
+}
+
 // NLLLoss(reduction = mean, ignore_index) on log-probabilities fp32 [M, n]: loss = -sum_{t_r != ignore} logp[r][t_r] / cnt
 // and (optionally) its gradient dlogp (dense, -scale / cnt at the targets).  Every workgroup sums the M targets itself, in the
 // same fixed order (M int64 reads: nothing beside a dense gradient of M x n floats), workgroup 0 stores the loss, and each
-// workgroup writes the gradient rows [blockIdx.x * rows_per_wg, ...): a wave per row, 16-byte stores.  (Round 5 wrote the
-// whole gradient from ONE workgroup with a division per element: 1.2 ms of a 2.6-ms teacher-forced decoder step at
-// 1280 positions x 4000 words, profiles/r06a_decoder_train_kernel_stats_before.csv.)
-__global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
-                                                        float* __restrict__ loss, float* __restrict__ dlogp,
-                                                        const float* __restrict__ gscale, int M, int n, int64_t ignore_index,
-                                                        int accumulate, int rows_per_wg) {
-  __shared__ float s_sum[16];
-  __shared__ float s_cnt[16];
+// workgroup (4 waves) writes the gradient rows [blockIdx.x * rows_per_wg, ...): a wave per row, 16-byte stores.  (Round 5 wrote
+// the whole gradient from ONE workgroup with a division per element: 1.2 ms of a 2.6-ms teacher-forced decoder step at
+// 1280 positions x 4000 words, profiles/r06a_decoder_train_kernel_stats_before.csv; 16 rows per 1024-thread workgroup left 80
+// workgroups for those 20 MB: 21 us.)
+__global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
+                                                       float* __restrict__ loss, float* __restrict__ dlogp,
+                                                       const float* __restrict__ gscale, int M, int n, int64_t ignore_index,
+                                                       int accumulate, int rows_per_wg) {
+  __shared__ float s_sum[4];
+  __shared__ float s_cnt[4];
   float s = 0.f, cnt = 0.f;
-  for (int r = threadIdx.x; r < M; r += 1024) {
-    const int64_t t = target[r];
-    if (t != ignore_index && t >= 0 && t < n) {
-      s -= logp[(int64_t)r * n + t];
-      cnt += 1.f;
+  // eight targets per thread and round: their loads, then the eight dependent loads of logp, are in flight together (one
+  // at a time this chain was 10 of the kernel's 17 us at M = 1280); only workgroup 0 stores the loss and needs the sum
+  const bool need_sum = blockIdx.x == 0 && loss != nullptr;
+  for (int r0 = threadIdx.x; r0 < M; r0 += 256 * 8) {
+    int64_t t[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int r = r0 + u * 256;
+      t[u] = r < M ? target[r] : ignore_index;
+      if (t[u] < 0 || t[u] >= n) t[u] = ignore_index;
     }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      v[u] = (need_sum && t[u] != ignore_index) ? logp[(int64_t)(r0 + u * 256) * n + t[u]] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (t[u] != ignore_index) {
+        s -= v[u];
+        cnt += 1.f;
+      }
   }
   s = wave_sum(s);
   cnt = wave_sum(cnt);
   if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = s; s_cnt[threadIdx.x >> 6] = cnt; }
   __syncthreads();
-  float ts = 0.f, tc = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { ts += s_sum[i]; tc += s_cnt[i]; }
+  const float ts = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]), tc = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
   const float inv = tc > 0.f ? 1.f / tc : 0.f;  // (torch returns nan for an all-ignored batch; the gradient is 0 either way)
   if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
     const float v = tc > 0.f ? ts * inv : __int_as_float(0x7fc00000);
@@ -399,7 +554,7 @@ __global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r_end = min(M, ((int)blockIdx.x + 1) * rows_per_wg);
   const bool vec = (n & 3) == 0 && ((uintptr_t)dlogp & 15) == 0;
-  for (int r = (int)blockIdx.x * rows_per_wg + wave; r < r_end; r += 16) {
+  for (int r = (int)blockIdx.x * rows_per_wg + wave; r < r_end; r += 4) {
     const int64_t t = target[r];
     const int hot = (t != ignore_index && t >= 0 && t < n) ? (int)t : -1;
     float* row = dlogp + (int64_t)r * n;
@@ -434,17 +589,29 @@ int embed_gather(int dtype, const int64_t* tokens, const void* table, int64_t ld
   return ovqa_check_launch("embed_gather");
 }
 
+int decoder_inputs(const int64_t* tokens, const float* emb, const float* pos_table, float* out, float* self_mask, int64_t B,
+                   int64_t T, int64_t D, int64_t padding_idx, hipStream_t st) {
+  OVQA_REQUIRE(D % 4 == 0 && (uintptr_t)emb % 16 == 0 && (uintptr_t)pos_table % 16 == 0 && (uintptr_t)out % 16 == 0,
+               OVQA_ERR_BAD_ARG, "decoder_inputs: rows must be 16-byte aligned and a multiple of 16 bytes wide");
+  hipLaunchKernelGGL(decoder_inputs_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, st, tokens, emb, pos_table, out,
+                     self_mask, (int)(B * T), (int)T, (int)D, padding_idx);
+  return ovqa_check_launch("decoder_inputs");
+}
+
 int embed_scatter(int dtype, const int64_t* tokens, const void* drows, int64_t ld_rows, float* dtable, int64_t ld_table,
                   int64_t rows_table, int64_t B, int64_t T, int64_t width, int time_major, int64_t padding_idx,
                   int accumulate, hipStream_t st) {
   OVQA_REQUIRE(width <= 1024, OVQA_ERR_UNSUPPORTED, "embed_scatter: rows wider than 1024 elements");
   const unsigned grid = (unsigned)((rows_table + 3) / 4);  // one wave per table row
-  if (dtype == OVQA_BF16)
-    hipLaunchKernelGGL(embed_scatter_kernel<bf16>, dim3(grid), dim3(256), 0, st, tokens, (const bf16*)drows, ld_rows, dtable,
-                       ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);
-  else
-    hipLaunchKernelGGL(embed_scatter_kernel<float>, dim3(grid), dim3(256), 0, st, tokens, (const float*)drows, ld_rows,
-                       dtable, ld_table, rows_table, (int)B, (int)T, (int)width, time_major, padding_idx, accumulate);
+  const int64_t vw = dtype == OVQA_BF16 ? 8 : 4;
+  const bool vec = (uintptr_t)drows % 16 == 0 && ld_rows % vw == 0 && width % vw == 0;
+#define OVQA_SCATTER(T, VEC)                                                                                              \
+  hipLaunchKernelGGL((embed_scatter_kernel<T, VEC>), dim3(grid), dim3(256), 0, st, tokens, (const T*)drows, ld_rows, dtable, \
+                     ld_table, rows_table, (int)B, (int)T_, (int)width, time_major, padding_idx, accumulate)
+  const int64_t T_ = T;
+  if (dtype == OVQA_BF16) { if (vec) OVQA_SCATTER(bf16, true); else OVQA_SCATTER(bf16, false); }
+  else { if (vec) OVQA_SCATTER(float, true); else OVQA_SCATTER(float, false); }
+#undef OVQA_SCATTER
   return ovqa_check_launch("embed_scatter");
 }
 
@@ -497,7 +664,21 @@ int pool_bwd(int feat_dtype, int dtype, const void* feat, const void* hpre, cons
   return ovqa_check_launch("pool_bwd");
 }
 
+// wide rows whose pieces are 16-byte aligned: a workgroup per row
+static bool lsm_rows(int dtype, const void* x, int64_t ld, const void* f32a, const void* f32b, int64_t n) {
+  const int64_t v = dtype == OVQA_BF16 ? 8 : 4;
+  return n >= 1024 && n <= LSM_MAXN && ld <= LSM_MAXN && n % v == 0 && ld % v == 0 && (uintptr_t)x % 16 == 0 &&
+         (uintptr_t)f32a % 16 == 0 && (uintptr_t)f32b % 16 == 0;
+}
+
 int log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M, int64_t n, hipStream_t st) {
+  if (lsm_rows(dtype, x, ld, out, nullptr, n)) {
+    if (dtype == OVQA_BF16)
+      hipLaunchKernelGGL(log_softmax_fwd_row_kernel<bf16>, dim3((unsigned)M), dim3(LSM_THREADS), 0, st, (const bf16*)x, ld, out, (int)n);
+    else
+      hipLaunchKernelGGL(log_softmax_fwd_row_kernel<float>, dim3((unsigned)M), dim3(LSM_THREADS), 0, st, (const float*)x, ld, out, (int)n);
+    return ovqa_check_launch("log_softmax_fwd");
+  }
   const unsigned grid = (unsigned)((M + 3) / 4);
   if (dtype == OVQA_BF16)
     hipLaunchKernelGGL(log_softmax_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, ld, out, (int)M, (int)n);
@@ -507,6 +688,13 @@ int log_softmax_fwd(int dtype, const void* x, int64_t ld, float* out, int64_t M,
 }
 
 int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int64_t ld, int64_t M, int64_t n, hipStream_t st) {
+  if (lsm_rows(dtype, dx, ld, g, logp, n)) {
+    if (dtype == OVQA_BF16)
+      hipLaunchKernelGGL(log_softmax_bwd_row_kernel<bf16>, dim3((unsigned)M), dim3(LSM_THREADS), 0, st, g, logp, (bf16*)dx, ld, (int)n);
+    else
+      hipLaunchKernelGGL(log_softmax_bwd_row_kernel<float>, dim3((unsigned)M), dim3(LSM_THREADS), 0, st, g, logp, (float*)dx, ld, (int)n);
+    return ovqa_check_launch("log_softmax_bwd");
+  }
   const unsigned grid = (unsigned)((M + 3) / 4);
   if (dtype == OVQA_BF16)
     hipLaunchKernelGGL(log_softmax_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, g, logp, (bf16*)dx, ld, (int)M, (int)n);
@@ -517,11 +705,11 @@ int log_softmax_bwd(int dtype, const float* g, const float* logp, void* dx, int6
 
 int nll_loss(const float* logp, const int64_t* target, float* loss, float* dlogp, const float* gscale, int64_t M, int64_t n,
              int64_t ignore_index, int accumulate, hipStream_t st) {
-  // the gradient rows are dealt to the workgroups 16 at a time (a wave per row), at most 1024 workgroups
-  int rows_per_wg = 16;
-  while ((M + rows_per_wg - 1) / rows_per_wg > 1024) rows_per_wg *= 2;
+  // the gradient rows are dealt to the workgroups 4 at a time (a wave per row), at most 4096 workgroups
+  int rows_per_wg = 4;
+  while ((M + rows_per_wg - 1) / rows_per_wg > 4096) rows_per_wg *= 2;
   const unsigned grid = dlogp ? (unsigned)std::max<int64_t>(1, (M + rows_per_wg - 1) / rows_per_wg) : 1u;
-  hipLaunchKernelGGL(nll_loss_kernel, dim3(grid), dim3(1024), 0, st, logp, target, loss, dlogp, gscale, (int)M, (int)n,
+  hipLaunchKernelGGL(nll_loss_kernel, dim3(grid), dim3(256), 0, st, logp, target, loss, dlogp, gscale, (int)M, (int)n,
                      ignore_index, accumulate, rows_per_wg);
   return ovqa_check_launch("nll_loss");
 }

@@ -185,6 +185,25 @@ class _WithValue(Function):
         return g.to(ctx.dt), None
 
 
+class _DecoderInputs(Function):
+    """(emb + pos_table[seq], self-attention mask) of a teacher-forced decoder pass (``ops.decoder_inputs``); the gradient of
+    the sum goes to the word embeddings unchanged (the position table is frozen, decoders.py:41-42)."""
+
+    @staticmethod
+    def forward(ctx, emb, tokens, pos_table, padding_idx):
+        out, mask = ops.decoder_inputs(tokens, _c(emb), pos_table, padding_idx)
+        ctx.mark_non_differentiable(mask)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        return g, None, None, None
+
+
+def decoder_inputs(emb, tokens, pos_table, padding_idx):
+    return _DecoderInputs.apply(emb, tokens, pos_table, padding_idx)
+
+
 def finalize(out, dtype):
     """Stack output in the caller's dtype: an fp32 caller of the bf16 mode gets the unrounded fp32 stream."""
     res = _twin(out)

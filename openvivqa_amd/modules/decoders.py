@@ -169,18 +169,25 @@ class Decoder(Module):
             encoder_features = encoder_features.repeat_interleave(encoder_group, 0)
             if encoder_attention_mask is not None and encoder_attention_mask.shape[0] != 1:
                 encoder_attention_mask = encoder_attention_mask.repeat_interleave(encoder_group, 0)
-        pad_mask = generate_padding_mask(answer_tokens, self.padding_idx).to(dev)
-        self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len, device=dev))
-        if self._is_stateful:  # decoders.py:55-57
-            self.running_mask_self_attention = torch.cat([self.running_mask_self_attention, self_mask], -1)
-            self_mask = self.running_mask_self_attention
-        seq = torch.arange(1, seq_len + 1, device=dev).view(1, -1).expand(b_s, -1)
-        seq = seq.masked_fill(pad_mask.squeeze(1).squeeze(1) != 0, 0)
-        if self._is_stateful:  # decoders.py:61-63
-            self.running_seq.add_(1)
-            seq = self.running_seq
-        embedded, _ = self.word_emb(answer_tokens)
-        out = embedded + self.pos_emb(seq)
+        pos = self.pos_emb.weight
+        if (answer_tokens.is_cuda and not self._is_stateful and type(self.word_emb).__name__ == "UsualEmbedding"
+                and self.d_model % 4 == 0 and pos.dtype == torch.float32 and seq_len + 1 <= pos.shape[0]):
+            # decoders.py:50-60,66 in one launch: the padding + causal mask and the position rows added to the word rows
+            embedded, _ = self.word_emb(answer_tokens)
+            out, self_mask = Fn.decoder_inputs(embedded.float(), answer_tokens.contiguous(), pos, self.padding_idx)
+        else:
+            pad_mask = generate_padding_mask(answer_tokens, self.padding_idx).to(dev)
+            self_mask = generate_self_attention_masks(pad_mask, generate_sequential_mask(seq_len, device=dev))
+            if self._is_stateful:  # decoders.py:55-57
+                self.running_mask_self_attention = torch.cat([self.running_mask_self_attention, self_mask], -1)
+                self_mask = self.running_mask_self_attention
+            seq = torch.arange(1, seq_len + 1, device=dev).view(1, -1).expand(b_s, -1)
+            seq = seq.masked_fill(pad_mask.squeeze(1).squeeze(1) != 0, 0)
+            if self._is_stateful:  # decoders.py:61-63
+                self.running_seq.add_(1)
+                seq = self.running_seq
+            embedded, _ = self.word_emb(answer_tokens)
+            out = embedded + self.pos_emb(seq)
         for layer in self.layers:
             out = layer(queries=out, keys=encoder_features, values=encoder_features,
                         self_attention_mask=self_mask, enc_attention_mask=encoder_attention_mask)

@@ -1216,6 +1216,21 @@ def embed_scatter(tokens, drows, dtable, time_major=False, padding_idx=-1, accum
                                               int(padding_idx), int(bool(accumulate)), _stream()), "embed_scatter")
 
 
+def decoder_inputs(tokens, emb, pos_table, padding_idx):
+    """(emb + pos_table[seq], self_mask [B, 1, T, T]) of a teacher-forced decoder pass in one launch
+    (``ovqa_decoder_inputs``; decoders.py:50-60,66).  tokens int64 [B, T]; emb fp32 [B, T, D]; pos_table fp32 [>= T + 1, D]."""
+    _dev(emb)
+    B, T = tokens.shape
+    D = emb.shape[-1]
+    assert emb.dtype == pos_table.dtype == torch.float32 and emb.is_contiguous() and pos_table.is_contiguous()
+    assert emb.shape == (B, T, D) and pos_table.shape[1] == D and tokens.is_contiguous() and tokens.dtype == torch.int64
+    out = torch.empty_like(emb)
+    mask = torch.empty(B, 1, T, T, dtype=torch.float32, device=emb.device)
+    _lib.check(_lib.load().ovqa_decoder_inputs(_p(tokens), _p(emb), _p(pos_table), pos_table.shape[0], _p(out), _p(mask),
+                                               B, T, D, int(padding_idx), _stream()), "decoder_inputs")
+    return out, mask
+
+
 def dropout_apply(x, drop):
     """x * keep / (1 - p) with the counter-hash mask of ``drop`` (flat element index); x itself when dropout is off."""
     if drop is None or drop.p <= 0.0:

@@ -1285,12 +1285,17 @@ def test_lstm_persistent_equals_per_step_kernels_and_is_deterministic_under_load
 # ---------------------------------------------------------------- the two ends of the model (csrc/model_ends.hip)
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("B,T,V,W,time_major", [(3, 6, 11, 16, True), (64, 20, 4000, 304, True), (5, 7, 50, 512, False),
-                                                 (128, 40, 300, 64, True), (70, 30, 97, 32, False)])
+                                                 (128, 40, 300, 64, True), (70, 30, 97, 32, False),
+                                                 (64, 20, 4000, 512, False), (9, 5, 30, 24, True)])
 def test_embed_gather_scatter(dtype, B, T, V, W, time_major):
+    """(the last two cases: <bos> at the head of every sample -- up to 64 hits for one table row, read four rows at a time;
+    a view of the row gradients that is not 16-byte aligned takes the scalar row reads: the same sums bit for bit)"""
     o = ops()
     g = torch.Generator().manual_seed(B * 100 + T)
     table = torch.randn(V, W, generator=g).to(DEV, dtype)
     tokens = torch.randint(0, V, (B, T), generator=g)
+    if W in (512, 24):
+        tokens[:, 0] = 1
     tokens[0, -2:] = 0  # padding tokens (index 0)
     tokens[-1] = tokens[0]  # repeated tokens: several rows add into one table row
     tok = tokens.to(DEV)
@@ -1311,6 +1316,37 @@ def test_embed_gather_scatter(dtype, B, T, V, W, time_major):
     a = torch.empty_like(dt)
     o.embed_scatter(tok, drows, a, time_major, padding_idx=0)
     assert torch.equal(a, dt), "the scatter is not deterministic"
+    wide = torch.zeros(B * T, W + 3, device=DEV, dtype=dtype)
+    wide[:, 1:W + 1] = drows
+    o.embed_scatter(tok, wide[:, 1:W + 1], a.fill_(3.0), time_major, padding_idx=0)
+    assert torch.equal(a, dt)
+
+
+@pytest.mark.parametrize("B,T,D", [(64, 20, 512), (3, 1, 32), (5, 77, 100), (2, 130, 64)])
+def test_decoder_inputs_equal_the_reference_mask_and_position_arithmetic(B, T, D):
+    """ovqa_decoder_inputs against the torch composition of decoders.py:50-60,66 (generate_padding_mask,
+    generate_sequential_mask, generate_self_attention_masks, the masked position ids, pos_emb lookup and add): bit for bit,
+    including the sign of the unmasked zeros."""
+    from openvivqa_amd.utils import (generate_padding_mask, generate_self_attention_masks, generate_sequential_mask,
+                                     sinusoid_encoding_table)
+    o = ops()
+    g = torch.Generator().manual_seed(B + T)
+    tokens = torch.randint(1, 50, (B, T), generator=g)
+    for b in range(B):
+        n = int(torch.randint(1, T + 1, (1,), generator=g))
+        tokens[b, n:] = 0
+    tokens[0, 0] = 0  # a padding token in front of words: its row of the mask still opens the causal prefix
+    tokens = tokens.to(DEV)
+    emb = torch.randn(B, T, D, generator=g).to(DEV)
+    pos = sinusoid_encoding_table(T + 3, D, padding_idx=0).to(DEV)
+    out, mask = o.decoder_inputs(tokens, emb, pos, 0)
+    pad = generate_padding_mask(tokens, 0)
+    ref_mask = generate_self_attention_masks(pad, generate_sequential_mask(T, device=DEV))
+    seq = torch.arange(1, T + 1, device=DEV).view(1, -1).expand(B, -1).masked_fill(pad.squeeze(1).squeeze(1) != 0, 0)
+    assert mask.shape == ref_mask.shape and torch.equal(mask.view(torch.int32), ref_mask.float().view(torch.int32))
+    assert torch.equal(out, emb + pos[seq])
+    with pytest.raises(RuntimeError, match="position table"):
+        o.decoder_inputs(tokens, emb, pos[:T], 0)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -1367,7 +1403,8 @@ def test_attention_pool_fwd_bwd(fdt, dtype, B, N, D, p):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("M,n,ld", [(3, 7, 8), (64, 353, 360), (1280, 4000, 4000), (5, 11, 16)])
+@pytest.mark.parametrize("M,n,ld", [(3, 7, 8), (64, 353, 360), (1280, 4000, 4000), (5, 11, 16), (40, 4000, 4096),
+                                    (7, 8192, 8192), (3, 1024, 1032), (2, 8200, 8200)])
 def test_log_softmax_and_nll(dtype, M, n, ld):
     o = ops()
     g = torch.Generator().manual_seed(M + n)
