@@ -68,7 +68,8 @@ __device__ __forceinline__ int perm32(int s) { return (s & ~31) | ((s & 12) << 1
 template <typename Epi, int FLAGS>
 __device__ __forceinline__ void tile_e(const Args& g, int c0, int r0, Epi& epi, char* smem) {
   constexpr bool ROTF = FLAGS & 1, PRIO = FLAGS & 2;
-  // ablation switches of the variant bench (wrong results, timing only): no DMA in the loop / no MFMAs / no fragment reads
+  // ablation switches of the variant bench (wrong results, timing only): no DMA in the loop / no MFMAs / no fragment reads;
+  // bit 9: 4 instead of 16 bytes per lane and DMA instruction; bit 10: every K step fetches the same two 64-byte column blocks
   constexpr bool NO_DMA = FLAGS & 16, NO_MFMA = FLAGS & 32, NO_READ = FLAGS & 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,8 +103,9 @@ __device__ __forceinline__ void tile_e(const Args& g, int c0, int r0, Epi& epi, 
     char* dst = dma_dst + (kt & 1) * STAGE_BYTES + (n >> 2) * HALF_BYTES + (n & 3) * 1024;
     uint32_t o = n < 4 ? vp[n & 3] : vq[n & 3];
     asm volatile("" : "+v"(o));
-    const char* src = (n < 4 ? pbase : qbase) + (int64_t)kt * (TK * 2) + o;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    const char* src = (n < 4 ? pbase : qbase) + (int64_t)((FLAGS & 1024) ? (kt & 1) : kt) * (TK * 2) + o;
+    if constexpr (FLAGS & 512) __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 4, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
   };
 
   const int frow = lane & 15;

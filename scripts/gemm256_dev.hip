@@ -108,6 +108,17 @@ int main(int argc, char** argv) {
       {"t256 flags=11 (early,rot,prio)", launch256<11>},
       {"t256 flags=11 group_c=4", launch256<11, 4>},
       {"t256 flags=11 one-phase epilogue", launch256<11, 0, EpiBias1>},
+      {"ablation: MFMA only", launch256<3 + 16 + 64>},
+      {"ablation: reads only", launch256<3 + 16 + 32>},
+      {"ablation: MFMA + reads (no DMA)", launch256<3 + 16>},
+      {"ablation: MFMA + DMA (no reads)", launch256<3 + 64>},
+      {"ablation: DMA + reads (no MFMA)", launch256<3 + 32>},
+      {"ablation: MFMA + reads, no ROT", launch256<2 + 16>},
+      {"ablation: MFMA only, no ROT", launch256<2 + 16 + 64>},
+      {"ablation: DMA only", launch256<3 + 32 + 64>},
+      {"ablation: DMA only, 4 B per lane", launch256<3 + 32 + 64 + 512>},
+      {"ablation: DMA only, same K block", launch256<3 + 32 + 64 + 1024>},
+      {"ablation: all, same K block", launch256<3 + 1024>},
   };
   const int shapes[][3] = {{6400, 2048, 512}, {6400, 1536, 512}, {6400, 512, 2048}, {6400, 3072, 768}, {8192, 4096, 4096},
                            {300, 264, 128}};
