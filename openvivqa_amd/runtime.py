@@ -44,7 +44,10 @@ def _footprint(p) -> tuple:
         rpad = 64 if rows % 64 and rows > 1024 else PAD
         return ((rows + rpad - 1) // rpad * rpad, (cols + cpad - 1) // cpad * cpad)
     if p.dim() == 1:
-        return ((p.shape[0] + PAD - 1) // PAD * PAD,)
+        # (the same rule as the rows of a matrix: the bias of a padded layer has to be as long as its weight is high)
+        n = p.shape[0]
+        pad = 64 if n % 64 and n > 1024 else PAD
+        return ((n + pad - 1) // pad * pad,)
     return tuple(p.shape)
 
 

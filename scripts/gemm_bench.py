@@ -34,6 +34,7 @@ for (M, N, K) in shapes:
     if "fwd" in which:
         for name, fn in (("bias", lambda: ops.linear_fwd(x, w, b, out=y)),
                          ("gelu", lambda: ops.linear_fwd(x, w, b, ops.EPI_BIAS_GELU, out=y, preact_out=u)),
+                         ("gelu_no_preact_store", lambda: ops.linear_fwd(x, w, b, ops.EPI_BIAS_GELU, out=y)),
                          ("resid", lambda: ops.linear_fwd(x, w, b, ops.EPI_BIAS_RESIDUAL, residual=r, out=y))):
             t = timeit(fn); row[name] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"
         t = timeit(lambda: torch.nn.functional.linear(x, w)); row["torch"] = f"{t*1e6:.1f}us {fl/t/1e12:.0f}TF"

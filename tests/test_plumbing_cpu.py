@@ -490,3 +490,22 @@ def test_feature_collator_alternating_shapes_never_alias_consecutive_batches():
             assert not (lo <= cur.data_ptr() < hi or cur.data_ptr() <= lo < cur.data_ptr() + cur.numel() * 4)
         prev, prev_expected = cur, expected
     assert len(col._slots["f"]) == 2 and all(s[0].numel() == 2 * 9 * 8 for s in col._slots["f"])
+
+
+@pytest.mark.parametrize("n_out,n_in", [(353, 300), (4000, 512), (5003, 768), (1030, 64), (1024, 8), (64, 2051)])
+def test_arena_footprints_of_weight_and_bias_agree(n_out, n_in):
+    """A Linear whose matrix is zero-padded in the arena (ragged rows / columns, long vocabularies up to whole 64-row tiles)
+    has a bias footprint as long as the weight footprint is high -- the GEMM epilogue reads bias[0 .. rows of the padded
+    weight) -- and the parameters stay [:rows, :cols] views of zero-padded buffers (round 6: a 5003-word classifier WITH a
+    bias tripped `bias.numel() == N` after the row padding of long output dimensions went to 64)."""
+    import torch.nn as nn
+    import openvivqa_amd.runtime as rt
+    lin = nn.Linear(n_in, n_out)
+    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+    arena = rt.ParamArena(rt.collect_groups(lin), torch.device("cpu"), torch.float32)
+    w, b = arena.packed([lin.weight], "master"), arena.packed([lin.bias], "master")
+    assert w.shape[0] == b.numel() and w.shape[0] >= n_out and w.shape[1] >= n_in
+    assert w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+    assert torch.equal(lin.weight.data, w0) and torch.equal(lin.bias.data, b0)
+    assert torch.equal(w[:n_out, :n_in], w0) and torch.equal(b[:n_out], b0)
+    assert float(w[n_out:].abs().sum()) == 0.0 and float(w[:, n_in:].abs().sum()) == 0.0 and float(b[n_out:].abs().sum()) == 0.0
