@@ -344,8 +344,15 @@ class GradAllReducer:
         # the process group offers no call that waits for the list to drain.
         if work is not None:
             work.wait()
-        torch.cuda.synchronize(self.device)
+        self.quiesce(work)
+
+    def quiesce(self, work=None) -> None:
+        """Everything issued so far has run, and the process group's watchdog has had three of its poll periods to retire
+        the eager collectives on its list (see ``warm``): called before a stream capture begins."""
+        if not self.active or self.stream is None or not self.capturable:  # (no capture with this backend / on the CPU)
+            return
         import time
+        torch.cuda.synchronize(self.device)
         t_end = time.monotonic() + 5.0
         while work is not None and not work.is_completed() and time.monotonic() < t_end:
             time.sleep(0.001)
@@ -1063,6 +1070,8 @@ class TrainStep:
             self._fwd_bwd(on_phase=self._release)
             self.reducer.finish(self.arena.grad)
             torch.cuda.synchronize()
+            # (the agreement, probe and exchange collectives above were eager as well: the same pause as behind warm())
+            self.reducer.quiesce()
         _fn.wgrad_queue().reserve(32)  # table buffers for the grouped dW / LayerNorm-reduce launches of the capture
         if self.use_graph and os.environ.get("OVQA_WHOLE_STEP_GRAPH", "1") != "0" and self.reducer.capturable:
             try:
