@@ -1170,6 +1170,9 @@ int launch(const void* P, int64_t ldp, const void* Q, int64_t ldq, int64_t R, in
     if (tiny_c) OVQA_GLDS(4, 8, 32, 128, grid)
     if (small_c) OVQA_GLDS(3, 8, 64, 128, grid)
   }
+  // (round 6: this tier on 4 waves of 64 x 64 outputs each -- 512 instead of 768 LDS bytes per MFMA, two workgroups per CU as
+  // here -- measured 3.066 / 3.070 against 3.028 / 3.016 ms per step, alternated on one box; 6400 x 2048 <- 512 alone 26.3
+  // against 26.1 us: fewer LDS bytes do not pay for half the waves)
   if (glds) OVQA_GLDS(2, 8, 128, 128, grid)
 #undef OVQA_GLDS
   OVQA_LAUNCH_TIMED((gemm_bf16_kernel<PK, QK, Epi>), grid, dim3(256), 4 * TILE_BYTES, st, g, epi);
