@@ -895,6 +895,7 @@ def train_bench(args, workload, device, world, rank, dist, dtype, steps=None, wa
     # further windows of the same K steps (not part of `value`): spread of the measurement
     windows = [dt] + [window() for _ in range(max(0, repeats - 1))]
     final_loss = float(loss_buf.item())
+    ts.check_device_status()  # (a persistent-kernel hand-off that gave up during the timed steps is an error, not a number)
     comm_stats = ts.timed_comm_step(*batch) if (dist is not None) else {}
     if rank != 0:
         return None, ts, cfg
