@@ -913,3 +913,69 @@ def test_config2_linearity_and_sample_order_properties():
         vo_p, lo_p = hip(vision_features=v[perm], vision_padding_mask=vm[perm], language_features=l[perm],
                          language_padding_mask=lm[perm])
     assert torch.equal(vo_p, vo[perm]) and torch.equal(lo_p, lo[perm])
+
+
+# ---- BASELINE configs[4], the training half, at ITS size: Decoder d = 512, L = 3, B = 64, T = 20, 237 encoder positions, 4000 words ----
+def _baseline_decoder(seed=41):
+    import openvivqa_amd.modules as M
+    from openvivqa_amd.config import ConfigNode, attention_config
+    from openvivqa_amd.utils import generate_padding_mask
+    V, T, NE, B = 4000, 20, 237, 64
+
+    class Vocab:
+        max_answer_length, padding_idx, bos_idx, eos_idx = T, 0, 1, 2
+
+        def __len__(self):
+            return V
+    cfg = ConfigNode(dict(
+        ARCHITECTURE="Decoder", D_MODEL=512, LAYERS=3,
+        ATTENTION=dict(SELF_ATTENTION=attention_config(can_be_stateful=True), ENC_ATTENTION=attention_config()),
+        TEXT_EMBEDDING=dict(ARCHITECTURE="UsualEmbedding", D_MODEL=512, D_EMBEDDING=300, WORD_EMBEDDING=None,
+                            WORD_EMBEDDING_CACHE=None, DROPOUT=0.1)))
+    torch.manual_seed(seed)
+    m = M.Decoder(cfg, Vocab()).to(DEV).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    ans = torch.randint(3, V, (B, T), generator=g)
+    ans[:, 0] = 1
+    na = torch.randint(6, T + 1, (B,), generator=g)
+    ans[torch.arange(T)[None, :] >= na[:, None]] = 0  # <bos> a_1 .. a_n <pad> ...
+    enc = torch.randn(B, NE, 512, generator=g)
+    ne = torch.randint(200, NE + 1, (B,), generator=g)
+    enc[torch.arange(NE)[None, :] >= ne[:, None]] = 0
+    enc = enc.to(DEV, BF16)
+    return m, ans.to(DEV), enc, generate_padding_mask(enc, 0), na
+
+
+def test_decoder_train_size_backward_is_linear_and_samples_are_independent():
+    """The teacher-forced Decoder at the size bench.py's `decoder_train` runs (no oracle, so the full size costs nothing on the
+    CPU): (1) an upstream gradient of the log-probabilities scaled by 4 scales the gradient of the encoder features and of
+    every trainable parameter -- the word embeddings' deterministic scatter, the row-per-workgroup log-softmax backward, the
+    4000-word classifier on its zero-padded footprint included -- by exactly 4, bit for bit; (2) a permutation of the batch
+    permutes the log-probabilities bit for bit; (3) rows of padded answer positions carry no gradient into the table beyond
+    the padding row's zeros."""
+    m, ans, enc, emask, na = _baseline_decoder()
+    gen = torch.Generator().manual_seed(5)
+    up = torch.randn(64, 20, 4000, generator=gen).to(DEV) * 1e-3
+    grads = []
+    for scale in (1.0, 4.0):
+        for p in m.parameters():
+            p.grad = None
+        e = enc.clone().requires_grad_()
+        logp = m(ans, e, emask)
+        assert logp.shape == (64, 20, 4000) and logp.dtype == F32
+        logp.backward(up * scale)
+        g = {"d encoder": e.grad.clone()}
+        g.update({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None})
+        grads.append(g)
+    assert len(grads[0]) >= 1 + 3 * 26  # the encoder features and every tensor of the three layers, the table, the classifier
+    for k, g1 in grads[0].items():
+        assert torch.equal(grads[1][k], g1 * 4.0), k
+        assert bool(torch.isfinite(g1).all()), k
+    table = grads[0]["word_emb.components.weight"]
+    assert float(table[0].abs().max()) == 0.0  # padding_idx
+    with torch.no_grad():
+        lp = m(ans, enc, emask)
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+        lp_p = m(ans[perm], enc[perm], emask[perm])
+        assert torch.equal(lp_p, lp[perm])
+        assert float((lp.exp().sum(-1) - 1).abs().max()) < 1e-3  # rows of a log-softmax
