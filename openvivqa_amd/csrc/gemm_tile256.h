@@ -64,8 +64,9 @@ __device__ __forceinline__ int perm32(int s) { return (s & ~31) | ((s & 12) << 1
 // -- while stage k+1 is still in flight and the 64 MFMAs of step k have not started: two stages in flight at any time.
 // MEASURED (8192 x 4096 x 4096, profiles/r06_gemm256_variants.txt sweeps D, E): MFMAs alone 1.05 us per K step, fragment reads alone
 // 0.57, both 1.47 (1.68 without ROT, 1.55 with every wave requesting a half step's reads one 32-MFMA block ahead of their use):
-// on this chip ds_read_b128 traffic and MFMAs add up rather than overlap, whatever the phase or the interleaving -- hipBLASLt's
-// 1.43 us per equivalent step is the same sum with 128 x 128 outputs per wave (256 instead of 384 LDS bytes per MFMA).
+// on this chip ds_read_b128 traffic and MFMAs add up rather than overlap, whatever the phase or the interleaving -- the 1.43 us
+// per equivalent step that hipBLASLt measures here is what the same sum gives for 128 x 128 outputs per wave (256 instead of
+// 384 LDS bytes per MFMA: 1.05 + 0.38); its kernel was not inspected.
 //   straight waves: [vmcnt, S_k] RD(k)  MM0(k)  16 of MM1(k)  [M_k]  the other 16 of MM1(k) || DMA(k+2)
 //   rotated waves : [vmcnt, S_k] MM1(k-1)  RD(k)  [M_k]  MM0(k) || DMA(k+2)              (ROT; MM1 of the last step after the loop)
 // Without ROT every wave runs: [vmcnt, S_k] RD(k) [M_k] DMA(k+2) MM0(k) MM1(k).
