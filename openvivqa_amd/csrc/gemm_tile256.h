@@ -66,7 +66,9 @@ __device__ __forceinline__ int perm32(int s) { return (s & ~31) | ((s & 12) << 1
 // 0.57, both 1.47 (1.68 without ROT, 1.55 with every wave requesting a half step's reads one 32-MFMA block ahead of their use):
 // on this chip ds_read_b128 traffic and MFMAs add up rather than overlap, whatever the phase or the interleaving -- the 1.43 us
 // per equivalent step that hipBLASLt measures here is what the same sum gives for 128 x 128 outputs per wave (256 instead of
-// 384 LDS bytes per MFMA: 1.05 + 0.38); its kernel was not inspected.
+// 384 LDS bytes per MFMA: 1.05 + 0.38); its kernel was not inspected.  That shape built here from this header's pieces -- FOUR waves of
+// 128 x 128 outputs, accumulators in AGPRs, no spills -- ran 2.03 us per K step (1059 TFLOP/s): MFMAs 1.12 + reads 0.46 add up there
+// too (1.62), and with one wave per SIMD the DMA's 0.94 has nothing to hide behind (sweep F).  Removed again.
 //   straight waves: [vmcnt, S_k] RD(k)  MM0(k)  16 of MM1(k)  [M_k]  the other 16 of MM1(k) || DMA(k+2)
 //   rotated waves : [vmcnt, S_k] MM1(k-1)  RD(k)  [M_k]  MM0(k) || DMA(k+2)              (ROT; MM1 of the last step after the loop)
 // Without ROT every wave runs: [vmcnt, S_k] RD(k) [M_k] DMA(k+2) MM0(k) MM1(k).
