@@ -112,6 +112,20 @@ def make_stream(device, priority: int = 0, cu_mask=None):
 
 
 # ---------------------------------------------------------------------------
+def _weight(w, what):
+    """A weight operand must be a dense [N, K] matrix.  The one way a caller gets anything else: a parameter whose reduction
+    length is not a multiple of 8 lives zero-padded in the arena and ``arena.compute(p)`` / ``p.data`` are its [:N, :K] corner
+    view -- ``functional.linear`` / ``linear_gelu_dropout`` / ``classify_log_softmax`` / ``embed_rows`` take the padded footprint
+    (``arena.padded(p)``, activation zero-padded to match); the fused attention / feed-forward / LSTM blocks require
+    d_model % 8 == 0 (every shipped config: 512, 768) and say so here instead of in an assertion."""
+    if not w.is_contiguous():
+        raise RuntimeError(f"{what}: the weight is a non-contiguous view {tuple(w.shape)} with strides {tuple(w.stride())} -- "
+                           "a parameter whose reduction length is not a multiple of 8 is zero-padded in the arena; the fused "
+                           "attention / feed-forward / LSTM blocks need d_model % 8 == 0 (use functional.linear, which takes "
+                           "the padded footprint, or pad the model dimension)")
+    return w
+
+
 def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=False, drop=None, out=None,
                preact_out=None):
     """y = epilogue(x w^T + bias).  x [..., K] (rows may be strided), w [N, K]."""
@@ -119,7 +133,8 @@ def linear_fwd(x, w, bias=None, epilogue=EPI_BIAS, residual=None, want_preact=Fa
     lib = _lib.load()
     ldx, M = _rows(x)
     N, K = w.shape
-    assert x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype
+    _weight(w, "linear_fwd")
+    assert x.shape[-1] == K and w.dtype == x.dtype
     y = out if out is not None else torch.empty(*x.shape[:-1], N, dtype=x.dtype, device=x.device)
     ldy, _ = _rows(y)
     preact = preact_out if preact_out is not None else (
@@ -162,7 +177,8 @@ def linear_fwd_split3(x, w, bias, outs):
     ldx, M = _rows(x)
     F3, K = w.shape
     F = F3 // 3
-    assert F3 == 3 * F and x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype and len(outs) == 3
+    _weight(w, "linear_fwd_split3")
+    assert F3 == 3 * F and x.shape[-1] == K and w.dtype == x.dtype and len(outs) == 3
     lds = []
     for o in outs:
         ldo, rows = _rows(o)
@@ -180,7 +196,8 @@ def linear_fwd_res32(x, w, bias, residual, drop=None):
     lib = _lib.load()
     ldx, M = _rows(x)
     N, K = w.shape
-    assert x.shape[-1] == K and w.is_contiguous() and w.dtype == x.dtype == torch.bfloat16
+    _weight(w, "linear_fwd_res32")
+    assert x.shape[-1] == K and w.dtype == x.dtype == torch.bfloat16
     ln = None
     if isinstance(residual, LnRef):
         ln, residual = residual.c(), residual.pre
@@ -698,7 +715,8 @@ def attention_qkv_fwd(x, w, bias, mask, H, scale=None, save_lse=True, lo_out=Non
     lib = _lib.load()
     B, n, Dm = x.shape
     d = w.shape[0] // (3 * H)
-    assert w.shape[0] == 3 * H * d and w.shape[1] == Dm and w.is_contiguous() and w.dtype == x.dtype
+    _weight(w, "attention_qkv_fwd")
+    assert w.shape[0] == 3 * H * d and w.shape[1] == Dm and w.dtype == x.dtype
     ldx, _ = _rows(x)
     scale = (1.0 / math.sqrt(d)) if scale is None else scale
     qkv = torch.empty(B, n, 3 * H * d, dtype=x.dtype, device=x.device)
@@ -722,7 +740,8 @@ def attention_q_fwd(x, w, bias, k, v, mask, H, scale=None, save_lse=True, lo_out
     B, nq, Dm = x.shape
     nk = k.shape[1]
     d = w.shape[0] // H
-    assert w.shape[0] == H * d and w.shape[1] == Dm and w.is_contiguous() and w.dtype == x.dtype
+    _weight(w, "attention_q_fwd")
+    assert w.shape[0] == H * d and w.shape[1] == Dm and w.dtype == x.dtype
     assert k.shape[0] == B and v.shape[:2] == k.shape[:2] and k.shape[2] == H * d == v.shape[2] and k.dtype == x.dtype
     ldx, _ = _rows(x)
     ldk, _ = _rows(k)
@@ -1125,7 +1144,9 @@ def lstm_fwd(x_tb, w_ih, w_hh, b_ih, b_hh, B, T, want_lp=False):
     H4, I = w_ih.shape
     H = H4 // 4
     assert x_tb.dim() == 2 and x_tb.shape == (T * B, I) and x_tb.stride(1) == 1 and w_hh.shape == (H4, H)
-    assert w_ih.is_contiguous() and w_hh.is_contiguous() and w_ih.dtype == w_hh.dtype == x_tb.dtype
+    _weight(w_ih, "lstm_fwd (w_ih)")
+    _weight(w_hh, "lstm_fwd (w_hh)")
+    assert w_ih.dtype == w_hh.dtype == x_tb.dtype
     assert b_ih.dtype == torch.float32 and b_hh.dtype == torch.float32 and b_ih.numel() == H4 == b_hh.numel()
     chunks = _lstm_chunks(lib, x_tb.dtype, B, I, H)
     if chunks is None:

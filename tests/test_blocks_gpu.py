@@ -662,3 +662,26 @@ def test_graphed_beam_search_equals_eager(beam):
         assert search.graph is not None
         assert torch.equal(out_g, out_e) and torch.equal(lp_g, lp_e), trial
     assert out_g.shape == (b_s, 10)
+
+
+def test_ragged_model_dimension_is_refused_with_an_explanation_and_plain_linear_takes_the_padded_footprint():
+    """a parameter whose reduction length is not a multiple of 8 (d_model = 300) is zero-padded in the
+    arena, so `arena.compute(p)` is a non-contiguous corner view.  `functional.linear` takes the padded footprint and
+    computes the layer; the fused feed-forward block needs d_model % 8 == 0 and says so (a RuntimeError that names the
+    cause, not a bare assertion)."""
+    import torch.nn as nn
+    import openvivqa_amd.functional as Fn
+    import openvivqa_amd.runtime as rt
+    from openvivqa_amd.config import ConfigNode
+    from openvivqa_amd.modules.positionwise_feed_forward import PositionWiseFeedForward
+    torch.manual_seed(3)
+    lin = nn.Linear(300, 64).to(DEV)
+    arena = rt.ensure_arena(lin)
+    x = torch.randn(40, 300, device=DEV)
+    with torch.no_grad():
+        y = Fn.linear(x.to(arena.compute_dtype), lin, arena)
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    assert y.shape == (40, 64) and rel_l2(y, ref) < 1e-2
+    ff = PositionWiseFeedForward(ConfigNode(dict(D_MODEL=300, D_FF=512, DROPOUT=0.0))).to(DEV)
+    with pytest.raises(RuntimeError, match="d_model % 8 == 0"):
+        ff(torch.randn(2, 5, 300, device=DEV))
