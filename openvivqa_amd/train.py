@@ -766,7 +766,7 @@ class TrainStep:
         want = (os.environ.get("OVQA_FUSE_ADAM", "0") == "1") if fuse_adam is None else bool(fuse_adam)
         self._fused = (_FusedAdam(self) if want and not self.reducer.active and self.arena.device.type == "cuda"
                        and getattr(self.arena, "shadow_t", None) is not None and self.arena.adam_tiles() is not None else None)
-        # Sharded optimiser (round 6; default with a gradient exchange over more than one rank, OVQA_SHARD_OPTIMIZER=0 turns it
+        # Sharded optimiser (round 6; default with a gradient exchange over more than one rank, shard_optimizer=False turns it
         # off): the weight matrices' gradients are reduce-SCATTERED -- rank r owns chunk r of every exchanged bucket --, Adam
         # runs on the owned chunks only (1/N of the 236 us every rank spent on the same update), and what the next forward
         # reads (the bf16 shadow; the masters themselves in fp32 mode) is all-gathered: the bytes on a link are
@@ -774,7 +774,7 @@ class TrainStep:
         # from the gathered one (one grouped-transpose launch).  The 1-D tail (biases, LayerNorm) stays all-reduced and
         # replicated.  Masters and moments of a chunk live on its owner only: ``state_dict()`` / ``gather_state()``
         # gather them.  Same bits as the replicated form (one update function, common.h), given the same gradient sums.
-        want_shard = (os.environ.get("OVQA_SHARD_OPTIMIZER", "1") != "0") if shard_optimizer is None else bool(shard_optimizer)
+        want_shard = True if shard_optimizer is None else bool(shard_optimizer)
         n_sh = rehearse_shard if (rehearse_shard and self.reducer.world == 1) else self.reducer.world
         self.shard = bool(want_shard and self.reducer.active and n_sh > 1 and rt.ALIGN % n_sh == 0 and self.arena.small_lo > 0)
         self.reducer.cut = self.arena.small_lo
